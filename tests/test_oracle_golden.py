@@ -1,0 +1,87 @@
+"""Pin the oracle (oracle/ggml_oracle.c) against the golden vectors generated from the
+reference's Python block-format definition (tests/golden/make_golden.py).
+
+Bar: bit-exact for (de)quantization (the reference's own test demands np.array_equal,
+gguf-py/tests/test_quants.py:116-119); MUL_MAT "exact" mode equals the float64 product
+of the reference dequantization to f32 rounding; the CPU-style integer path stays inside
+the reference's op gate NMSE <= 5e-4 (tests/test-backend-ops.cpp:3106-3108).
+"""
+import numpy as np
+import pytest
+
+import oracle as orc
+
+NAMES = {"q4_0": orc.Q4_0, "q8_0": orc.Q8_0, "q4_K": orc.Q4_K, "q5_K": orc.Q5_K, "q6_K": orc.Q6_K, "mxfp4": orc.MXFP4}
+
+
+@pytest.mark.parametrize("name", list(NAMES))
+def test_dequantize_bit_exact(name, golden_dir):
+    g = np.load(golden_dir / f"dequant_{name}.npz")
+    got = orc.dequantize(g["blocks"], NAMES[name])
+    assert got.dtype == np.float32
+    assert np.array_equal(got.view(np.uint32), g["expected"].view(np.uint32)), name
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q8_0", "mxfp4"])
+def test_quantize_bit_exact(name, golden_dir):
+    g = np.load(golden_dir / f"quant_{name}.npz")
+    got = orc.quantize(g["x"], NAMES[name])
+    assert np.array_equal(got, g["expected"]), name
+
+
+@pytest.mark.parametrize("k", [256, 1024])
+@pytest.mark.parametrize("name", list(NAMES))
+def test_mul_mat_exact_matches_reference_dequant(name, k, golden_dir):
+    g = np.load(golden_dir / f"mulmat_{name}_k{k}.npz")
+    for n in (1, 2, 3, 4, 5, 6, 7, 8, 9, 16):
+        got = orc.mul_mat_2d(g["w"], NAMES[name], g["x"][:n], "exact")
+        exp = g["expected"][:n]
+        np.testing.assert_allclose(got, exp.astype(np.float32), rtol=0, atol=float(np.abs(exp).max()) * 2e-7)
+
+
+@pytest.mark.parametrize("k", [256, 1024])
+@pytest.mark.parametrize("name", list(NAMES))
+def test_mul_mat_cpu_style_within_reference_gate(name, k, golden_dir):
+    g = np.load(golden_dir / f"mulmat_{name}_k{k}.npz")
+    got = orc.mul_mat_2d(g["w"], NAMES[name], g["x"], "cpu")
+    assert orc.nmse(g["expected"], got) < 5e-4
+
+
+@pytest.mark.parametrize("name", list(NAMES))
+def test_mul_mat_id_matches_reference(name, golden_dir):
+    g = np.load(golden_dir / f"mulmatid_{name}.npz")
+    got = orc.mul_mat_id(g["w"], NAMES[name], g["b"], g["ids"], "exact")
+    exp = g["expected"]
+    np.testing.assert_allclose(got, exp.astype(np.float32), rtol=0, atol=float(np.abs(exp).max()) * 2e-7)
+    got_cpu = orc.mul_mat_id(g["w"], NAMES[name], g["b"], g["ids"], "cpu")
+    assert orc.nmse(exp, got_cpu) < 5e-4
+
+
+@pytest.mark.parametrize("name", ["q4_0", "q8_0", "mxfp4"])
+def test_vec_dot_error_gate(name):
+    """tests/test-quantize-fns.cpp:82-99: |vec_dot(from_float(a), q8(b)) - a.b| / n <= 0.02 on 0.1+2cos(i+off)."""
+    n = 32 * 128
+    i = np.arange(n, dtype=np.float32)
+    a = (0.1 + 2 * np.cos(i + np.float32(0.0))).astype(np.float32)
+    b = (0.1 + 2 * np.cos(i + np.float32(1.0))).astype(np.float32)
+    qa = orc.quantize(a[None, :], NAMES[name])[0]
+    qb = orc.quantize(b[None, :], orc.vec_dot_type(NAMES[name]))[0]
+    got = orc.vec_dot(NAMES[name], qa, qb, n)
+    ref = float(np.dot(a.astype(np.float64), b.astype(np.float64)))
+    limit = 0.02
+    assert abs(got - ref) / n <= limit
+
+
+def test_q8_K_round_trip_and_bsums():
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((4, 512)).astype(np.float32)
+    x[0, :256] = 0
+    q = orc.quantize(x, orc.Q8_K).reshape(4, 2, 292)
+    d = q[:, :, 0:4].copy().view(np.float32).reshape(4, 2)
+    qs = q[:, :, 4:260].view(np.int8).astype(np.int32)
+    bs = q[:, :, 260:292].copy().view(np.int16).reshape(4, 2, 16).astype(np.int32)
+    assert d[0, 0] == 0 and not qs[0, 0].any()
+    assert np.array_equal(bs, qs.reshape(4, 2, 16, 16).sum(-1))
+    rec = (qs * d[:, :, None]).reshape(4, 512)
+    amax = np.abs(x.reshape(4, 2, 256)).max(-1, keepdims=True)
+    assert np.all(np.abs(rec.reshape(4, 2, 256) - x.reshape(4, 2, 256)) <= amax / 127 * 0.5001 + 1e-12)
