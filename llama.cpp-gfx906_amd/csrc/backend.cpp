@@ -1,0 +1,948 @@
+// backend.cpp — the ggml-facing half of the MI355X backend: registry, device, buffer types,
+// buffers, the stream backend and graph_compute. This is the ONLY translation
+// unit that depends on the ggml struct layouts (include/ggml-compat/*.h, or a real ggml's
+// headers). Everything below the op switch is plain-pointer HIP code in kernels.h.
+//
+// Conventions kept from the reference's call sites:
+//  * alloc failure -> NULL (src/llama-model.cpp:5602,5611); compute -> enum ggml_status
+//    (src/llama-context.cpp:1101-1106); unsupported op -> supports_op says no, graph_compute never
+//    meets one; supports_op never dereferences tensor->data (dummy tensors, src/llama-model.cpp:278-283).
+//  * one ggml_backend_t = one ordered HIP stream driven by one host thread at a time
+//    (tests/test-thread-safety.cpp:1-4); graph_compute is asynchronous (src/llama-context.cpp:1449).
+//  * device type GPU so that it is auto-selected for offload (src/llama.cpp:183-190);
+//    caps.async && caps.events so that pipeline parallelism can turn on (src/llama-context.cpp:262-279).
+#include "ggml-mi355x.h"
+#include "ggml-backend-impl.h"
+#include "ggml-impl.h"
+
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <stddef.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace mi355x;
+
+#define MI_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    GGML_ABORT("MI355X backend: HIP error %s (%s) at %s:%d", hipGetErrorName(e_), hipGetErrorString(e_), __FILE__, __LINE__); } } while (0)
+
+#define MI_LOG(...) do { fprintf(stderr, "ggml-mi355x: " __VA_ARGS__); } while (0)
+
+static constexpr size_t MI_BUFFER_ALIGN = 128;
+static constexpr size_t MI_TENSOR_PAD   = 256;   // readable slack after quantized tensors (wave-wide 16 B loads may run past the last block)
+
+// ---------------------------------------------------------------------------------------------
+// device table
+// ---------------------------------------------------------------------------------------------
+struct mi_device {
+    int id;
+    std::string name;         // "MI355X0"
+    std::string description;
+    size_t total_mem;
+    struct ggml_backend_device dev;
+    struct ggml_backend_buffer_type buft;
+};
+
+struct mi_globals {
+    int n_devices = 0;
+    mi_device devices[GGML_MI355X_MAX_DEVICES];
+    struct ggml_backend_reg reg;
+    struct ggml_backend_buffer_type host_buft;
+    bool initialised = false;
+};
+
+static mi_globals & G();
+
+extern "C" {
+int    ggml_backend_mi355x_test_quantize(ggml_backend_t backend, const float * x, int64_t k, int64_t n, int kind, int8_t * qs, float * d, int16_t * bsums);
+double ggml_backend_mi355x_test_hbm_read_gbps(ggml_backend_t backend, size_t bytes, int iters);
+}
+
+static void set_device(int id) { MI_CHECK(hipSetDevice(id)); }
+
+// ---------------------------------------------------------------------------------------------
+// device buffer
+// ---------------------------------------------------------------------------------------------
+struct mi_buffer_ctx {
+    int device;
+    void * base;
+};
+
+static void buf_free(ggml_backend_buffer_t buffer) {
+    mi_buffer_ctx * c = (mi_buffer_ctx *) buffer->context;
+    set_device(c->device);
+    MI_CHECK(hipFree(c->base));
+    delete c;
+}
+static void * buf_get_base(ggml_backend_buffer_t buffer) { return ((mi_buffer_ctx *) buffer->context)->base; }
+
+static enum ggml_status buf_init_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor) {
+    mi_buffer_ctx * c = (mi_buffer_ctx *) buffer->context;
+    if (tensor->view_src != NULL) return GGML_STATUS_SUCCESS;
+    if (ggml_is_quantized(tensor->type) && tensor->view_src == NULL) {
+        // zero the padding after the last block so over-reads see defined bytes
+        const size_t size = ggml_nbytes(tensor);
+        const size_t alloc = ggml_backend_buft_get_alloc_size(buffer->buft, tensor);
+        if (alloc > size) {
+            set_device(c->device);
+            MI_CHECK(hipMemset((char *) tensor->data + size, 0, alloc - size));
+        }
+    }
+    return GGML_STATUS_SUCCESS;
+}
+static void buf_memset_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, uint8_t value, size_t offset, size_t size) {
+    mi_buffer_ctx * c = (mi_buffer_ctx *) buffer->context;
+    set_device(c->device);
+    MI_CHECK(hipMemsetAsync((char *) tensor->data + offset, value, size, hipStreamPerThread));
+    MI_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+static void buf_set_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    mi_buffer_ctx * c = (mi_buffer_ctx *) buffer->context;
+    set_device(c->device);
+    MI_CHECK(hipMemcpyAsync((char *) tensor->data + offset, data, size, hipMemcpyHostToDevice, hipStreamPerThread));
+    MI_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+static void buf_get_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    mi_buffer_ctx * c = (mi_buffer_ctx *) buffer->context;
+    set_device(c->device);
+    MI_CHECK(hipMemcpyAsync(data, (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost, hipStreamPerThread));
+    MI_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+
+static bool buffer_is_mi355x(ggml_backend_buffer_t buffer);
+
+static bool buf_cpy_tensor(ggml_backend_buffer_t buffer, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    ggml_backend_buffer_t sbuf = src->view_src ? src->view_src->buffer : src->buffer;
+    if (!sbuf || !buffer_is_mi355x(sbuf)) return false;
+    mi_buffer_ctx * sc = (mi_buffer_ctx *) sbuf->context;
+    mi_buffer_ctx * dc = (mi_buffer_ctx *) buffer->context;
+    set_device(dc->device);
+    if (sc->device == dc->device) {
+        MI_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(src), hipMemcpyDeviceToDevice, hipStreamPerThread));
+    } else {
+        MI_CHECK(hipMemcpyPeerAsync(dst->data, dc->device, src->data, sc->device, ggml_nbytes(src), hipStreamPerThread));   // xGMI hop
+    }
+    MI_CHECK(hipStreamSynchronize(hipStreamPerThread));
+    return true;
+}
+static void buf_clear(ggml_backend_buffer_t buffer, uint8_t value) {
+    mi_buffer_ctx * c = (mi_buffer_ctx *) buffer->context;
+    set_device(c->device);
+    MI_CHECK(hipMemsetAsync(c->base, value, buffer->size, hipStreamPerThread));
+    MI_CHECK(hipStreamSynchronize(hipStreamPerThread));
+}
+
+static const struct ggml_backend_buffer_i mi_buffer_iface = {
+    /* .free_buffer   = */ buf_free,
+    /* .get_base      = */ buf_get_base,
+    /* .init_tensor   = */ buf_init_tensor,
+    /* .memset_tensor = */ buf_memset_tensor,
+    /* .set_tensor    = */ buf_set_tensor,
+    /* .get_tensor    = */ buf_get_tensor,
+    /* .cpy_tensor    = */ buf_cpy_tensor,
+    /* .clear         = */ buf_clear,
+    /* .reset         = */ NULL,
+};
+
+static bool buffer_is_mi355x(ggml_backend_buffer_t buffer) { return buffer->iface.free_buffer == buf_free; }
+
+// ---------------------------------------------------------------------------------------------
+// device buffer type
+// ---------------------------------------------------------------------------------------------
+static const char * buft_get_name(ggml_backend_buffer_type_t buft) { return ((mi_device *) buft->context)->name.c_str(); }
+
+static ggml_backend_buffer_t buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    mi_device * d = (mi_device *) buft->context;
+    set_device(d->id);
+    void * p = NULL;
+    hipError_t err = hipMalloc(&p, size + MI_TENSOR_PAD);
+    if (err != hipSuccess) {
+        (void) hipGetLastError();
+        MI_LOG("allocating %.2f MiB on device %d failed: %s\n", size/1024.0/1024.0, d->id, hipGetErrorString(err));
+        return NULL;
+    }
+    mi_buffer_ctx * c = new mi_buffer_ctx{ d->id, p };
+    return ggml_backend_buffer_init(buft, mi_buffer_iface, c, size);
+}
+static size_t buft_get_alignment(ggml_backend_buffer_type_t) { return MI_BUFFER_ALIGN; }
+static size_t buft_get_alloc_size(ggml_backend_buffer_type_t, const struct ggml_tensor * tensor) {
+    size_t size = ggml_nbytes(tensor);
+    if (ggml_is_quantized(tensor->type)) size += MI_TENSOR_PAD;
+    return size;
+}
+static bool buft_is_host_no(ggml_backend_buffer_type_t) { return false; }
+
+static const struct ggml_backend_buffer_type_i mi_buft_iface = {
+    /* .get_name       = */ buft_get_name,
+    /* .alloc_buffer   = */ buft_alloc_buffer,
+    /* .get_alignment  = */ buft_get_alignment,
+    /* .get_max_size   = */ NULL,
+    /* .get_alloc_size = */ buft_get_alloc_size,
+    /* .is_host        = */ buft_is_host_no,
+};
+
+// ---------------------------------------------------------------------------------------------
+// pinned host buffer type (src/llama-model-loader.cpp:951-959 uses it for the 4 x 1 MiB upload ring)
+// ---------------------------------------------------------------------------------------------
+static void host_buf_free(ggml_backend_buffer_t buffer) { MI_CHECK(hipHostFree(buffer->context)); }
+static void * host_buf_get_base(ggml_backend_buffer_t buffer) { return buffer->context; }
+static void host_buf_memset_tensor(ggml_backend_buffer_t, struct ggml_tensor * t, uint8_t v, size_t off, size_t size) { memset((char *) t->data + off, v, size); }
+static void host_buf_set_tensor(ggml_backend_buffer_t, struct ggml_tensor * t, const void * data, size_t off, size_t size) { memcpy((char *) t->data + off, data, size); }
+static void host_buf_get_tensor(ggml_backend_buffer_t, const struct ggml_tensor * t, void * data, size_t off, size_t size) { memcpy(data, (const char *) t->data + off, size); }
+static void host_buf_clear(ggml_backend_buffer_t buffer, uint8_t value) { memset(buffer->context, value, buffer->size); }
+
+static const struct ggml_backend_buffer_i mi_host_buffer_iface = {
+    host_buf_free, host_buf_get_base, NULL, host_buf_memset_tensor, host_buf_set_tensor, host_buf_get_tensor, NULL, host_buf_clear, NULL,
+};
+
+static const char * host_buft_get_name(ggml_backend_buffer_type_t) { return GGML_MI355X_NAME "_Host"; }
+static ggml_backend_buffer_t host_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    void * p = NULL;
+    hipError_t err = hipHostMalloc(&p, size, hipHostMallocDefault);
+    if (err != hipSuccess) {
+        (void) hipGetLastError();
+        MI_LOG("failed to allocate %.2f MiB of pinned memory: %s\n", size/1024.0/1024.0, hipGetErrorString(err));
+        return NULL;
+    }
+    return ggml_backend_buffer_init(buft, mi_host_buffer_iface, p, size);
+}
+static size_t host_buft_get_alignment(ggml_backend_buffer_type_t) { return 64; }
+static bool host_buft_is_host(ggml_backend_buffer_type_t) { return true; }
+
+static const struct ggml_backend_buffer_type_i mi_host_buft_iface = {
+    host_buft_get_name, host_buft_alloc_buffer, host_buft_get_alignment, NULL, NULL, host_buft_is_host,
+};
+
+// ---------------------------------------------------------------------------------------------
+// backend (stream)
+// ---------------------------------------------------------------------------------------------
+// What must be unchanged for a captured hipGraph to be replayed: per node, the ggml_tensor fields up to
+// (not including) `name` — type, ne, nb, op, op_params, flags, src pointers, view_src, data — plus the data
+// pointers of its sources (leaf tensors are not nodes, and split graphs carry no leaf list).
+static constexpr size_t MI_SIG_PREFIX = offsetof(struct ggml_tensor, name);
+static constexpr size_t MI_SIG_BYTES  = MI_SIG_PREFIX + sizeof(void *) + GGML_MAX_SRC*sizeof(void *);
+
+struct mi_backend_ctx {
+    int device;
+    std::string name;
+    hipStream_t stream = nullptr;
+
+    void * scratch = nullptr;      // quantized activations
+    size_t scratch_size = 0;
+
+    // activation-quantisation reuse inside one graph_compute
+    struct { const void * data; int64_t k, n_inner, n_outer; size_t s_inner, s_outer; int kind; act_q8 q; bool valid; size_t span; } aq = {};
+
+    // hipGraph cache (one entry: llama.cpp re-submits the same decode graph, src/llama-context.cpp:728)
+    bool use_graphs = true;
+    bool use_fusion = true;
+    std::vector<uint8_t> sig;      // n_nodes * MI_SIG_BYTES
+    int sig_nodes = -1;
+    hipGraphExec_t graph_exec = nullptr;
+    int  warm_count = 0;           // identical submissions seen before capturing
+
+    struct ggml_backend_mi355x_counters cnt = {};
+};
+
+static ggml_guid_t mi_guid(void) {
+    static ggml_guid guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x63, 0x64, 0x6e, 0x34 };
+    return &guid;
+}
+
+static const char * be_get_name(ggml_backend_t backend) { return ((mi_backend_ctx *) backend->context)->name.c_str(); }
+
+static void be_free(ggml_backend_t backend) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    if (c->stream) (void) hipStreamSynchronize(c->stream);
+    if (c->graph_exec) (void) hipGraphExecDestroy(c->graph_exec);
+    if (c->scratch) (void) hipFree(c->scratch);
+    if (c->stream) (void) hipStreamDestroy(c->stream);
+    delete c;
+    delete backend;
+}
+
+static void be_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    MI_CHECK(hipMemcpyAsync((char *) tensor->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
+}
+static void be_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    MI_CHECK(hipMemcpyAsync(data, (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+}
+
+// layer-split hand-off: a point-to-point copy of [n_embd, n_tokens] F32 over one xGMI link,
+// ordered after the producer stream's work and before the consumer stream's next op, no host sync.
+static bool be_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backend_dst, const struct ggml_tensor * src, struct ggml_tensor * dst) {
+    if (!ggml_backend_is_mi355x(backend_src) || !ggml_backend_is_mi355x(backend_dst)) return false;
+    ggml_backend_buffer_t sbuf = src->view_src ? src->view_src->buffer : src->buffer;
+    ggml_backend_buffer_t dbuf = dst->view_src ? dst->view_src->buffer : dst->buffer;
+    if (!buffer_is_mi355x(sbuf) || !buffer_is_mi355x(dbuf)) return false;
+    mi_backend_ctx * cs = (mi_backend_ctx *) backend_src->context;
+    mi_backend_ctx * cd = (mi_backend_ctx *) backend_dst->context;
+    mi_buffer_ctx * bs = (mi_buffer_ctx *) sbuf->context;
+    mi_buffer_ctx * bd = (mi_buffer_ctx *) dbuf->context;
+    if (cs->device != bs->device || cd->device != bd->device) return false;
+    if (backend_src != backend_dst) {
+        set_device(cs->device);
+        if (cs->device == cd->device) {
+            MI_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, cs->stream));
+        } else {
+            MI_CHECK(hipMemcpyPeerAsync(dst->data, cd->device, src->data, cs->device, ggml_nbytes(dst), cs->stream));
+        }
+        // make the destination stream wait for the copy
+        hipEvent_t ev;
+        MI_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        MI_CHECK(hipEventRecord(ev, cs->stream));
+        set_device(cd->device);
+        MI_CHECK(hipStreamWaitEvent(cd->stream, ev, 0));
+        MI_CHECK(hipEventDestroy(ev));
+    } else {
+        set_device(cs->device);
+        MI_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, cs->stream));
+    }
+    return true;
+}
+
+static void be_synchronize(ggml_backend_t backend) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    MI_CHECK(hipStreamSynchronize(c->stream));
+}
+
+// ---- op support -----------------------------------------------------------------------------------
+static bool is_view_op(enum ggml_op op) {
+    return op == GGML_OP_NONE || op == GGML_OP_RESHAPE || op == GGML_OP_VIEW || op == GGML_OP_PERMUTE || op == GGML_OP_TRANSPOSE;
+}
+static bool float_type(enum ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16 || t == GGML_TYPE_BF16; }
+
+static bool mi_supports_op(const struct ggml_tensor * op) {
+    const struct ggml_tensor * s0 = op->src[0];
+    const struct ggml_tensor * s1 = op->src[1];
+    switch (op->op) {
+        case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
+            return true;
+        case GGML_OP_MUL_MAT: {
+            if (op->type != GGML_TYPE_F32) return false;
+            if (ggml_is_quantized(s0->type)) {
+                // quantized weights x F32 activations: the hot path
+                if (!mul_mat_vec_q_supported((int) s0->type)) return false;
+                if (s1->type != GGML_TYPE_F32) return false;
+                if (s0->ne[0] % ggml_blck_size(s0->type) != 0) return false;
+                if (s1->nb[0] != sizeof(float)) return false;
+                if (s0->nb[0] != ggml_type_size(s0->type)) return false;
+                return true;
+            }
+            if (s0->type == GGML_TYPE_F16 || s0->type == GGML_TYPE_F32 || s0->type == GGML_TYPE_BF16) {
+                return s1->type == GGML_TYPE_F32 || s1->type == GGML_TYPE_F16;
+            }
+            return false;
+        }
+        case GGML_OP_MUL_MAT_ID: {
+            if (op->type != GGML_TYPE_F32 || s1->type != GGML_TYPE_F32) return false;
+            if (!ggml_is_quantized(s0->type) || !mul_mat_vec_q_supported((int) s0->type)) return false;
+            if (s0->ne[0] % ggml_blck_size(s0->type) != 0) return false;
+            if (s1->nb[0] != sizeof(float)) return false;
+            return op->src[2]->type == GGML_TYPE_I32;
+        }
+        case GGML_OP_RMS_NORM:
+            return s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == sizeof(float);
+        case GGML_OP_ADD: case GGML_OP_MUL: case GGML_OP_DIV: case GGML_OP_SUB:
+            return float_type(s0->type) && float_type(s1->type) && float_type(op->type);
+        case GGML_OP_ADD_ID:
+            return s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_F32 && op->src[2]->type == GGML_TYPE_I32;
+        case GGML_OP_SCALE:
+            return s0->type == GGML_TYPE_F32;
+        case GGML_OP_CPY: case GGML_OP_CONT: case GGML_OP_DUP: {
+            const enum ggml_type st = s0->type, dt = op->op == GGML_OP_CPY ? s1->type : op->type;
+            return (float_type(st) && float_type(dt)) || (st == GGML_TYPE_I32 && dt == GGML_TYPE_I32);
+        }
+        case GGML_OP_SET_ROWS:
+            return s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_I64 && float_type(op->type);
+        case GGML_OP_GET_ROWS:
+            return (float_type(s0->type) || s0->type == GGML_TYPE_I32) && s1->type == GGML_TYPE_I32 && s0->nb[0] == ggml_type_size(s0->type);
+        case GGML_OP_SUM_ROWS:
+            return s0->type == GGML_TYPE_F32;
+        case GGML_OP_ARGSORT:
+            return s0->type == GGML_TYPE_F32 && s0->ne[0] <= 1024;
+        case GGML_OP_UNARY:
+            return float_type(s0->type) && (int) ggml_get_unary_op(op) <= (int) GGML_UNARY_OP_GELU_ERF;
+        case GGML_OP_GLU:
+            return float_type(s0->type) && (int) ggml_get_glu_op(op) < (int) GGML_GLU_OP_COUNT;
+        case GGML_OP_ROPE: {
+            const int mode = op->op_params[2];
+            if (mode & (GGML_ROPE_TYPE_MROPE | 16)) return false;    // mrope / vision: not on the path
+            return float_type(s0->type) && s0->type == op->type;
+        }
+        case GGML_OP_SOFT_MAX:
+            return s0->type == GGML_TYPE_F32 && s0->nb[0] == sizeof(float) && (s1 == NULL || s1->type == GGML_TYPE_F32 || s1->type == GGML_TYPE_F16);
+        default:
+            return false;
+    }
+}
+
+// ---- helpers ----------------------------------------------------------------------------------------
+static tensor_desc desc(const struct ggml_tensor * t) {
+    tensor_desc d;
+    d.data = t->data; d.type = (int) t->type;
+    for (int i = 0; i < 4; i++) { d.ne[i] = t->ne[i]; d.nb[i] = t->nb[i]; }
+    return d;
+}
+static float op_f32(const struct ggml_tensor * t, int i) { float f; memcpy(&f, &t->op_params[i], 4); return f; }
+
+static bool ranges_overlap(const void * a, size_t na, const void * b, size_t nb) {
+    const char * pa = (const char *) a; const char * pb = (const char *) b;
+    return pa < pb + nb && pb < pa + na;
+}
+
+// scratch needed by the largest quantized mat-mul in the graph
+static size_t graph_scratch_need(const struct ggml_cgraph * g) {
+    size_t need = 0;
+    for (int i = 0; i < g->n_nodes; i++) {
+        const struct ggml_tensor * n = g->nodes[i];
+        if ((n->op == GGML_OP_MUL_MAT || n->op == GGML_OP_MUL_MAT_ID) && ggml_is_quantized(n->src[0]->type)) {
+            const int kind = act_kind_for((int) n->src[0]->type);
+            if (kind < 0) continue;
+            const struct ggml_tensor * b = n->src[1];
+            const int64_t rows = n->op == GGML_OP_MUL_MAT ? b->ne[1] : b->ne[1]*b->ne[2];
+            const size_t s = act_q8_bytes(kind, b->ne[0], rows);
+            if (s > need) need = s;
+        }
+    }
+    return need;
+}
+
+// quantize (or reuse) the activations of a quantized mat-mul: rows r -> x + (r % n_inner)*s_inner + (r / n_inner)*s_outer
+static act_q8 get_act(mi_backend_ctx * c, const void * x, int64_t k, int64_t n_inner, int64_t n_outer, size_t s_inner, size_t s_outer, int kind) {
+    if (c->aq.valid && c->aq.data == x && c->aq.k == k && c->aq.n_inner == n_inner && c->aq.n_outer == n_outer &&
+        c->aq.s_inner == s_inner && c->aq.s_outer == s_outer && c->aq.kind == kind) {
+        c->cnt.act_quant_reused++;
+        return c->aq.q;
+    }
+    act_q8 q = act_q8_carve(c->scratch, kind, k, n_inner*n_outer);
+    quantize_act((const float *) x, n_inner, s_inner, s_outer, q, c->stream);
+    c->cnt.act_quant_launches++; c->cnt.kernels_launched++;
+    c->aq = { x, k, n_inner, n_outer, s_inner, s_outer, kind, q, true,
+              (size_t)(n_outer - 1)*s_outer + (size_t)(n_inner - 1)*s_inner + (size_t) k*4 };
+    return q;
+}
+
+static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * b = dst->src[1];
+    if (ggml_is_quantized(a->type)) {
+        const int kind = act_kind_for((int) a->type);
+        const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
+        const int64_t r2 = b->ne[2]/a->ne[2], r3 = b->ne[3]/a->ne[3];
+        for (int64_t i13 = 0; i13 < b->ne[3]; i13++) {
+            for (int64_t i12 = 0; i12 < b->ne[2]; i12++) {
+                const char * bp = (const char *) b->data + i12*b->nb[2] + i13*b->nb[3];
+                const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
+                const char * W = (const char *) a->data + (i12/r2)*a->nb[2] + (i13/r3)*a->nb[3];
+                float * d = (float *) ((char *) dst->data + i12*dst->nb[2] + i13*dst->nb[3]);
+                if (N <= MMVQ_MAX_N) {
+                    mul_mat_vec_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
+                    c->cnt.mmvq_launches++;
+                } else {
+                    mul_mat_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
+                    c->cnt.mmq_launches++;
+                }
+                c->cnt.kernels_launched++;
+                c->cnt.weight_bytes += (uint64_t) M*ggml_row_size(a->type, K);
+            }
+        }
+        return;
+    }
+    mm_dense_args p;
+    p.a = a->data; p.type_a = (int) a->type;
+    p.ne00 = a->ne[0]; p.ne01 = a->ne[1]; p.ne02 = a->ne[2]; p.ne03 = a->ne[3];
+    p.nb00 = a->nb[0]; p.nb01 = a->nb[1]; p.nb02 = a->nb[2]; p.nb03 = a->nb[3];
+    p.b = b->data; p.type_b = (int) b->type;
+    p.ne10 = b->ne[0]; p.ne11 = b->ne[1]; p.ne12 = b->ne[2]; p.ne13 = b->ne[3];
+    p.nb10 = b->nb[0]; p.nb11 = b->nb[1]; p.nb12 = b->nb[2]; p.nb13 = b->nb[3];
+    p.dst = (float *) dst->data; p.nb1 = dst->nb[1]; p.nb2 = dst->nb[2]; p.nb3 = dst->nb[3];
+    mul_mat_dense(p, c->stream);
+    c->cnt.kernels_launched++;
+}
+
+static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
+    const struct ggml_tensor * as  = dst->src[0];
+    const struct ggml_tensor * b   = dst->src[1];
+    const struct ggml_tensor * ids = dst->src[2];
+    const int kind = act_kind_for((int) as->type);
+    const int64_t K = as->ne[0], M = as->ne[1];
+    const int64_t n_used = ids->ne[0], n_tokens = ids->ne[1], n_b = b->ne[1];
+    const act_q8 q = get_act(c, b->data, K, n_b, n_tokens, b->nb[1], b->nb[2], kind);
+    mul_mat_vec_q_id((int) as->type, as->data, as->nb[1], as->nb[2], M, K, q,
+                     (const int32_t *) ids->data, ids->nb[0], ids->nb[1], n_used, n_tokens, n_b,
+                     (float *) dst->data, dst->nb[1], dst->nb[2], c->stream);
+    c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
+    c->cnt.weight_bytes += (uint64_t) n_used*n_tokens*M*ggml_row_size(as->type, K);
+}
+
+// returns the number of graph nodes consumed (>= 1)
+static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * node = g->nodes[i];
+    if (ggml_is_empty(node) || is_view_op(node->op)) return 1;
+    const struct ggml_tensor * s0 = node->src[0];
+    const struct ggml_tensor * s1 = node->src[1];
+
+    int consumed = 1;
+    switch (node->op) {
+        case GGML_OP_MUL_MAT:    op_mul_mat(c, node); break;
+        case GGML_OP_MUL_MAT_ID: op_mul_mat_id(c, node); break;
+        case GGML_OP_RMS_NORM: {
+            // fusion: RMS_NORM -> MUL(by weight) [-> ADD], when the intermediate has no other reader
+            // (the pattern build_norm emits, src/llama-graph.cpp:597-630; pinned by tests/test-backend-ops.cpp:2856)
+            if (c->use_fusion && i + 1 < g->n_nodes) {
+                struct ggml_tensor * mul = g->nodes[i + 1];
+                if (mul->op == GGML_OP_MUL && (mul->src[0] == node || mul->src[1] == node) && mul->type == GGML_TYPE_F32 &&
+                    !(node->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                    const struct ggml_tensor * w = mul->src[0] == node ? mul->src[1] : mul->src[0];
+                    bool only_reader = true;
+                    for (int j = i + 2; j < g->n_nodes && only_reader; j++) {
+                        for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[j]->src[s] == node) { only_reader = false; break; }
+                    }
+                    if (only_reader && w->type == GGML_TYPE_F32 && w->nb[0] == sizeof(float) && ggml_are_same_shape(node, mul) &&
+                        ggml_can_repeat(w, node) && mul->nb[0] == sizeof(float)) {
+                        rms_norm_mul(desc(s0), desc(w), nullptr, desc(mul), op_f32(node, 0), c->stream);
+                        c->cnt.kernels_launched++;
+                        consumed = 2;
+                        break;
+                    }
+                }
+            }
+            rms_norm(desc(s0), desc(node), op_f32(node, 0), c->stream);
+            c->cnt.kernels_launched++;
+        } break;
+        case GGML_OP_ADD: bin_bcast(BIN_ADD, desc(s0), desc(s1), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_MUL: bin_bcast(BIN_MUL, desc(s0), desc(s1), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_DIV: bin_bcast(BIN_DIV, desc(s0), desc(s1), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_SUB: bin_bcast(BIN_SUB, desc(s0), desc(s1), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_ADD_ID: add_id(desc(s0), desc(s1), desc(node->src[2]), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_SCALE: scale(desc(s0), desc(node), op_f32(node, 0), op_f32(node, 1), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_CPY:  cpy(desc(s0), desc(s1), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_CONT: case GGML_OP_DUP: cpy(desc(s0), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_SET_ROWS: set_rows(desc(s0), desc(s1), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_GET_ROWS: get_rows(desc(s0), desc(s1), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_SUM_ROWS: sum_rows(desc(s0), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_ARGSORT: argsort(desc(s0), desc(node), node->op_params[0], c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_UNARY: unary((int) ggml_get_unary_op(node), desc(s0), desc(node), c->stream); c->cnt.kernels_launched++; break;
+        case GGML_OP_GLU: {
+            tensor_desc b;
+            if (s1) b = desc(s1);
+            glu((int) ggml_get_glu_op(node), node->op_params[1] != 0, desc(s0), s1 ? &b : nullptr, desc(node), op_f32(node, 2), op_f32(node, 3), c->stream);
+            c->cnt.kernels_launched++;
+        } break;
+        case GGML_OP_ROPE: {
+            rope_params p;
+            p.n_dims = node->op_params[1]; p.mode = node->op_params[2]; p.n_ctx_orig = node->op_params[4];
+            p.freq_base = op_f32(node, 5); p.freq_scale = op_f32(node, 6); p.ext_factor = op_f32(node, 7);
+            p.attn_factor = op_f32(node, 8); p.beta_fast = op_f32(node, 9); p.beta_slow = op_f32(node, 10);
+            rope(desc(s0), (const int32_t *) s1->data, node->src[2] ? (const float *) node->src[2]->data : nullptr, desc(node), p, c->stream);
+            c->cnt.kernels_launched++;
+        } break;
+        case GGML_OP_SOFT_MAX: {
+            tensor_desc m;
+            if (s1) m = desc(s1);
+            soft_max(desc(s0), s1 ? &m : nullptr, node->src[2] ? (const float *) node->src[2]->data : nullptr, desc(node),
+                     op_f32(node, 0), op_f32(node, 1), c->stream);
+            c->cnt.kernels_launched++;
+        } break;
+        default:
+            GGML_ABORT("MI355X backend: graph_compute met unsupported op %s (supports_op should have refused it)", ggml_op_name(node->op));
+    }
+
+    // any write into the memory the cached quantized activations were made from invalidates them
+    for (int j = i; j < i + consumed; j++) {
+        const struct ggml_tensor * w = g->nodes[j];
+        if (c->aq.valid && w->data && ranges_overlap(w->data, ggml_nbytes(w), c->aq.data, c->aq.span)) {
+            c->aq.valid = false;
+        }
+    }
+    c->cnt.nodes_computed += consumed;
+    return consumed;
+}
+
+static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
+    c->aq.valid = false;
+    for (int i = 0; i < g->n_nodes; ) i += compute_node(c, g, i);
+    c->aq.valid = false;
+}
+
+static void fill_sig(uint8_t * s, const struct ggml_tensor * n) {
+    memcpy(s, n, MI_SIG_PREFIX);
+    memcpy(s + MI_SIG_PREFIX, &n, sizeof(void *));
+    const void * sd[GGML_MAX_SRC];
+    for (int j = 0; j < GGML_MAX_SRC; j++) sd[j] = n->src[j] ? n->src[j]->data : NULL;
+    memcpy(s + MI_SIG_PREFIX + sizeof(void *), sd, sizeof(sd));
+}
+
+static bool graph_matches(mi_backend_ctx * c, const struct ggml_cgraph * g) {
+    if (c->sig_nodes != g->n_nodes) return false;
+    uint8_t s[MI_SIG_BYTES];
+    for (int i = 0; i < g->n_nodes; i++) {
+        fill_sig(s, g->nodes[i]);
+        if (memcmp(s, c->sig.data() + (size_t) i*MI_SIG_BYTES, MI_SIG_BYTES) != 0) return false;
+    }
+    return true;
+}
+
+static void graph_remember(mi_backend_ctx * c, const struct ggml_cgraph * g) {
+    c->sig.resize((size_t) g->n_nodes*MI_SIG_BYTES);
+    for (int i = 0; i < g->n_nodes; i++) fill_sig(c->sig.data() + (size_t) i*MI_SIG_BYTES, g->nodes[i]);
+    c->sig_nodes = g->n_nodes;
+}
+
+static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgraph * g) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    c->cnt.graphs_computed++;
+
+    const size_t need = graph_scratch_need(g);
+    if (need > c->scratch_size) {
+        MI_CHECK(hipStreamSynchronize(c->stream));
+        if (c->scratch) MI_CHECK(hipFree(c->scratch));
+        c->scratch = nullptr; c->scratch_size = 0;
+        if (c->graph_exec) { MI_CHECK(hipGraphExecDestroy(c->graph_exec)); c->graph_exec = nullptr; }
+        c->sig_nodes = -1;
+        const size_t sz = need + (need >> 2);
+        if (hipMalloc(&c->scratch, sz) != hipSuccess) { (void) hipGetLastError(); return GGML_STATUS_ALLOC_FAILED; }
+        c->scratch_size = sz;
+    }
+
+    // hipGraph path: launch-bound decode graphs (~10^3 tiny kernels per token) are captured once their
+    // signature has been seen twice, then replayed while the signature is unchanged.
+    const bool try_graph = c->use_graphs && g->n_nodes >= 8;
+    if (try_graph) {
+        if (graph_matches(c, g)) {
+            if (c->graph_exec) {
+                MI_CHECK(hipGraphLaunch(c->graph_exec, c->stream));
+                c->cnt.graph_replays++;
+                return GGML_STATUS_SUCCESS;
+            }
+            if (++c->warm_count >= 1) {
+                hipGraph_t graph = nullptr;
+                MI_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+                run_nodes(c, g);
+                MI_CHECK(hipStreamEndCapture(c->stream, &graph));
+                hipError_t err = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
+                MI_CHECK(hipGraphDestroy(graph));
+                if (err == hipSuccess) {
+                    c->cnt.graph_captures++;
+                    MI_CHECK(hipGraphLaunch(c->graph_exec, c->stream));
+                    return GGML_STATUS_SUCCESS;
+                }
+                (void) hipGetLastError();
+                c->graph_exec = nullptr;
+                c->use_graphs = false;   // instantiate failed: stay eager
+            }
+        } else {
+            if (c->graph_exec) { MI_CHECK(hipGraphExecDestroy(c->graph_exec)); c->graph_exec = nullptr; }
+            graph_remember(c, g);
+            c->warm_count = 0;
+        }
+    }
+    run_nodes(c, g);
+    return GGML_STATUS_SUCCESS;
+}
+
+static void be_event_record(ggml_backend_t backend, ggml_backend_event_t event) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    MI_CHECK(hipEventRecord((hipEvent_t) event->context, c->stream));
+}
+static void be_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    MI_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t) event->context, 0));
+}
+
+static const struct ggml_backend_i mi_backend_iface = {
+    /* .get_name           = */ be_get_name,
+    /* .free               = */ be_free,
+    /* .set_tensor_async   = */ be_set_tensor_async,
+    /* .get_tensor_async   = */ be_get_tensor_async,
+    /* .cpy_tensor_async   = */ be_cpy_tensor_async,
+    /* .synchronize        = */ be_synchronize,
+    /* .graph_plan_create  = */ NULL,
+    /* .graph_plan_free    = */ NULL,
+    /* .graph_plan_update  = */ NULL,
+    /* .graph_plan_compute = */ NULL,
+    /* .graph_compute      = */ be_graph_compute,
+    /* .event_record       = */ be_event_record,
+    /* .event_wait         = */ be_event_wait,
+};
+
+// ---------------------------------------------------------------------------------------------
+// device
+// ---------------------------------------------------------------------------------------------
+static const char * dev_get_name(ggml_backend_dev_t dev) { return ((mi_device *) dev->context)->name.c_str(); }
+static const char * dev_get_description(ggml_backend_dev_t dev) { return ((mi_device *) dev->context)->description.c_str(); }
+static void dev_get_memory(ggml_backend_dev_t dev, size_t * free, size_t * total) {
+    mi_device * d = (mi_device *) dev->context;
+    set_device(d->id);
+    MI_CHECK(hipMemGetInfo(free, total));
+}
+static enum ggml_backend_dev_type dev_get_type(ggml_backend_dev_t) { return GGML_BACKEND_DEVICE_TYPE_GPU; }
+static void dev_get_props(ggml_backend_dev_t dev, struct ggml_backend_dev_props * props) {
+    props->name = dev_get_name(dev);
+    props->description = dev_get_description(dev);
+    props->type = GGML_BACKEND_DEVICE_TYPE_GPU;
+    dev_get_memory(dev, &props->memory_free, &props->memory_total);
+    props->caps.async = true;
+    props->caps.host_buffer = true;
+    props->caps.buffer_from_host_ptr = false;
+    props->caps.events = true;
+}
+static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
+    return ggml_backend_mi355x_init(((mi_device *) dev->context)->id);
+}
+static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi_device *) dev->context)->buft; }
+static ggml_backend_buffer_type_t dev_get_host_buffer_type(ggml_backend_dev_t) { return ggml_backend_mi355x_host_buffer_type(); }
+static bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) { return mi_supports_op(op); }
+static bool dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
+    if (buft->iface.get_name == host_buft_get_name) return false;   // kernels read device memory only
+    if (buft->iface.get_name != buft_get_name) return false;
+    return ((mi_device *) buft->context)->id == ((mi_device *) dev->context)->id;
+}
+static bool dev_offload_op(ggml_backend_dev_t, const struct ggml_tensor * op) {
+    // worth uploading host-resident weights for large batches only (same rule of thumb as the reference's GPU backends)
+    const int min_batch = 32;
+    if (op->op == GGML_OP_GET_ROWS) return false;
+    if (op->op == GGML_OP_MUL_MAT_ID) return op->ne[2] >= min_batch;
+    return op->ne[1] >= min_batch;
+}
+static ggml_backend_event_t dev_event_new(ggml_backend_dev_t dev) {
+    mi_device * d = (mi_device *) dev->context;
+    set_device(d->id);
+    hipEvent_t ev;
+    MI_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    return new ggml_backend_event{ dev, ev };
+}
+static void dev_event_free(ggml_backend_dev_t, ggml_backend_event_t event) {
+    MI_CHECK(hipEventDestroy((hipEvent_t) event->context));
+    delete event;
+}
+static void dev_event_synchronize(ggml_backend_dev_t, ggml_backend_event_t event) { MI_CHECK(hipEventSynchronize((hipEvent_t) event->context)); }
+
+static const struct ggml_backend_device_i mi_device_iface = {
+    dev_get_name, dev_get_description, dev_get_memory, dev_get_type, dev_get_props, dev_init_backend,
+    dev_get_buffer_type, dev_get_host_buffer_type, NULL /* buffer_from_host_ptr */,
+    dev_supports_op, dev_supports_buft, dev_offload_op, dev_event_new, dev_event_free, dev_event_synchronize,
+};
+
+// ---------------------------------------------------------------------------------------------
+// registry
+// ---------------------------------------------------------------------------------------------
+static const char * reg_get_name(ggml_backend_reg_t) { return GGML_MI355X_NAME; }
+static size_t reg_get_device_count(ggml_backend_reg_t) { return (size_t) G().n_devices; }
+static ggml_backend_dev_t reg_get_device(ggml_backend_reg_t, size_t index) {
+    GGML_ASSERT(index < (size_t) G().n_devices);
+    return &G().devices[index].dev;
+}
+
+static struct ggml_backend_feature * mi_get_features(ggml_backend_reg_t) {
+    static struct ggml_backend_feature features[] = {
+        { "ARCH", "gfx950" }, { "WAVE", "64" }, { "MMVQ", "sdot4+dpp" }, { "MMQ", "mfma_i32_32x32x32_i8" }, { "GRAPHS", "1" }, { NULL, NULL },
+    };
+    return features;
+}
+
+static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
+    if (strcmp(name, "ggml_backend_get_features") == 0)        return (void *) mi_get_features;
+    if (strcmp(name, "ggml_backend_mi355x_get_stream") == 0)   return (void *) ggml_backend_mi355x_get_stream;
+    if (strcmp(name, "ggml_backend_mi355x_get_counters") == 0) return (void *) ggml_backend_mi355x_get_counters;
+    if (strcmp(name, "ggml_backend_mi355x_reset_counters") == 0) return (void *) ggml_backend_mi355x_reset_counters;
+    if (strcmp(name, "ggml_backend_mi355x_set_option") == 0)   return (void *) ggml_backend_mi355x_set_option;
+    if (strcmp(name, "ggml_backend_mi355x_test_quantize") == 0) return (void *) ggml_backend_mi355x_test_quantize;
+    if (strcmp(name, "ggml_backend_mi355x_test_hbm_read_gbps") == 0) return (void *) ggml_backend_mi355x_test_hbm_read_gbps;
+    return NULL;
+}
+
+static const struct ggml_backend_reg_i mi_reg_iface = { reg_get_name, reg_get_device_count, reg_get_device, reg_get_proc_address };
+
+static bool arch_is_gfx950(const hipDeviceProp_t & prop) { return strncmp(prop.gcnArchName, "gfx950", 6) == 0; }
+
+static mi_globals & G() {
+    static mi_globals g;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); n = 0; }
+        g.reg = { GGML_BACKEND_API_VERSION, mi_reg_iface, NULL };
+        g.host_buft = { mi_host_buft_iface, NULL, NULL };
+        for (int i = 0; i < n && g.n_devices < GGML_MI355X_MAX_DEVICES; i++) {
+            hipDeviceProp_t prop;
+            if (hipGetDeviceProperties(&prop, i) != hipSuccess) { (void) hipGetLastError(); continue; }
+            if (!arch_is_gfx950(prop)) {
+                MI_LOG("skipping device %d (%s, %s): this backend carries gfx950 code objects only\n", i, prop.name, prop.gcnArchName);
+                continue;
+            }
+            mi_device & d = g.devices[g.n_devices];
+            d.id = i;
+            d.name = std::string(GGML_MI355X_NAME) + std::to_string(g.n_devices);
+            d.description = prop.name;
+            d.total_mem = prop.totalGlobalMem;
+            d.dev = { mi_device_iface, &g.reg, &d };
+            d.buft = { mi_buft_iface, &d.dev, &d };
+            g.n_devices++;
+        }
+        if (g.n_devices > 0) g.host_buft.device = &g.devices[0].dev;
+        // peer access for the layer-split hand-off over xGMI
+        for (int i = 0; i < g.n_devices; i++) {
+            for (int j = 0; j < g.n_devices; j++) {
+                if (i == j) continue;
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, g.devices[i].id, g.devices[j].id) == hipSuccess && can) {
+                    (void) hipSetDevice(g.devices[i].id);
+                    hipError_t e = hipDeviceEnablePeerAccess(g.devices[j].id, 0);
+                    if (e != hipSuccess) (void) hipGetLastError();
+                }
+            }
+        }
+        g.initialised = true;
+    });
+    return g;
+}
+
+// ---------------------------------------------------------------------------------------------
+// exported C-ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+ggml_backend_reg_t ggml_backend_mi355x_reg(void) { return &G().reg; }
+
+ggml_backend_reg_t ggml_backend_init(void) { return ggml_backend_mi355x_reg(); }
+
+int ggml_backend_score(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); return 0; }
+    for (int i = 0; i < n; i++) {
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, i) == hipSuccess && arch_is_gfx950(prop)) return 100;
+    }
+    return 0;
+}
+
+int ggml_backend_mi355x_get_device_count(void) { return G().n_devices; }
+
+void ggml_backend_mi355x_get_device_description(int device, char * description, size_t description_size) {
+    GGML_ASSERT(device >= 0 && device < G().n_devices);
+    snprintf(description, description_size, "%s", G().devices[device].description.c_str());
+}
+void ggml_backend_mi355x_get_device_memory(int device, size_t * free, size_t * total) {
+    GGML_ASSERT(device >= 0 && device < G().n_devices);
+    dev_get_memory(&G().devices[device].dev, free, total);
+}
+
+ggml_backend_buffer_type_t ggml_backend_mi355x_buffer_type(int device) {
+    if (device < 0 || device >= G().n_devices) return NULL;
+    return &G().devices[device].buft;
+}
+ggml_backend_buffer_type_t ggml_backend_mi355x_host_buffer_type(void) {
+    G();
+    return &G().host_buft;
+}
+
+ggml_backend_t ggml_backend_mi355x_init(int device) {
+    if (device < 0 || device >= G().n_devices) {
+        MI_LOG("invalid device %d (have %d gfx950 device(s))\n", device, G().n_devices);
+        return NULL;
+    }
+    mi_device & d = G().devices[device];
+    set_device(d.id);
+    mi_backend_ctx * c = new mi_backend_ctx;
+    c->device = d.id;
+    c->name = d.name;
+    MI_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+    if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->use_graphs = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_FUSION")) c->use_fusion = atoi(e) != 0;
+    ggml_backend_t backend = new ggml_backend{ mi_guid(), mi_backend_iface, &d.dev, c };
+    return backend;
+}
+
+bool ggml_backend_is_mi355x(ggml_backend_t backend) { return backend != NULL && ggml_guid_matches(backend->guid, mi_guid()); }
+
+void * ggml_backend_mi355x_get_stream(ggml_backend_t backend) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    return (void *) ((mi_backend_ctx *) backend->context)->stream;
+}
+void ggml_backend_mi355x_get_counters(ggml_backend_t backend, struct ggml_backend_mi355x_counters * out) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    *out = ((mi_backend_ctx *) backend->context)->cnt;
+}
+void ggml_backend_mi355x_reset_counters(ggml_backend_t backend) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    ((mi_backend_ctx *) backend->context)->cnt = {};
+}
+int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int value) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    if (strcmp(key, "graphs") == 0) { c->use_graphs = value != 0; return 0; }
+    if (strcmp(key, "fusion") == 0) {
+        c->use_fusion = value != 0;
+        if (c->graph_exec) { (void) hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
+        c->sig_nodes = -1;
+        return 0;
+    }
+    return -1;
+}
+
+// ---- test hooks (reached by name through get_proc_address; not part of the ggml contract) --------------
+// quantize host activations on the device and return the int8 blocks: lets tests/ compare the device
+// quantizer with the oracle bit for bit.
+int ggml_backend_mi355x_test_quantize(ggml_backend_t backend, const float * x, int64_t k, int64_t n, int kind,
+                                      int8_t * qs, float * d, int16_t * bsums) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    if (kind != T_Q8_0 && kind != T_Q8_K) return -1;
+    if (k % (kind == T_Q8_0 ? 32 : 256) != 0) return -2;
+    float * dx = nullptr; void * scratch = nullptr;
+    const size_t sb = act_q8_bytes(kind, k, n);
+    MI_CHECK(hipMalloc(&dx, (size_t) k*n*4));
+    MI_CHECK(hipMalloc(&scratch, sb));
+    MI_CHECK(hipMemcpy(dx, x, (size_t) k*n*4, hipMemcpyHostToDevice));
+    const act_q8 q = act_q8_carve(scratch, kind, k, n);
+    quantize_act(dx, n, (size_t) k*4, 0, q, c->stream);
+    MI_CHECK(hipStreamSynchronize(c->stream));
+    const int64_t nd = kind == T_Q8_0 ? k/32 : k/256, nbs = kind == T_Q8_0 ? k/32 : k/16;
+    MI_CHECK(hipMemcpy(qs, q.qs, (size_t) k*n, hipMemcpyDeviceToHost));
+    MI_CHECK(hipMemcpy(d, q.d, (size_t) nd*n*4, hipMemcpyDeviceToHost));
+    MI_CHECK(hipMemcpy(bsums, q.bsums, (size_t) nbs*n*2, hipMemcpyDeviceToHost));
+    MI_CHECK(hipFree(dx)); MI_CHECK(hipFree(scratch));
+    return 0;
+}
+
+// achievable HBM read rate on this box (GB/s) with the same 16 B/lane nontemporal loads the mat-vec kernels use
+double ggml_backend_mi355x_test_hbm_read_gbps(ggml_backend_t backend, size_t bytes, int iters) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    void * p = nullptr; unsigned * sink = nullptr;
+    MI_CHECK(hipMalloc(&p, bytes)); MI_CHECK(hipMalloc(&sink, 256));
+    MI_CHECK(hipMemset(p, 1, bytes));
+    hipEvent_t e0, e1;
+    MI_CHECK(hipEventCreate(&e0)); MI_CHECK(hipEventCreate(&e1));
+    hbm_read_probe(p, bytes, sink, c->stream);
+    MI_CHECK(hipEventRecord(e0, c->stream));
+    for (int i = 0; i < iters; i++) hbm_read_probe(p, bytes, sink, c->stream);
+    MI_CHECK(hipEventRecord(e1, c->stream));
+    MI_CHECK(hipEventSynchronize(e1));
+    float ms = 0; MI_CHECK(hipEventElapsedTime(&ms, e0, e1));
+    MI_CHECK(hipEventDestroy(e0)); MI_CHECK(hipEventDestroy(e1));
+    MI_CHECK(hipFree(p)); MI_CHECK(hipFree(sink));
+    return (double) bytes*iters/(ms*1e-3)/1e9;
+}
+
+} // extern "C"

@@ -1,0 +1,119 @@
+// dev_common.h — device-side helpers for gfx950 (CDNA4): wave64 DPP reductions,
+// f16 conversion, integer dot, loads of arbitrarily aligned block bytes.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include <stdint.h>
+
+#define MI_WAVE 64
+
+#define MI_HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
+    fprintf(stderr, "HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, __LINE__, hipGetErrorString(e_)); abort(); } } while (0)
+
+namespace mi355x {
+
+typedef int   int4v   __attribute__((ext_vector_type(4)));
+typedef int   int2v   __attribute__((ext_vector_type(2)));
+typedef float float4v __attribute__((ext_vector_type(4)));
+
+// ---- wave64 reductions: DPP inside a 16-lane row, readlane across the 4 rows ---------------
+template <int CTRL>
+static __device__ __forceinline__ float dpp_f(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+template <int CTRL>
+static __device__ __forceinline__ int dpp_i(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true);
+}
+
+// sum over the 16 lanes of each DPP row; every lane of the row ends with the row total
+static __device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);   // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);   // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);  // row_half_mirror
+    v += dpp_f<0x140>(v);  // row_mirror
+    return v;
+}
+static __device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
+    return v;
+}
+static __device__ __forceinline__ float readlane_f(float v, int lane) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), lane));
+}
+// full-wave sum; the result is wave-uniform (held in SGPR-fed adds)
+static __device__ __forceinline__ float wave_sum(float v) {
+    v = row16_sum(v);
+    return (readlane_f(v, 0) + readlane_f(v, 16)) + (readlane_f(v, 32) + readlane_f(v, 48));
+}
+static __device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    return fmaxf(fmaxf(readlane_f(v, 0), readlane_f(v, 16)), fmaxf(readlane_f(v, 32), readlane_f(v, 48)));
+}
+// sum over aligned groups of 8 lanes (half a DPP row)
+static __device__ __forceinline__ float group8_sum(float v) {
+    v += dpp_f<0xB1>(v);
+    v += dpp_f<0x4E>(v);
+    v += dpp_f<0x141>(v);
+    return v;
+}
+static __device__ __forceinline__ float group8_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    return v;
+}
+static __device__ __forceinline__ int group8_sum_i(int v) {
+    v += dpp_i<0xB1>(v);
+    v += dpp_i<0x4E>(v);
+    v += dpp_i<0x141>(v);
+    return v;
+}
+
+// ---- numerics ----------------------------------------------------------------------------------
+static __device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
+    return __half2float(__ushort_as_half(h));
+}
+static __device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+    return __half_as_ushort(__float2half_rn(f));
+}
+// gguf-py/gguf/quants.py:663-665
+static __device__ __forceinline__ float e8m0_to_f32_half(uint32_t x) {
+    const uint32_t bits = x < 2 ? (0x00200000u << x) : ((x - 1) << 23);
+    return __builtin_bit_cast(float, bits);
+}
+
+// 4 x int8 dot with int32 accumulate: v_dot4_i32_i8
+static __device__ __forceinline__ int dot4(int a, int b, int c) {
+    return __builtin_amdgcn_sdot4(a, b, c, false);
+}
+
+// ---- loads --------------------------------------------------------------------------------------
+// Block bytes in raw GGUF layout are only 1- or 2-byte aligned for Q4_0/Q8_0/Q6_K/MXFP4
+// (18/34/210/17-byte blocks). gfx950 global memory is accessed in unaligned mode, so the packed
+// vector types below lower to single global_load_dwordx{1,2,4} instructions at any byte address.
+struct __attribute__((packed, aligned(1))) u32_u { uint32_t v; };
+struct __attribute__((packed, aligned(1))) u32x2_u { uint32_t x, y; };
+struct __attribute__((packed, aligned(1))) u32x4_u { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(2))) u16_u { uint16_t v; };
+
+static __device__ __forceinline__ uint32_t ld_u32(const void * p)  { return ((const u32_u *) p)->v; }
+static __device__ __forceinline__ uint16_t ld_u16(const void * p)  { return ((const u16_u *) p)->v; }
+static __device__ __forceinline__ int4v ld_b128(const void * p) {
+    const u32x4_u t = *(const u32x4_u *) p;
+    return int4v{ (int) t.x, (int) t.y, (int) t.z, (int) t.w };
+}
+static __device__ __forceinline__ int2v ld_b64(const void * p) {
+    const u32x2_u t = *(const u32x2_u *) p;
+    return int2v{ (int) t.x, (int) t.y };
+}
+// 16-byte aligned, streamed-once weight bytes: nontemporal (MI355X_MICROARCH.md "nt-weights")
+static __device__ __forceinline__ int4v ld_b128_nt(const void * p) {
+    return __builtin_nontemporal_load((const int4v *) p);
+}
+
+} // namespace mi355x

@@ -1,0 +1,99 @@
+// kernels.h — host-callable launchers for the gfx950 kernels. Plain pointers,
+// strides in BYTES (ggml nb[] convention) and a hipStream_t; no ggml types, so the
+// kernels can be driven from backend.cpp (ggml tensors) or from the flat C-ABI in
+// include/ggml-mi355x.h. Every launcher is asynchronous on `stream` and performs
+// no allocation or synchronisation (safe under hipGraph capture).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mi355x {
+
+// ggml_type ids used on the path (gguf-py/gguf/constants.py:2698-2730)
+enum : int {
+    T_F32 = 0, T_F16 = 1, T_Q4_0 = 2, T_Q8_0 = 8, T_Q4_K = 12, T_Q5_K = 13, T_Q6_K = 14, T_Q8_K = 15,
+    T_I32 = 26, T_I64 = 27, T_BF16 = 30, T_MXFP4 = 39,
+};
+
+// ---- activation quantisation (the CPU path's vec_dot_type: Q8_0 for Q4_0/Q8_0/MXFP4, Q8_K for K-quants)
+// Device layout (SoA, internal): for a [k, n] activation
+//   qs    : int8  [n][k]
+//   d     : float [n][k/32]   (Q8_0: value of the f16-rounded scale)  | float [n][k/256] (Q8_K)
+//   bsums : int16 [n][k/32]   (Q8_0: sum of the 32 quants)            | int16 [n][k/16]  (Q8_K)
+struct act_q8 {
+    int8_t  * qs;
+    float   * d;
+    int16_t * bsums;
+    int       kind;   // T_Q8_0 or T_Q8_K
+    int64_t   k;
+    int64_t   n;
+};
+
+size_t act_q8_bytes(int kind, int64_t k, int64_t n);            // scratch bytes needed
+act_q8 act_q8_carve(void * scratch, int kind, int64_t k, int64_t n);
+int    act_kind_for(int type_a);                                   // T_Q8_0 / T_Q8_K / -1
+
+// x: f32, rows of k contiguous floats; row r (< q.n) lives at
+//   x + (r % n_inner)*stride_inner + (r / n_inner)*stride_outer      (bytes)
+// (n_inner = q.n, stride_outer = 0 for a plain 2-D activation; the two-level form serves MUL_MAT_ID's [k, n_b, n_tokens] src1)
+void quantize_act(const float * x, int64_t n_inner, size_t stride_inner, size_t stride_outer, const act_q8 & q, hipStream_t stream);
+
+// ---- quantized mat-vec (decode, n <= MMVQ_MAX_N): dst[col*dst_stride + row] = W[row,:] . x[col,:]
+constexpr int MMVQ_MAX_N = 8;
+bool mul_mat_vec_q_supported(int type_a);
+void mul_mat_vec_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
+                   const act_q8 & act, int64_t n, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
+
+// MUL_MAT_ID decode form: for pair p (< n_pairs): dst[p*dst_stride + :] = W[expert[p]] . act row (p % act rows as given by act_row[p])
+void mul_mat_vec_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
+                      const act_q8 & act, const int32_t * ids, size_t ids_nb0, size_t ids_nb1,
+                      int64_t n_used, int64_t n_tokens, int64_t n_b,
+                      float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream);
+
+// ---- quantized mat-mat (prefill, n > MMVQ_MAX_N): MFMA int8 tiles on Q8-quantised activations
+void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
+               const act_q8 & act, int64_t n, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
+
+// ---- dense f16/f32 x f32 mat-mul with ggml broadcast (attention K.Q and V.KQ; tests/test-backend-ops.cpp:5791-5813)
+struct mm_dense_args {
+    const void * a; int type_a; int64_t ne00, ne01, ne02, ne03; size_t nb00, nb01, nb02, nb03;
+    const void * b; int type_b; int64_t ne10, ne11, ne12, ne13; size_t nb10, nb11, nb12, nb13;
+    float * dst; size_t nb1, nb2, nb3;
+};
+void mul_mat_dense(const mm_dense_args & p, hipStream_t stream);
+
+// ---- element kernels ---------------------------------------------
+struct tensor_desc {           // a strided 4-D view, ggml convention (ne = elements, nb = bytes)
+    void * data; int type; int64_t ne[4]; size_t nb[4];
+};
+
+void rms_norm(const tensor_desc & src, const tensor_desc & dst, float eps, hipStream_t stream);
+// fused RMS_NORM * w (+ add) — tests/test-backend-ops.cpp:2856
+void rms_norm_mul(const tensor_desc & src, const tensor_desc & w, const tensor_desc * add, const tensor_desc & dst, float eps, hipStream_t stream);
+enum bin_op { BIN_ADD = 0, BIN_MUL = 1, BIN_DIV = 2, BIN_SUB = 3 };
+void bin_bcast(int op, const tensor_desc & a, const tensor_desc & b, const tensor_desc & dst, hipStream_t stream);
+void add_id(const tensor_desc & a, const tensor_desc & bias, const tensor_desc & ids, const tensor_desc & dst, hipStream_t stream);
+void scale(const tensor_desc & src, const tensor_desc & dst, float s, float b, hipStream_t stream);
+void cpy(const tensor_desc & src, const tensor_desc & dst, hipStream_t stream);      // f32<->f16/f32 strided copy/convert (CPY, CONT, DUP)
+void set_rows(const tensor_desc & src, const tensor_desc & idx, const tensor_desc & dst, hipStream_t stream);
+void get_rows(const tensor_desc & src, const tensor_desc & idx, const tensor_desc & dst, hipStream_t stream);
+void sum_rows(const tensor_desc & src, const tensor_desc & dst, hipStream_t stream);
+void argsort(const tensor_desc & src, const tensor_desc & dst, int order, hipStream_t stream);
+void unary(int op, const tensor_desc & src, const tensor_desc & dst, hipStream_t stream);
+void glu(int glu_op, bool swapped, const tensor_desc & a, const tensor_desc * b, const tensor_desc & dst, float alpha, float limit, hipStream_t stream);
+
+struct rope_params {
+    int n_dims, mode, n_ctx_orig;
+    float freq_base, freq_scale, ext_factor, attn_factor, beta_fast, beta_slow;
+};
+void rope(const tensor_desc & src, const int32_t * pos, const float * freq_factors, const tensor_desc & dst, const rope_params & p, hipStream_t stream);
+
+void soft_max(const tensor_desc & src, const tensor_desc * mask, const float * sinks, const tensor_desc & dst,
+              float scale, float max_bias, hipStream_t stream);
+
+// ---- test / bench support ------------------------------------------------------------------
+// raw streaming read of `bytes` (16 B/lane, nontemporal) — measures the achievable HBM rate on the box
+void hbm_read_probe(const void * p, size_t bytes, unsigned * sink, hipStream_t stream);
+
+} // namespace mi355x

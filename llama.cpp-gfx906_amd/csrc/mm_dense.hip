@@ -1,0 +1,76 @@
+// mm_dense.hip — f16/f32 x f32 -> f32 mat-mul with ggml's dim-2/3 broadcast, for the attention
+// products of build_attn_mha (src/llama-graph.cpp:1285 kq = mul_mat(k, q); :1320 kqv = mul_mat(v, kq)):
+// `a` is an F16 view of the KV cache (K: [head_dim, n_kv, n_head_kv], V transposed: [n_kv, head_dim, n_head_kv]),
+// `b` F32 (possibly a permuted view), GQA broadcast r2 = ne12/ne02. Pinned by
+// tests/test-backend-ops.cpp:5791-5813 (f16 x f32, permuted / strided, nr = [4,1]).
+//
+// At decode these are a few hundred KB of L2-resident data per layer: launch-bound, so one simple
+// wave-per-output-row kernel (DPP reduction) serves; K/V bytes are read once per column tile of 8.
+// dst[i0=i01, i1=i11, i2=i12, i3=i13] = sum_k a[k, i01, i12/r2, i13/r3] * b[k, i11, i12, i13]
+#include "dev_common.h"
+#include "kernels.h"
+
+namespace mi355x {
+
+static __device__ __forceinline__ float ld_a(const char * p, int type) {
+    return type == T_F16 ? f16_bits_to_f32(*(const uint16_t *) p)
+         : type == T_BF16 ? __builtin_bit_cast(float, (uint32_t)(*(const uint16_t *) p) << 16)
+         : *(const float *) p;
+}
+
+template <int NC, bool FAST>   // FAST: a contiguous f16 along k, b contiguous f32 along k
+__global__ void __launch_bounds__(256) k_mm_dense(const mm_dense_args p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t i01 = (int64_t) blockIdx.x*4 + (threadIdx.x >> 6);
+    if (i01 >= p.ne01) return;
+    const int64_t c0 = (int64_t) blockIdx.y*NC;
+    const int64_t i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
+    const int64_t i02 = i12/(p.ne12/p.ne02), i03 = i13/(p.ne13/p.ne03);
+    const char * a = (const char *) p.a + i01*p.nb01 + i02*p.nb02 + i03*p.nb03;
+    const char * b = (const char *) p.b + i12*p.nb12 + i13*p.nb13;
+    const int64_t K = p.ne00;
+
+    float acc[NC];
+#pragma unroll
+    for (int c = 0; c < NC; c++) acc[c] = 0.0f;
+
+    if (FAST) {
+        for (int64_t k = lane*2; k < K; k += 128) {   // K is even on this path
+            const uint32_t av = ld_u32(a + k*2);
+            const float a0 = f16_bits_to_f32((uint16_t)(av & 0xFFFF)), a1 = f16_bits_to_f32((uint16_t)(av >> 16));
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c0 + c < p.ne11) {
+                    const int2v bv = ld_b64(b + (c0 + c)*p.nb11 + k*4);
+                    acc[c] += a0*__builtin_bit_cast(float, bv.x) + a1*__builtin_bit_cast(float, bv.y);
+                }
+            }
+        }
+    } else {
+        for (int64_t k = lane; k < K; k += 64) {
+            const float av = ld_a(a + k*p.nb00, p.type_a);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c0 + c < p.ne11) acc[c] += av*ld_a(b + (c0 + c)*p.nb11 + k*p.nb10, p.type_b);
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; c++) {
+        const float s = wave_sum(acc[c]);
+        if (lane == 0 && c0 + c < p.ne11) {
+            *(float *) ((char *) p.dst + i01*4 + (c0 + c)*p.nb1 + i12*p.nb2 + i13*p.nb3) = s;
+        }
+    }
+}
+
+void mul_mat_dense(const mm_dense_args & p, hipStream_t stream) {
+    if (p.ne01 == 0 || p.ne11 == 0 || p.ne12*p.ne13 == 0) return;
+    const bool fast = p.type_a == T_F16 && p.type_b == T_F32 && p.nb00 == 2 && p.nb10 == 4 && (p.ne00 % 2 == 0);
+    constexpr int NC = 8;
+    const dim3 grid((unsigned)((p.ne01 + 3)/4), (unsigned)((p.ne11 + NC - 1)/NC), (unsigned)(p.ne12*p.ne13));
+    if (fast) hipLaunchKernelGGL((k_mm_dense<NC, true>),  grid, dim3(256), 0, stream, p);
+    else      hipLaunchKernelGGL((k_mm_dense<NC, false>), grid, dim3(256), 0, stream, p);
+}
+
+} // namespace mi355x

@@ -1,0 +1,129 @@
+"""GPU parity for the hot path: GGML_OP_MUL_MAT on quantized weights, driven through the backend's
+C-ABI exactly as tests/test-backend-ops.cpp:1082-1240 drives a backend, checked against the oracle.
+
+Gates:
+  * vs the exact product of the reference dequantization (oracle "exact"): NMSE <= 5e-4 — the reference's
+    own MUL_MAT gate (tests/test-backend-ops.cpp:3106-3108);
+  * vs the CPU-backend-style integer path (oracle "cpu": quantize src1 to Q8_0/Q8_K, integer vec_dot):
+    only the order of the final f32 additions differs -> max |diff| <= 2e-5 * max|ref| (stated tolerance).
+  * device activation quantizer vs oracle: bit-exact.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle as orc
+from gpu_util import QTYPES, backend, gg, proc, run_mul_mat
+
+pytestmark = pytest.mark.gpu
+
+CPU_STYLE_RTOL = 2e-5
+
+
+def check(qtype, w, x, got, exact_gate=True):
+    exact = orc.mul_mat_2d(w, qtype, x, "exact")
+    cpu = orc.mul_mat_2d(w, qtype, x, "cpu")
+    assert np.isfinite(got).all()
+    # the reference gate compares a backend with the CPU backend, whose int8 activation quantization is part of
+    # the result; against the exact product that quantization error itself can exceed 5e-4 on outlier-heavy
+    # activations, so exact_gate is switched off for that one input and the CPU-style comparison carries it.
+    assert orc.nmse(cpu, got) <= 5e-4
+    if exact_gate:
+        assert orc.nmse(exact, got) <= 5e-4, f"NMSE vs exact {orc.nmse(exact, got)}"
+    scale = float(np.abs(cpu).max()) + 1e-30
+    assert float(np.abs(got - cpu).max()) <= CPU_STYLE_RTOL * scale, f"max diff vs cpu-style {np.abs(got - cpu).max()} / {scale}"
+
+
+@pytest.mark.parametrize("kind", ["q8_0", "q8_K"])
+def test_activation_quantizer_bit_exact(kind):
+    fn = proc("ggml_backend_mi355x_test_quantize", C.c_int,
+              [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p])
+    rng = np.random.default_rng(7)
+    k, n = 2048, 5
+    x = rng.standard_normal((n, k)).astype(np.float32)
+    x[0, :256] = 0                       # zero block
+    x[1, 256:512] *= 1e-8
+    x[2, 5] = 7.0; x[2, 9] = -7.0         # +/- tie for the Q8_K "first max" rule
+    x[3, :] = (0.1 + 2*np.cos(np.arange(k, dtype=np.float32))).astype(np.float32)   # tests/test-quantize-fns.cpp:31-35
+    kid = orc.Q8_0 if kind == "q8_0" else orc.Q8_K
+    blk = 32 if kind == "q8_0" else 256
+    nbs = 32 if kind == "q8_0" else 16
+    qs = np.empty((n, k), np.int8); d = np.empty((n, k // blk), np.float32); bs = np.empty((n, k // nbs), np.int16)
+    rc = fn(backend().be, x.ctypes.data, k, n, kid, qs.ctypes.data, d.ctypes.data, bs.ctypes.data)
+    assert rc == 0
+    ref = orc.quantize(x, kid)
+    if kind == "q8_0":
+        r = ref.reshape(n, k // 32, 34)
+        rd = r[:, :, 0:2].copy().view(np.float16).astype(np.float32).reshape(n, -1)
+        rq = r[:, :, 2:].view(np.int8).reshape(n, k)
+        assert np.array_equal(qs, rq)
+        assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+        assert np.array_equal(bs.astype(np.int32), rq.reshape(n, -1, 32).astype(np.int32).sum(-1))
+    else:
+        r = ref.reshape(n, k // 256, 292)
+        rd = r[:, :, 0:4].copy().view(np.float32).reshape(n, -1)
+        rq = r[:, :, 4:260].view(np.int8).reshape(n, k)
+        rb = r[:, :, 260:292].copy().view(np.int16).reshape(n, -1)
+        assert np.array_equal(qs, rq)
+        assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+        assert np.array_equal(bs, rb)
+
+
+# tests/test-backend-ops.cpp:5709-5713: every type x n in 1..9, m=16, k=256
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 6, 7, 8, 9])
+@pytest.mark.parametrize("name", list(QTYPES))
+def test_mul_mat_small(name, n):
+    rng = np.random.default_rng(1234 + n)
+    m, k = 16, 256
+    w = orc.random_blocks(rng, QTYPES[name], (m,), k)
+    x = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
+    got = run_mul_mat(QTYPES[name], w, x, m, k)
+    check(QTYPES[name], w, x, got)
+
+
+# golden fixtures (reference dequantization x f64 product), k = 256 and the "stream-k fixup" k = 1024 (:5759-5761)
+@pytest.mark.parametrize("k", [256, 1024])
+@pytest.mark.parametrize("name", list(QTYPES))
+def test_mul_mat_golden(name, k, golden_dir):
+    g = np.load(golden_dir / f"mulmat_{name}_k{k}.npz")
+    for n in (1, 4, 16):
+        got = run_mul_mat(QTYPES[name], g["w"], g["x"][:n], 16, k)
+        assert orc.nmse(g["expected"][:n], got) <= 5e-4
+
+
+# model shapes: ragged m (tail rows), k not a multiple of the wave step, gpt-oss k=2880
+@pytest.mark.parametrize("name,m,k,n", [
+    ("q4_K", 1027, 4096, 1), ("q6_K", 515, 4096, 1), ("q5_K", 259, 2048, 2), ("q8_0", 130, 2880, 1),
+    ("q4_0", 77, 4096, 3), ("mxfp4", 2880, 2880, 1), ("q4_K", 64, 14336, 1), ("q6_K", 64, 14336, 8),
+    ("q4_K", 33, 768, 1), ("q8_0", 17, 288, 1), ("mxfp4", 9, 96, 4), ("q4_0", 5, 32, 1),
+])
+def test_mul_mat_model_shapes(name, m, k, n):
+    rng = np.random.default_rng(m * 131 + k)
+    w = orc.random_blocks(rng, QTYPES[name], (m,), k)
+    x = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
+    got = run_mul_mat(QTYPES[name], w, x, m, k)
+    check(QTYPES[name], w, x, got)
+
+
+def test_mul_mat_zero_and_outlier_activations():
+    rng = np.random.default_rng(5)
+    m, k = 64, 1024
+    for name in QTYPES:
+        w = orc.random_blocks(rng, QTYPES[name], (m,), k)
+        x = np.zeros((2, k), np.float32)
+        x[1] = rng.standard_normal(k).astype(np.float32); x[1, 17] = 250.0   # massive-activation outlier
+        got = run_mul_mat(QTYPES[name], w, x, m, k)
+        assert not got[0].any()
+        check(QTYPES[name], w, x, got, exact_gate=False)
+
+
+def test_prefill_width_matches_decode_width():
+    """n > 8 takes the prefill path; column c of the result must equal the n=1 result for that column."""
+    rng = np.random.default_rng(9)
+    m, k, n = 96, 512, 40
+    for name in QTYPES:
+        w = orc.random_blocks(rng, QTYPES[name], (m,), k)
+        x = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
+        got = run_mul_mat(QTYPES[name], w, x, m, k)
+        check(QTYPES[name], w, x, got)
