@@ -1,0 +1,267 @@
+#!/usr/bin/env python3
+"""bench.py — the reference's headline benchmark on the MI355X backend: llama-bench tg128 (+ pp512) for
+Llama-3-8B Q4_K_M (BASELINE.json configs[1]) on synthetic weights of that architecture.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one decoded token through the whole hot path (225 quantized mat-vecs + the element ops of
+llm_build_llama), driven with llama-bench's protocol (tools/llama-bench/llama-bench.cpp:1791-1810: one
+llama_decode per token, synchronize after every token, tokens are random ids). Inputs (weights, KV cache)
+are resident in HBM when the timed region starts.
+
+N = 1 : the single-GPU configuration the metric is quoted on.
+N > 1 : `-sm layer` split, one process per GPU, activations handed over by RCCL send/recv (layer_split.py);
+        N independent sequences are kept in flight so that every stage is busy (weak scaling).
+
+Rank 0 prints ONE JSON line: the contract fields + `roofline` (dominant kernel: the quantized mat-vec, HBM-bound,
+timed live with HIP events on the backend's own stream) + `cpu_baseline` (the oracle's CPU restatement of the
+same mat-vec work on the host cores, a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import numpy as np
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E peak (spec)
+TYPE_NAMES = {2: "q4_0", 8: "q8_0", 12: "q4_K", 13: "q5_K", 14: "q6_K", 39: "mxfp4"}
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def cpu_baseline(model_cfg, ftype, budget_s=20.0):
+    """Time the oracle (CPU restatement, OpenMP) on the same mat-vec work: a bounded sample of layers + the lm_head."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import oracle as orc
+    native = orc.build(native=True, out_dir=Path(os.environ.get("TMPDIR", "/tmp")))
+    L = orc.lib(native)
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    rng = np.random.default_rng(0)
+    c = model_cfg
+    assert ftype == "Q4_K_M"
+    shapes = [("attn_q", c["n_embd"], c["n_embd"], orc.Q4_K), ("attn_k", c["n_embd_head"] * c["n_head_kv"], c["n_embd"], orc.Q4_K),
+              ("attn_v", c["n_embd_head"] * c["n_head_kv"], c["n_embd"], orc.Q6_K), ("attn_output", c["n_embd"], c["n_embd"], orc.Q4_K),
+              ("ffn_gate", c["n_ff"], c["n_embd"], orc.Q4_K), ("ffn_up", c["n_ff"], c["n_embd"], orc.Q4_K),
+              ("ffn_down", c["n_embd"], c["n_ff"], orc.Q6_K)]
+    n_sample_layers = 3
+    layers = []
+    for _ in range(n_sample_layers):
+        lw = []
+        for _, m, k, qt in shapes:
+            bs, ts = orc.QUANT_SIZES[qt]
+            w = rng.integers(0, 256, size=(m, k // bs * ts), dtype=np.uint8)     # timing only: any bytes cost the same
+            lw.append((w, m, k, qt))
+        layers.append(lw)
+    x = {k: rng.uniform(-1, 1, size=(1, k)).astype(np.float32) for k in (c["n_embd"], c["n_ff"])}
+    import ctypes
+    def matvec(w, m, k, qt):
+        dst = np.empty((1, m), np.float32)
+        L.orc_mul_mat(qt, ctypes.c_void_p(w.ctypes.data), ctypes.c_void_p(x[k].ctypes.data), ctypes.c_void_p(dst.ctypes.data), m, 1, k, 1)
+    for lw in layers[:1]:
+        for w, m, k, qt in lw:
+            matvec(w, m, k, qt)
+    t0 = time.perf_counter(); reps = 0
+    while True:
+        for lw in layers:
+            for w, m, k, qt in lw:
+                matvec(w, m, k, qt)
+        reps += 1
+        if time.perf_counter() - t0 > budget_s * 0.6 or reps >= 40:
+            break
+    t_layer = (time.perf_counter() - t0) / (reps * n_sample_layers)
+    # lm_head: 128256 x 4096 Q6_K, once
+    bs, ts = orc.QUANT_SIZES[orc.Q6_K]
+    w = rng.integers(0, 256, size=(c["n_vocab"], c["n_embd"] // bs * ts), dtype=np.uint8)
+    matvec(w[:1024], 1024, c["n_embd"], orc.Q6_K)
+    t1 = time.perf_counter(); matvec(w, c["n_vocab"], c["n_embd"], orc.Q6_K); t_head = time.perf_counter() - t1
+    t_tok = t_layer * c["n_layer"] + t_head
+    return {"value": round(1.0 / t_tok, 3), "unit": "tok/s", "cores": cores, "kind": "port",
+            "sample": f"oracle/ggml_oracle.c (Q8_K activation quantize + integer vec_dot, OpenMP): {n_sample_layers} distinct "
+                      f"Llama-3-8B Q4_K_M layers x {reps} reps + one full lm_head mat-vec, extrapolated to {c['n_layer']} layers; "
+                      f"mat-vec work only (attention/norm/rope excluded)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=128)
+    ap.add_argument("--model", default="llama3-8b")
+    ap.add_argument("--ftype", default="Q4_K_M")
+    ap.add_argument("--pp", type=int, default=512, help="prompt length for the extra pp measurement (0 = skip)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1")); local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("bench.py --gpus N>1 must be launched with torch.distributed.run (one process per GPU)")
+    import torch   # first: its HIP runtime is the one in the process
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import __graft_entry__ as ge
+    pkg = ge.load_package()
+    gg, ls, lsp = pkg.ggml, pkg.llama_synth, pkg.layer_split
+
+    be = gg.Backend(local_rank)
+    cfg = ls.MODELS[args.model]
+    K, W = args.steps, args.warmup
+    ranges = lsp.layer_ranges(cfg["n_layer"], world)
+    lb, le, has_out = ranges[rank]
+    n_seq = world
+    steps_per_seq = (max(K, W) + n_seq - 1) // n_seq + 1
+    n_ctx = max(32, (steps_per_seq + 31) // 32 * 32) if world > 1 else max(128, (K + 31) // 32 * 32)
+    t0 = time.time()
+    m = ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, layer_begin=lb, layer_end=le, has_output=has_out, n_seq_max=n_seq)
+    log(f"[rank {rank}] layers [{lb},{le}) output={has_out} weights {m.weight_bytes/1e9:.3f} GB, model ready in {time.time()-t0:.1f}s")
+    rng = np.random.default_rng(1)   # llama-bench: std::rand() % n_vocab, default seed (tools/llama-bench/llama-bench.cpp:1798)
+    tokens = rng.integers(0, cfg["n_vocab"], size=max(K, W) + 8).astype(np.int32)
+
+    def sync_all():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    result = {}
+    if world == 1:
+        def run_tokens(n):
+            for i in range(n):
+                m.decode(tokens[i:i + 1], want_host=True, sync=True)     # llama_decode + llama_synchronize per token
+        # warm-up: builds the graphs for every n_kv bucket and lets the backend capture them
+        done = 0
+        while done < W:
+            m.kv_clear(); n = min(W - done, n_ctx); run_tokens(n); done += n
+        m.kv_clear()
+        be.reset_counters()
+        sync_all(); t0 = time.perf_counter()
+        run_tokens(K)
+        sync_all(); dt = time.perf_counter() - t0
+        cnt = be.counters()
+        tok_s = K / dt
+        result.update(value=tok_s, ms_per_step=dt / K * 1e3)
+        extra = {"graph_replays": cnt["graph_replays"], "kernels_per_token": None, "graph_nodes": m.graph_nodes(1),
+                 "weight_GB_per_token": m.weight_bytes / 1e9,
+                 "hbm_frac_whole_token": (m.weight_bytes * tok_s / 1e9) / HBM_PEAK_GBPS}
+        # kernel count per token from one eager token
+        be.set_option("graphs", 0); m.kv_clear(); be.reset_counters(); run_tokens(1)
+        extra["kernels_per_token"] = be.counters()["kernels_launched"]
+        be.set_option("graphs", 1)
+
+        roof = None
+        if not args.no_profile:
+            # dominant kernel, timed live with HIP events on the backend stream (option "profile": eager, event pair per launch)
+            be.set_option("profile", 1); m.kv_clear(); run_tokens(min(K, 32)); prof = be.profile(); be.set_option("profile", 0)
+            prof.sort(key=lambda e: -e["total_ms"])
+            top = prof[0]
+            avg_s = top["total_ms"] / top["launches"] * 1e-3
+            ach = top["bytes_per_launch"] / avg_s / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+                    "traffic": None,
+                    "kernel": f"k_mmvq<{TYPE_NAMES.get(top['type'], top['type'])}> m={top['m']} k={top['k']} n={top['n']}",
+                    "bytes_per_launch": top["bytes_per_launch"], "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": top["launches"],
+                    "all": [{"type": TYPE_NAMES.get(e["type"], e["type"]), "m": e["m"], "k": e["k"], "n": e["n"], "launches": e["launches"],
+                             "avg_us": round(e["total_ms"] / e["launches"] * 1e3, 2),
+                             "GBps": round(e["bytes_per_launch"] / (e["total_ms"] / e["launches"] * 1e-3) / 1e9, 1)} for e in prof]}
+        # achievable streaming-read rate on this box, same load instruction as the kernels
+        import ctypes as C
+        p = gg.base().ggml_backend_reg_get_proc_address(be.reg, b"ggml_backend_mi355x_test_hbm_read_gbps")
+        hbm = C.CFUNCTYPE(C.c_double, C.c_void_p, C.c_size_t, C.c_int)(p)
+        extra["hbm_read_probe_GBps"] = round(max(hbm(be.be, 2 << 30, 5) for _ in range(2)), 1)
+        m.free()
+
+        if args.pp > 0:
+            mp = ls.SynthLlama(be, args.model, args.ftype, n_ctx=args.pp, seed=1)
+            ptoks = rng.integers(0, cfg["n_vocab"], size=args.pp).astype(np.int32)
+            mp.decode(ptoks); mp.kv_clear()                       # warm-up prompt pass (llama-bench.cpp:1949-1971)
+            reps = []
+            for _ in range(3):
+                mp.kv_clear(); torch.cuda.synchronize(); t0 = time.perf_counter(); mp.decode(ptoks); torch.cuda.synchronize()
+                reps.append(args.pp / (time.perf_counter() - t0))
+            extra[f"pp{args.pp}_tok_s"] = round(float(np.mean(reps)), 1)
+            mp.free()
+        result["extra"] = extra
+        result["roofline"] = roof
+        if not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(cfg, args.ftype)
+            except Exception as e:   # the baseline is reporting only; never let it take the bench line down
+                result["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
+    else:
+        n_embd = cfg["n_embd"]
+        recv_buf = [torch.empty(n_embd, dtype=torch.float32, device="cuda") for _ in range(lsp.N_BUF)]
+        send_buf = [torch.empty(n_embd, dtype=torch.float32, device="cuda") for _ in range(lsp.N_BUF)]
+        recv_work = [None] * lsp.N_BUF; send_work = [None] * lsp.N_BUF
+        tcur = torch.cuda.current_stream()
+
+        def post_recv(j):
+            recv_work[j % lsp.N_BUF] = dist.irecv(recv_buf[j % lsp.N_BUF], src=rank - 1)
+        def wait_recv(j):
+            recv_work[j % lsp.N_BUF].wait(); tcur.synchronize()
+        def send(j):
+            b = j % lsp.N_BUF
+            send_work[b] = dist.isend(send_buf[b], dst=rank + 1)
+        def flush():
+            for w in send_work:
+                if w is not None:
+                    w.wait()
+            tcur.synchronize()
+        tr = lsp.Transport(rank, world, post_recv, wait_recv, send, flush)
+        pos = [0] * n_seq
+
+        def stage(seq, j, has_input):
+            b = j % lsp.N_BUF
+            if send_work[b] is not None:          # buffer reuse: the send issued N_BUF steps ago must be done
+                send_work[b].wait(); tcur.synchronize(); send_work[b] = None
+            m.decode(tokens[j % len(tokens):j % len(tokens) + 1] if not has_input else None, n_tokens=1, seq=seq,
+                     dev_act_in=recv_buf[b].data_ptr() if has_input else None,
+                     dev_result_out=send_buf[b].data_ptr() if rank < world - 1 else None,
+                     want_host=has_out, sync=True)
+            pos[seq] += 1
+        lsp.run_steps(tr, W, stage, 0, n_seq)
+        m.kv_clear()
+        sync_all(); t0 = time.perf_counter()
+        lsp.run_steps(tr, K, stage, 0, n_seq)
+        sync_all(); dt = time.perf_counter() - t0
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        result.update(value=K / dt, ms_per_step=dt / K * 1e3)
+        result["extra"] = {"layers": [list(r) for r in ranges], "sequences_in_flight": n_seq, "handoff_bytes": n_embd * 4}
+        result["roofline"] = None
+        m.free()
+
+    if rank == 0:
+        out = {
+            "metric": "llama-bench tg128 tok/s, Llama-3-8B Q4_K_M" if (args.model, args.ftype) == ("llama3-8b", "Q4_K_M") else f"llama-bench tg tok/s, {args.model} {args.ftype}",
+            "value": round(result["value"], 2), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "int8 dot (4-6 bit weights x Q8 activations), f32 accumulate", "data": "synthetic",
+            "config": {"workload": f"{args.model} {args.ftype}, llama-bench tg{K} protocol (BASELINE.json configs[1]): 1 token/step, sync per token, "
+                                   f"f16 KV cache, no flash-attn, n_ctx={n_ctx}",
+                       "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs, {world} sequences in flight, RCCL p2p hand-off"},
+            "roofline": result.get("roofline"), "cpu_baseline": result.get("cpu_baseline"),
+        }
+        out.update(result.get("extra", {}))
+        print(json.dumps(out), flush=True)
+    be.free()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,8 +74,21 @@ struct ggml_backend_mi355x_counters {
 GGML_BACKEND_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
 GGML_BACKEND_API void   ggml_backend_mi355x_get_counters(ggml_backend_t backend, struct ggml_backend_mi355x_counters * out);
 GGML_BACKEND_API void   ggml_backend_mi355x_reset_counters(ggml_backend_t backend);
-// options: "graphs" (0/1 hipGraph capture+replay), "fusion" (0/1 node fusion)
+// options: "graphs" (0/1 hipGraph capture+replay), "fusion" (0/1 node fusion),
+//          "profile" (0/1: eager execution with every quantized mat-mul launch bracketed by a hipEvent pair)
 GGML_BACKEND_API int    ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int value);
+
+
+// measurement leg: durations of the quantized mat-mul launches recorded while option "profile" was on
+struct ggml_backend_mi355x_prof_entry {
+    int32_t  type;              // ggml_type of the weights
+    int32_t  n;                 // activation columns
+    int64_t  m, k;              // weight rows, row length
+    uint64_t launches;
+    double   total_ms;          // sum over launches of (end event - start event) on the backend's stream
+    uint64_t bytes_per_launch;  // algorithmic weight bytes: m * row_size(type, k)
+};
+GGML_BACKEND_API int ggml_backend_mi355x_get_profile(ggml_backend_t backend, struct ggml_backend_mi355x_prof_entry * out, int cap);
 
 #ifdef __cplusplus
 }

@@ -6,6 +6,8 @@ tests drive a backend with). The directory name is not a Python identifier; impo
 `graft_pkg.load()` at the repo root (alias `llama_cpp_gfx906_amd`).
 """
 from . import ggml_ctypes as ggml  # noqa: F401
+from . import llama_synth  # noqa: F401
+from . import layer_split  # noqa: F401
 from . import build as _build
 
 

@@ -64,7 +64,7 @@ def build(verbose=True):
         jobs.append(ex.submit(compile_obj, CSRC / "backend.cpp", ["-x", "hip", *HIPFLAGS]))
         harness_srcs = sorted((CSRC / "harness").glob("*.cpp")) if (CSRC / "harness").exists() else []
         for s in harness_srcs:
-            jobs.append(ex.submit(compile_obj, s, ["-x", "hip", *HIPFLAGS]))
+            jobs.append(ex.submit(compile_obj, s, ["-x", "c++"]))
         objs = [j.result() for j in jobs]
     compat_o, kern_o, backend_o, harness_o = objs[0], objs[1:1 + len(KERNEL_SRCS)], objs[1 + len(KERNEL_SRCS)], objs[2 + len(KERNEL_SRCS):]
 

@@ -223,11 +223,25 @@ static const struct ggml_backend_buffer_type_i mi_host_buft_iface = {
 // ---------------------------------------------------------------------------------------------
 // backend (stream)
 // ---------------------------------------------------------------------------------------------
-// What must be unchanged for a captured hipGraph to be replayed: per node, the ggml_tensor fields up to
-// (not including) `name` — type, ne, nb, op, op_params, flags, src pointers, view_src, data — plus the data
-// pointers of its sources (leaf tensors are not nodes, and split graphs carry no leaf list).
-static constexpr size_t MI_SIG_PREFIX = offsetof(struct ggml_tensor, name);
-static constexpr size_t MI_SIG_BYTES  = MI_SIG_PREFIX + sizeof(void *) + GGML_MAX_SRC*sizeof(void *);
+// What must be unchanged for a captured hipGraph to be replayed, per node (the checks the reference's GPU
+// backends make before reusing a captured graph): the node itself, its op/type/shape/strides/data pointer,
+// a hash of op_params, and the data pointers + leading shape of its sources (leaf tensors are not nodes and
+// split graphs carry no leaf list, so their placement is pinned through the nodes that read them).
+struct node_sig {
+    const void * node; const void * data;
+    int32_t op, type;
+    int64_t ne[4]; size_t nb[3];
+    const void * src_data[4]; int64_t src_ne1[2];
+    uint32_t params_hash; uint32_t flags;
+};
+
+struct graph_entry {
+    std::vector<node_sig> sig;
+    hipGraphExec_t exec = nullptr;
+    uint64_t last_use = 0;
+    int seen = 0;              // identical submissions observed (capture on the 2nd)
+};
+static constexpr int MI_MAX_GRAPHS = 24;
 
 struct mi_backend_ctx {
     int device;
@@ -243,13 +257,34 @@ struct mi_backend_ctx {
     // hipGraph cache (one entry: llama.cpp re-submits the same decode graph, src/llama-context.cpp:728)
     bool use_graphs = true;
     bool use_fusion = true;
-    std::vector<uint8_t> sig;      // n_nodes * MI_SIG_BYTES
-    int sig_nodes = -1;
-    hipGraphExec_t graph_exec = nullptr;
-    int  warm_count = 0;           // identical submissions seen before capturing
+    std::vector<graph_entry> graphs;     // small LRU: decode graphs differ only in n_kv (one per 32 tokens of context)
+    std::vector<node_sig> cur_sig;
+    uint64_t graph_tick = 0;
 
     struct ggml_backend_mi355x_counters cnt = {};
+
+    // "profile" option: every quantized mat-mul launch is bracketed by a hipEvent pair on this stream (eager mode)
+    struct prof_rec { int type; int64_t m, k, n; hipEvent_t e0, e1; };
+    bool profiling = false;
+    std::vector<prof_rec> prof;
+    std::vector<hipEvent_t> ev_pool;
 };
+
+static hipEvent_t prof_event(mi_backend_ctx * c) {
+    if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
+    hipEvent_t e; MI_CHECK(hipEventCreate(&e)); return e;
+}
+static void prof_begin(mi_backend_ctx * c, int type, int64_t m, int64_t k, int64_t n) {
+    if (!c->profiling) return;
+    mi_backend_ctx::prof_rec r = { type, m, k, n, prof_event(c), prof_event(c) };
+    MI_CHECK(hipEventRecord(r.e0, c->stream));
+    c->prof.push_back(r);
+}
+static void prof_end(mi_backend_ctx * c) {
+    if (!c->profiling) return;
+    MI_CHECK(hipEventRecord(c->prof.back().e1, c->stream));
+}
+
 
 static ggml_guid_t mi_guid(void) {
     static ggml_guid guid = { 0x4d, 0x49, 0x33, 0x35, 0x35, 0x58, 0x67, 0x66, 0x78, 0x39, 0x35, 0x30, 0x63, 0x64, 0x6e, 0x34 };
@@ -262,7 +297,7 @@ static void be_free(ggml_backend_t backend) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    if (c->graph_exec) (void) hipGraphExecDestroy(c->graph_exec);
+    for (auto & e : c->graphs) if (e.exec) (void) hipGraphExecDestroy(e.exec);
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
@@ -272,12 +307,12 @@ static void be_free(ggml_backend_t backend) {
 static void be_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
-    MI_CHECK(hipMemcpyAsync((char *) tensor->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
+    MI_CHECK(hipMemcpyAsync((char *) tensor->data + offset, data, size, hipMemcpyDefault, c->stream));   // `data` may be pinned host or device memory
 }
 static void be_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
-    MI_CHECK(hipMemcpyAsync(data, (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost, c->stream));
+    MI_CHECK(hipMemcpyAsync(data, (const char *) tensor->data + offset, size, hipMemcpyDefault, c->stream));
 }
 
 // layer-split hand-off: a point-to-point copy of [n_embd, n_tokens] F32 over one xGMI link,
@@ -449,6 +484,7 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
                 const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
                 const char * W = (const char *) a->data + (i12/r2)*a->nb[2] + (i13/r3)*a->nb[3];
                 float * d = (float *) ((char *) dst->data + i12*dst->nb[2] + i13*dst->nb[3]);
+                prof_begin(c, (int) a->type, M, K, N);
                 if (N <= MMVQ_MAX_N) {
                     mul_mat_vec_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
                     c->cnt.mmvq_launches++;
@@ -456,6 +492,7 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
                     mul_mat_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
                     c->cnt.mmq_launches++;
                 }
+                prof_end(c);
                 c->cnt.kernels_launched++;
                 c->cnt.weight_bytes += (uint64_t) M*ggml_row_size(a->type, K);
             }
@@ -579,28 +616,52 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
     c->aq.valid = false;
 }
 
-static void fill_sig(uint8_t * s, const struct ggml_tensor * n) {
-    memcpy(s, n, MI_SIG_PREFIX);
-    memcpy(s + MI_SIG_PREFIX, &n, sizeof(void *));
-    const void * sd[GGML_MAX_SRC];
-    for (int j = 0; j < GGML_MAX_SRC; j++) sd[j] = n->src[j] ? n->src[j]->data : NULL;
-    memcpy(s + MI_SIG_PREFIX + sizeof(void *), sd, sizeof(sd));
+static inline uint32_t hash_params(const int32_t * p) {
+    uint32_t h = 2166136261u;
+    for (int i = 0; i < (int)(GGML_MAX_OP_PARAMS/sizeof(int32_t)); i++) { h ^= (uint32_t) p[i]; h *= 16777619u; }
+    return h;
 }
 
-static bool graph_matches(mi_backend_ctx * c, const struct ggml_cgraph * g) {
-    if (c->sig_nodes != g->n_nodes) return false;
-    uint8_t s[MI_SIG_BYTES];
-    for (int i = 0; i < g->n_nodes; i++) {
-        fill_sig(s, g->nodes[i]);
-        if (memcmp(s, c->sig.data() + (size_t) i*MI_SIG_BYTES, MI_SIG_BYTES) != 0) return false;
+static inline void fill_sig(node_sig & s, const struct ggml_tensor * n) {
+    s.node = n; s.data = n->data; s.op = (int32_t) n->op; s.type = (int32_t) n->type;
+    for (int d = 0; d < 4; d++) s.ne[d] = n->ne[d];
+    for (int d = 0; d < 3; d++) s.nb[d] = n->nb[d + 1];
+    for (int j = 0; j < 4; j++) s.src_data[j] = n->src[j] ? n->src[j]->data : NULL;
+    s.src_ne1[0] = n->src[0] ? n->src[0]->ne[1] : 0;
+    s.src_ne1[1] = n->src[1] ? n->src[1]->ne[1] : 0;
+    s.params_hash = hash_params(n->op_params);
+    s.flags = (uint32_t) n->flags;
+}
+
+static void drop_graphs(mi_backend_ctx * c) {
+    for (auto & e : c->graphs) if (e.exec) (void) hipGraphExecDestroy(e.exec);
+    c->graphs.clear();
+}
+
+// find (or create) the cache entry whose signature equals this graph's
+static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph * g) {
+    c->cur_sig.resize(g->n_nodes);
+    memset(c->cur_sig.data(), 0, sizeof(node_sig)*g->n_nodes);   // padding bytes take part in memcmp
+    for (int i = 0; i < g->n_nodes; i++) fill_sig(c->cur_sig[i], g->nodes[i]);
+    graph_entry * lru = nullptr;
+    // most recently used first: consecutive decode steps re-submit the same graph (src/llama-context.cpp:728)
+    graph_entry * best = nullptr;
+    for (auto & e : c->graphs) {
+        if (!lru || e.last_use < lru->last_use) lru = &e;
+        if ((int) e.sig.size() == g->n_nodes && (!best || e.last_use > best->last_use) &&
+            memcmp(e.sig.data(), c->cur_sig.data(), sizeof(node_sig)*g->n_nodes) == 0) best = &e;
     }
-    return true;
-}
-
-static void graph_remember(mi_backend_ctx * c, const struct ggml_cgraph * g) {
-    c->sig.resize((size_t) g->n_nodes*MI_SIG_BYTES);
-    for (int i = 0; i < g->n_nodes; i++) fill_sig(c->sig.data() + (size_t) i*MI_SIG_BYTES, g->nodes[i]);
-    c->sig_nodes = g->n_nodes;
+    if (best) { best->last_use = ++c->graph_tick; best->seen++; return *best; }
+    if ((int) c->graphs.size() >= MI_MAX_GRAPHS) {
+        if (lru->exec) { MI_CHECK(hipStreamSynchronize(c->stream)); MI_CHECK(hipGraphExecDestroy(lru->exec)); }
+        *lru = graph_entry();
+        lru->sig = c->cur_sig; lru->last_use = ++c->graph_tick; lru->seen = 1;
+        return *lru;
+    }
+    c->graphs.emplace_back();
+    graph_entry & e = c->graphs.back();
+    e.sig = c->cur_sig; e.last_use = ++c->graph_tick; e.seen = 1;
+    return e;
 }
 
 static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgraph * g) {
@@ -613,43 +674,37 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
         MI_CHECK(hipStreamSynchronize(c->stream));
         if (c->scratch) MI_CHECK(hipFree(c->scratch));
         c->scratch = nullptr; c->scratch_size = 0;
-        if (c->graph_exec) { MI_CHECK(hipGraphExecDestroy(c->graph_exec)); c->graph_exec = nullptr; }
-        c->sig_nodes = -1;
+        drop_graphs(c);   // captured graphs hold the old scratch pointer
         const size_t sz = need + (need >> 2);
         if (hipMalloc(&c->scratch, sz) != hipSuccess) { (void) hipGetLastError(); return GGML_STATUS_ALLOC_FAILED; }
         c->scratch_size = sz;
     }
 
-    // hipGraph path: launch-bound decode graphs (~10^3 tiny kernels per token) are captured once their
-    // signature has been seen twice, then replayed while the signature is unchanged.
-    const bool try_graph = c->use_graphs && g->n_nodes >= 8;
+    // hipGraph path: launch-bound decode graphs (~10^3 tiny kernels per token) are captured the second time their
+    // signature is seen, then replayed while the signature is unchanged.
+    const bool try_graph = c->use_graphs && !c->profiling && g->n_nodes >= 8;
     if (try_graph) {
-        if (graph_matches(c, g)) {
-            if (c->graph_exec) {
-                MI_CHECK(hipGraphLaunch(c->graph_exec, c->stream));
-                c->cnt.graph_replays++;
+        graph_entry & e = graph_lookup(c, g);
+        if (e.exec) {
+            MI_CHECK(hipGraphLaunch(e.exec, c->stream));
+            c->cnt.graph_replays++;
+            return GGML_STATUS_SUCCESS;
+        }
+        if (e.seen >= 2) {
+            hipGraph_t graph = nullptr;
+            MI_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            run_nodes(c, g);
+            MI_CHECK(hipStreamEndCapture(c->stream, &graph));
+            hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
+            MI_CHECK(hipGraphDestroy(graph));
+            if (err == hipSuccess) {
+                c->cnt.graph_captures++;
+                MI_CHECK(hipGraphLaunch(e.exec, c->stream));
                 return GGML_STATUS_SUCCESS;
             }
-            if (++c->warm_count >= 1) {
-                hipGraph_t graph = nullptr;
-                MI_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
-                run_nodes(c, g);
-                MI_CHECK(hipStreamEndCapture(c->stream, &graph));
-                hipError_t err = hipGraphInstantiate(&c->graph_exec, graph, nullptr, nullptr, 0);
-                MI_CHECK(hipGraphDestroy(graph));
-                if (err == hipSuccess) {
-                    c->cnt.graph_captures++;
-                    MI_CHECK(hipGraphLaunch(c->graph_exec, c->stream));
-                    return GGML_STATUS_SUCCESS;
-                }
-                (void) hipGetLastError();
-                c->graph_exec = nullptr;
-                c->use_graphs = false;   // instantiate failed: stay eager
-            }
-        } else {
-            if (c->graph_exec) { MI_CHECK(hipGraphExecDestroy(c->graph_exec)); c->graph_exec = nullptr; }
-            graph_remember(c, g);
-            c->warm_count = 0;
+            (void) hipGetLastError();
+            e.exec = nullptr;
+            c->use_graphs = false;   // instantiate failed: stay eager
         }
     }
     run_nodes(c, g);
@@ -764,6 +819,7 @@ static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (strcmp(name, "ggml_backend_mi355x_get_counters") == 0) return (void *) ggml_backend_mi355x_get_counters;
     if (strcmp(name, "ggml_backend_mi355x_reset_counters") == 0) return (void *) ggml_backend_mi355x_reset_counters;
     if (strcmp(name, "ggml_backend_mi355x_set_option") == 0)   return (void *) ggml_backend_mi355x_set_option;
+    if (strcmp(name, "ggml_backend_mi355x_get_profile") == 0)  return (void *) ggml_backend_mi355x_get_profile;
     if (strcmp(name, "ggml_backend_mi355x_test_quantize") == 0) return (void *) ggml_backend_mi355x_test_quantize;
     if (strcmp(name, "ggml_backend_mi355x_test_hbm_read_gbps") == 0) return (void *) ggml_backend_mi355x_test_hbm_read_gbps;
     return NULL;
@@ -889,13 +945,39 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
     GGML_ASSERT(ggml_backend_is_mi355x(backend));
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     if (strcmp(key, "graphs") == 0) { c->use_graphs = value != 0; return 0; }
+    if (strcmp(key, "profile") == 0) { c->profiling = value != 0; return 0; }
     if (strcmp(key, "fusion") == 0) {
         c->use_fusion = value != 0;
-        if (c->graph_exec) { (void) hipGraphExecDestroy(c->graph_exec); c->graph_exec = nullptr; }
-        c->sig_nodes = -1;
+        MI_CHECK(hipStreamSynchronize(c->stream));
+        drop_graphs(c);
         return 0;
     }
     return -1;
+}
+
+// per-kernel timing of the quantized mat-mul launches recorded while option "profile" was on (SURVEY.md §5:
+// "expose per-kernel bytes/time counters"). Synchronises the stream, aggregates by (type, m, k, n), clears the log.
+int ggml_backend_mi355x_get_profile(ggml_backend_t backend, struct ggml_backend_mi355x_prof_entry * out, int cap) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    MI_CHECK(hipStreamSynchronize(c->stream));
+    int n = 0;
+    for (auto & r : c->prof) {
+        float ms = 0.0f;
+        MI_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
+        c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1);
+        int j = 0;
+        for (; j < n; j++) if (out[j].type == r.type && out[j].m == r.m && out[j].k == r.k && out[j].n == r.n) break;
+        if (j == n) {
+            if (n == cap) continue;
+            out[n] = { r.type, (int32_t) r.n, r.m, r.k, 0, 0.0, (uint64_t) r.m*ggml_row_size((enum ggml_type) r.type, r.k) };
+            n++;
+        }
+        out[j].launches++; out[j].total_ms += ms;
+    }
+    c->prof.clear();
+    return n;
 }
 
 // ---- test hooks (reached by name through get_proc_address; not part of the ggml contract) --------------

@@ -1,0 +1,512 @@
+// llama_harness.cpp — synthetic Llama-family model driver (HARNESS, caller side of the boundary).
+//
+// The reference's libllama cannot be built here (its ggml/ submodule is empty), and no GGUF weights
+// exist on the GPU box, so this file restates — through the ggml API only, exactly as libllama uses it —
+// the minimum of the CALLER rows of SURVEY.md §8:
+//   a9  llm_build_llama               src/llama-model.cpp:5969-6123   (per-layer op sequence)
+//   a6  build_attn_mha (no-FA branch) src/llama-graph.cpp:1220-1341
+//   a7  build_attn / cpy_k / cpy_v    src/llama-graph.cpp:1438-1488, src/llama-kv-cache-unified.cpp:1056-1190
+//   a4  build_ffn (SILU, PAR)         src/llama-graph.cpp:632-774
+//   a8  build_norm (RMS)              src/llama-graph.cpp:597-630
+//   a11 process_ubatch / decode       src/llama-context.cpp:714-776,946-1254 (set_inputs, graph reuse,
+//                                     async compute, logits readback, synchronize)
+//   a15 llama_tensor_get_type         src/llama-quant.cpp:178-434 (which tensor gets which type in a "Q4_K_M" file)
+// with random VALID blocks as weights (SURVEY.md §8d "Concrete synthetic inputs") and the llama-bench
+// protocol on top (tools/llama-bench/llama-bench.cpp:1762-1810). It contains no arithmetic of its own:
+// every FLOP happens in the backend it is given.
+#include "ggml.h"
+#include "ggml-backend.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <string>
+#include <thread>
+#include <tuple>
+#include <vector>
+
+extern "C" {
+
+// llama_ftype values (include/llama.h) for the configs of BASELINE.json
+enum { MI_FTYPE_Q4_0 = 2, MI_FTYPE_Q8_0 = 7, MI_FTYPE_Q4_K_M = 15, MI_FTYPE_Q5_K_M = 17, MI_FTYPE_Q6_K = 18 };
+
+struct mi_llama_hparams {
+    int32_t n_embd, n_ff, n_layer, n_head, n_head_kv, n_embd_head, n_vocab;
+    int32_t n_ctx;            // KV cache size (llama-bench: n_prompt + n_gen, tools/llama-bench/llama-bench.cpp:1005)
+    int32_t ftype;            // MI_FTYPE_*
+    int32_t rope_type;        // 0 = NORM (llama), 2 = NEOX
+    int32_t n_ctx_orig;
+    int32_t has_rope_freqs;   // Llama-3.1 rope_freqs tensor (src/llama-model.cpp:2218)
+    int32_t is_70b;           // the LLM_TYPE_70B attn_v bump (src/llama-quant.cpp:305-310)
+    float   rope_freq_base, rope_freq_scale, f_norm_rms_eps;
+    int32_t layer_begin, layer_end;   // this instance holds layers [begin, end) — layer split (src/llama-model.cpp:1949-1972)
+    int32_t has_output;               // holds output_norm + output (the last device, src/llama-model.cpp:1972)
+    int32_t n_seq_max;                // independent sequences, each with its own KV cache stream (llama_context_params.n_seq_max, kv_unified = false)
+};
+
+struct mi_llama;
+
+} // extern "C"
+
+namespace {
+
+struct rng64 {
+    uint64_t s;
+    explicit rng64(uint64_t seed) : s(seed*0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull) { next(); next(); }
+    uint64_t next() { s ^= s >> 12; s ^= s << 25; s ^= s >> 27; return s*0x2545F4914F6CDD1Dull; }
+    float unif() { return (float)(next() >> 40)*(1.0f/16777216.0f); }   // [0,1)
+};
+
+// random valid blocks with super-scales chosen so that dequantized weights have std ~ sigma
+void fill_random_blocks(enum ggml_type type, uint8_t * dst, size_t nbytes, float sigma, uint64_t seed) {
+    const size_t ts = ggml_type_size(type);
+    const size_t nblk = nbytes/ts;
+    const unsigned nthr = std::max(1u, std::min(16u, std::thread::hardware_concurrency()));
+    std::vector<std::thread> th;
+    for (unsigned t = 0; t < nthr; t++) {
+        th.emplace_back([=]() {
+            rng64 r(seed*1315423911ull + t);
+            const size_t b0 = nblk*t/nthr, b1 = nblk*(t + 1)/nthr;
+            uint64_t * p = (uint64_t *) (dst + b0*ts);
+            const size_t n8 = ((b1 - b0)*ts)/8;
+            for (size_t i = 0; i < n8; i++) p[i] = r.next();
+            for (size_t i = b0*ts + n8*8; i < b1*ts; i++) dst[i] = (uint8_t) r.next();
+            for (size_t b = b0; b < b1; b++) {
+                uint8_t * blk = dst + b*ts;
+                const float u = 0.75f + 0.5f*r.unif();
+                switch (type) {
+                    case GGML_TYPE_Q4_K: case GGML_TYPE_Q5_K: {
+                        const float qmean = type == GGML_TYPE_Q4_K ? 7.5f : 15.5f;
+                        const float sd = type == GGML_TYPE_Q4_K ? 258.0f : 530.0f;
+                        const ggml_fp16_t d = ggml_fp32_to_fp16(u*sigma/sd), dm = ggml_fp32_to_fp16(u*sigma/sd*qmean);
+                        memcpy(blk, &d, 2); memcpy(blk + 2, &dm, 2);
+                    } break;
+                    case GGML_TYPE_Q6_K: { const ggml_fp16_t d = ggml_fp32_to_fp16(u*sigma/1367.0f); memcpy(blk + 208, &d, 2); } break;
+                    case GGML_TYPE_Q8_0: { const ggml_fp16_t d = ggml_fp32_to_fp16(u*sigma/73.9f);  memcpy(blk, &d, 2); } break;
+                    case GGML_TYPE_Q4_0: { const ggml_fp16_t d = ggml_fp32_to_fp16(u*sigma/4.61f);  memcpy(blk, &d, 2); } break;
+                    case GGML_TYPE_MXFP4: {
+                        int e = 128 + (int) lrintf(log2f(sigma/5.85f));
+                        blk[0] = (uint8_t) std::max(1, std::min(254, e));
+                    } break;
+                    default: break;
+                }
+            }
+        });
+    }
+    for (auto & t : th) t.join();
+}
+
+void fill_f32(float * p, size_t n, float lo, float hi, uint64_t seed) {
+    rng64 r(seed);
+    for (size_t i = 0; i < n; i++) p[i] = lo + (hi - lo)*r.unif();
+}
+
+bool use_more_bits(int i_layer, int n_layers) {   // src/llama-quant.cpp:185-187
+    return i_layer < n_layers/8 || i_layer >= 7*n_layers/8 || (i_layer - n_layers/8)%3 == 2;
+}
+
+struct layer_types { enum ggml_type wq, wk, wv, wo, gate, up, down; };
+
+// src/llama-quant.cpp:178-434 restricted to the dense-llama tensors and the ftypes of BASELINE.json's configs
+layer_types types_for_layer(const mi_llama_hparams & hp, int il) {
+    layer_types t;
+    enum ggml_type base;
+    switch (hp.ftype) {
+        case MI_FTYPE_Q4_0:   base = GGML_TYPE_Q4_0; break;
+        case MI_FTYPE_Q8_0:   base = GGML_TYPE_Q8_0; break;
+        case MI_FTYPE_Q6_K:   base = GGML_TYPE_Q6_K; break;
+        case MI_FTYPE_Q5_K_M: base = GGML_TYPE_Q5_K; break;
+        default:              base = GGML_TYPE_Q4_K; break;
+    }
+    t.wq = t.wk = t.wv = t.wo = t.gate = t.up = t.down = base;
+    if (hp.ftype == MI_FTYPE_Q4_K_M || hp.ftype == MI_FTYPE_Q5_K_M) {
+        if (use_more_bits(il, hp.n_layer)) { t.wv = GGML_TYPE_Q6_K; t.down = GGML_TYPE_Q6_K; }   // :302-303, :358-364
+        if (hp.is_70b && t.wv == GGML_TYPE_Q4_K) t.wv = GGML_TYPE_Q5_K;                          // :305-310
+    }
+    return t;
+}
+enum ggml_type output_type(const mi_llama_hparams & hp) {   // :205-227
+    return hp.ftype == MI_FTYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q6_K;
+}
+
+struct layer {
+    ggml_tensor * attn_norm, * wq, * wk, * wv, * wo, * ffn_norm, * ffn_gate, * ffn_up, * ffn_down;
+    std::vector<ggml_tensor *> k_cache, v_cache;   // one per sequence stream
+};
+
+struct graph_inst {
+    ggml_context * ctx = nullptr;
+    ggml_backend_buffer_t buf = nullptr;
+    ggml_cgraph * gf = nullptr;
+    ggml_tensor * inp_embd = nullptr, * inp_pos = nullptr, * kq_mask = nullptr, * k_idxs = nullptr, * v_idxs = nullptr, * out_ids = nullptr;
+    ggml_tensor * result = nullptr;    // logits (has_output) or the last layer's l_out
+    int64_t last_use = 0;
+};
+
+} // namespace
+
+struct mi_llama {
+    mi_llama_hparams hp;
+    ggml_backend_t backend;
+    ggml_context * wctx = nullptr;
+    ggml_backend_buffer_t wbuf = nullptr;
+    ggml_context * kvctx = nullptr;
+    ggml_backend_buffer_t kvbuf = nullptr;
+    std::vector<layer> layers;
+    ggml_tensor * output_norm = nullptr, * output = nullptr, * rope_freqs = nullptr;
+    std::map<std::tuple<int, int, int>, graph_inst> graphs;   // (seq, n_tokens, n_kv) -> graph: the reuse of src/llama-context.cpp:728
+    int64_t tick = 0;
+    std::vector<int> n_past;                            // cells [0, n_past[s]) of sequence s are in use
+    uint64_t weight_bytes = 0;                          // bytes of every MUL_MAT weight held here (= algorithmic bytes / token)
+    uint64_t seed;
+    // pinned staging for the per-step inputs (set_inputs: src/llama-graph.cpp:16-58)
+    ggml_backend_buffer_t hbuf = nullptr;
+    uint8_t * hbase = nullptr; size_t hsize = 0; int hslot = 0;   // 4-slot ring: a slot is reused only 4 decodes later
+    std::vector<float> logits;
+};
+
+namespace {
+
+const int KV_PAD = 32;   // get_padding without flash attention (src/llama-kv-cache-unified.cpp:2407-2410)
+
+ggml_tensor * new_weight(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t ne1, const char * name) {
+    ggml_tensor * t = ggml_new_tensor_2d(m->wctx, type, ne0, ne1);
+    ggml_set_name(t, name);
+    if (ne1 > 1) m->weight_bytes += ggml_nbytes(t);
+    return t;
+}
+
+void upload_random(mi_llama * m, ggml_tensor * t, float sigma, uint64_t seed, std::vector<uint8_t> & tmp) {
+    const size_t nb = ggml_nbytes(t);
+    tmp.resize(nb);
+    if (t->type == GGML_TYPE_F32) fill_f32((float *) tmp.data(), nb/4, 0.5f, 1.5f, seed);      // norm weights ~ 1
+    else fill_random_blocks(t->type, tmp.data(), nb, sigma, seed);
+    ggml_backend_tensor_set(t, tmp.data(), 0, nb);
+}
+
+// llm_build_llama for n_tokens tokens attending to n_kv cache cells
+graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
+    const mi_llama_hparams & hp = m->hp;
+    graph_inst g;
+    g.ctx = ggml_init({ 0, NULL, true });
+    ggml_context * ctx0 = g.ctx;
+    g.gf = ggml_new_graph_custom(ctx0, 8192, false);
+
+    const int64_t n_embd = hp.n_embd, hd = hp.n_embd_head, n_head = hp.n_head, n_head_kv = hp.n_head_kv;
+    const int64_t n_embd_k_gqa = hd*n_head_kv, n_embd_v_gqa = hd*n_head_kv, kv_size = hp.n_ctx;
+    const float kq_scale = 1.0f/sqrtf((float) hd);
+    const bool last_rank = hp.has_output != 0;
+
+    // inputs. build_inp_embd: the token-embedding lookup runs on the CPU (input layer, src/llama-model.cpp:1963);
+    // the backend receives its F32 result. On a layer-split rank > 0 this is the activation handed over by the previous rank.
+    g.inp_embd = ggml_new_tensor_2d(ctx0, GGML_TYPE_F32, n_embd, n_tokens); ggml_set_input(g.inp_embd); ggml_set_name(g.inp_embd, "inp_embd");
+    g.inp_pos  = ggml_new_tensor_1d(ctx0, GGML_TYPE_I32, n_tokens);         ggml_set_input(g.inp_pos);  ggml_set_name(g.inp_pos, "inp_pos");
+    g.kq_mask  = ggml_new_tensor_2d(ctx0, GGML_TYPE_F32, n_kv, GGML_PAD(n_tokens, GGML_KQ_MASK_PAD)); ggml_set_input(g.kq_mask);   // src/llama-graph.cpp:1421
+    g.k_idxs   = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, n_tokens);                 ggml_set_input(g.k_idxs);   // :1195
+    g.v_idxs   = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, n_tokens*n_embd_v_gqa);    ggml_set_input(g.v_idxs);   // :1208 (v_trans)
+    const int n_outputs = 1;                                                       // llama_batch_get_one: logits for the last token only
+    g.out_ids  = ggml_new_tensor_1d(ctx0, GGML_TYPE_I32, n_outputs);                ggml_set_input(g.out_ids);
+
+    ggml_tensor * inpL = g.inp_embd;
+    ggml_tensor * cur = nullptr;
+    const int n_local = (int) m->layers.size();
+    for (int li = 0; li < n_local; li++) {
+        const layer & L = m->layers[li];
+        const bool last_layer = last_rank && li == n_local - 1;
+        ggml_tensor * inpSA = inpL;
+
+        // build_norm(inpL, attn_norm, NULL, LLM_NORM_RMS)
+        cur = ggml_rms_norm(ctx0, inpL, hp.f_norm_rms_eps);
+        cur = ggml_mul(ctx0, cur, L.attn_norm);
+
+        // self-attention
+        ggml_tensor * Qcur = ggml_mul_mat(ctx0, L.wq, cur);
+        ggml_tensor * Kcur = ggml_mul_mat(ctx0, L.wk, cur);
+        ggml_tensor * Vcur = ggml_mul_mat(ctx0, L.wv, cur);
+        Qcur = ggml_reshape_3d(ctx0, Qcur, hd, n_head,    n_tokens);
+        Kcur = ggml_reshape_3d(ctx0, Kcur, hd, n_head_kv, n_tokens);
+        Vcur = ggml_reshape_3d(ctx0, Vcur, hd, n_head_kv, n_tokens);
+        Qcur = ggml_rope_ext(ctx0, Qcur, g.inp_pos, m->rope_freqs, (int) hd, hp.rope_type, hp.n_ctx_orig, hp.rope_freq_base, hp.rope_freq_scale, 0.0f, 1.0f, 32.0f, 1.0f);
+        Kcur = ggml_rope_ext(ctx0, Kcur, g.inp_pos, m->rope_freqs, (int) hd, hp.rope_type, hp.n_ctx_orig, hp.rope_freq_base, hp.rope_freq_scale, 0.0f, 1.0f, 32.0f, 1.0f);
+
+        // build_attn: q/k/v first so that they are not reordered (src/llama-graph.cpp:1449-1453)
+        ggml_build_forward_expand(g.gf, Qcur);
+        ggml_build_forward_expand(g.gf, Kcur);
+        ggml_build_forward_expand(g.gf, Vcur);
+        {   // store to KV cache: cpy_k / cpy_v with set_rows (src/llama-kv-cache-unified.cpp:1108-1190)
+            ggml_tensor * k_cur2 = ggml_reshape_2d(ctx0, Kcur, n_embd_k_gqa, n_tokens);
+            ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, L.k_cache[seq], k_cur2, g.k_idxs));
+            ggml_tensor * v_cur2 = ggml_reshape_2d(ctx0, Vcur, n_embd_v_gqa, n_tokens);
+            ggml_tensor * v_view = ggml_reshape_2d(ctx0, L.v_cache[seq], 1, n_embd_v_gqa*kv_size);     // the row becomes a single element
+            v_cur2 = ggml_reshape_2d(ctx0, v_cur2, 1, n_embd_v_gqa*n_tokens);
+            ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, v_view, v_cur2, g.v_idxs));
+        }
+        // get_k / get_v (:1056-1106), v_trans layout
+        ggml_tensor * k = ggml_view_4d(ctx0, L.k_cache[seq], hd, n_head_kv, n_kv, 1,
+                ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa*kv_size), 0);
+        ggml_tensor * v = ggml_view_4d(ctx0, L.v_cache[seq], n_kv, n_head_kv, hd, 1,
+                ggml_row_size(GGML_TYPE_F16, kv_size*hd), ggml_row_size(GGML_TYPE_F16, kv_size), ggml_row_size(GGML_TYPE_F16, kv_size*n_embd_v_gqa), 0);
+        {   // build_attn_mha, no flash attention (src/llama-graph.cpp:1283-1341)
+            ggml_tensor * q = ggml_reshape_4d(ctx0, Qcur, Qcur->ne[0], Qcur->ne[1], Qcur->ne[2], 1);
+            q = ggml_permute(ctx0, q, 0, 2, 1, 3);
+            k = ggml_permute(ctx0, k, 0, 2, 1, 3);
+            v = ggml_permute(ctx0, v, 0, 2, 1, 3);
+            ggml_tensor * kq = ggml_mul_mat(ctx0, k, q);
+            ggml_mul_mat_set_prec(kq, GGML_PREC_F32);
+            kq = ggml_soft_max_ext(ctx0, kq, g.kq_mask, kq_scale, 0.0f);
+            ggml_tensor * kqv = ggml_mul_mat(ctx0, v, kq);
+            cur = ggml_permute(ctx0, kqv, 0, 2, 1, 3);
+            cur = ggml_cont_2d(ctx0, cur, cur->ne[0]*cur->ne[1], cur->ne[2]*cur->ne[3]);
+            ggml_build_forward_expand(g.gf, cur);
+        }
+        cur = ggml_mul_mat(ctx0, L.wo, cur);
+
+        if (last_layer) {   // src/llama-model.cpp:6052-6055
+            cur   = ggml_get_rows(ctx0, cur,   g.out_ids);
+            inpSA = ggml_get_rows(ctx0, inpSA, g.out_ids);
+        }
+        ggml_tensor * ffn_inp = ggml_add(ctx0, cur, inpSA);
+
+        // feed-forward: build_norm + build_ffn(LLM_FFN_SILU, LLM_FFN_PAR)
+        cur = ggml_rms_norm(ctx0, ffn_inp, hp.f_norm_rms_eps);
+        cur = ggml_mul(ctx0, cur, L.ffn_norm);
+        ggml_tensor * tmp = ggml_mul_mat(ctx0, L.ffn_up, cur);
+        cur = ggml_mul_mat(ctx0, L.ffn_gate, cur);
+        cur = ggml_swiglu_split(ctx0, cur, tmp);
+        cur = ggml_mul_mat(ctx0, L.ffn_down, cur);
+        cur = ggml_add(ctx0, cur, ffn_inp);
+        inpL = cur;
+    }
+    cur = inpL;
+    if (last_rank) {
+        cur = ggml_rms_norm(ctx0, cur, hp.f_norm_rms_eps);
+        cur = ggml_mul(ctx0, cur, m->output_norm);
+        cur = ggml_mul_mat(ctx0, m->output, cur);     // lm_head
+    }
+    ggml_set_output(cur);
+    g.result = cur;
+    ggml_build_forward_expand(g.gf, cur);
+
+    g.buf = ggml_backend_alloc_ctx_tensors(ctx0, m->backend);
+    if (!g.buf) { fprintf(stderr, "mi_llama: compute buffer allocation failed\n"); abort(); }
+    return g;
+}
+
+void free_graph(graph_inst & g) {
+    if (g.buf) ggml_backend_buffer_free(g.buf);
+    if (g.ctx) ggml_free(g.ctx);
+    g = graph_inst();
+}
+
+// deterministic synthetic embedding row for a token id (stands in for get_rows(tok_embd) on the CPU)
+void synth_embedding(float * dst, int n_embd, int32_t token, uint64_t seed) {
+    rng64 r(seed ^ (0x5851F42D4C957F2Dull*(uint64_t)(token + 1)));
+    for (int i = 0; i < n_embd; i++) dst[i] = 2.0f*r.unif() - 1.0f;
+}
+
+} // namespace
+
+extern "C" {
+
+GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct mi_llama_hparams * hp_in, uint64_t seed) {
+    mi_llama * m = new mi_llama;
+    m->hp = *hp_in; m->backend = backend; m->seed = seed;
+    m->n_past.assign(std::max(1, hp_in->n_seq_max), 0);
+    const mi_llama_hparams & hp = m->hp;
+    const int64_t n_embd = hp.n_embd, hd = hp.n_embd_head, n_ff = hp.n_ff;
+    const int64_t n_embd_k_gqa = hd*hp.n_head_kv, n_embd_v_gqa = hd*hp.n_head_kv;
+    const int kv_size = hp.n_ctx;
+    if (kv_size % KV_PAD != 0) { fprintf(stderr, "mi_llama: n_ctx must be a multiple of %d\n", KV_PAD); delete m; return nullptr; }
+
+    m->wctx = ggml_init({ 0, NULL, true });
+    m->kvctx = ggml_init({ 0, NULL, true });
+    char name[64];
+    for (int il = hp.layer_begin; il < hp.layer_end; il++) {
+        const layer_types t = types_for_layer(hp, il);
+        layer L;
+        snprintf(name, sizeof(name), "blk.%d.attn_norm.weight", il);   L.attn_norm = new_weight(m, GGML_TYPE_F32, n_embd, 1, name);
+        snprintf(name, sizeof(name), "blk.%d.attn_q.weight", il);      L.wq = new_weight(m, t.wq, n_embd, hd*hp.n_head, name);
+        snprintf(name, sizeof(name), "blk.%d.attn_k.weight", il);      L.wk = new_weight(m, t.wk, n_embd, n_embd_k_gqa, name);
+        snprintf(name, sizeof(name), "blk.%d.attn_v.weight", il);      L.wv = new_weight(m, t.wv, n_embd, n_embd_v_gqa, name);
+        snprintf(name, sizeof(name), "blk.%d.attn_output.weight", il); L.wo = new_weight(m, t.wo, hd*hp.n_head, n_embd, name);
+        snprintf(name, sizeof(name), "blk.%d.ffn_norm.weight", il);    L.ffn_norm = new_weight(m, GGML_TYPE_F32, n_embd, 1, name);
+        snprintf(name, sizeof(name), "blk.%d.ffn_gate.weight", il);    L.ffn_gate = new_weight(m, t.gate, n_embd, n_ff, name);
+        snprintf(name, sizeof(name), "blk.%d.ffn_up.weight", il);      L.ffn_up = new_weight(m, t.up, n_embd, n_ff, name);
+        snprintf(name, sizeof(name), "blk.%d.ffn_down.weight", il);    L.ffn_down = new_weight(m, t.down, n_ff, n_embd, name);
+        // KV cache on the layer's device, F16 (src/llama-kv-cache-unified.cpp:114-132)
+        for (int sq = 0; sq < std::max(1, hp.n_seq_max); sq++) {
+            L.k_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_k_gqa, kv_size));
+            L.v_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_v_gqa, kv_size));
+        }
+        m->layers.push_back(L);
+    }
+    if (hp.has_rope_freqs) m->rope_freqs = new_weight(m, GGML_TYPE_F32, hd/2, 1, "rope_freqs.weight");
+    if (hp.has_output) {
+        m->output_norm = new_weight(m, GGML_TYPE_F32, n_embd, 1, "output_norm.weight");
+        m->output = new_weight(m, output_type(hp), n_embd, hp.n_vocab, "output.weight");
+    }
+    m->wbuf = ggml_backend_alloc_ctx_tensors(m->wctx, backend);
+    m->kvbuf = ggml_backend_alloc_ctx_tensors(m->kvctx, backend);
+    if (!m->wbuf || !m->kvbuf) { fprintf(stderr, "mi_llama: weight/KV allocation failed\n"); delete m; return nullptr; }
+    ggml_backend_buffer_set_usage(m->wbuf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);   // src/llama-model.cpp:5633
+    ggml_backend_buffer_clear(m->kvbuf, 0);                                      // src/llama-kv-cache-unified.cpp:175-182
+
+    std::vector<uint8_t> tmp;
+    uint64_t s = seed*7919 + 13;
+    for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
+        if (t == m->rope_freqs) {
+            std::vector<float> ff(t->ne[0]);
+            for (size_t i = 0; i < ff.size(); i++) ff[i] = i < ff.size()/2 ? 1.0f : 8.0f;   // llama-3.1-like long/short factors
+            ggml_backend_tensor_set(t, ff.data(), 0, ggml_nbytes(t));
+            continue;
+        }
+        upload_random(m, t, 1.0f/sqrtf((float) t->ne[0]), s++, tmp);
+    }
+
+    // pinned staging for per-step inputs
+    ggml_backend_buffer_type_t hbt = ggml_backend_dev_host_buffer_type(ggml_backend_get_device(backend));
+    m->hsize = 128u << 20;
+    if (hbt) {
+        m->hbuf = ggml_backend_buft_alloc_buffer(hbt, m->hsize);
+        if (m->hbuf) m->hbase = (uint8_t *) ggml_backend_buffer_get_base(m->hbuf);
+    }
+    if (!m->hbase) m->hbase = (uint8_t *) malloc(m->hsize);
+    m->logits.resize(hp.has_output ? hp.n_vocab : hp.n_embd);
+    return m;
+}
+
+GGML_API void mi_llama_free(struct mi_llama * m) {
+    if (!m) return;
+    ggml_backend_synchronize(m->backend);
+    for (auto & kv : m->graphs) free_graph(kv.second);
+    if (m->hbuf) ggml_backend_buffer_free(m->hbuf); else free(m->hbase);
+    if (m->wbuf) ggml_backend_buffer_free(m->wbuf);
+    if (m->kvbuf) ggml_backend_buffer_free(m->kvbuf);
+    ggml_free(m->wctx); ggml_free(m->kvctx);
+    delete m;
+}
+
+GGML_API uint64_t mi_llama_weight_bytes(const struct mi_llama * m) { return m->weight_bytes; }
+GGML_API int      mi_llama_n_past(const struct mi_llama * m, int seq) { return m->n_past[seq]; }
+GGML_API void     mi_llama_kv_clear(struct mi_llama * m) { for (auto & p : m->n_past) p = 0; }   // llama_memory_clear(mem, false): metadata only (llama-bench.cpp:1974)
+GGML_API int      mi_llama_n_result(const struct mi_llama * m) { return (int) m->logits.size(); }
+
+// tensor access for graph-level parity tests
+GGML_API struct ggml_tensor * mi_llama_get_tensor(struct mi_llama * m, const char * name) {
+    for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
+        if (strcmp(t->name, name) == 0) return t;
+    }
+    return nullptr;
+}
+
+// One llama_decode() of n_tokens tokens of sequence 0 (src/llama-context.cpp:946-1254 restricted to one ubatch):
+// find the KV slot, (re)use the graph, set_inputs, graph_compute_async, read the result back, synchronize.
+//   tokens   : token ids (seed the synthetic embeddings); ignored when dev_act_in != NULL
+//   dev_act_in  : optional DEVICE pointer, f32 [n_embd, n_tokens]: activations handed over from the previous layer-split rank
+//   result_host : optional host buffer for the result (n_vocab logits of the last token, or [n_embd, n_tokens] l_out on non-final ranks)
+//   dev_result_out : optional DEVICE pointer that receives the result instead (hand-off to the next rank)
+GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * tokens, int n_tokens, const void * dev_act_in,
+                             float * result_host, void * dev_result_out, int do_sync) {
+    const mi_llama_hparams & hp = m->hp;
+    if (seq < 0 || seq >= (int) m->n_past.size()) return -1;
+    if (n_tokens <= 0 || m->n_past[seq] + n_tokens > hp.n_ctx) return 1;   // "could not find a KV slot" (src/llama-context.cpp:1006)
+    const int head = m->n_past[seq];
+    const int n_kv = std::min(hp.n_ctx, std::max(KV_PAD, (int) GGML_PAD(head + n_tokens, KV_PAD)));   // get_n_kv (:1040-1050)
+
+    auto key = std::make_tuple(seq, n_tokens, n_kv);
+    auto it = m->graphs.find(key);
+    if (it == m->graphs.end()) {
+        if (m->graphs.size() >= 6*m->n_past.size()) {   // bound the number of live compute buffers
+            auto victim = m->graphs.begin();
+            for (auto j = m->graphs.begin(); j != m->graphs.end(); ++j) if (j->second.last_use < victim->second.last_use) victim = j;
+            ggml_backend_synchronize(m->backend);
+            free_graph(victim->second);
+            m->graphs.erase(victim);
+        }
+        it = m->graphs.emplace(key, build_graph(m, seq, n_tokens, n_kv)).first;
+    }
+    graph_inst & g = it->second;
+    g.last_use = ++m->tick;
+
+    // ---- set_inputs (src/llama-graph.cpp:16-58, src/llama-kv-cache-unified.cpp:1219-1400) through pinned staging
+    const int64_t n_embd = hp.n_embd, n_embd_v_gqa = (int64_t) hp.n_embd_head*hp.n_head_kv, kv_size = hp.n_ctx;
+    const size_t slot_size = m->hsize/4;
+    uint8_t * hp_ = m->hbase + (size_t) m->hslot*slot_size; size_t off = 0;
+    m->hslot = (m->hslot + 1) % 4;
+    auto stage = [&](size_t bytes) { uint8_t * p = hp_ + off; off += (bytes + 255) & ~(size_t) 255; if (off > slot_size) { fprintf(stderr, "mi_llama: staging overflow\n"); abort(); } return p; };
+
+    if (dev_act_in) {
+        ggml_backend_tensor_set_async(m->backend, g.inp_embd, dev_act_in, 0, ggml_nbytes(g.inp_embd));   // device-to-device
+    } else {
+        float * e = (float *) stage((size_t) n_embd*n_tokens*4);
+        for (int i = 0; i < n_tokens; i++) synth_embedding(e + (size_t) i*n_embd, (int) n_embd, tokens ? tokens[i] : i, m->seed);
+        ggml_backend_tensor_set_async(m->backend, g.inp_embd, e, 0, ggml_nbytes(g.inp_embd));
+    }
+    {
+        int32_t * p = (int32_t *) stage((size_t) n_tokens*4);
+        for (int i = 0; i < n_tokens; i++) p[i] = head + i;
+        ggml_backend_tensor_set_async(m->backend, g.inp_pos, p, 0, ggml_nbytes(g.inp_pos));
+    }
+    {   // causal mask over the used cells (set_input_kq_mask)
+        const int64_t ne0 = g.kq_mask->ne[0], ne1 = g.kq_mask->ne[1];
+        float * p = (float *) stage((size_t) ne0*ne1*4);
+        for (int64_t i = 0; i < ne0*ne1; i++) p[i] = -INFINITY;
+        for (int i = 0; i < n_tokens; i++) {
+            const int p1 = head + i;
+            for (int j = 0; j <= p1 && j < n_kv; j++) p[(int64_t) i*ne0 + j] = 0.0f;
+        }
+        ggml_backend_tensor_set_async(m->backend, g.kq_mask, p, 0, ggml_nbytes(g.kq_mask));
+    }
+    {
+        int64_t * p = (int64_t *) stage((size_t) n_tokens*8);
+        for (int i = 0; i < n_tokens; i++) p[i] = head + i;
+        ggml_backend_tensor_set_async(m->backend, g.k_idxs, p, 0, ggml_nbytes(g.k_idxs));
+    }
+    {   // v_trans: one index per element (set_input_v_idxs :1252-1267)
+        int64_t * p = (int64_t *) stage((size_t) n_tokens*n_embd_v_gqa*8);
+        for (int i = 0; i < n_tokens; i++)
+            for (int64_t j = 0; j < n_embd_v_gqa; j++) p[(int64_t) i*n_embd_v_gqa + j] = j*kv_size + head + i;
+        ggml_backend_tensor_set_async(m->backend, g.v_idxs, p, 0, ggml_nbytes(g.v_idxs));
+    }
+    {
+        int32_t * p = (int32_t *) stage(4);
+        p[0] = n_tokens - 1;
+        ggml_backend_tensor_set_async(m->backend, g.out_ids, p, 0, 4);
+    }
+
+    // ---- graph_compute (src/llama-context.cpp:1432-1457)
+    const enum ggml_status st = ggml_backend_graph_compute_async(m->backend, g.gf);
+    if (st != GGML_STATUS_SUCCESS) return st == GGML_STATUS_ALLOC_FAILED ? -2 : (st == GGML_STATUS_ABORTED ? 2 : -3);   // :1101-1106
+
+    // ---- results (src/llama-context.cpp:1132)
+    const size_t rbytes = ggml_nbytes(g.result);
+    if (dev_result_out) {
+        // device-to-device hand-off buffer (consumed by the caller's RCCL send)
+        ggml_backend_tensor_get_async(m->backend, g.result, dev_result_out, 0, rbytes);
+    }
+    if (result_host || (!dev_result_out && hp.has_output)) {
+        if (m->logits.size()*4 < rbytes) m->logits.resize(rbytes/4);
+        ggml_backend_tensor_get_async(m->backend, g.result, result_host ? result_host : m->logits.data(), 0, rbytes);
+    }
+    m->n_past[seq] += n_tokens;
+    if (do_sync) ggml_backend_synchronize(m->backend);   // llama_synchronize (llama-bench.cpp:1806 does it after every token)
+    return 0;
+}
+
+// the synthetic embedding row the harness feeds for `token` (so that tests can rebuild the same input)
+GGML_API void mi_llama_synth_embedding(const struct mi_llama * m, int32_t token, float * out) {
+    synth_embedding(out, m->hp.n_embd, token, m->seed);
+}
+
+GGML_API const float * mi_llama_last_logits(const struct mi_llama * m) { return m->logits.data(); }
+
+// number of graph nodes in the decode graph for (n_tokens, n_kv) — reporting only
+GGML_API int mi_llama_graph_nodes(struct mi_llama * m, int n_tokens) {
+    for (auto & kv : m->graphs) if (std::get<1>(kv.first) == n_tokens) return ggml_graph_n_nodes(kv.second.gf);
+    return 0;
+}
+
+} // extern "C"

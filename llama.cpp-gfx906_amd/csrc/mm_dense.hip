@@ -42,7 +42,9 @@ __global__ void __launch_bounds__(256) k_mm_dense(const mm_dense_args p) {
             for (int c = 0; c < NC; c++) {
                 if (c0 + c < p.ne11) {
                     const int2v bv = ld_b64(b + (c0 + c)*p.nb11 + k*4);
-                    acc[c] += a0*__builtin_bit_cast(float, bv.x) + a1*__builtin_bit_cast(float, bv.y);
+                    // NB: __builtin_bit_cast on an ext-vector ELEMENT (bv.y) reads element 0 with this toolchain (ROCm 7.2 clang) — go through scalars
+                    const int bx = bv.x, by = bv.y;
+                    acc[c] += a0*__int_as_float(bx) + a1*__int_as_float(by);
                 }
             }
         }

@@ -67,6 +67,11 @@ class mi355x_counters(C.Structure):
         "mmq_launches", "weight_bytes", "act_quant_launches", "act_quant_reused")]
 
 
+class mi355x_prof_entry(C.Structure):
+    _fields_ = [("type", C.c_int32), ("n", C.c_int32), ("m", C.c_int64), ("k", C.c_int64), ("launches", C.c_uint64),
+                ("total_ms", C.c_double), ("bytes_per_launch", C.c_uint64)]
+
+
 class dev_caps(C.Structure):
     _fields_ = [("async_", C.c_bool), ("host_buffer", C.c_bool), ("buffer_from_host_ptr", C.c_bool), ("events", C.c_bool)]
 
@@ -85,6 +90,7 @@ MI355X_EXPORTS = [
     "ggml_backend_mi355x_get_device_count", "ggml_backend_mi355x_get_device_description", "ggml_backend_mi355x_get_device_memory",
     "ggml_backend_mi355x_buffer_type", "ggml_backend_mi355x_host_buffer_type", "ggml_backend_mi355x_get_stream",
     "ggml_backend_mi355x_get_counters", "ggml_backend_mi355x_reset_counters", "ggml_backend_mi355x_set_option",
+    "ggml_backend_mi355x_get_profile",
 ]
 
 
@@ -259,6 +265,8 @@ class Backend:
         self._lib.ggml_backend_mi355x_get_counters.argtypes = [C.c_void_p, C.POINTER(mi355x_counters)]
         self._lib.ggml_backend_mi355x_reset_counters.argtypes = [C.c_void_p]
         self._lib.ggml_backend_mi355x_set_option.argtypes = [C.c_void_p, C.c_char_p, C.c_int]
+        self._lib.ggml_backend_mi355x_get_profile.restype = C.c_int
+        self._lib.ggml_backend_mi355x_get_profile.argtypes = [C.c_void_p, C.POINTER(mi355x_prof_entry), C.c_int]
 
     def name(self):
         return self.L.ggml_backend_name(self.be).decode()
@@ -276,6 +284,13 @@ class Backend:
 
     def set_option(self, key, value):
         return self._lib.ggml_backend_mi355x_set_option(self.be, key.encode(), int(value))
+
+    def profile(self, cap=64):
+        """aggregated (type, m, k, n) -> launches / total_ms of the mat-mul launches recorded under option 'profile'"""
+        arr = (mi355x_prof_entry * cap)()
+        n = self._lib.ggml_backend_mi355x_get_profile(self.be, arr, cap)
+        return [dict(type=e.type, n=e.n, m=e.m, k=e.k, launches=e.launches, total_ms=e.total_ms, bytes_per_launch=e.bytes_per_launch)
+                for e in arr[:n]]
 
     def supports_op(self, t):
         return bool(self.L.ggml_backend_supports_op(self.be, t))

@@ -1,0 +1,141 @@
+"""llama_synth.py — Python handle on the C++ synthetic-model harness (csrc/harness/llama_harness.cpp).
+
+The harness restates the reference's CALLER rows (llm_build_llama, build_attn, the unified KV cache's
+set_rows writes, llama_context::decode — SURVEY.md §8 a4-a11) through the ggml API; this module only
+fills in hyper-parameters and forwards calls. Model shapes: SURVEY.md §8 header.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import ggml_ctypes as gg
+
+# llama_ftype ids (include/llama.h) used by BASELINE.json's configs
+FTYPE = {"Q4_0": 2, "Q8_0": 7, "Q4_K_M": 15, "Q5_K_M": 17, "Q6_K": 18}
+
+
+class hparams(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_embd", "n_ff", "n_layer", "n_head", "n_head_kv", "n_embd_head", "n_vocab", "n_ctx",
+                                         "ftype", "rope_type", "n_ctx_orig", "has_rope_freqs", "is_70b")] + \
+               [(n, C.c_float) for n in ("rope_freq_base", "rope_freq_scale", "f_norm_rms_eps")] + \
+               [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max")]
+
+
+# model shapes used by the configs
+MODELS = {
+    # Llama-3-8B: n_embd=4096, n_ff=14336, n_layer=32, n_head=32, n_head_kv=8, head=128, n_vocab=128256
+    "llama3-8b": dict(n_embd=4096, n_ff=14336, n_layer=32, n_head=32, n_head_kv=8, n_embd_head=128, n_vocab=128256,
+                      rope_freq_base=500000.0, n_ctx_orig=8192, is_70b=0),
+    # Llama-3-70B: 8192/28672/80/64/8/128/128256
+    "llama3-70b": dict(n_embd=8192, n_ff=28672, n_layer=80, n_head=64, n_head_kv=8, n_embd_head=128, n_vocab=128256,
+                       rope_freq_base=500000.0, n_ctx_orig=8192, is_70b=1),
+    # stories15M (tinyllama): 288/768/6/6/6/48/32000 — BASELINE.json configs[0] shape
+    "stories15m": dict(n_embd=288, n_ff=768, n_layer=6, n_head=6, n_head_kv=6, n_embd_head=48, n_vocab=32000,
+                       rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
+    # small model for graph-level parity tests (oracle finishes in seconds)
+    "tiny": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
+                 rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
+}
+
+_hz = None
+
+
+def harness():
+    global _hz
+    if _hz is None:
+        gg.base()
+        p = gg.LIBDIR / "libmi355x-harness.so"
+        if not p.exists():
+            raise RuntimeError(f"{p} is missing: build the native code first (no fallback exists)")
+        L = C.CDLL(str(p), mode=C.RTLD_GLOBAL)
+        L.mi_llama_create.restype = C.c_void_p; L.mi_llama_create.argtypes = [C.c_void_p, C.POINTER(hparams), C.c_uint64]
+        L.mi_llama_free.argtypes = [C.c_void_p]
+        L.mi_llama_weight_bytes.restype = C.c_uint64; L.mi_llama_weight_bytes.argtypes = [C.c_void_p]
+        L.mi_llama_n_past.restype = C.c_int; L.mi_llama_n_past.argtypes = [C.c_void_p, C.c_int]
+        L.mi_llama_kv_clear.argtypes = [C.c_void_p]
+        L.mi_llama_n_result.restype = C.c_int; L.mi_llama_n_result.argtypes = [C.c_void_p]
+        L.mi_llama_get_tensor.restype = gg.tensor_p; L.mi_llama_get_tensor.argtypes = [C.c_void_p, C.c_char_p]
+        L.mi_llama_decode.restype = C.c_int
+        L.mi_llama_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+        L.mi_llama_synth_embedding.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.mi_llama_graph_nodes.restype = C.c_int; L.mi_llama_graph_nodes.argtypes = [C.c_void_p, C.c_int]
+        _hz = L
+    return _hz
+
+
+class SynthLlama:
+    def __init__(self, backend: gg.Backend, model="llama3-8b", ftype="Q4_K_M", n_ctx=128, seed=1, layer_begin=0, layer_end=None,
+                 has_output=None, rope_type=0, has_rope_freqs=False, n_seq_max=1, **over):
+        cfg = dict(MODELS[model]); cfg.update(over)
+        self.cfg = cfg
+        n_layer = cfg["n_layer"]
+        layer_end = n_layer if layer_end is None else layer_end
+        has_output = (layer_end == n_layer) if has_output is None else has_output
+        hp = hparams()
+        for k in ("n_embd", "n_ff", "n_layer", "n_head", "n_head_kv", "n_embd_head", "n_vocab", "n_ctx_orig", "is_70b"):
+            setattr(hp, k, cfg[k])
+        hp.n_ctx = (n_ctx + 31) // 32 * 32
+        hp.ftype = FTYPE[ftype]
+        hp.rope_type = rope_type
+        hp.has_rope_freqs = int(has_rope_freqs)
+        hp.rope_freq_base = cfg["rope_freq_base"]; hp.rope_freq_scale = 1.0; hp.f_norm_rms_eps = 1e-5
+        hp.layer_begin, hp.layer_end, hp.has_output = layer_begin, layer_end, int(has_output)
+        hp.n_seq_max = n_seq_max
+        self.hp = hp
+        self.backend = backend
+        self.L = harness()
+        self.m = self.L.mi_llama_create(backend.be, C.byref(hp), seed)
+        if not self.m:
+            raise RuntimeError("mi_llama_create failed")
+        self.has_output = bool(has_output)
+        self.n_result = self.L.mi_llama_n_result(self.m)
+
+    @property
+    def weight_bytes(self):
+        """bytes of every MUL_MAT weight tensor held by this instance = algorithmic bytes read per decoded token"""
+        return int(self.L.mi_llama_weight_bytes(self.m))
+
+    @property
+    def n_past(self):
+        return self.L.mi_llama_n_past(self.m, 0)
+
+    def kv_clear(self):
+        self.L.mi_llama_kv_clear(self.m)
+
+    def tensor(self, name):
+        t = self.L.mi_llama_get_tensor(self.m, name.encode())
+        if not t:
+            raise KeyError(name)
+        return t
+
+    def decode(self, tokens, dev_act_in=None, dev_result_out=None, want_host=True, sync=True, n_tokens=None, seq=0):
+        """one llama_decode of len(tokens) tokens; returns the host result (logits of the last token) or None"""
+        if tokens is not None:
+            tok = np.ascontiguousarray(tokens, dtype=np.int32)
+            n = tok.size; tp = tok.ctypes.data_as(C.c_void_p)
+        else:
+            n = n_tokens; tp = None
+        out = None; op = None
+        if want_host:
+            n_res = self.n_result if self.has_output else self.cfg["n_embd"] * n
+            out = np.empty(n_res, dtype=np.float32); op = out.ctypes.data_as(C.c_void_p)
+        rc = self.L.mi_llama_decode(self.m, seq, tp, n, C.c_void_p(dev_act_in) if dev_act_in else None, op,
+                                    C.c_void_p(dev_result_out) if dev_result_out else None, int(sync))
+        if rc != 0:
+            raise RuntimeError(f"mi_llama_decode returned {rc}")
+        return out
+
+    def embedding(self, token):
+        out = np.empty(self.cfg["n_embd"], dtype=np.float32)
+        self.L.mi_llama_synth_embedding(self.m, int(token), out.ctypes.data_as(C.c_void_p))
+        return out
+
+    def graph_nodes(self, n_tokens=1):
+        return self.L.mi_llama_graph_nodes(self.m, n_tokens)
+
+    def free(self):
+        if self.m:
+            self.L.mi_llama_free(self.m)
+            self.m = None

@@ -1,0 +1,309 @@
+"""GPU parity for the remaining ops of the decode graph, each driven as a one-op ggml graph through the
+backend C-ABI (the way tests/test-backend-ops.cpp:1082-1240 does) and compared with oracle/ops_ref.py.
+Gates are the reference's: default NMSE 1e-7 (tests/test-backend-ops.cpp:948-950), SOFT_MAX / CPY 1e-6,
+MUL_MAT / MUL_MAT_ID 5e-4; ROPE within the reference's max asymmetry 1e-3 (:3775)."""
+import numpy as np
+import pytest
+
+import oracle as orc
+import ops_ref as ref
+from gpu_util import QTYPES, backend, gg
+
+pytestmark = pytest.mark.gpu
+L = gg.base()
+
+
+def run(ctx, out, inputs):
+    be = backend()
+    assert be.supports_op(out), "backend refused an op on the path"
+    assert ctx.alloc(be)
+    for t, arr in inputs:
+        gg.tensor_set(t, arr)
+    be.compute(gg.graph_of(ctx, out))
+    return gg.tensor_get(out)
+
+
+@pytest.mark.parametrize("ne", [(64, 5, 4, 3), (4096, 1, 1, 1), (4096, 7, 1, 1), (288, 3, 1, 1), (10, 2, 1, 1)])
+def test_rms_norm(ne):
+    rng = np.random.default_rng(0)
+    x = rng.uniform(-1, 1, size=ne[::-1]).astype(np.float32)
+    for eps in (0.0, 1e-6, 1e-1):
+        with gg.Context() as ctx:
+            a = ctx.new_tensor(gg.F32, ne)
+            got = run(ctx, L.ggml_rms_norm(ctx.ctx, a, eps), [(a, x)])
+        assert orc.nmse(ref.rms_norm(x, eps), got) <= 1e-7
+
+
+def test_rms_norm_mul_add_fused_matches_unfused():
+    """tests/test-backend-ops.cpp:2856 test_rms_norm_mul_add"""
+    rng = np.random.default_rng(1)
+    ne = (4096, 3, 1, 1)
+    x = rng.uniform(-1, 1, size=ne[::-1]).astype(np.float32)
+    w = rng.uniform(-1, 1, size=(1, 1, 1, 4096)).astype(np.float32)
+    c = rng.uniform(-1, 1, size=ne[::-1]).astype(np.float32)
+    outs = {}
+    be = backend()
+    for fusion in (1, 0):
+        be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            a = ctx.new_tensor(gg.F32, ne); b = ctx.new_tensor(gg.F32, (4096,)); d = ctx.new_tensor(gg.F32, ne)
+            o = L.ggml_add(ctx.ctx, L.ggml_mul(ctx.ctx, L.ggml_rms_norm(ctx.ctx, a, 1e-5), b), d)
+            outs[fusion] = run(ctx, o, [(a, x), (b, w), (d, c)]).copy()
+    be.set_option("fusion", 1)
+    exp = ref.rms_norm(x, 1e-5) * w + c
+    assert orc.nmse(exp, outs[1]) <= 1e-7 and orc.nmse(exp, outs[0]) <= 1e-7
+    assert np.array_equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("op", ["add", "mul", "div"])
+@pytest.mark.parametrize("ne,nr", [((4096, 1, 1, 1), (1, 1, 1, 1)), ((64, 5, 3, 2), (1, 1, 1, 1)), ((16, 5, 4, 3), (1, 2, 1, 1)),
+                                   ((4096, 8, 1, 1), (1, 8, 1, 1)), ((1, 4, 7, 1), (32, 1, 1, 1))])
+def test_bin_bcast(op, ne, nr):
+    rng = np.random.default_rng(2)
+    ne_a = tuple(n * r for n, r in zip(ne, nr))
+    x = rng.uniform(-1, 1, size=ne_a[::-1]).astype(np.float32)
+    y = rng.uniform(0.5, 1.5, size=ne[::-1]).astype(np.float32)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, ne_a); b = ctx.new_tensor(gg.F32, ne)
+        got = run(ctx, getattr(L, f"ggml_{op}")(ctx.ctx, a, b), [(a, x), (b, y)])
+    yb = ref.bcast(y.astype(np.float64), x.shape)
+    exp = {"add": x + yb, "mul": x * yb, "div": x / yb}[op]
+    assert orc.nmse(exp, got) <= 1e-7
+
+
+def test_scale_and_sum_rows_and_unary():
+    rng = np.random.default_rng(3)
+    x = rng.uniform(-2, 2, size=(1, 3, 5, 70)).astype(np.float32)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (70, 5, 3))
+        got = run(ctx, L.ggml_scale_bias(ctx.ctx, a, 0.37, -1.5), [(a, x)])
+    assert orc.nmse(x.astype(np.float64) * 0.37 - 1.5, got) <= 1e-7
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (70, 5, 3))
+        got = run(ctx, L.ggml_sum_rows(ctx.ctx, a), [(a, x)])
+    assert orc.nmse(x.astype(np.float64).sum(-1, keepdims=True), got) <= 1e-7
+    for uop, fn in ((gg.UNARY_SILU, ref.silu), (gg.UNARY_SIGMOID, lambda v: 1 / (1 + np.exp(-v.astype(np.float64)))), (gg.UNARY_GELU, ref.gelu)):
+        with gg.Context() as ctx:
+            a = ctx.new_tensor(gg.F32, (70, 5, 3))
+            got = run(ctx, L.ggml_unary(ctx.ctx, a, uop), [(a, x)])
+        assert orc.nmse(fn(x), got) <= 1e-6
+
+
+def test_glu_split_swiglu_and_oai():
+    """inputs in +-150 to catch NaN (tests/test-backend-ops.cpp:1882-1886)"""
+    rng = np.random.default_rng(4)
+    a_ = rng.uniform(-150, 150, size=(1, 1, 7, 128)).astype(np.float32)
+    b_ = rng.uniform(-150, 150, size=(1, 1, 7, 128)).astype(np.float32)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (128, 7)); b = ctx.new_tensor(gg.F32, (128, 7))
+        got = run(ctx, L.ggml_swiglu_split(ctx.ctx, a, b), [(a, a_), (b, b_)])
+    assert np.isfinite(got).all() and orc.nmse(ref.swiglu(a_, b_), got) <= 1e-7
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (128, 7)); b = ctx.new_tensor(gg.F32, (128, 7))
+        got = run(ctx, L.ggml_swiglu_oai(ctx.ctx, a, b, 1.702, 7.0), [(a, a_), (b, b_)])
+    assert np.isfinite(got).all() and orc.nmse(ref.swiglu_oai(a_, b_), got) <= 1e-7
+    # strided (non-contiguous rows) inputs: views of a wider tensor, as build_ffn's fused gate_up produces
+    wide = rng.uniform(-5, 5, size=(1, 1, 7, 256)).astype(np.float32)
+    with gg.Context() as ctx:
+        t = ctx.new_tensor(gg.F32, (256, 7))
+        va = L.ggml_view_2d(ctx.ctx, t, 128, 7, 256 * 4, 0)
+        vb = L.ggml_view_2d(ctx.ctx, t, 128, 7, 256 * 4, 128 * 4)
+        got = run(ctx, L.ggml_swiglu_split(ctx.ctx, va, vb), [(t, wide)])
+    assert orc.nmse(ref.swiglu(wide[..., :128], wide[..., 128:]), got) <= 1e-7
+
+
+@pytest.mark.parametrize("mode", [0, gg.GGML_ROPE_TYPE_NEOX])
+@pytest.mark.parametrize("with_ff,ext", [(False, 0.0), (True, 0.0), (False, 1.0)])
+def test_rope(mode, with_ff, ext):
+    """model-shaped cases tests/test-backend-ops.cpp:5975-6005: head 128 x 32 heads, n_dims = 128 and partial 64"""
+    rng = np.random.default_rng(5)
+    for n_dims, heads, ntok in ((128, 32, 3), (64, 8, 2)):
+        x = rng.uniform(-1, 1, size=(1, ntok, heads, 128)).astype(np.float32)
+        pos = rng.integers(0, 500, size=ntok).astype(np.int32)
+        ff = rng.uniform(0.9, 1.1, size=n_dims // 2).astype(np.float32)
+        fs = 0.5 if ext else 1.0
+        with gg.Context() as ctx:
+            a = ctx.new_tensor(gg.F32, (128, heads, ntok)); p = ctx.new_tensor(gg.I32, (ntok,))
+            f = ctx.new_tensor(gg.F32, (n_dims // 2,)) if with_ff else None
+            o = L.ggml_rope_ext(ctx.ctx, a, p, f, n_dims, mode, 8192, 500000.0, fs, ext, 1.0, 32.0, 1.0)
+            got = run(ctx, o, [(a, x), (p, pos)] + ([(f, ff)] if with_ff else []))
+        exp = ref.rope(x, pos, n_dims, mode, 8192, 500000.0, fs, ext, 1.0, 32.0, 1.0, ff if with_ff else None)
+        assert orc.nmse(exp, got) <= 1e-6
+        assert np.abs(exp - got).max() <= 1e-3
+
+
+@pytest.mark.parametrize("ne0,ne1,heads", [(32, 1, 32), (128, 1, 32), (96, 7, 8), (1000, 3, 4), (4100, 2, 2)])
+@pytest.mark.parametrize("mask_t,max_bias,sinks", [(None, 0.0, False), (gg.F32, 0.0, False), (gg.F16, 0.0, True), (gg.F32, 8.0, False)])
+def test_soft_max(ne0, ne1, heads, mask_t, max_bias, sinks):
+    rng = np.random.default_rng(6)
+    x = rng.uniform(-4, 4, size=(1, heads, ne1, ne0)).astype(np.float32)
+    ne1p = (ne1 + 63) // 64 * 64            # GGML_KQ_MASK_PAD (src/llama-graph.cpp:1421)
+    m = rng.uniform(-1, 0, size=(1, 1, ne1p, ne0)).astype(np.float32)
+    m[..., ne0 // 2:] = -np.inf               # causal-style masking
+    m[..., 0] = 0
+    sk = rng.uniform(-1, 1, size=heads).astype(np.float32)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (ne0, ne1, heads))
+        mt = ctx.new_tensor(mask_t, (ne0, ne1p)) if mask_t is not None else None
+        o = L.ggml_soft_max_ext(ctx.ctx, a, mt, 0.125, max_bias)
+        ins = [(a, x)]
+        if mt is not None:
+            ins.append((mt, m if mask_t == gg.F32 else m.astype(np.float16)))
+        if sinks:
+            s = ctx.new_tensor(gg.F32, (heads,)); L.ggml_soft_max_add_sinks(o, s); ins.append((s, sk))
+        got = run(ctx, o, ins)
+    mm = None if mask_t is None else (m if mask_t == gg.F32 else m.astype(np.float16).astype(np.float32))
+    exp = ref.soft_max(x, mm, 0.125, max_bias, sk if sinks else None)
+    assert np.isfinite(got).all() and orc.nmse(exp, got) <= 1e-6
+
+
+@pytest.mark.parametrize("dst_t", [gg.F16, gg.F32])
+def test_set_rows_kv_write(dst_t):
+    """K write: [1024, n_tok] f32 rows scattered into the f16 cache [1024, kv_size] by I64 indices
+    (src/llama-kv-cache-unified.cpp:1123); V-transposed write: element scatter on a [1, N] view (:1157-1167)."""
+    rng = np.random.default_rng(7)
+    n_embd, kv, ntok = 1024, 64, 5
+    cache0 = rng.uniform(-1, 1, size=(1, 1, kv, n_embd)).astype(np.float16 if dst_t == gg.F16 else np.float32)
+    cur = rng.uniform(-1, 1, size=(1, 1, ntok, n_embd)).astype(np.float32)
+    idx = rng.permutation(kv)[:ntok].astype(np.int64)
+    with gg.Context() as ctx:
+        c = ctx.new_tensor(dst_t, (n_embd, kv)); s = ctx.new_tensor(gg.F32, (n_embd, ntok)); i = ctx.new_tensor(gg.I64, (ntok,))
+        o = L.ggml_set_rows(ctx.ctx, c, s, i)
+        be = backend(); assert be.supports_op(o); ctx.alloc(be)
+        gg.tensor_set(c, cache0); gg.tensor_set(s, cur); gg.tensor_set(i, idx)
+        be.compute(gg.graph_of(ctx, o))
+        got = gg.tensor_get(c)
+    exp = ref.set_rows(cache0, cur, idx.reshape(1, 1, ntok))
+    assert np.array_equal(got, exp)          # f32 -> f16 conversion is exact-rounding on both sides
+    # element scatter (v_trans): dst viewed as [1, kv*n_embd], one I64 index per element
+    n_el = ntok * 16
+    flat0 = rng.uniform(-1, 1, size=(1, 1, 1, kv * 16)).astype(np.float16 if dst_t == gg.F16 else np.float32)
+    vals = rng.uniform(-1, 1, size=(1, 1, n_el, 1)).astype(np.float32)
+    eidx = rng.permutation(kv * 16)[:n_el].astype(np.int64)
+    with gg.Context() as ctx:
+        c = ctx.new_tensor(dst_t, (kv * 16,)); s = ctx.new_tensor(gg.F32, (1, n_el)); i = ctx.new_tensor(gg.I64, (n_el,))
+        cv = L.ggml_reshape_2d(ctx.ctx, c, 1, kv * 16)
+        o = L.ggml_set_rows(ctx.ctx, cv, s, i)
+        be = backend(); assert be.supports_op(o); ctx.alloc(be)
+        gg.tensor_set(c, flat0); gg.tensor_set(s, vals); gg.tensor_set(i, eidx)
+        be.compute(gg.graph_of(ctx, o))
+        got = gg.tensor_get(c)
+    exp = flat0.copy(); exp[0, 0, 0, eidx] = vals[0, 0, :, 0].astype(exp.dtype)
+    assert np.array_equal(got, exp)
+
+
+def test_get_rows_and_cpy_cont():
+    rng = np.random.default_rng(8)
+    src = rng.uniform(-1, 1, size=(1, 1, 50, 96)).astype(np.float32)
+    idx = rng.integers(0, 50, size=(1, 1, 9)).astype(np.int32)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (96, 50)); i = ctx.new_tensor(gg.I32, (9,))
+        got = run(ctx, L.ggml_get_rows(ctx.ctx, a, i), [(a, src), (i, idx)])
+    assert np.array_equal(got[0, 0], src[0, 0][idx[0, 0]])
+    # CONT of a permuted tensor (src/llama-graph.cpp:1327-1330: kqv permute(0,2,1,3) then cont_2d)
+    x = rng.uniform(-1, 1, size=(1, 4, 6, 32)).astype(np.float32)      # ggml ne = (32, 6, 4)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (32, 6, 4))
+        p = L.ggml_permute(ctx.ctx, a, 0, 2, 1, 3)                       # -> ne (32, 4, 6)
+        got = run(ctx, L.ggml_cont_2d(ctx.ctx, p, 32 * 4, 6), [(a, x)])
+    assert np.array_equal(got[0, 0], x[0].transpose(1, 0, 2).reshape(6, 128))
+    # CPY f32 -> f16 (legacy KV path, src/llama-kv-cache-unified.cpp:1135)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (32, 6, 4)); d = ctx.new_tensor(gg.F16, (32, 6, 4))
+        o = L.ggml_cpy(ctx.ctx, a, d)
+        be = backend(); ctx.alloc(be); gg.tensor_set(a, x); be.compute(gg.graph_of(ctx, o))
+        got = gg.tensor_get(d)
+    assert np.array_equal(got, x.astype(np.float16))
+
+
+def test_add_id_and_argsort_topk():
+    rng = np.random.default_rng(9)
+    n_expert, n_used, ntok, ne0 = 32, 4, 3, 2880
+    a_ = rng.uniform(-1, 1, size=(1, ntok, n_used, ne0)).astype(np.float32)
+    bias = rng.uniform(-1, 1, size=(1, 1, n_expert, ne0)).astype(np.float32)
+    ids = np.stack([rng.permutation(n_expert)[:n_used] for _ in range(ntok)]).astype(np.int32)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(gg.F32, (ne0, n_used, ntok)); b = ctx.new_tensor(gg.F32, (ne0, n_expert)); i = ctx.new_tensor(gg.I32, (n_used, ntok))
+        got = run(ctx, L.ggml_add_id(ctx.ctx, a, b, i), [(a, a_), (b, bias), (i, ids.reshape(1, 1, ntok, n_used))])
+    assert orc.nmse(ref.add_id(a_[0], bias[0, 0], ids), got[0]) <= 1e-7
+    # argsort desc (+ top_k view) over router logits
+    for ne0 in (8, 32, 100, 128):
+        logits = rng.permutation(ne0 * 5).astype(np.float32).reshape(1, 1, 5, ne0)   # distinct values: order is unique
+        with gg.Context() as ctx:
+            a = ctx.new_tensor(gg.F32, (ne0, 5))
+            got = run(ctx, L.ggml_argsort(ctx.ctx, a, gg.GGML_SORT_ORDER_DESC), [(a, logits)])
+        assert np.array_equal(got, ref.argsort_desc(logits))
+
+
+@pytest.mark.parametrize("name", list(QTYPES))
+@pytest.mark.parametrize("n_mats,n_used,bcast_b,n", [(4, 1, False, 1), (4, 2, True, 1), (8, 2, False, 1), (8, 4, False, 5), (8, 2, True, 32), (8, 8, False, 3)])
+def test_mul_mat_id(name, n_mats, n_used, bcast_b, n):
+    """tests/test-backend-ops.cpp:5821-5856; ids = a strided view of a shuffled [n_mats, n] tensor (:3231-3236)"""
+    rng = np.random.default_rng(10 + n)
+    m, k = 64, 256
+    qt = QTYPES[name]
+    w = orc.random_blocks(rng, qt, (n_mats, m), k)
+    ids_full = np.stack([rng.permutation(n_mats) for _ in range(n)]).astype(np.int32)
+    nb = 1 if bcast_b else n_used
+    b_ = rng.uniform(-1, 1, size=(1, n, nb, k)).astype(np.float32)
+    with gg.Context() as ctx:
+        as_ = ctx.new_tensor(qt, (k, m, n_mats)); ids = ctx.new_tensor(gg.I32, (n_mats, n)); b = ctx.new_tensor(gg.F32, (k, nb, n))
+        idv = L.ggml_view_2d(ctx.ctx, ids, n_used, n, n_mats * 4, 0) if n_used != n_mats else ids
+        got = run(ctx, L.ggml_mul_mat_id(ctx.ctx, as_, b, idv), [(as_, w), (ids, ids_full.reshape(1, 1, n, n_mats)), (b, b_)])
+    exp = orc.mul_mat_id(w, qt, b_[0], ids_full[:, :n_used], "exact")
+    cpu = orc.mul_mat_id(w, qt, b_[0], ids_full[:, :n_used], "cpu")
+    assert orc.nmse(exp, got[0]) <= 5e-4
+    assert np.abs(got[0] - cpu).max() <= 2e-5 * (np.abs(cpu).max() + 1e-30)
+
+
+@pytest.mark.parametrize("name", list(QTYPES))
+def test_mul_mat_id_golden(name, golden_dir):
+    g = np.load(golden_dir / f"mulmatid_{name}.npz")
+    n_mats, m, _ = g["w"].shape; n, n_used, k = g["b"].shape
+    with gg.Context() as ctx:
+        as_ = ctx.new_tensor(QTYPES[name], (k, m, n_mats)); ids = ctx.new_tensor(gg.I32, (n_used, n)); b = ctx.new_tensor(gg.F32, (k, n_used, n))
+        got = run(ctx, L.ggml_mul_mat_id(ctx.ctx, as_, b, ids), [(as_, g["w"]), (ids, g["ids"]), (b, g["b"])])
+    assert orc.nmse(g["expected"], got[0]) <= 5e-4
+
+
+def test_attention_matmuls_f16_kv_views():
+    """kq = mul_mat(k, q), kqv = mul_mat(v, kq) on F16 cache views with GQA broadcast 32/8
+    (src/llama-graph.cpp:1285,1320; src/llama-kv-cache-unified.cpp:1056-1106; tests/test-backend-ops.cpp:5791-5813)."""
+    rng = np.random.default_rng(11)
+    hd, n_head, n_head_kv, kv_size, n_kv = 128, 32, 8, 256, 96
+    for ntok in (1, 3, 17):
+        kc = rng.uniform(-1, 1, size=(1, 1, kv_size, hd * n_head_kv)).astype(np.float16)       # cache [n_embd_k_gqa, kv_size]
+        vc = rng.uniform(-1, 1, size=(1, 1, hd * n_head_kv, kv_size)).astype(np.float16)       # transposed V cache [kv_size, n_embd_v_gqa]
+        q_ = rng.uniform(-1, 1, size=(1, ntok, n_head, hd)).astype(np.float32)                 # q_cur [hd, n_head, n_tok]
+        with gg.Context() as ctx:
+            k_l = ctx.new_tensor(gg.F16, (hd * n_head_kv, kv_size)); v_l = ctx.new_tensor(gg.F16, (kv_size, hd * n_head_kv))
+            q_cur = ctx.new_tensor(gg.F32, (hd, n_head, ntok))
+            k = L.ggml_view_3d(ctx.ctx, k_l, hd, n_kv, n_head_kv, hd * n_head_kv * 2, hd * 2, 0)    # get_k
+            v = L.ggml_view_3d(ctx.ctx, v_l, n_kv, hd, n_head_kv, kv_size * 2, kv_size * hd * 2, 0)  # get_v (v_trans)
+            q = L.ggml_permute(ctx.ctx, q_cur, 0, 2, 1, 3)
+            kq = L.ggml_mul_mat(ctx.ctx, k, q)
+            L.ggml_mul_mat_set_prec(kq, 10)
+            kqv = L.ggml_mul_mat(ctx.ctx, v, kq)
+            be = backend(); assert be.supports_op(kq) and be.supports_op(kqv); ctx.alloc(be)
+            gg.tensor_set(k_l, kc); gg.tensor_set(v_l, vc); gg.tensor_set(q_cur, q_)
+            be.compute(gg.graph_of(ctx, kqv))
+            got_kq = gg.tensor_get(kq); got_kqv = gg.tensor_get(kqv)
+        K = kc[0, 0, :n_kv].reshape(n_kv, n_head_kv, hd).transpose(1, 0, 2)[None].astype(np.float32)      # [1, hkv, n_kv, hd]
+        Q = q_.transpose(0, 2, 1, 3)                                                                       # [1, n_head, ntok, hd]
+        exp_kq = ref.mul_mat_dense(K, Q)
+        assert orc.nmse(exp_kq, got_kq) <= 5e-4
+        V = vc[0, 0].reshape(n_head_kv, hd, kv_size)[:, :, :n_kv][None].astype(np.float32)                # [1, hkv, hd, n_kv]
+        exp_kqv = ref.mul_mat_dense(V, got_kq)
+        assert orc.nmse(exp_kqv, got_kqv) <= 5e-4
+
+
+def test_mul_mat_f32_f16_generic_strided():
+    rng = np.random.default_rng(12)
+    a_ = rng.uniform(-1, 1, size=(2, 3, 16, 40)).astype(np.float32)
+    b_ = rng.uniform(-1, 1, size=(2, 6, 9, 40)).astype(np.float32)
+    for ta in (gg.F32, gg.F16):
+        with gg.Context() as ctx:
+            a = ctx.new_tensor(ta, (40, 16, 3, 2)); b = ctx.new_tensor(gg.F32, (40, 9, 6, 2))
+            got = run(ctx, L.ggml_mul_mat(ctx.ctx, a, b), [(a, a_ if ta == gg.F32 else a_.astype(np.float16)), (b, b_)])
+        aa = a_ if ta == gg.F32 else a_.astype(np.float16).astype(np.float32)
+        assert orc.nmse(ref.mul_mat_dense(aa, b_), got) <= 5e-4
