@@ -26,6 +26,7 @@
 
 #include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 using namespace mi355x;
@@ -257,6 +258,8 @@ struct mi_backend_ctx {
     // hipGraph cache (one entry: llama.cpp re-submits the same decode graph, src/llama-context.cpp:728)
     bool use_graphs = true;
     bool use_fusion = true;
+    std::unordered_map<const struct ggml_tensor *, int> uses;   // consumers per tensor in the graph being run (fusion legality)
+    int64_t inkq_max_k = 16384;          // largest k whose activation is quantized in the mat-vec prologue instead of by its own launch
     std::vector<graph_entry> graphs;     // small LRU: decode graphs differ only in n_kv (one per 32 tokens of context)
     std::vector<node_sig> cur_sig;
     uint64_t graph_tick = 0;
@@ -264,7 +267,7 @@ struct mi_backend_ctx {
     struct ggml_backend_mi355x_counters cnt = {};
 
     // "profile" option: every quantized mat-mul launch is bracketed by a hipEvent pair on this stream (eager mode)
-    struct prof_rec { int type; int64_t m, k, n; hipEvent_t e0, e1; };
+    struct prof_rec { int type; int64_t m, k, n; uint64_t bytes; hipEvent_t e0, e1; };
     bool profiling = false;
     std::vector<prof_rec> prof;
     std::vector<hipEvent_t> ev_pool;
@@ -274,9 +277,9 @@ static hipEvent_t prof_event(mi_backend_ctx * c) {
     if (!c->ev_pool.empty()) { hipEvent_t e = c->ev_pool.back(); c->ev_pool.pop_back(); return e; }
     hipEvent_t e; MI_CHECK(hipEventCreate(&e)); return e;
 }
-static void prof_begin(mi_backend_ctx * c, int type, int64_t m, int64_t k, int64_t n) {
+static void prof_begin(mi_backend_ctx * c, int type, int64_t m, int64_t k, int64_t n, uint64_t bytes) {
     if (!c->profiling) return;
-    mi_backend_ctx::prof_rec r = { type, m, k, n, prof_event(c), prof_event(c) };
+    mi_backend_ctx::prof_rec r = { type, m, k, n, bytes, prof_event(c), prof_event(c) };
     MI_CHECK(hipEventRecord(r.e0, c->stream));
     c->prof.push_back(r);
 }
@@ -484,7 +487,7 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
                 const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
                 const char * W = (const char *) a->data + (i12/r2)*a->nb[2] + (i13/r3)*a->nb[3];
                 float * d = (float *) ((char *) dst->data + i12*dst->nb[2] + i13*dst->nb[3]);
-                prof_begin(c, (int) a->type, M, K, N);
+                prof_begin(c, (int) a->type, M, K, N, (uint64_t) M*ggml_row_size(a->type, K));
                 if (N <= MMVQ_MAX_N) {
                     mul_mat_vec_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
                     c->cnt.mmvq_launches++;
@@ -526,6 +529,198 @@ static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
     c->cnt.weight_bytes += (uint64_t) n_used*n_tokens*M*ggml_row_size(as->type, K);
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// decode fusions (decode_fused.hip). Each matcher checks op, type, shape, layout AND that every skipped intermediate
+// has exactly one consumer and is not a graph output; anything else falls back to node-by-node execution.
+// ---------------------------------------------------------------------------------------------------------------
+static int next_real(const struct ggml_cgraph * g, int i) {
+    for (int j = i + 1; j < g->n_nodes; j++) {
+        if (!is_view_op(g->nodes[j]->op) && !ggml_is_empty(g->nodes[j])) return j;
+    }
+    return -1;
+}
+static int n_uses(mi_backend_ctx * c, const struct ggml_tensor * t) {
+    auto it = c->uses.find(t);
+    return it == c->uses.end() ? 0 : it->second;
+}
+static bool is_internal(mi_backend_ctx * c, const struct ggml_tensor * t) {   // safe to leave unwritten
+    return n_uses(c, t) == 1 && !(t->flags & GGML_TENSOR_FLAG_OUTPUT);
+}
+static bool is_row_vec_f32(const struct ggml_tensor * t) {   // [ne0, 1, 1, 1] contiguous f32, 16-byte aligned
+    return t->type == GGML_TYPE_F32 && t->ne[1] == 1 && t->ne[2] == 1 && t->ne[3] == 1 && t->nb[0] == 4 && ((uintptr_t) t->data % 16) == 0;
+}
+static bool fusable_mmv(const struct ggml_tensor * n) {       // quantized weights x one f32 column
+    if (n->op != GGML_OP_MUL_MAT) return false;
+    const struct ggml_tensor * a = n->src[0]; const struct ggml_tensor * b = n->src[1];
+    if (!ggml_is_quantized(a->type) || !mul_mat_vec_q_supported((int) a->type)) return false;
+    if (a->ne[2] != 1 || a->ne[3] != 1 || !is_row_vec_f32(b)) return false;
+    if (a->nb[0] != ggml_type_size(a->type)) return false;
+    return mul_mat_vec_q_fused_supported(a->ne[0], act_kind_for((int) a->type)) && a->ne[1] < (1 << 30);
+}
+
+struct mmv_chain { mmvq_group grp; int last; bool has_rope; mmvq_rope rope; const void * out_ptr; size_t out_bytes; };
+
+// the chain of nodes that starts at mat-vec node i and can run as one group of the fused launch
+static mmv_chain match_mmv_chain(mi_backend_ctx * c, const struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * n = g->nodes[i];
+    const struct ggml_tensor * a = n->src[0];
+    mmv_chain ch = {};
+    ch.grp = { (const char *) a->data, nullptr, a->nb[1], (int) a->ne[1], (int) a->type, (float *) n->data, EPI_NONE, nullptr };
+    ch.last = i; ch.has_rope = false; ch.out_ptr = n->data; ch.out_bytes = ggml_nbytes(n);
+
+    // MUL_MAT -> RESHAPE -> ROPE (NORM pairs): src/llama-model.cpp:6017-6040
+    if (i + 2 < g->n_nodes && is_internal(c, n)) {
+        struct ggml_tensor * rs = g->nodes[i + 1]; struct ggml_tensor * rp = g->nodes[i + 2];
+        if (rs->op == GGML_OP_RESHAPE && rs->src[0] == n && is_internal(c, rs) && rp->op == GGML_OP_ROPE && rp->src[0] == rs &&
+            rp->type == GGML_TYPE_F32 && ggml_is_contiguous(rp) && (rp->op_params[2] & ~0) == 0 /* NORM */ && rp->ne[2] == 1 && rp->ne[3] == 1 &&
+            rp->op_params[1] % 2 == 0 && rp->ne[0] % 2 == 0 && a->ne[1] % 2 == 0 && rp->src[1]->type == GGML_TYPE_I32) {
+            ch.grp.dst = (float *) rp->data; ch.grp.epi = EPI_ROPE; ch.last = i + 2; ch.has_rope = true;
+            ch.rope.pos = (const int32_t *) rp->src[1]->data;
+            ch.rope.freq_factors = rp->src[2] ? (const float *) rp->src[2]->data : nullptr;
+            ch.rope.head_dim = (int) rp->ne[0];
+            ch.rope.p.n_dims = rp->op_params[1]; ch.rope.p.mode = rp->op_params[2]; ch.rope.p.n_ctx_orig = rp->op_params[4];
+            ch.rope.p.freq_base = op_f32(rp, 5); ch.rope.p.freq_scale = op_f32(rp, 6); ch.rope.p.ext_factor = op_f32(rp, 7);
+            ch.rope.p.attn_factor = op_f32(rp, 8); ch.rope.p.beta_fast = op_f32(rp, 9); ch.rope.p.beta_slow = op_f32(rp, 10);
+            ch.out_ptr = rp->data; ch.out_bytes = ggml_nbytes(rp);
+            return ch;
+        }
+    }
+    const int j = next_real(g, i);
+    if (j < 0) return ch;
+    struct ggml_tensor * nx = g->nodes[j];
+    // MUL_MAT -> ADD(residual): src/llama-model.cpp:6057,6096
+    if (nx->op == GGML_OP_ADD && is_internal(c, n) && (nx->src[0] == n || nx->src[1] == n) && nx->type == GGML_TYPE_F32) {
+        const struct ggml_tensor * other = nx->src[0] == n ? nx->src[1] : nx->src[0];
+        if (other->type == GGML_TYPE_F32 && ggml_are_same_shape(other, n) && ggml_is_contiguous(other) && ggml_is_contiguous(nx) && ggml_are_same_shape(nx, n)) {
+            ch.grp.dst = (float *) nx->data; ch.grp.epi = EPI_ADD; ch.grp.res = (const float *) other->data; ch.last = j;
+            ch.out_ptr = nx->data; ch.out_bytes = ggml_nbytes(nx);
+            return ch;
+        }
+    }
+    // MUL_MAT(up) ; MUL_MAT(gate) -> GLU(swiglu, gate, up): src/llama-graph.cpp:646-691
+    if (fusable_mmv(nx) && nx->src[1] == n->src[1] && nx->src[0]->type == a->type && ggml_are_same_shape(nx->src[0], a) &&
+        nx->src[0]->nb[1] == a->nb[1] && is_internal(c, n) && is_internal(c, nx)) {
+        const int j2 = next_real(g, j);
+        if (j2 > 0) {
+            struct ggml_tensor * gl = g->nodes[j2];
+            if (gl->op == GGML_OP_GLU && ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU && gl->op_params[1] == 0 && gl->src[0] == nx && gl->src[1] == n &&
+                gl->type == GGML_TYPE_F32 && ggml_is_contiguous(gl)) {
+                ch.grp.W = (const char *) nx->src[0]->data;   // gate
+                ch.grp.W2 = (const char *) a->data;           // up
+                ch.grp.dst = (float *) gl->data; ch.grp.epi = EPI_GLU; ch.last = j2;
+                ch.out_ptr = gl->data; ch.out_bytes = ggml_nbytes(gl);
+                return ch;
+            }
+        }
+    }
+    return ch;
+}
+
+// run the mat-vec at node i together with the mat-vecs that directly follow it on the same activation; returns nodes consumed (0 = not fused)
+static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * n = g->nodes[i];
+    if (!fusable_mmv(n)) return 0;
+    const struct ggml_tensor * b = n->src[1];
+    const int kind = act_kind_for((int) n->src[0]->type);
+    mmv_chain chains[MMVQ_MAX_GROUPS];
+    int nc = 0, last = i;
+    chains[nc++] = match_mmv_chain(c, g, i);
+    last = chains[0].last;
+    while (nc < MMVQ_MAX_GROUPS) {
+        const int j = next_real(g, last);
+        if (j < 0) break;
+        struct ggml_tensor * m = g->nodes[j];
+        if (!fusable_mmv(m) || m->src[1] != b || act_kind_for((int) m->src[0]->type) != kind) break;
+        mmv_chain ch = match_mmv_chain(c, g, j);
+        if (ch.has_rope && chains[0].has_rope && memcmp(&ch.rope, &chains[0].rope, sizeof(ch.rope)) != 0) break;   // one rope descriptor per launch
+        // groups run concurrently: no output may alias another group's output, residual, or the shared activation
+        bool ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, b->data, ggml_nbytes(b));
+        for (int q = 0; q < nc && ok; q++) {
+            ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, chains[q].out_ptr, chains[q].out_bytes);
+            if (ok && chains[q].grp.res) ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, chains[q].grp.res, (size_t) chains[q].grp.m*4);
+            if (ok && ch.grp.res)       ok = !ranges_overlap(chains[q].out_ptr, chains[q].out_bytes, ch.grp.res, (size_t) ch.grp.m*4);
+        }
+        // ... nor may any node between the groups read/write what the hoisted group writes (none: the groups are adjacent up to view ops)
+        if (!ok) break;
+        chains[nc++] = ch;
+        last = ch.last;
+    }
+    mmvq_group grp[MMVQ_MAX_GROUPS];
+    const mmvq_rope * rope = nullptr;
+    uint64_t wbytes = 0;
+    for (int q = 0; q < nc; q++) {
+        grp[q] = chains[q].grp;
+        if (chains[q].has_rope) rope = &chains[q].rope;
+        wbytes += (uint64_t) grp[q].m*grp[q].row_stride*(grp[q].epi == EPI_GLU ? 2 : 1);
+    }
+    const int64_t K = n->src[0]->ne[0];
+    const bool cached = c->aq.valid && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == 1 && c->aq.n_outer == 1 && c->aq.kind == kind;
+    if (c->profiling) prof_begin(c, grp[0].type, nc == 1 && grp[0].epi != EPI_GLU ? grp[0].m : -(int64_t)(wbytes/1024), K, 1, wbytes);   // m < 0: grouped launch, |m| = KiB of weights
+    if (cached || K > c->inkq_max_k) {
+        const act_q8 q = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);
+        mul_mat_vec_q_fused(grp, nc, K, &q, nullptr, kind, rope, c->stream);
+    } else {
+        mul_mat_vec_q_fused(grp, nc, K, nullptr, (const float *) b->data, kind, rope, c->stream);   // quantize in the prologue
+    }
+    if (c->profiling) prof_end(c);
+    c->cnt.mmvq_launches++; c->cnt.kernels_launched++; c->cnt.weight_bytes += wbytes;
+    return last - i + 1;
+}
+
+// SET_ROWS(k) immediately followed by SET_ROWS(v as [1, N] element scatter), f32 -> f16 (src/llama-kv-cache-unified.cpp:1123,1157-1167)
+static int try_fused_kv_store(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * sk = g->nodes[i];
+    const int j = next_real(g, i);
+    if (j < 0) return 0;
+    struct ggml_tensor * sv = g->nodes[j];
+    if (sv->op != GGML_OP_SET_ROWS) return 0;
+    const struct ggml_tensor * ks = sk->src[0]; const struct ggml_tensor * ki = sk->src[1];
+    const struct ggml_tensor * vs = sv->src[0]; const struct ggml_tensor * vi = sv->src[1];
+    if (sk->type != GGML_TYPE_F16 || sv->type != GGML_TYPE_F16 || ks->type != GGML_TYPE_F32 || vs->type != GGML_TYPE_F32) return 0;
+    if (ki->type != GGML_TYPE_I64 || vi->type != GGML_TYPE_I64 || !ggml_is_contiguous(ki) || !ggml_is_contiguous(vi)) return 0;
+    if (ks->ne[2] != 1 || ks->ne[3] != 1 || vs->ne[2] != 1 || vs->ne[3] != 1 || ks->nb[0] != 4 || sk->nb[0] != 2) return 0;
+    if (vs->ne[0] != 1 || vs->nb[1] != 4 || sv->ne[0] != 1 || sv->nb[1] != 2) return 0;
+    if (ks->ne[0]*ks->ne[1] + vs->ne[1] >= (1ll << 31)) return 0;
+    kv_store_f16((const float *) ks->data, ks->nb[1], (const int64_t *) ki->data, sk->data, sk->nb[1], ks->ne[0], ks->ne[1],
+                 (const float *) vs->data, (const int64_t *) vi->data, sv->data, vs->ne[1], c->stream);
+    c->cnt.kernels_launched++;
+    return j - i + 1;
+}
+
+// MUL_MAT(k, q) -> SOFT_MAX -> MUL_MAT(v, kq) -> PERMUTE -> CONT (src/llama-graph.cpp:1283-1330)
+static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * kq = g->nodes[i];
+    const struct ggml_tensor * k = kq->src[0]; const struct ggml_tensor * q = kq->src[1];
+    if (k->type != GGML_TYPE_F16 || q->type != GGML_TYPE_F32 || k->ne[3] != 1 || q->ne[3] != 1) return 0;
+    const int64_t hd = k->ne[0], n_kv = k->ne[1], n_head_kv = k->ne[2], T = q->ne[1], n_head = q->ne[2];
+    if (T > 8 || !attn_decode_supported(hd, n_kv) || n_head % n_head_kv != 0) return 0;
+    if (k->nb[0] != 2 || q->nb[0] != 4 || k->nb[1] % 16 || k->nb[2] % 16 || (uintptr_t) k->data % 16 || q->nb[1] % 16 || q->nb[2] % 16 || (uintptr_t) q->data % 16) return 0;
+    const int j1 = next_real(g, i); if (j1 < 0) return 0;
+    struct ggml_tensor * sm = g->nodes[j1];
+    if (sm->op != GGML_OP_SOFT_MAX || sm->src[0] != kq || op_f32(sm, 1) != 0.0f || !is_internal(c, kq)) return 0;
+    const struct ggml_tensor * mask = sm->src[1];
+    if (mask && (mask->ne[0] != n_kv || mask->ne[2] != 1 || mask->ne[3] != 1 || !(mask->type == GGML_TYPE_F32 || mask->type == GGML_TYPE_F16))) return 0;
+    const int j2 = next_real(g, j1); if (j2 < 0) return 0;
+    struct ggml_tensor * kqv = g->nodes[j2];
+    if (kqv->op != GGML_OP_MUL_MAT || kqv->src[1] != sm || !is_internal(c, sm)) return 0;
+    const struct ggml_tensor * v = kqv->src[0];
+    if (v->type != GGML_TYPE_F16 || v->nb[0] != 2 || v->ne[0] != n_kv || v->ne[1] != hd || v->ne[2] != n_head_kv || v->ne[3] != 1) return 0;
+    // PERMUTE(0,2,1,3) view then CONT into [hd*n_head, T]
+    const int j3 = next_real(g, j2); if (j3 < 0) return 0;
+    struct ggml_tensor * ct = g->nodes[j3];
+    if (ct->op != GGML_OP_CONT || !is_internal(c, kqv)) return 0;
+    const struct ggml_tensor * pm = ct->src[0];
+    if (pm->op != GGML_OP_PERMUTE || pm->src[0] != kqv || !is_internal(c, pm)) return 0;
+    if (pm->ne[0] != hd || pm->ne[1] != n_head || pm->ne[2] != T || pm->ne[3] != 1) return 0;
+    if (ct->type != GGML_TYPE_F32 || !ggml_is_contiguous(ct) || ggml_nelements(ct) != hd*n_head*T) return 0;
+    attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2],
+                mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, mask && mask->type == GGML_TYPE_F16,
+                sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
+                hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream);
+    c->cnt.kernels_launched++;
+    return j3 - i + 1;
+}
+
 // returns the number of graph nodes consumed (>= 1)
 static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * node = g->nodes[i];
@@ -534,6 +729,16 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     const struct ggml_tensor * s1 = node->src[1];
 
     int consumed = 1;
+    bool fresh_aq = false;   // this step produced the cached quantized activations itself
+    if (c->use_fusion) {
+        int f = 0;
+        if (node->op == GGML_OP_MUL_MAT) { f = try_fused_mmv(c, g, i); if (!f) f = try_fused_attn(c, g, i); }
+        else if (node->op == GGML_OP_SET_ROWS) f = try_fused_kv_store(c, g, i);
+        if (f) {
+            consumed = f;
+            goto done;
+        }
+    }
     switch (node->op) {
         case GGML_OP_MUL_MAT:    op_mul_mat(c, node); break;
         case GGML_OP_MUL_MAT_ID: op_mul_mat_id(c, node); break;
@@ -551,6 +756,25 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                     }
                     if (only_reader && w->type == GGML_TYPE_F32 && w->nb[0] == sizeof(float) && ggml_are_same_shape(node, mul) &&
                         ggml_can_repeat(w, node) && mul->nb[0] == sizeof(float)) {
+                        // ... and when a quantized mat-mul reads the result next, quantize it in the same kernel
+                        const int jn = next_real(g, i + 1);
+                        const struct ggml_tensor * mm = jn > 0 ? g->nodes[jn] : nullptr;
+                        if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&
+                            act_kind_for((int) mm->src[0]->type) > 0 && node->ne[0] % 256 == 0 && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 &&
+                            w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] && s0->nb[0] == 4 &&
+                            ((uintptr_t) s0->data % 16) == 0 && (s0->nb[1] % 16) == 0 && ((uintptr_t) mul->data % 16) == 0 && (mul->nb[1] % 16) == 0 &&
+                            ((uintptr_t) w->data % 16) == 0) {
+                            const int kind = act_kind_for((int) mm->src[0]->type);
+                            const act_q8 q = act_q8_carve(c->scratch, kind, node->ne[0], node->ne[1]);
+                            rms_norm_mul_quant((const float *) s0->data, s0->nb[1], (const float *) w->data, (float *) mul->data, mul->nb[1], q,
+                                               node->ne[0], node->ne[1], op_f32(node, 0), c->stream);
+                            c->aq = { mul->data, node->ne[0], node->ne[1], 1, mul->nb[1], 0, kind, q, true,
+                                      (size_t)(node->ne[1] - 1)*mul->nb[1] + (size_t) node->ne[0]*4 };
+                            c->cnt.kernels_launched++; c->cnt.act_quant_launches++;
+                            consumed = 2;
+                            fresh_aq = true;
+                            break;
+                        }
                         rms_norm_mul(desc(s0), desc(w), nullptr, desc(mul), op_f32(node, 0), c->stream);
                         c->cnt.kernels_launched++;
                         consumed = 2;
@@ -599,10 +823,11 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             GGML_ABORT("MI355X backend: graph_compute met unsupported op %s (supports_op should have refused it)", ggml_op_name(node->op));
     }
 
+done:
     // any write into the memory the cached quantized activations were made from invalidates them
     for (int j = i; j < i + consumed; j++) {
         const struct ggml_tensor * w = g->nodes[j];
-        if (c->aq.valid && w->data && ranges_overlap(w->data, ggml_nbytes(w), c->aq.data, c->aq.span)) {
+        if (c->aq.valid && !fresh_aq && w->data && ranges_overlap(w->data, ggml_nbytes(w), c->aq.data, c->aq.span)) {
             c->aq.valid = false;
         }
     }
@@ -612,6 +837,12 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
 
 static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
     c->aq.valid = false;
+    c->uses.clear();
+    if (c->use_fusion) {
+        for (int i = 0; i < g->n_nodes; i++) {
+            for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[i]->src[s]) c->uses[g->nodes[i]->src[s]]++;
+        }
+    }
     for (int i = 0; i < g->n_nodes; ) i += compute_node(c, g, i);
     c->aq.valid = false;
 }
@@ -923,6 +1154,7 @@ ggml_backend_t ggml_backend_mi355x_init(int device) {
     MI_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->use_fusion = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_INKQ_MAX_K")) c->inkq_max_k = atoll(e);
     ggml_backend_t backend = new ggml_backend{ mi_guid(), mi_backend_iface, &d.dev, c };
     return backend;
 }
@@ -946,6 +1178,7 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     if (strcmp(key, "graphs") == 0) { c->use_graphs = value != 0; return 0; }
     if (strcmp(key, "profile") == 0) { c->profiling = value != 0; return 0; }
+    if (strcmp(key, "inkq_max_k") == 0) { c->inkq_max_k = value; MI_CHECK(hipStreamSynchronize(c->stream)); drop_graphs(c); return 0; }
     if (strcmp(key, "fusion") == 0) {
         c->use_fusion = value != 0;
         MI_CHECK(hipStreamSynchronize(c->stream));
@@ -971,7 +1204,7 @@ int ggml_backend_mi355x_get_profile(ggml_backend_t backend, struct ggml_backend_
         for (; j < n; j++) if (out[j].type == r.type && out[j].m == r.m && out[j].k == r.k && out[j].n == r.n) break;
         if (j == n) {
             if (n == cap) continue;
-            out[n] = { r.type, (int32_t) r.n, r.m, r.k, 0, 0.0, (uint64_t) r.m*ggml_row_size((enum ggml_type) r.type, r.k) };
+            out[n] = { r.type, (int32_t) r.n, r.m, r.k, 0, 0.0, r.bytes };
             n++;
         }
         out[j].launches++; out[j].total_ms += ms;

@@ -92,6 +92,37 @@ void rope(const tensor_desc & src, const int32_t * pos, const float * freq_facto
 void soft_max(const tensor_desc & src, const tensor_desc * mask, const float * sinks, const tensor_desc & dst,
               float scale, float max_bias, hipStream_t stream);
 
+// ---- fused decode kernels (decode_fused.hip): same arithmetic as the node-by-node kernels, fewer launches -----
+// RMS_NORM * w -> f32 row y AND its quantized form q (rows of ne0 floats, ne0 % 256 == 0)
+void rms_norm_mul_quant(const float * x, size_t x_stride, const float * w, float * y, size_t y_stride, const act_q8 & q,
+                        int64_t ne0, int64_t nrows, float eps, hipStream_t stream);
+// swiglu(g, u) = silu(g)*u -> f32 row y AND its quantized form q
+void swiglu_quant(const float * g, size_t g_stride, const float * u, size_t u_stride, float * y, size_t y_stride, const act_q8 & q,
+                  int64_t ne0, int64_t nrows, hipStream_t stream);
+// SET_ROWS(k) + SET_ROWS(v, element scatter) into the f16 cache, one launch
+void kv_store_f16(const float * k_src, size_t k_src_nb1, const int64_t * k_idx, void * k_dst, size_t k_dst_nb1, int64_t k_ne0, int64_t k_rows,
+                  const float * v_src, const int64_t * v_idx, void * v_dst, int64_t v_n, hipStream_t stream);
+// K.q -> softmax -> V^T.p -> [hd*n_head, T] for T query tokens over the f16 cache
+bool attn_decode_supported(int64_t head_dim, int64_t n_kv);
+void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
+                 const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
+                 int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream);
+
+// grouped mat-vec (n = 1): up to MMVQ_MAX_GROUPS weight tensors that share one activation vector, each with an epilogue
+constexpr int MMVQ_MAX_GROUPS = 3;
+enum mmvq_epilogue { EPI_NONE = 0, EPI_ADD = 1, EPI_ROPE = 2, EPI_GLU = 3 };
+struct mmvq_group {
+    const char * W; const char * W2;   // W2: the second weight tensor of EPI_GLU (dst = silu(W.x) * (W2.x))
+    size_t row_stride; int m; int type;
+    float * dst; int epi;
+    const float * res;                 // EPI_ADD: dst[row] = W.x + res[row]
+};
+struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; };   // EPI_ROPE (NORM pairs)
+bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
+// activation: either already quantized (`act`) or f32 `x_f32` to be quantized in the kernel prologue
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const act_q8 * act, const float * x_f32, int act_kind,
+                         const mmvq_rope * rope, hipStream_t stream);
+
 // ---- test / bench support ------------------------------------------------------------------
 // raw streaming read of `bytes` (16 B/lane, nontemporal) — measures the achievable HBM rate on the box
 void hbm_read_probe(const void * p, size_t bytes, unsigned * sink, hipStream_t stream);

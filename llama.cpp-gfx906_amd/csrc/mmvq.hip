@@ -19,267 +19,9 @@
 //   * the int8 activation vector (shared by every row) is staged ONCE per workgroup into LDS for
 //     n == 1 (k + k/16 bytes), or read through L1/L2 for 2 <= n <= 8.
 //   * per-lane partial sums are reduced with DPP row operations + v_readlane (dev_common.h).
-#include "blocks.h"
-#include "dev_common.h"
-#include "kernels.h"
+#include "mmvq_core.h"
 
 namespace mi355x {
-
-// activation view handed to the fragment loaders (pointers may be LDS or global; everything is
-// force-inlined so the address space is resolved at compile time)
-struct act_view {
-    const int8_t  * qs;     // [k]
-    const float   * d;      // [k/32] or [k/256]
-    const int16_t * bs;     // [k/32] or [k/16]
-};
-
-static __device__ __forceinline__ int4v lds_or_global_b128(const int8_t * p) { return *(const int4v *) p; }
-static __device__ __forceinline__ int2v lds_or_global_b64 (const int8_t * p) { return *(const int2v *) p; }
-
-static __device__ __forceinline__ int dot16(const int4v & w, const int4v & a) {
-    return dot4(w.x, a.x, dot4(w.y, a.y, dot4(w.z, a.z, dot4(w.w, a.w, 0))));
-}
-
-// 6-bit scale/min pair for sub-blocks (2g, 2g+1) of a K-quant header — gguf-py/gguf/quants.py:479-501.
-// s0,s1,s2 = the 12 scale bytes as 3 little-endian dwords. Returns sc packed as (sc[2g] | sc[2g+1]<<8), same for m.
-static __device__ __forceinline__ void k4_scales(uint32_t s0, uint32_t s1, uint32_t s2, int g, uint32_t & sc2, uint32_t & m2) {
-    const int sh = (g & 1)*16;
-    const uint32_t a0 = (s0 >> sh) & 0xFFFF, a1 = (s1 >> sh) & 0xFFFF, a2 = (s2 >> sh) & 0xFFFF;
-    if (g < 2) {
-        sc2 = a0 & 0x3F3F;
-        m2  = a1 & 0x3F3F;
-    } else {
-        sc2 = (a2 & 0x0F0F)        | ((a0 >> 2) & 0x3030);
-        m2  = ((a2 >> 4) & 0x0F0F) | ((a1 >> 2) & 0x3030);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// per-type fragments. LPB = lanes per block; `slot` = lane % LPB; `ib` = block index inside the row
-// ------------------------------------------------------------------------------------------------
-template <int TYPE> struct mmvq_t;
-
-// ---- Q4_K ---------------------------------------------------------------------------------------
-template <> struct mmvq_t<T_Q4_K> {
-    static constexpr int LPB = 8, BLOCK_BYTES = 144, QK = 256, ACT = T_Q8_K;
-    struct afrag { int4v lo, hi; float d8; int bs_lo, bs_hi; };
-    struct wfrag { int4v hdr, qs; };
-    static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int slot) {
-        const int g = slot >> 1, h = slot & 1;
-        afrag f;
-        const int8_t * p = a.qs + ib*256 + 64*g + 16*h;
-        f.lo = lds_or_global_b128(p);
-        f.hi = lds_or_global_b128(p + 32);
-        f.d8 = a.d[ib];
-        f.bs_lo = a.bs[ib*16 + 4*g + h];
-        f.bs_hi = a.bs[ib*16 + 4*g + 2 + h];
-        return f;
-    }
-    static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int slot) {
-        const char * b = row + ib*BLOCK_BYTES;
-        wfrag w;
-        w.hdr = *(const int4v *) b;                       // d, dmin, 12 scale bytes: shared by the 8 lanes (one 16-byte line)
-        w.qs  = ld_b128_nt(b + 16 + 16*slot);
-        return w;
-    }
-    static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int slot) {
-        const int g = slot >> 1;
-        uint32_t sc2, m2;
-        k4_scales((uint32_t) w.hdr.y, (uint32_t) w.hdr.z, (uint32_t) w.hdr.w, g, sc2, m2);
-        int4v lo, hi;
-        lo.x = w.qs.x & 0x0F0F0F0F; hi.x = (w.qs.x >> 4) & 0x0F0F0F0F;
-        lo.y = w.qs.y & 0x0F0F0F0F; hi.y = (w.qs.y >> 4) & 0x0F0F0F0F;
-        lo.z = w.qs.z & 0x0F0F0F0F; hi.z = (w.qs.z >> 4) & 0x0F0F0F0F;
-        lo.w = w.qs.w & 0x0F0F0F0F; hi.w = (w.qs.w >> 4) & 0x0F0F0F0F;
-        const int isum = (int)(sc2 & 0xFF)*dot16(lo, a.lo) + (int)(sc2 >> 8)*dot16(hi, a.hi);
-        const int msum = (int)(m2  & 0xFF)*a.bs_lo        + (int)(m2  >> 8)*a.bs_hi;
-        const float d    = f16_bits_to_f32((uint16_t)((uint32_t) w.hdr.x & 0xFFFF));
-        const float dmin = f16_bits_to_f32((uint16_t)((uint32_t) w.hdr.x >> 16));
-        return (d*a.d8)*(float) isum - (dmin*a.d8)*(float) msum;
-    }
-};
-
-// ---- Q5_K ---------------------------------------------------------------------------------------
-template <> struct mmvq_t<T_Q5_K> {
-    static constexpr int LPB = 8, BLOCK_BYTES = 176, QK = 256, ACT = T_Q8_K;
-    typedef mmvq_t<T_Q4_K>::afrag afrag;
-    struct wfrag { int4v hdr, qh, qs; };
-    static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int slot) { return mmvq_t<T_Q4_K>::load_a(a, ib, slot); }
-    static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int slot) {
-        const char * b = row + ib*BLOCK_BYTES;
-        wfrag w;
-        w.hdr = *(const int4v *) b;
-        w.qh  = *(const int4v *) (b + 16 + 16*(slot & 1));  // high bits for byte positions 16h..16h+15, all 8 sub-blocks
-        w.qs  = ld_b128_nt(b + 48 + 16*slot);
-        return w;
-    }
-    static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int slot) {
-        const int g = slot >> 1;
-        uint32_t sc2, m2;
-        k4_scales((uint32_t) w.hdr.y, (uint32_t) w.hdr.z, (uint32_t) w.hdr.w, g, sc2, m2);
-        const int b0 = 2*g, b1 = 2*g + 1;   // bit of qh holding the 5th bit of sub-blocks 2g / 2g+1
-        int4v lo, hi;
-#define MI_Q5(c) \
-        lo.c = (w.qs.c & 0x0F0F0F0F)        | ((((uint32_t) w.qh.c >> b0) & 0x01010101) << 4); \
-        hi.c = ((w.qs.c >> 4) & 0x0F0F0F0F) | ((((uint32_t) w.qh.c >> b1) & 0x01010101) << 4);
-        MI_Q5(x) MI_Q5(y) MI_Q5(z) MI_Q5(w)
-#undef MI_Q5
-        const int isum = (int)(sc2 & 0xFF)*dot16(lo, a.lo) + (int)(sc2 >> 8)*dot16(hi, a.hi);
-        const int msum = (int)(m2  & 0xFF)*a.bs_lo        + (int)(m2  >> 8)*a.bs_hi;
-        const float d    = f16_bits_to_f32((uint16_t)((uint32_t) w.hdr.x & 0xFFFF));
-        const float dmin = f16_bits_to_f32((uint16_t)((uint32_t) w.hdr.x >> 16));
-        return (d*a.d8)*(float) isum - (dmin*a.d8)*(float) msum;
-    }
-};
-
-// ---- Q6_K ---------------------------------------------------------------------------------------
-// lane slot j: half n = j>>2 (128 elements each), l0 = 8*(j&3): the lane owns l = l0..l0+7 of that half, i.e.
-// elements 128n + {0,32,64,96} + l (quants.py:554-572): ql[64n+l] lo/hi nibble, ql[64n+32+l] lo/hi nibble,
-// qh[32n+l] 2-bit fields. 24 bytes of quants per lane.
-template <> struct mmvq_t<T_Q6_K> {
-    static constexpr int LPB = 8, BLOCK_BYTES = 210, QK = 256, ACT = T_Q8_K;
-    struct afrag { int2v a[4]; int s[4]; float d8; };   // s[i] = sum of the 8 int8 of a[i] (for the -32 offset)
-    struct wfrag { int2v qla, qlb, qh; int2v sc; uint32_t d; };
-    static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int slot) {
-        const int n = slot >> 2, l0 = 8*(slot & 3);
-        afrag f;
-        const int8_t * p = a.qs + ib*256 + 128*n + l0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            f.a[i] = lds_or_global_b64(p + 32*i);
-            f.s[i] = dot4(0x01010101, f.a[i].x, dot4(0x01010101, f.a[i].y, 0));
-        }
-        f.d8 = a.d[ib];
-        return f;
-    }
-    static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int slot) {
-        const int n = slot >> 2, l0 = 8*(slot & 3);
-        const char * b = row + ib*BLOCK_BYTES;   // only 2-byte aligned: unaligned-mode global loads
-        wfrag w;
-        w.qla = ld_b64(b + 64*n + l0);
-        w.qlb = ld_b64(b + 64*n + 32 + l0);
-        w.qh  = ld_b64(b + 128 + 32*n + l0);
-        w.sc  = ld_b64(b + 192 + 8*n);           // scales[8n .. 8n+7]
-        w.d   = ld_u16(b + 208);
-        return w;
-    }
-    static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int slot) {
-        const int is = (slot & 3) >> 1;          // l0/16
-        // the four scales this lane needs are bytes is, is+2, is+4, is+6 of sc
-        const uint32_t sx = (uint32_t) w.sc.x >> (8*is), sy = (uint32_t) w.sc.y >> (8*is);
-        const int sc0 = (int8_t)(sx & 0xFF), sc1 = (int8_t)((sx >> 16) & 0xFF), sc2 = (int8_t)(sy & 0xFF), sc3 = (int8_t)((sy >> 16) & 0xFF);
-        int acc[4];
-#define MI_Q6(c, A0, A1, A2, A3) { \
-        const uint32_t qa = (uint32_t) w.qla.c, qb = (uint32_t) w.qlb.c, qh = (uint32_t) w.qh.c; \
-        const int v0 = (int)((qa & 0x0F0F0F0F)        | ((qh << 4) & 0x30303030)); \
-        const int v1 = (int)((qb & 0x0F0F0F0F)        | ((qh << 2) & 0x30303030)); \
-        const int v2 = (int)(((qa >> 4) & 0x0F0F0F0F) | ( qh       & 0x30303030)); \
-        const int v3 = (int)(((qb >> 4) & 0x0F0F0F0F) | ((qh >> 2) & 0x30303030)); \
-        A0 = dot4(v0, a.a[0].c, A0); A1 = dot4(v1, a.a[1].c, A1); A2 = dot4(v2, a.a[2].c, A2); A3 = dot4(v3, a.a[3].c, A3); }
-        acc[0] = acc[1] = acc[2] = acc[3] = 0;
-        MI_Q6(x, acc[0], acc[1], acc[2], acc[3])
-        MI_Q6(y, acc[0], acc[1], acc[2], acc[3])
-#undef MI_Q6
-        // sum (q-32)*a = sum q*a - 32*sum a
-        const int isum = sc0*(acc[0] - 32*a.s[0]) + sc1*(acc[1] - 32*a.s[1]) + sc2*(acc[2] - 32*a.s[2]) + sc3*(acc[3] - 32*a.s[3]);
-        return (f16_bits_to_f32((uint16_t) w.d)*a.d8)*(float) isum;
-    }
-};
-
-// ---- Q8_0 ---------------------------------------------------------------------------------------
-template <> struct mmvq_t<T_Q8_0> {
-    static constexpr int LPB = 2, BLOCK_BYTES = 34, QK = 32, ACT = T_Q8_0;
-    struct afrag { int4v a; float d8; };
-    struct wfrag { int4v qs; uint32_t d; };
-    static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int slot) {
-        afrag f;
-        f.a = lds_or_global_b128(a.qs + ib*32 + 16*slot);
-        f.d8 = a.d[ib];
-        return f;
-    }
-    static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int slot) {
-        const char * b = row + ib*BLOCK_BYTES;
-        wfrag w;
-        w.qs = ld_b128(b + 2 + 16*slot);
-        w.d  = ld_u16(b);
-        return w;
-    }
-    static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int) {
-        return (float) dot16(w.qs, a.a)*(f16_bits_to_f32((uint16_t) w.d)*a.d8);
-    }
-};
-
-// ---- Q4_0 ---------------------------------------------------------------------------------------
-template <> struct mmvq_t<T_Q4_0> {
-    static constexpr int LPB = 1, BLOCK_BYTES = 18, QK = 32, ACT = T_Q8_0;
-    struct afrag { int4v lo, hi; float d8; int bs; };
-    struct wfrag { int4v qs; uint32_t d; };
-    static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int) {
-        afrag f;
-        f.lo = lds_or_global_b128(a.qs + ib*32);
-        f.hi = lds_or_global_b128(a.qs + ib*32 + 16);
-        f.d8 = a.d[ib];
-        f.bs = a.bs[ib];
-        return f;
-    }
-    static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int) {
-        const char * b = row + ib*BLOCK_BYTES;
-        wfrag w;
-        w.qs = ld_b128(b + 2);
-        w.d  = ld_u16(b);
-        return w;
-    }
-    static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int) {
-        int4v lo, hi;
-        lo.x = w.qs.x & 0x0F0F0F0F; hi.x = (w.qs.x >> 4) & 0x0F0F0F0F;
-        lo.y = w.qs.y & 0x0F0F0F0F; hi.y = (w.qs.y >> 4) & 0x0F0F0F0F;
-        lo.z = w.qs.z & 0x0F0F0F0F; hi.z = (w.qs.z >> 4) & 0x0F0F0F0F;
-        lo.w = w.qs.w & 0x0F0F0F0F; hi.w = (w.qs.w >> 4) & 0x0F0F0F0F;
-        const int sumi = dot16(lo, a.lo) + dot16(hi, a.hi) - 8*a.bs;      // sum (q-8)*a
-        return ((float) sumi*f16_bits_to_f32((uint16_t) w.d))*a.d8;
-    }
-};
-
-// ---- MXFP4 --------------------------------------------------------------------------------------
-// 16-entry int8 lookup (quants.py:659) for 4 packed 4-bit indices with two v_perm_b32 + a bit-select
-static __device__ __forceinline__ int mxfp4_lut4(uint32_t idx) {
-    // kvalues = 0,1,2,3,4,6,8,12 | 0,-1,-2,-3,-4,-6,-8,-12
-    const uint32_t pos_lo = 0x03020100u, pos_hi = 0x0C080604u, neg_lo = 0xFDFEFF00u, neg_hi = 0xF4F8FAFCu;
-    const uint32_t sel = idx & 0x07070707u;
-    const uint32_t p = __builtin_amdgcn_perm(pos_hi, pos_lo, sel);
-    const uint32_t n = __builtin_amdgcn_perm(neg_hi, neg_lo, sel);
-    const uint32_t m = ((idx >> 3) & 0x01010101u)*0xFFu;   // 0xFF in bytes whose index has bit 3 set
-    return (int)((p & ~m) | (n & m));
-}
-
-template <> struct mmvq_t<T_MXFP4> {
-    static constexpr int LPB = 1, BLOCK_BYTES = 17, QK = 32, ACT = T_Q8_0;
-    struct afrag { int4v lo, hi; float d8; };
-    struct wfrag { int4v qs; uint32_t e; };
-    static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int) {
-        afrag f;
-        f.lo = lds_or_global_b128(a.qs + ib*32);
-        f.hi = lds_or_global_b128(a.qs + ib*32 + 16);
-        f.d8 = a.d[ib];
-        return f;
-    }
-    static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int) {
-        const char * b = row + ib*BLOCK_BYTES;
-        wfrag w;
-        w.qs = ld_b128(b + 1);
-        w.e  = *(const uint8_t *) b;
-        return w;
-    }
-    static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int) {
-        int4v lo, hi;
-        lo.x = mxfp4_lut4((uint32_t) w.qs.x); hi.x = mxfp4_lut4((uint32_t) w.qs.x >> 4);
-        lo.y = mxfp4_lut4((uint32_t) w.qs.y); hi.y = mxfp4_lut4((uint32_t) w.qs.y >> 4);
-        lo.z = mxfp4_lut4((uint32_t) w.qs.z); hi.z = mxfp4_lut4((uint32_t) w.qs.z >> 4);
-        lo.w = mxfp4_lut4((uint32_t) w.qs.w); hi.w = mxfp4_lut4((uint32_t) w.qs.w >> 4);
-        const int sumi = dot16(lo, a.lo) + dot16(hi, a.hi);
-        return (a.d8*e8m0_to_f32_half(w.e))*(float) sumi;
-    }
-};
 
 // ------------------------------------------------------------------------------------------------
 // the kernel

@@ -10,6 +10,7 @@
 // HBM-bound elementwise work: 16 B/lane loads, DPP reductions inside 8-lane groups / the wave, no LDS.
 #include "dev_common.h"
 #include "kernels.h"
+#include "quant_core.h"
 
 namespace mi355x {
 
@@ -49,18 +50,13 @@ __global__ void __launch_bounds__(256) k_quantize_q8_0(const float * __restrict_
     const bool valid = i0 < k;   // k % 32 == 0, so an 8-lane group is valid or invalid as a whole
     float4v v = { 0.f, 0.f, 0.f, 0.f };
     if (valid) v = __builtin_bit_cast(float4v, ld_b128((const char *) x + roff + i0*4));   // rows may be only 4-byte aligned views
-    float amax = fmaxf(fmaxf(fabsf(v.x), fabsf(v.y)), fmaxf(fabsf(v.z), fabsf(v.w)));
-    amax = group8_max(amax);
-    const float dd = amax / 127.0f;
-    const float id = dd != 0.0f ? 1.0f/dd : 0.0f;
-    const int q0 = (int) roundf(v.x*id), q1 = (int) roundf(v.y*id), q2 = (int) roundf(v.z*id), q3 = (int) roundf(v.w*id);
-    const int sum = group8_sum_i(q0 + q1 + q2 + q3);
+    float dd; int sum;
+    const uint32_t packed = quant_frag_q8_0(v, dd, sum);
     if (valid) {
-        const uint32_t packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
         *(uint32_t *) (qs + row*k + i0) = packed;
         if ((threadIdx.x & 7) == 0) {
             const int64_t ib = row*(k/32) + i0/32;
-            d[ib] = f16_bits_to_f32(f32_to_f16_bits(dd));   // the CPU path stores d as f16 and reads it back
+            d[ib] = dd;
             bsums[ib] = (int16_t) sum;
         }
     }
@@ -73,36 +69,9 @@ __global__ void __launch_bounds__(256) k_quantize_q8_K(const float * __restrict_
     const size_t roff = (size_t)(row % n_inner)*stride_inner + (size_t)(row / n_inner)*stride_outer;
     const int lane = threadIdx.x & 63;
     const int64_t blk = (int64_t) blockIdx.x*4 + (threadIdx.x >> 6);
-    const int64_t i0 = blk*256 + lane*4;
     if (blk*256 >= k) return;   // wave-uniform
-    const float4v v = __builtin_bit_cast(float4v, ld_b128((const char *) x + roff + i0*4));
-    // first element of largest magnitude, in element order (strict > keeps the first)
-    float amax = fabsf(v.x), mx = v.x;
-    if (fabsf(v.y) > amax) { amax = fabsf(v.y); mx = v.y; }
-    if (fabsf(v.z) > amax) { amax = fabsf(v.z); mx = v.z; }
-    if (fabsf(v.w) > amax) { amax = fabsf(v.w); mx = v.w; }
-    const float wmax = wave_max(amax);
-    int8_t * qrow = qs + row*k + i0;
-    const int64_t ib = row*(k/256) + blk;
-    if (wmax == 0.0f) {
-        *(uint32_t *) qrow = 0;
-        if ((lane & 3) == 0) bsums[ib*16 + (lane >> 2)] = 0;
-        if (lane == 0) d[ib] = 0.0f;
-        return;
-    }
-    const unsigned long long ball = __ballot(amax == wmax);
-    const int first = __builtin_ctzll(ball);
-    const float maxv = readlane_f(mx, first);
-    const float iscale = -127.0f/maxv;
-    int q0 = __float2int_rn(iscale*v.x), q1 = __float2int_rn(iscale*v.y), q2 = __float2int_rn(iscale*v.z), q3 = __float2int_rn(iscale*v.w);
-    q0 = min(127, q0); q1 = min(127, q1); q2 = min(127, q2); q3 = min(127, q3);
-    const uint32_t packed = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3 & 0xFF) << 24);
-    *(uint32_t *) qrow = packed;
-    int s = q0 + q1 + q2 + q3;       // 16-element bsum = 4 lanes = one DPP quad
-    s += dpp_i<0xB1>(s);
-    s += dpp_i<0x4E>(s);
-    if ((lane & 3) == 0) bsums[ib*16 + (lane >> 2)] = (int16_t) s;
-    if (lane == 0) d[ib] = 1.0f/iscale;
+    const float4v v = __builtin_bit_cast(float4v, ld_b128((const char *) x + roff + (blk*256 + lane*4)*4));
+    quant_store_chunk256<T_Q8_K>(v, (int) blk, lane, qs + row*k, d + row*(k/256), bsums + row*(k/16));
 }
 
 void quantize_act(const float * x, int64_t n_inner, size_t stride_inner, size_t stride_outer, const act_q8 & q, hipStream_t stream) {

@@ -102,10 +102,13 @@ def test_synthetic_llama_matches_oracle(ftype):
         m.free()
 
 
-def test_graph_replay_and_fusion_are_bitwise_neutral():
+def test_graph_replay_is_bitwise_neutral_and_fusion_stays_within_tolerance():
+    """hipGraph replay must not change a bit. The decode fusions keep each op's arithmetic but the fused attention
+    kernel sums V.p in a different lane order than the node-by-node kernels, so fusion on/off agree to f32 rounding,
+    amplified at most by an int8 re-quantization flip downstream (same bound as against the oracle)."""
     be = backend()
     outs = {}
-    for graphs, fusion in ((0, 0), (0, 1), (1, 1)):
+    for graphs, fusion in ((0, 0), (1, 0), (0, 1), (1, 1)):
         be.set_option("graphs", graphs); be.set_option("fusion", fusion)
         m = ls.SynthLlama(be, "tiny", "Q4_K_M", n_ctx=64, seed=5)
         be.reset_counters()
@@ -116,10 +119,16 @@ def test_graph_replay_and_fusion_are_bitwise_neutral():
             assert cnt["graph_replays"] >= 8, cnt      # single-token steps re-submit an identical graph (src/llama-context.cpp:728)
         else:
             assert cnt["graph_replays"] == 0
+        if not graphs:                                  # replays launch nothing through the op switch
+            if fusion:
+                assert cnt["kernels_launched"] < 0.6 * base_kernels, (cnt["kernels_launched"], base_kernels)
+            else:
+                base_kernels = cnt["kernels_launched"]
         m.free()
     be.set_option("graphs", 1); be.set_option("fusion", 1)
+    assert np.array_equal(outs[(0, 0)], outs[(1, 0)])
     assert np.array_equal(outs[(0, 1)], outs[(1, 1)])
-    assert np.array_equal(outs[(0, 0)], outs[(0, 1)])
+    assert orc.nmse(outs[(0, 0)], outs[(0, 1)]) <= 5e-4
 
 
 def test_kv_clear_restarts_sequence():
