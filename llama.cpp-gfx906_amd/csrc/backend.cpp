@@ -259,7 +259,6 @@ struct mi_backend_ctx {
     bool use_graphs = true;
     bool use_fusion = true;
     std::unordered_map<const struct ggml_tensor *, int> uses;   // consumers per tensor in the graph being run (fusion legality)
-    int64_t inkq_max_k = 16384;          // largest k whose activation is quantized in the mat-vec prologue instead of by its own launch
     std::vector<graph_entry> graphs;     // small LRU: decode graphs differ only in n_kv (one per 32 tokens of context)
     std::vector<node_sig> cur_sig;
     uint64_t graph_tick = 0;
@@ -597,16 +596,17 @@ static mmv_chain match_mmv_chain(mi_backend_ctx * c, const struct ggml_cgraph * 
             return ch;
         }
     }
-    // MUL_MAT(up) ; MUL_MAT(gate) -> GLU(swiglu, gate, up): src/llama-graph.cpp:646-691
+    // MUL_MAT(gate) ; MUL_MAT(up) -> GLU(swiglu, gate, up), in either graph order (the DFS of ggml_build_forward_expand puts
+    // GLU's src[0] = gate first): src/llama-graph.cpp:646-691
     if (fusable_mmv(nx) && nx->src[1] == n->src[1] && nx->src[0]->type == a->type && ggml_are_same_shape(nx->src[0], a) &&
         nx->src[0]->nb[1] == a->nb[1] && is_internal(c, n) && is_internal(c, nx)) {
         const int j2 = next_real(g, j);
         if (j2 > 0) {
             struct ggml_tensor * gl = g->nodes[j2];
-            if (gl->op == GGML_OP_GLU && ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU && gl->op_params[1] == 0 && gl->src[0] == nx && gl->src[1] == n &&
-                gl->type == GGML_TYPE_F32 && ggml_is_contiguous(gl)) {
-                ch.grp.W = (const char *) nx->src[0]->data;   // gate
-                ch.grp.W2 = (const char *) a->data;           // up
+            if (gl->op == GGML_OP_GLU && ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU && gl->op_params[1] == 0 && gl->src[1] != NULL &&
+                ((gl->src[0] == nx && gl->src[1] == n) || (gl->src[0] == n && gl->src[1] == nx)) && gl->type == GGML_TYPE_F32 && ggml_is_contiguous(gl)) {
+                ch.grp.W  = (const char *) gl->src[0]->src[0]->data;   // gate weights (silu side)
+                ch.grp.W2 = (const char *) gl->src[1]->src[0]->data;   // up weights
                 ch.grp.dst = (float *) gl->data; ch.grp.epi = EPI_GLU; ch.last = j2;
                 ch.out_ptr = gl->data; ch.out_bytes = ggml_nbytes(gl);
                 return ch;
@@ -632,6 +632,13 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         struct ggml_tensor * m = g->nodes[j];
         if (!fusable_mmv(m) || m->src[1] != b || act_kind_for((int) m->src[0]->type) != kind) break;
         mmv_chain ch = match_mmv_chain(c, g, j);
+        if (ch.grp.epi == EPI_GLU || chains[0].grp.epi == EPI_GLU) break;   // the dual (GLU) kernel runs alone
+        {   // at most two distinct weight types per launch, and only pairs that have a kernel
+            int t2 = -1; bool ok_t = true;
+            for (int q = 0; q < nc; q++) if (chains[q].grp.type != chains[0].grp.type) t2 = chains[q].grp.type;
+            if (ch.grp.type != chains[0].grp.type) { if (t2 >= 0 && t2 != ch.grp.type) ok_t = false; else ok_t = mul_mat_vec_q_fused_can_group(chains[0].grp.type, ch.grp.type); }
+            if (!ok_t) break;
+        }
         if (ch.has_rope && chains[0].has_rope && memcmp(&ch.rope, &chains[0].rope, sizeof(ch.rope)) != 0) break;   // one rope descriptor per launch
         // groups run concurrently: no output may alias another group's output, residual, or the shared activation
         bool ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, b->data, ggml_nbytes(b));
@@ -654,14 +661,9 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         wbytes += (uint64_t) grp[q].m*grp[q].row_stride*(grp[q].epi == EPI_GLU ? 2 : 1);
     }
     const int64_t K = n->src[0]->ne[0];
-    const bool cached = c->aq.valid && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == 1 && c->aq.n_outer == 1 && c->aq.kind == kind;
+    const act_q8 q = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);      // reused when the producer already quantized it
     if (c->profiling) prof_begin(c, grp[0].type, nc == 1 && grp[0].epi != EPI_GLU ? grp[0].m : -(int64_t)(wbytes/1024), K, 1, wbytes);   // m < 0: grouped launch, |m| = KiB of weights
-    if (cached || K > c->inkq_max_k) {
-        const act_q8 q = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);
-        mul_mat_vec_q_fused(grp, nc, K, &q, nullptr, kind, rope, c->stream);
-    } else {
-        mul_mat_vec_q_fused(grp, nc, K, nullptr, (const float *) b->data, kind, rope, c->stream);   // quantize in the prologue
-    }
+    mul_mat_vec_q_fused(grp, nc, K, q, rope, c->stream);
     if (c->profiling) prof_end(c);
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++; c->cnt.weight_bytes += wbytes;
     return last - i + 1;
@@ -760,7 +762,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                         const int jn = next_real(g, i + 1);
                         const struct ggml_tensor * mm = jn > 0 ? g->nodes[jn] : nullptr;
                         if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&
-                            act_kind_for((int) mm->src[0]->type) > 0 && node->ne[0] % 256 == 0 && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 &&
+                            act_kind_for((int) mm->src[0]->type) > 0 && rms_norm_mul_quant_supported(node->ne[0]) && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 &&
                             w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] && s0->nb[0] == 4 &&
                             ((uintptr_t) s0->data % 16) == 0 && (s0->nb[1] % 16) == 0 && ((uintptr_t) mul->data % 16) == 0 && (mul->nb[1] % 16) == 0 &&
                             ((uintptr_t) w->data % 16) == 0) {
@@ -1154,7 +1156,6 @@ ggml_backend_t ggml_backend_mi355x_init(int device) {
     MI_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->use_fusion = atoi(e) != 0;
-    if (const char * e = getenv("GGML_MI355X_INKQ_MAX_K")) c->inkq_max_k = atoll(e);
     ggml_backend_t backend = new ggml_backend{ mi_guid(), mi_backend_iface, &d.dev, c };
     return backend;
 }
@@ -1178,7 +1179,6 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     if (strcmp(key, "graphs") == 0) { c->use_graphs = value != 0; return 0; }
     if (strcmp(key, "profile") == 0) { c->profiling = value != 0; return 0; }
-    if (strcmp(key, "inkq_max_k") == 0) { c->inkq_max_k = value; MI_CHECK(hipStreamSynchronize(c->stream)); drop_graphs(c); return 0; }
     if (strcmp(key, "fusion") == 0) {
         c->use_fusion = value != 0;
         MI_CHECK(hipStreamSynchronize(c->stream));

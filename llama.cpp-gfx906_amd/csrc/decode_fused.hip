@@ -34,7 +34,8 @@ static __device__ __forceinline__ float block_sum4(float v, float * sh) {   // 2
 // RMS_NORM * w  -> f32 row + quantized row           (src/llama-graph.cpp:597-630 + the MUL_MAT's activation quantizer)
 // one workgroup (256 threads) per row; ne0 % 256 == 0 (Q8_K) or % 32 == 0 (Q8_0, chunks of 256 still: ne0 % 256 == 0 required)
 // ---------------------------------------------------------------------------------------------------------------
-template <int ACT>
+// CH = 256-element chunks per wave held in registers (ne0 <= CH*1024): x and w are read ONCE, all loads issued up front.
+template <int ACT, int CH>
 __global__ void __launch_bounds__(256) k_rms_norm_mul_quant(const float * __restrict__ x, size_t x_stride, const float * __restrict__ w,
                                                             float * __restrict__ y, size_t y_stride, int8_t * qs, float * d, int16_t * bs,
                                                             int ne0, float eps) {
@@ -43,28 +44,51 @@ __global__ void __launch_bounds__(256) k_rms_norm_mul_quant(const float * __rest
     const float * xr = (const float *) ((const char *) x + (size_t) row*x_stride);
     float * yr = (float *) ((char *) y + (size_t) row*y_stride);
     const int nchunk = ne0/256;
-    float ss = 0.0f;
-    for (int c = wave; c < nchunk; c += 4) {
-        const float4v v = *(const float4v *) (xr + c*256 + lane*4);
-        ss += v.x*v.x + v.y*v.y + v.z*v.z + v.w*v.w;
+    float4v xv[CH], wv[CH];
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int c = min(wave + 4*i, nchunk - 1);
+        xv[i] = *(const float4v *) (xr + c*256 + lane*4);
+        wv[i] = *(const float4v *) (w + c*256 + lane*4);
     }
+    float ss = 0.0f;
+#pragma unroll
+    for (int i = 0; i < CH; i++) if (wave + 4*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
     ss = block_sum4(ss, sh);
     const float scale = 1.0f/sqrtf(ss/(float) ne0 + eps);
     constexpr int ND = ACT == T_Q8_0 ? 32 : 256, NBS = ACT == T_Q8_0 ? 32 : 16;
     int8_t * qr = qs + (size_t) row*ne0; float * dr = d + (size_t) row*(ne0/ND); int16_t * br = bs + (size_t) row*(ne0/NBS);
-    for (int c = wave; c < nchunk; c += 4) {
-        float4v v = *(const float4v *) (xr + c*256 + lane*4);
-        const float4v ww = *(const float4v *) (w + c*256 + lane*4);
-        v.x = (v.x*scale)*ww.x; v.y = (v.y*scale)*ww.y; v.z = (v.z*scale)*ww.z; v.w = (v.w*scale)*ww.w;   // RMS_NORM then MUL: two roundings, as unfused
-        *(float4v *) (yr + c*256 + lane*4) = v;
-        quant_store_chunk256<ACT>(v, c, lane, qr, dr, br);
+#pragma unroll
+    for (int i = 0; i < CH; i++) {
+        const int c = wave + 4*i;
+        if (c < nchunk) {   // wave-uniform
+            float4v v = xv[i];
+            v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w;   // RMS_NORM then MUL: two roundings, as unfused
+            *(float4v *) (yr + c*256 + lane*4) = v;
+            quant_store_chunk256<ACT>(v, c, lane, qr, dr, br);
+        }
     }
 }
 
+// NOTE on summation order: sum(x^2) is accumulated per lane over its chunks, then DPP/LDS-reduced — a different order from
+// elem.hip's k_rms_norm (which strides by thread); both are f32 sums of the same terms (relative difference ~1e-7).
+template <int ACT>
+static void launch_rms_norm_mul_quant(const float * x, size_t x_stride, const float * w, float * y, size_t y_stride, const act_q8 & q,
+                                      int64_t ne0, int64_t nrows, float eps, hipStream_t stream) {
+    const dim3 g((unsigned) nrows), b(256);
+    const int64_t ch = (ne0/256 + 3)/4;
+    if      (ch <= 1) hipLaunchKernelGGL((k_rms_norm_mul_quant<ACT, 1>), g, b, 0, stream, x, x_stride, w, y, y_stride, q.qs, q.d, q.bsums, (int) ne0, eps);
+    else if (ch <= 2) hipLaunchKernelGGL((k_rms_norm_mul_quant<ACT, 2>), g, b, 0, stream, x, x_stride, w, y, y_stride, q.qs, q.d, q.bsums, (int) ne0, eps);
+    else if (ch <= 4) hipLaunchKernelGGL((k_rms_norm_mul_quant<ACT, 4>), g, b, 0, stream, x, x_stride, w, y, y_stride, q.qs, q.d, q.bsums, (int) ne0, eps);
+    else              hipLaunchKernelGGL((k_rms_norm_mul_quant<ACT, 8>), g, b, 0, stream, x, x_stride, w, y, y_stride, q.qs, q.d, q.bsums, (int) ne0, eps);
+}
+
+bool rms_norm_mul_quant_supported(int64_t ne0) { return ne0 % 256 == 0 && ne0 <= 8192; }
+
 void rms_norm_mul_quant(const float * x, size_t x_stride, const float * w, float * y, size_t y_stride, const act_q8 & q,
                         int64_t ne0, int64_t nrows, float eps, hipStream_t stream) {
-    if (q.kind == T_Q8_0) hipLaunchKernelGGL((k_rms_norm_mul_quant<T_Q8_0>), dim3((unsigned) nrows), dim3(256), 0, stream, x, x_stride, w, y, y_stride, q.qs, q.d, q.bsums, (int) ne0, eps);
-    else                  hipLaunchKernelGGL((k_rms_norm_mul_quant<T_Q8_K>), dim3((unsigned) nrows), dim3(256), 0, stream, x, x_stride, w, y, y_stride, q.qs, q.d, q.bsums, (int) ne0, eps);
+    if (q.kind == T_Q8_0) launch_rms_norm_mul_quant<T_Q8_0>(x, x_stride, w, y, y_stride, q, ne0, nrows, eps, stream);
+    else                  launch_rms_norm_mul_quant<T_Q8_K>(x, x_stride, w, y, y_stride, q, ne0, nrows, eps, stream);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -136,6 +160,18 @@ struct attn_args {
     float scale;
 };
 
+static __device__ __forceinline__ float dot8_f16_f32(const int4v kv, const float4v a, const float4v b) {
+    const uint32_t k0 = (uint32_t) kv.x, k1 = (uint32_t) kv.y, k2 = (uint32_t) kv.z, k3 = (uint32_t) kv.w;
+    float acc;
+    acc  = f16_bits_to_f32((uint16_t) k0)*a.x + f16_bits_to_f32((uint16_t)(k0 >> 16))*a.y;
+    acc += f16_bits_to_f32((uint16_t) k1)*a.z + f16_bits_to_f32((uint16_t)(k1 >> 16))*a.w;
+    acc += f16_bits_to_f32((uint16_t) k2)*b.x + f16_bits_to_f32((uint16_t)(k2 >> 16))*b.y;
+    acc += f16_bits_to_f32((uint16_t) k3)*b.z + f16_bits_to_f32((uint16_t)(k3 >> 16))*b.w;
+    return acc;
+}
+
+// Latency is the enemy here (a few hundred KB, one dependent chain per workgroup): every phase issues its independent
+// 16-byte loads in batches of U before touching the data.
 template <int HD>
 __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -144,36 +180,37 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     const int h = blockIdx.x, t = blockIdx.y;
     const int hk = h/(p.n_head/p.n_head_kv);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int LPC = HD/8;                            // lanes per cell (8 f16 = 16 B each)
-    constexpr int CPW = 64/LPC;                          // cells per wave step
+    constexpr int LPC = HD/8;                            // lanes per K row (8 f16 = 16 B each)
+    constexpr int CPW = 64/LPC;                          // K rows per wave step
+    constexpr int U = 4;
     const int sub = lane % LPC, cw = lane / LPC;
 
-    // this lane's 8 query elements
+    // ---- scores: s[j] = scale * K[j].q + mask[j] ----
     const float * qp = (const float *) (p.q + (size_t) t*p.q_nb1 + (size_t) h*p.q_nb2) + sub*8;
     const float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
     const char * kbase = p.k + (size_t) hk*p.k_nb2 + sub*16;
     const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 : nullptr;
-
     float mx = p.sinks ? p.sinks[h] : -INFINITY;
-    for (int j0 = wave*CPW; j0 < p.n_kv; j0 += 4*CPW) {
-        const int j = j0 + cw;
-        float acc = 0.0f;
-        if (j < p.n_kv) {
-            const int4v kv = *(const int4v *) (kbase + (size_t) j*p.k_nb1);
-            const uint32_t k0 = (uint32_t) kv.x, k1 = (uint32_t) kv.y, k2 = (uint32_t) kv.z, k3 = (uint32_t) kv.w;
-            acc  = f16_bits_to_f32((uint16_t) k0)*q0.x + f16_bits_to_f32((uint16_t)(k0 >> 16))*q0.y;
-            acc += f16_bits_to_f32((uint16_t) k1)*q0.z + f16_bits_to_f32((uint16_t)(k1 >> 16))*q0.w;
-            acc += f16_bits_to_f32((uint16_t) k2)*q1.x + f16_bits_to_f32((uint16_t)(k2 >> 16))*q1.y;
-            acc += f16_bits_to_f32((uint16_t) k3)*q1.z + f16_bits_to_f32((uint16_t)(k3 >> 16))*q1.w;
+    for (int j0 = wave*CPW + cw; j0 < p.n_kv; j0 += 4*CPW*U) {
+        int4v kreg[U]; float mreg[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = min(j0 + u*4*CPW, p.n_kv - 1);
+            kreg[u] = *(const int4v *) (kbase + (size_t) j*p.k_nb1);
+            mreg[u] = 0.0f;
+            if (mrow) mreg[u] = p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (mrow + (size_t) j*2)) : *(const float *) (mrow + (size_t) j*4);
         }
-        // sum over the LPC lanes of the cell (LPC = 16: a DPP row; LPC = 8: half a row)
-        acc += dpp_f<0xB1>(acc); acc += dpp_f<0x4E>(acc); acc += dpp_f<0x141>(acc);
-        if (LPC == 16) acc += dpp_f<0x140>(acc);
-        if (j < p.n_kv) {
-            float v = acc*p.scale;
-            if (mrow) v += p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (mrow + (size_t) j*2)) : *(const float *) (mrow + (size_t) j*4);
-            if (sub == 0) s[j] = v;
-            mx = fmaxf(mx, v);
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int j = j0 + u*4*CPW;
+            float acc = dot8_f16_f32(kreg[u], q0, q1);
+            acc += dpp_f<0xB1>(acc); acc += dpp_f<0x4E>(acc); acc += dpp_f<0x141>(acc);   // sum over the LPC lanes of the row
+            if (LPC == 16) acc += dpp_f<0x140>(acc);
+            if (j < p.n_kv) {
+                const float v = acc*p.scale + mreg[u];
+                if (sub == 0) s[j] = v;
+                mx = fmaxf(mx, v);
+            }
         }
     }
     mx = wave_max(mx);
@@ -189,29 +226,30 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     for (int j = threadIdx.x; j < p.n_kv; j += 256) s[j] *= inv;   // the unfused SOFT_MAX normalises before V.p
     __syncthreads();
 
-    // out[d] = sum_j V[d][j]*p[j]: one wave per output row d, lanes stride the cells 8 at a time
-    const char * vbase = p.v + (size_t) hk*p.v_nb2;
-    for (int d = wave; d < HD; d += 4) {
-        const char * vr = vbase + (size_t) d*p.v_nb1;
-        float acc = 0.0f;
-        for (int j = lane*8; j < p.n_kv; j += 512) {
-            if (j + 8 <= p.n_kv) {
-                const int4v vv = ld_b128(vr + (size_t) j*2);
-                const uint32_t v0 = (uint32_t) vv.x, v1 = (uint32_t) vv.y, v2 = (uint32_t) vv.z, v3 = (uint32_t) vv.w;
-                acc += f16_bits_to_f32((uint16_t) v0)*s[j]     + f16_bits_to_f32((uint16_t)(v0 >> 16))*s[j + 1];
-                acc += f16_bits_to_f32((uint16_t) v1)*s[j + 2] + f16_bits_to_f32((uint16_t)(v1 >> 16))*s[j + 3];
-                acc += f16_bits_to_f32((uint16_t) v2)*s[j + 4] + f16_bits_to_f32((uint16_t)(v2 >> 16))*s[j + 5];
-                acc += f16_bits_to_f32((uint16_t) v3)*s[j + 6] + f16_bits_to_f32((uint16_t)(v3 >> 16))*s[j + 7];
-            } else {
-                for (int jj = j; jj < p.n_kv; jj++) acc += f16_bits_to_f32(*(const uint16_t *) (vr + (size_t) jj*2))*s[jj];
-            }
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) *(float *) ((char *) p.dst + (size_t) t*p.dst_nb1 + (size_t)(h*HD + d)*4) = acc;
+    // ---- out[d] = sum_j V[d][j]*p[j]: 16 lanes per V row, 4 rows per wave, HD/16 row groups per workgroup ----
+    constexpr int NG = HD/16;                            // row groups: d = g*16 + wave*4 + rw
+    const int l16 = lane & 15, rw = lane >> 4;
+    const char * vbase = p.v + (size_t) hk*p.v_nb2 + (size_t)(wave*4 + rw)*p.v_nb1;
+    float acc[NG];
+#pragma unroll
+    for (int g = 0; g < NG; g++) acc[g] = 0.0f;
+    const int nchunk = p.n_kv >> 3;                      // n_kv % 8 == 0
+    for (int c = l16; c < nchunk; c += 16) {
+        int4v vreg[NG];
+#pragma unroll
+        for (int g = 0; g < NG; g++) vreg[g] = ld_b128(vbase + (size_t)(g*16)*p.v_nb1 + (size_t) c*16);
+        const float4v p0 = *(const float4v *) (s + c*8), p1 = *(const float4v *) (s + c*8 + 4);
+#pragma unroll
+        for (int g = 0; g < NG; g++) acc[g] += dot8_f16_f32(vreg[g], p0, p1);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; g++) {
+        const float r = row16_sum(acc[g]);
+        if (l16 == 0) *(float *) ((char *) p.dst + (size_t) t*p.dst_nb1 + (size_t)(h*HD + g*16 + wave*4 + rw)*4) = r;
     }
 }
 
-bool attn_decode_supported(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv*4 <= 60*1024; }
+bool attn_decode_supported(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv % 8 == 0 && n_kv*4 <= 60*1024; }
 
 void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                  const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
@@ -238,8 +276,10 @@ struct fused_mmvq_args {
     int block_end[MMVQ_MAX_GROUPS];       // cumulative workgroup counts
     int k;
     int act_kind;
-    const int8_t * a_qs; const float * a_d; const int16_t * a_bs;   // quantized activation (global), or:
-    const float * x_f32;                                              // f32 activation to quantize in the prologue (a_qs == null)
+    // quantized activation column as ONE contiguous image in global memory: qs | d | bsums at the offsets act_q8_carve
+    // gives for n = 1; staged verbatim into LDS
+    const char * act; int act_chunks;     // 16-byte chunks
+    int off_d, off_bs;                    // byte offsets of d / bsums inside the image
     fused_rope rope;
 };
 
@@ -262,31 +302,84 @@ static __device__ __forceinline__ void rope_pair(const fused_rope & r, int row_i
     x1 = a*s + b*c;
 }
 
-template <int TYPE>
-static __device__ __forceinline__ void fused_group_rows(const mmvq_group & g, const fused_mmvq_args & p, const act_view & av, int blk_in_group,
-                                                        int lane, int wave) {
-    constexpr int R = 2;
-    const int64_t nb = p.k / mmvq_t<TYPE>::QK;
+// One workgroup = 4 waves x R rows of one group. Order of issue is the point of this kernel:
+//   (1) the activation image loads (L2-resident, a few KB), (2) the first two steps of packed weight loads (HBM),
+//   (3) ds_write of the image + barrier — the compiler's counted vmcnt wait covers only (1), so the weight stream is
+//   already in flight while the workgroup synchronises, (4) integer dots, rolling two weight steps ahead.
+// Every load is unconditional (clamped address) so that the number of outstanding loads is the same on every path.
+template <int TYPE, bool GLU, int NACT>
+static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fused_mmvq_args & p, char * smem, const int4v (&areg)[NACT],
+                                                  int blk_in_group, int lane, int wave) {
+    typedef mmvq_t<TYPE> T;
+    constexpr int R = 2, LPB = T::LPB, BPW = 64/LPB;
+    const int nb = p.k / T::QK;
+    const int iters = (nb + BPW - 1)/BPW;
     const int row0 = (blk_in_group*4 + wave)*R;
-    if (row0 >= g.m) return;
-    const char * rows[R];
+    const int slot = lane % LPB, ibl = lane / LPB;
+    const char * rows[R]; const char * rows2[R];
 #pragma unroll
-    for (int r = 0; r < R; r++) rows[r] = g.W + (size_t) min(row0 + r, g.m - 1)*g.row_stride;
-    const act_view avs[1] = { av };
-    float acc[1][R] = { { 0.0f, 0.0f } };
-    mmvq_wave_partial<TYPE, 1, R>(rows, avs, nb, lane, acc);
-    float s0 = wave_sum(acc[0][0]), s1 = wave_sum(acc[0][1]);
-    if (g.epi == EPI_GLU) {
-        const char * rows2[R];
-#pragma unroll
-        for (int r = 0; r < R; r++) rows2[r] = g.W2 + (size_t) min(row0 + r, g.m - 1)*g.row_stride;
-        float acc2[1][R] = { { 0.0f, 0.0f } };
-        mmvq_wave_partial<TYPE, 1, R>(rows2, avs, nb, lane, acc2);
-        const float u0 = wave_sum(acc2[0][0]), u1 = wave_sum(acc2[0][1]);
-        s0 = (s0/(1.0f + expf(-s0)))*u0;      // silu(gate)*up, as elem.hip k_glu
-        s1 = (s1/(1.0f + expf(-s1)))*u1;
+    for (int r = 0; r < R; r++) {
+        const size_t off = (size_t) min(row0 + r, g.m - 1)*g.row_stride;   // tail rows recompute the last row, never stored
+        rows[r] = g.W + off;
+        rows2[r] = GLU ? g.W2 + off : nullptr;
     }
-    if (lane != 0) return;
+    typename T::wfrag w0[R], w1[R], u0[R], u1[R];
+    {
+        const int ib0 = min(ibl, nb - 1), ib1 = min(BPW + ibl, nb - 1);
+#pragma unroll
+        for (int r = 0; r < R; r++) { w0[r] = T::load_w(rows[r], ib0, slot); if (GLU) u0[r] = T::load_w(rows2[r], ib0, slot); }
+#pragma unroll
+        for (int r = 0; r < R; r++) { w1[r] = T::load_w(rows[r], ib1, slot); if (GLU) u1[r] = T::load_w(rows2[r], ib1, slot); }
+    }
+    // stage the activation image
+#pragma unroll
+    for (int i = 0; i < NACT; i++) {
+        const int idx = threadIdx.x + i*256;
+        if (idx < p.act_chunks) *(int4v *) (smem + (size_t) idx*16) = areg[i];
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    act_view av;
+    av.qs = (const int8_t *) smem; av.d = (const float *) (smem + p.off_d); av.bs = (const int16_t *) (smem + p.off_bs);
+
+    float acc[R] = { 0.0f, 0.0f }, acu[R] = { 0.0f, 0.0f };
+    for (int it = 0; it + 2 < iters; it++) {
+        typename T::wfrag wn[R], un[R];
+        const int ibn = min((it + 2)*BPW + ibl, nb - 1);
+#pragma unroll
+        for (int r = 0; r < R; r++) { wn[r] = T::load_w(rows[r], ibn, slot); if (GLU) un[r] = T::load_w(rows2[r], ibn, slot); }
+        const int ib = it*BPW + ibl;    // < nb here: only the last step can be ragged
+        const typename T::afrag a = T::load_a(av, ib, slot);
+#pragma unroll
+        for (int r = 0; r < R; r++) { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
+#pragma unroll
+        for (int r = 0; r < R; r++) { w0[r] = w1[r]; w1[r] = wn[r]; if (GLU) { u0[r] = u1[r]; u1[r] = un[r]; } }
+    }
+    if (iters >= 2) {
+        const int ib = (iters - 2)*BPW + ibl;
+        const typename T::afrag a = T::load_a(av, ib, slot);
+#pragma unroll
+        for (int r = 0; r < R; r++) { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
+    }
+    {
+        const int ib = (iters - 1)*BPW + ibl;
+        if (ib < nb) {
+            const typename T::afrag a = T::load_a(av, ib, slot);
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if (iters >= 2) { acc[r] += T::dot(w1[r], a, slot); if (GLU) acu[r] += T::dot(u1[r], a, slot); }
+                else            { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
+            }
+        }
+    }
+
+    float s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
+    if (GLU) {
+        const float u0s = wave_sum(acu[0]), u1s = wave_sum(acu[1]);
+        s0 = (s0/(1.0f + expf(-s0)))*u0s;      // silu(gate)*up, as elem.hip k_glu
+        s1 = (s1/(1.0f + expf(-s1)))*u1s;
+    }
+    if (lane != 0 || row0 >= g.m) return;
     if (g.epi == EPI_ADD) {
         s0 += g.res[row0];
         if (row0 + 1 < g.m) s1 += g.res[row0 + 1];
@@ -297,57 +390,54 @@ static __device__ __forceinline__ void fused_group_rows(const mmvq_group & g, co
     if (row0 + 1 < g.m) g.dst[row0 + 1] = s1;
 }
 
+// One instantiation per {weight type or pair of types} x {GLU} x {activation image size}: a single kernel switching over all six
+// formats at run time allocates registers for the fattest path (227 VGPRs -> 2 waves/SIMD), which starves the HBM stream.
+template <int TA, int TB, bool GLU, int NACT>
 __global__ void __launch_bounds__(256) k_mmvq_fused(const fused_mmvq_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    act_view av;
-    if (p.a_qs) {
-        if (p.act_kind == T_Q8_0) av = stage_act_lds<T_Q8_0>(smem, p.a_qs, p.a_d, p.a_bs, p.k);
-        else                      av = stage_act_lds<T_Q8_K>(smem, p.a_qs, p.a_d, p.a_bs, p.k);
-    } else {
-        // prologue quantization of the f32 activation vector straight into LDS (k % 256 == 0)
-        const int nd = p.act_kind == T_Q8_0 ? 32 : 256, nbs = p.act_kind == T_Q8_0 ? 32 : 16;
-        const int64_t qs_b = (p.k + 15) & ~15, d_b = ((p.k/nd)*4 + 15) & ~15;
-        int8_t * qs = (int8_t *) smem; float * d = (float *) (smem + qs_b); int16_t * bs = (int16_t *) (smem + qs_b + d_b);
-        for (int c = wave; c < p.k/256; c += 4) {
-            const float4v v = *(const float4v *) (p.x_f32 + c*256 + lane*4);
-            if (p.act_kind == T_Q8_0) quant_store_chunk256<T_Q8_0>(v, c, lane, qs, d, bs);
-            else                      quant_store_chunk256<T_Q8_K>(v, c, lane, qs, d, bs);
-        }
-        av.qs = qs; av.d = d; av.bs = bs;
+    int4v areg[NACT];
+#pragma unroll
+    for (int i = 0; i < NACT; i++) {
+        const int idx = min((int) threadIdx.x + i*256, p.act_chunks - 1);
+        areg[i] = *(const int4v *) (p.act + (size_t) idx*16);
     }
-    __syncthreads();
-
     int gi = 0;
     while (gi < p.n_groups - 1 && (int) blockIdx.x >= p.block_end[gi]) gi++;
     const int blk = (int) blockIdx.x - (gi ? p.block_end[gi - 1] : 0);
     const mmvq_group & g = p.g[gi];
-    switch (g.type) {
-        case T_Q4_K:  fused_group_rows<T_Q4_K >(g, p, av, blk, lane, wave); break;
-        case T_Q6_K:  fused_group_rows<T_Q6_K >(g, p, av, blk, lane, wave); break;
-        case T_Q5_K:  fused_group_rows<T_Q5_K >(g, p, av, blk, lane, wave); break;
-        case T_Q8_0:  fused_group_rows<T_Q8_0 >(g, p, av, blk, lane, wave); break;
-        case T_Q4_0:  fused_group_rows<T_Q4_0 >(g, p, av, blk, lane, wave); break;
-        case T_MXFP4: fused_group_rows<T_MXFP4>(g, p, av, blk, lane, wave); break;
-        default: break;
-    }
+    if (TA == TB || g.type == TA) fused_body<TA, GLU, NACT>(g, p, smem, areg, blk, lane, wave);
+    else                          fused_body<TB, GLU, NACT>(g, p, smem, areg, blk, lane, wave);
 }
 
 static float rope_corr_dim_h(int n_dims, int n_ctx_orig, float n_rot, float base) {
     return n_dims*logf(n_ctx_orig/(n_rot*2*(float) M_PI))/(2*logf(base));
 }
 
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const act_q8 * act, const float * x_f32, int act_kind,
-                         const mmvq_rope * rope, hipStream_t stream) {
+static size_t pad256h(size_t x) { return (x + 255) & ~(size_t) 255; }
+
+// the activation must be the n = 1 image act_q8_carve lays out: qs | pad | d | pad | bsums, contiguous
+bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind) {
+    const int64_t nd = act_kind == T_Q8_0 ? k/32 : k/256, nbs = act_kind == T_Q8_0 ? k/32 : k/16;
+    const size_t bytes = pad256h(k) + pad256h(nd*4) + ((nbs*2 + 15) & ~15);
+    return k % (act_kind == T_Q8_0 ? 32 : 256) == 0 && bytes <= 8*256*16;
+}
+
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const act_q8 & act, const mmvq_rope * rope, hipStream_t stream) {
     fused_mmvq_args a = {};
-    a.n_groups = n_groups; a.k = (int) k; a.act_kind = act_kind;
+    a.n_groups = n_groups; a.k = (int) k; a.act_kind = act.kind;
     int blocks = 0;
     for (int i = 0; i < n_groups; i++) {
         a.g[i] = groups[i];
         blocks += (int)((groups[i].m + 7)/8);
         a.block_end[i] = blocks;
     }
-    if (act) { a.a_qs = act->qs; a.a_d = act->d; a.a_bs = act->bsums; } else { a.x_f32 = x_f32; }
+    const int64_t nbs = act.kind == T_Q8_0 ? k/32 : k/16;
+    a.act = (const char *) act.qs;
+    a.off_d = (int)((const char *) act.d - (const char *) act.qs);
+    a.off_bs = (int)((const char *) act.bsums - (const char *) act.qs);
+    const size_t bytes = (size_t) a.off_bs + ((nbs*2 + 15) & ~15);
+    a.act_chunks = (int)(bytes/16);
     if (rope) {
         a.rope.pos = rope->pos; a.rope.ff = rope->freq_factors; a.rope.n_dims = rope->p.n_dims; a.rope.head_dim = rope->head_dim;
         a.rope.n_ctx_orig = rope->p.n_ctx_orig; a.rope.freq_scale = rope->p.freq_scale; a.rope.ext_factor = rope->p.ext_factor;
@@ -357,9 +447,32 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
         const float end   = ceilf (rope_corr_dim_h(rope->p.n_dims, rope->p.n_ctx_orig, rope->p.beta_slow, rope->p.freq_base));
         a.rope.corr_lo = fmaxf(0.0f, start); a.rope.corr_hi = fminf((float)(rope->p.n_dims - 1), end);
     }
-    hipLaunchKernelGGL(k_mmvq_fused, dim3((unsigned) blocks), dim3(256), act_lds_bytes(act_kind, k), stream, a);
+    const dim3 grid((unsigned) blocks);
+    int ta = groups[0].type, tb = groups[0].type;
+    for (int i = 1; i < n_groups; i++) if (groups[i].type != ta) tb = groups[i].type;
+    if (tb < ta) { const int t = ta; ta = tb; tb = t; }
+    const bool glu = groups[0].epi == EPI_GLU;
+    const int nact = a.act_chunks <= 2*256 ? 2 : (a.act_chunks <= 4*256 ? 4 : 8);
+#define MI_LAUNCH(TA_, TB_, GLU_) do { \
+        if      (nact == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, 2>), grid, dim3(256), bytes, stream, a); \
+        else if (nact == 4) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, 4>), grid, dim3(256), bytes, stream, a); \
+        else                hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, 8>), grid, dim3(256), bytes, stream, a); } while (0)
+#define MI_SINGLE(T_) if (ta == T_ && tb == T_) { if (glu) MI_LAUNCH(T_, T_, true); else MI_LAUNCH(T_, T_, false); return; }
+    MI_SINGLE(T_Q4_K) MI_SINGLE(T_Q6_K) MI_SINGLE(T_Q5_K) MI_SINGLE(T_Q8_0) MI_SINGLE(T_Q4_0) MI_SINGLE(T_MXFP4)
+    if (ta == T_Q4_K && tb == T_Q5_K) { MI_LAUNCH(T_Q4_K, T_Q5_K, false); return; }
+    if (ta == T_Q4_K && tb == T_Q6_K) { MI_LAUNCH(T_Q4_K, T_Q6_K, false); return; }
+    if (ta == T_Q5_K && tb == T_Q6_K) { MI_LAUNCH(T_Q5_K, T_Q6_K, false); return; }
+#undef MI_SINGLE
+#undef MI_LAUNCH
+    fprintf(stderr, "mul_mat_vec_q_fused: type pair (%d, %d) has no kernel (check mul_mat_vec_q_fused_can_group)\n", ta, tb);
+    abort();
 }
 
-bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind) { return k % 256 == 0 && act_lds_bytes(act_kind, k) <= 64*1024; }
+// which weight types may share one grouped launch (the mixtures llama_tensor_get_type produces, src/llama-quant.cpp:178-434)
+bool mul_mat_vec_q_fused_can_group(int type_a, int type_b) {
+    if (type_a == type_b) return true;
+    const int lo = type_a < type_b ? type_a : type_b, hi = type_a < type_b ? type_b : type_a;
+    return (lo == T_Q4_K && (hi == T_Q5_K || hi == T_Q6_K)) || (lo == T_Q5_K && hi == T_Q6_K);
+}
 
 } // namespace mi355x

@@ -93,7 +93,8 @@ void soft_max(const tensor_desc & src, const tensor_desc * mask, const float * s
               float scale, float max_bias, hipStream_t stream);
 
 // ---- fused decode kernels (decode_fused.hip): same arithmetic as the node-by-node kernels, fewer launches -----
-// RMS_NORM * w -> f32 row y AND its quantized form q (rows of ne0 floats, ne0 % 256 == 0)
+// RMS_NORM * w -> f32 row y AND its quantized form q (rows of ne0 floats, ne0 % 256 == 0, ne0 <= 8192)
+bool rms_norm_mul_quant_supported(int64_t ne0);
 void rms_norm_mul_quant(const float * x, size_t x_stride, const float * w, float * y, size_t y_stride, const act_q8 & q,
                         int64_t ne0, int64_t nrows, float eps, hipStream_t stream);
 // swiglu(g, u) = silu(g)*u -> f32 row y AND its quantized form q
@@ -119,9 +120,9 @@ struct mmvq_group {
 };
 struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; };   // EPI_ROPE (NORM pairs)
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
-// activation: either already quantized (`act`) or f32 `x_f32` to be quantized in the kernel prologue
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const act_q8 * act, const float * x_f32, int act_kind,
-                         const mmvq_rope * rope, hipStream_t stream);
+bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);   // may these two weight types share one grouped launch
+// `act` must be a single quantized column laid out by act_q8_carve(…, n = 1) (one contiguous image)
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const act_q8 & act, const mmvq_rope * rope, hipStream_t stream);
 
 // ---- test / bench support ------------------------------------------------------------------
 // raw streaming read of `bytes` (16 B/lane, nontemporal) — measures the achievable HBM rate on the box
