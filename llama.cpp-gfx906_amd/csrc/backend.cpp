@@ -564,7 +564,7 @@ static mmv_chain match_mmv_chain(mi_backend_ctx * c, const struct ggml_cgraph * 
     struct ggml_tensor * n = g->nodes[i];
     const struct ggml_tensor * a = n->src[0];
     mmv_chain ch = {};
-    ch.grp = { (const char *) a->data, nullptr, a->nb[1], (int) a->ne[1], (int) a->type, (float *) n->data, EPI_NONE, nullptr };
+    ch.grp = { (const char *) a->data, nullptr, a->nb[1], (int) a->ne[1], (int) a->type, (float *) n->data, EPI_NONE, nullptr, nullptr, nullptr, 0, 0 };
     ch.last = i; ch.has_rope = false; ch.out_ptr = n->data; ch.out_bytes = ggml_nbytes(n);
 
     // MUL_MAT -> RESHAPE -> ROPE (NORM pairs): src/llama-model.cpp:6017-6040
@@ -616,23 +616,32 @@ static mmv_chain match_mmv_chain(mi_backend_ctx * c, const struct ggml_cgraph * 
     return ch;
 }
 
-// run the mat-vec at node i together with the mat-vecs that directly follow it on the same activation; returns nodes consumed (0 = not fused)
-static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+static const struct ggml_tensor * base_of(const struct ggml_tensor * t) {   // strip view ops
+    while (t && is_view_op(t->op) && t->op != GGML_OP_NONE && t->src[0]) t = t->src[0];
+    return t;
+}
+
+// Run the mat-vec at node i together with the mat-vecs that directly follow it on the same activation.
+//   norm/normw != NULL: the activation is MUL(RMS_NORM(norm->src[0]), normw) and the caller has checked that every consumer of
+//   that product is a mat-vec; if they all fit into this launch the norm is computed in the prologue (PRO_NORM).
+// Returns the index of the last node consumed (-1 = not fused).
+static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm, const struct ggml_tensor * normw) {
     struct ggml_tensor * n = g->nodes[i];
-    if (!fusable_mmv(n)) return 0;
+    if (!fusable_mmv(n)) return -1;
     const struct ggml_tensor * b = n->src[1];
     const int kind = act_kind_for((int) n->src[0]->type);
     mmv_chain chains[MMVQ_MAX_GROUPS];
-    int nc = 0, last = i;
+    int nc = 0, last = i, n_mm = 0;
     chains[nc++] = match_mmv_chain(c, g, i);
     last = chains[0].last;
-    while (nc < MMVQ_MAX_GROUPS) {
+    n_mm += chains[0].grp.epi == EPI_GLU ? 2 : 1;
+    while (nc < MMVQ_MAX_GROUPS && chains[0].grp.epi != EPI_GLU) {
         const int j = next_real(g, last);
         if (j < 0) break;
         struct ggml_tensor * m = g->nodes[j];
         if (!fusable_mmv(m) || m->src[1] != b || act_kind_for((int) m->src[0]->type) != kind) break;
         mmv_chain ch = match_mmv_chain(c, g, j);
-        if (ch.grp.epi == EPI_GLU || chains[0].grp.epi == EPI_GLU) break;   // the dual (GLU) kernel runs alone
+        if (ch.grp.epi == EPI_GLU) break;   // the dual (GLU) kernel runs alone
         {   // at most two distinct weight types per launch, and only pairs that have a kernel
             int t2 = -1; bool ok_t = true;
             for (int q = 0; q < nc; q++) if (chains[q].grp.type != chains[0].grp.type) t2 = chains[q].grp.type;
@@ -647,11 +656,43 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             if (ok && chains[q].grp.res) ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, chains[q].grp.res, (size_t) chains[q].grp.m*4);
             if (ok && ch.grp.res)       ok = !ranges_overlap(chains[q].out_ptr, chains[q].out_bytes, ch.grp.res, (size_t) ch.grp.m*4);
         }
-        // ... nor may any node between the groups read/write what the hoisted group writes (none: the groups are adjacent up to view ops)
         if (!ok) break;
         chains[nc++] = ch;
         last = ch.last;
+        n_mm++;
     }
+
+    // the KV-cache writes that follow wk / wv: SET_ROWS(k_cache, rope(k)) ; SET_ROWS(v_view[1,N], v[1,N]) — src/llama-kv-cache-unified.cpp:1123,1157-1167
+    {
+        const int j1 = next_real(g, last);
+        const int j2 = j1 > 0 ? next_real(g, j1) : -1;
+        if (j2 > 0 && g->nodes[j1]->op == GGML_OP_SET_ROWS && g->nodes[j2]->op == GGML_OP_SET_ROWS) {
+            struct ggml_tensor * sk = g->nodes[j1]; struct ggml_tensor * sv = g->nodes[j2];
+            const struct ggml_tensor * ks = sk->src[0]; const struct ggml_tensor * ki = sk->src[1];
+            const struct ggml_tensor * vs = sv->src[0]; const struct ggml_tensor * vi = sv->src[1];
+            int qk = -1, qv = -1;
+            for (int q = 0; q < nc; q++) {
+                if (base_of(ks)->data == chains[q].out_ptr && ks->data == chains[q].out_ptr) qk = q;
+                if (base_of(vs)->data == chains[q].out_ptr && vs->data == chains[q].out_ptr) qv = q;
+            }
+            const bool ok = qk >= 0 && qv >= 0 && qk != qv && sk->type == GGML_TYPE_F16 && sv->type == GGML_TYPE_F16 &&
+                ks->type == GGML_TYPE_F32 && vs->type == GGML_TYPE_F32 && ki->type == GGML_TYPE_I64 && vi->type == GGML_TYPE_I64 &&
+                ggml_is_contiguous(ki) && ggml_is_contiguous(vi) && ggml_is_contiguous(ks) && ggml_is_contiguous(vs) &&
+                ks->ne[1] == 1 && ks->ne[2] == 1 && ks->ne[3] == 1 && ks->ne[0] == chains[qk].grp.m && sk->nb[0] == 2 && sk->nb[1] % 2 == 0 &&
+                vs->ne[0] == 1 && vs->ne[1] == chains[qv].grp.m && vs->ne[2] == 1 && vs->ne[3] == 1 && sv->ne[0] == 1 && sv->nb[1] == 2 &&
+                ggml_nelements(vi) == chains[qv].grp.m && chains[qv].grp.epi == EPI_NONE &&
+                // the cache rows written must not be read by anything inside the launch (they are not: only weights and the activation are)
+                !ranges_overlap(sk->data, ggml_nbytes(sk), b->data, ggml_nbytes(b)) && !ranges_overlap(sv->data, ggml_nbytes(sv), b->data, ggml_nbytes(b));
+            if (ok) {
+                chains[qk].grp.st16 = (uint16_t *) sk->data; chains[qk].grp.st_idx = (const int64_t *) ki->data;
+                chains[qk].grp.st_row_elems = (int64_t)(sk->nb[1]/2); chains[qk].grp.st_mode = 1;
+                chains[qv].grp.st16 = (uint16_t *) sv->data; chains[qv].grp.st_idx = (const int64_t *) vi->data;
+                chains[qv].grp.st_row_elems = 0; chains[qv].grp.st_mode = 2;
+                last = j2;
+            }
+        }
+    }
+
     mmvq_group grp[MMVQ_MAX_GROUPS];
     const mmvq_rope * rope = nullptr;
     uint64_t wbytes = 0;
@@ -661,12 +702,25 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         wbytes += (uint64_t) grp[q].m*grp[q].row_stride*(grp[q].epi == EPI_GLU ? 2 : 1);
     }
     const int64_t K = n->src[0]->ne[0];
-    const act_q8 q = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);      // reused when the producer already quantized it
+    mmvq_input in = {};
+    in.act_kind = kind;
+    const bool cached = c->aq.valid && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == 1 && c->aq.n_outer == 1 && c->aq.kind == kind;
+    if (norm && n_mm == n_uses(c, b) && mul_mat_vec_q_fused_prologue_supported(K) && ((uintptr_t) normw->data % 16) == 0) {
+        in.mode = PRO_NORM; in.x = (const float *) norm->src[0]->data; in.norm_w = (const float *) normw->data; in.eps = op_f32(norm, 0);
+    } else if (norm) {
+        return -1;      // the caller runs the norm (+ quantization) as its own kernel, then comes back without `norm`
+    } else if (cached) {
+        in.mode = PRO_Q8; in.act = c->aq.q; c->cnt.act_quant_reused++;
+    } else if (mul_mat_vec_q_fused_prologue_supported(K)) {
+        in.mode = PRO_QUANT; in.x = (const float *) b->data;
+    } else {
+        in.mode = PRO_Q8; in.act = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);
+    }
     if (c->profiling) prof_begin(c, grp[0].type, nc == 1 && grp[0].epi != EPI_GLU ? grp[0].m : -(int64_t)(wbytes/1024), K, 1, wbytes);   // m < 0: grouped launch, |m| = KiB of weights
-    mul_mat_vec_q_fused(grp, nc, K, q, rope, c->stream);
+    mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream);
     if (c->profiling) prof_end(c);
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++; c->cnt.weight_bytes += wbytes;
-    return last - i + 1;
+    return last;
 }
 
 // SET_ROWS(k) immediately followed by SET_ROWS(v as [1, N] element scatter), f32 -> f16 (src/llama-kv-cache-unified.cpp:1123,1157-1167)
@@ -734,7 +788,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     bool fresh_aq = false;   // this step produced the cached quantized activations itself
     if (c->use_fusion) {
         int f = 0;
-        if (node->op == GGML_OP_MUL_MAT) { f = try_fused_mmv(c, g, i); if (!f) f = try_fused_attn(c, g, i); }
+        if (node->op == GGML_OP_MUL_MAT) { const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0; if (!f) f = try_fused_attn(c, g, i); }
         else if (node->op == GGML_OP_SET_ROWS) f = try_fused_kv_store(c, g, i);
         if (f) {
             consumed = f;
@@ -761,6 +815,12 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                         // ... and when a quantized mat-mul reads the result next, quantize it in the same kernel
                         const int jn = next_real(g, i + 1);
                         const struct ggml_tensor * mm = jn > 0 ? g->nodes[jn] : nullptr;
+                        // best case: every reader of the product is a mat-vec of ONE grouped launch -> the norm runs in its prologue
+                        if (mm && fusable_mmv(mm) && mm->src[1] == mul && node->ne[1] == 1 && w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] &&
+                            is_row_vec_f32(s0) && !(mul->flags & GGML_TENSOR_FLAG_OUTPUT)) {
+                            const int l = try_fused_mmv(c, g, jn, node, w);
+                            if (l >= 0) { consumed = l - i + 1; break; }
+                        }
                         if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&
                             act_kind_for((int) mm->src[0]->type) > 0 && rms_norm_mul_quant_supported(node->ne[0]) && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 &&
                             w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] && s0->nb[0] == 4 &&

@@ -276,10 +276,11 @@ struct fused_mmvq_args {
     int block_end[MMVQ_MAX_GROUPS];       // cumulative workgroup counts
     int k;
     int act_kind;
-    // quantized activation column as ONE contiguous image in global memory: qs | d | bsums at the offsets act_q8_carve
-    // gives for n = 1; staged verbatim into LDS
+    // PRO_Q8: quantized activation column as ONE contiguous image in global memory (qs | d | bsums at the offsets
+    // act_q8_carve gives for n = 1), staged verbatim into LDS. PRO_QUANT / PRO_NORM build the same image in LDS from x.
     const char * act; int act_chunks;     // 16-byte chunks
     int off_d, off_bs;                    // byte offsets of d / bsums inside the image
+    const float * x; const float * norm_w; float eps;
     fused_rope rope;
 };
 
@@ -302,112 +303,159 @@ static __device__ __forceinline__ void rope_pair(const fused_rope & r, int row_i
     x1 = a*s + b*c;
 }
 
-// One workgroup = 4 waves x R rows of one group. Order of issue is the point of this kernel:
-//   (1) the activation image loads (L2-resident, a few KB), (2) the first two steps of packed weight loads (HBM),
-//   (3) ds_write of the image + barrier — the compiler's counted vmcnt wait covers only (1), so the weight stream is
-//   already in flight while the workgroup synchronises, (4) integer dots, rolling two weight steps ahead.
+// PERSISTENT grouped mat-vec. A launch has about (CUs x 2) workgroups of 8 waves; each workgroup belongs to one group (weight
+// tensor) and its waves walk that tensor's row pairs with a grid stride, so that
+//   * the activation is prepared ONCE per workgroup (copy / quantize / rms-norm + quantize into LDS) instead of once per 8 rows,
+//   * the packed-weight stream never stops: loads run two steps ahead across row boundaries, and the DPP reduction + epilogue of
+//     one row pair overlaps the loads of the next.
+// Order of issue: (1) activation loads (L2-resident, a few KB), (2) the first two steps of weight loads (HBM), (3) prologue into
+// LDS + barrier — the compiler's counted vmcnt wait covers only (1) — (4) integer dots, (5) reduction + epilogue per row pair.
 // Every load is unconditional (clamped address) so that the number of outstanding loads is the same on every path.
-template <int TYPE, bool GLU, int NACT>
-static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fused_mmvq_args & p, char * smem, const int4v (&areg)[NACT],
-                                                  int blk_in_group, int lane, int wave) {
+//   PRO  : where the activation comes from (mmvq_prologue)
+//   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*2048)
+constexpr int FW = 8;            // waves per workgroup
+template <int TYPE, bool GLU, int PRO, int NA>
+static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fused_mmvq_args & p, char * smem, int wg_in_group, int nwg_group,
+                                                  int lane, int wave) {
     typedef mmvq_t<TYPE> T;
-    constexpr int R = 2, LPB = T::LPB, BPW = 64/LPB;
+    constexpr int R = 2, LPB = T::LPB, BPW = 64/LPB, ACT = T::ACT;
     const int nb = p.k / T::QK;
     const int iters = (nb + BPW - 1)/BPW;
-    const int row0 = (blk_in_group*4 + wave)*R;
     const int slot = lane % LPB, ibl = lane / LPB;
-    const char * rows[R]; const char * rows2[R];
+    const int P = (g.m + R - 1)/R;                       // row pairs in this group
+    const int stride = nwg_group*FW;
+    int p_cur = wg_in_group*FW + wave;
+
+    // ---- (1) activation loads ----
+    int4v areg[PRO == PRO_Q8 ? NA : 1];
+    float4v xv[PRO != PRO_Q8 ? NA : 1], wv[PRO == PRO_NORM ? NA : 1];
+    const int nchunk = p.k >> 8;
+    if (PRO == PRO_Q8) {
 #pragma unroll
-    for (int r = 0; r < R; r++) {
-        const size_t off = (size_t) min(row0 + r, g.m - 1)*g.row_stride;   // tail rows recompute the last row, never stored
-        rows[r] = g.W + off;
-        rows2[r] = GLU ? g.W2 + off : nullptr;
+        for (int i = 0; i < NA; i++) {
+            const int idx = min((int) threadIdx.x + i*(FW*64), p.act_chunks - 1);
+            areg[i] = *(const int4v *) (p.act + (size_t) idx*16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int c = min(wave + FW*i, nchunk - 1);
+            xv[i] = *(const float4v *) (p.x + c*256 + lane*4);
+            if (PRO == PRO_NORM) wv[i] = *(const float4v *) (p.norm_w + c*256 + lane*4);
+        }
     }
+
+    // ---- (2) weight prefetch: the first two steps of this wave's stream ----
+    // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch
+    int p_pf = p_cur, it_pf = 0;
     typename T::wfrag w0[R], w1[R], u0[R], u1[R];
-    {
-        const int ib0 = min(ibl, nb - 1), ib1 = min(BPW + ibl, nb - 1);
+#define MI_FETCH(WDST, UDST) { \
+        const int pp = min(p_pf, P - 1); \
+        const int ibf = min(it_pf*BPW + ibl, nb - 1); \
+        _Pragma("unroll") for (int r = 0; r < R; r++) { \
+            const size_t off = (size_t) min(pp*R + r, g.m - 1)*g.row_stride; \
+            WDST[r] = T::load_w(g.W + off, ibf, slot); \
+            if (GLU) UDST[r] = T::load_w(g.W2 + off, ibf, slot); \
+        } \
+        if (++it_pf == iters) { it_pf = 0; p_pf += stride; } }
+    MI_FETCH(w0, u0)
+    MI_FETCH(w1, u1)
+
+    // ---- (3) prologue: build the quantized activation image in LDS ----
+    int8_t * l_qs = (int8_t *) smem; float * l_d = (float *) (smem + p.off_d); int16_t * l_bs = (int16_t *) (smem + p.off_bs);
+    if (PRO == PRO_Q8) {
 #pragma unroll
-        for (int r = 0; r < R; r++) { w0[r] = T::load_w(rows[r], ib0, slot); if (GLU) u0[r] = T::load_w(rows2[r], ib0, slot); }
+        for (int i = 0; i < NA; i++) {
+            const int idx = threadIdx.x + i*(FW*64);
+            if (idx < p.act_chunks) *(int4v *) (smem + (size_t) idx*16) = areg[i];
+        }
+    } else {
+        float scale = 1.0f;
+        if (PRO == PRO_NORM) {
+            float * red = (float *) (smem + p.off_bs + (((p.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15));   // FW floats after the image
+            float ss = 0.0f;
 #pragma unroll
-        for (int r = 0; r < R; r++) { w1[r] = T::load_w(rows[r], ib1, slot); if (GLU) u1[r] = T::load_w(rows2[r], ib1, slot); }
-    }
-    // stage the activation image
+            for (int i = 0; i < NA; i++) if (wave + FW*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
+            ss = wave_sum(ss);
+            if (lane == 0) red[wave] = ss;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+            scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
+        }
 #pragma unroll
-    for (int i = 0; i < NACT; i++) {
-        const int idx = threadIdx.x + i*256;
-        if (idx < p.act_chunks) *(int4v *) (smem + (size_t) idx*16) = areg[i];
+        for (int i = 0; i < NA; i++) {
+            const int c = wave + FW*i;
+            if (c < nchunk) {   // wave-uniform
+                float4v v = xv[i];
+                if (PRO == PRO_NORM) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
+                quant_store_chunk256<ACT>(v, c, lane, l_qs, l_d, l_bs);
+            }
+        }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     act_view av;
-    av.qs = (const int8_t *) smem; av.d = (const float *) (smem + p.off_d); av.bs = (const int16_t *) (smem + p.off_bs);
+    av.qs = l_qs; av.d = l_d; av.bs = l_bs;
 
-    float acc[R] = { 0.0f, 0.0f }, acu[R] = { 0.0f, 0.0f };
-    for (int it = 0; it + 2 < iters; it++) {
-        typename T::wfrag wn[R], un[R];
-        const int ibn = min((it + 2)*BPW + ibl, nb - 1);
+    // ---- (4)+(5) stream ----
+    while (p_cur < P) {
+        float acc[R] = { 0.0f, 0.0f }, acu[R] = { 0.0f, 0.0f };
+        for (int it = 0; it < iters; it++) {
+            typename T::wfrag wn[R], un[R];
+            MI_FETCH(wn, un)
+            const int ib = it*BPW + ibl;
+            if (ib < nb) {
+                const typename T::afrag a = T::load_a(av, ib, slot);
 #pragma unroll
-        for (int r = 0; r < R; r++) { wn[r] = T::load_w(rows[r], ibn, slot); if (GLU) un[r] = T::load_w(rows2[r], ibn, slot); }
-        const int ib = it*BPW + ibl;    // < nb here: only the last step can be ragged
-        const typename T::afrag a = T::load_a(av, ib, slot);
+                for (int r = 0; r < R; r++) { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
+            }
 #pragma unroll
-        for (int r = 0; r < R; r++) { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
-#pragma unroll
-        for (int r = 0; r < R; r++) { w0[r] = w1[r]; w1[r] = wn[r]; if (GLU) { u0[r] = u1[r]; u1[r] = un[r]; } }
-    }
-    if (iters >= 2) {
-        const int ib = (iters - 2)*BPW + ibl;
-        const typename T::afrag a = T::load_a(av, ib, slot);
-#pragma unroll
-        for (int r = 0; r < R; r++) { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
-    }
-    {
-        const int ib = (iters - 1)*BPW + ibl;
-        if (ib < nb) {
-            const typename T::afrag a = T::load_a(av, ib, slot);
-#pragma unroll
-            for (int r = 0; r < R; r++) {
-                if (iters >= 2) { acc[r] += T::dot(w1[r], a, slot); if (GLU) acu[r] += T::dot(u1[r], a, slot); }
-                else            { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
+            for (int r = 0; r < R; r++) { w0[r] = w1[r]; w1[r] = wn[r]; if (GLU) { u0[r] = u1[r]; u1[r] = un[r]; } }
+        }
+        float s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
+        if (GLU) {
+            const float u0s = wave_sum(acu[0]), u1s = wave_sum(acu[1]);
+            s0 = (s0/(1.0f + expf(-s0)))*u0s;      // silu(gate)*up, as elem.hip k_glu
+            s1 = (s1/(1.0f + expf(-s1)))*u1s;
+        }
+        const int row0 = p_cur*R;
+        if (lane == 0) {
+            if (g.epi == EPI_ADD) {
+                s0 += g.res[row0];
+                if (row0 + 1 < g.m) s1 += g.res[row0 + 1];
+            } else if (g.epi == EPI_ROPE) {
+                rope_pair(p.rope, row0 % p.rope.head_dim, s0, s1);   // m is even on this path
+            }
+            g.dst[row0] = s0;
+            if (row0 + 1 < g.m) g.dst[row0 + 1] = s1;
+            if (g.st_mode == 1) {
+                uint16_t * o = g.st16 + g.st_idx[0]*g.st_row_elems + row0;
+                o[0] = f32_to_f16_bits(s0);
+                if (row0 + 1 < g.m) o[1] = f32_to_f16_bits(s1);
+            } else if (g.st_mode == 2) {
+                g.st16[g.st_idx[row0]] = f32_to_f16_bits(s0);
+                if (row0 + 1 < g.m) g.st16[g.st_idx[row0 + 1]] = f32_to_f16_bits(s1);
             }
         }
+        p_cur += stride;
     }
-
-    float s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
-    if (GLU) {
-        const float u0s = wave_sum(acu[0]), u1s = wave_sum(acu[1]);
-        s0 = (s0/(1.0f + expf(-s0)))*u0s;      // silu(gate)*up, as elem.hip k_glu
-        s1 = (s1/(1.0f + expf(-s1)))*u1s;
-    }
-    if (lane != 0 || row0 >= g.m) return;
-    if (g.epi == EPI_ADD) {
-        s0 += g.res[row0];
-        if (row0 + 1 < g.m) s1 += g.res[row0 + 1];
-    } else if (g.epi == EPI_ROPE) {
-        rope_pair(p.rope, row0 % p.rope.head_dim, s0, s1);   // m is even on this path
-    }
-    g.dst[row0] = s0;
-    if (row0 + 1 < g.m) g.dst[row0 + 1] = s1;
+#undef MI_FETCH
 }
 
-// One instantiation per {weight type or pair of types} x {GLU} x {activation image size}: a single kernel switching over all six
-// formats at run time allocates registers for the fattest path (227 VGPRs -> 2 waves/SIMD), which starves the HBM stream.
-template <int TA, int TB, bool GLU, int NACT>
-__global__ void __launch_bounds__(256) k_mmvq_fused(const fused_mmvq_args p) {
+// One instantiation per {weight type or pair of types} x {GLU} x {prologue} x {activation size class}: a single kernel switching
+// over all six formats at run time allocates registers for the fattest path (227 VGPRs -> 2 waves/SIMD), which starves the HBM stream.
+template <int TA, int TB, bool GLU, int PRO, int NA>
+__global__ void __launch_bounds__(512, 2) k_mmvq_fused(const fused_mmvq_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    int4v areg[NACT];
-#pragma unroll
-    for (int i = 0; i < NACT; i++) {
-        const int idx = min((int) threadIdx.x + i*256, p.act_chunks - 1);
-        areg[i] = *(const int4v *) (p.act + (size_t) idx*16);
-    }
     int gi = 0;
     while (gi < p.n_groups - 1 && (int) blockIdx.x >= p.block_end[gi]) gi++;
-    const int blk = (int) blockIdx.x - (gi ? p.block_end[gi - 1] : 0);
+    const int first = gi ? p.block_end[gi - 1] : 0;
+    const int blk = (int) blockIdx.x - first, nwg = p.block_end[gi] - first;
     const mmvq_group & g = p.g[gi];
-    if (TA == TB || g.type == TA) fused_body<TA, GLU, NACT>(g, p, smem, areg, blk, lane, wave);
-    else                          fused_body<TB, GLU, NACT>(g, p, smem, areg, blk, lane, wave);
+    if (TA == TB || g.type == TA) fused_body<TA, GLU, PRO, NA>(g, p, smem, blk, nwg, lane, wave);
+    else                          fused_body<TB, GLU, PRO, NA>(g, p, smem, blk, nwg, lane, wave);
 }
 
 static float rope_corr_dim_h(int n_dims, int n_ctx_orig, float n_rot, float base) {
@@ -416,28 +464,53 @@ static float rope_corr_dim_h(int n_dims, int n_ctx_orig, float n_rot, float base
 
 static size_t pad256h(size_t x) { return (x + 255) & ~(size_t) 255; }
 
-// the activation must be the n = 1 image act_q8_carve lays out: qs | pad | d | pad | bsums, contiguous
-bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind) {
+static size_t act_image_bytes(int64_t k, int act_kind) {
     const int64_t nd = act_kind == T_Q8_0 ? k/32 : k/256, nbs = act_kind == T_Q8_0 ? k/32 : k/16;
-    const size_t bytes = pad256h(k) + pad256h(nd*4) + ((nbs*2 + 15) & ~15);
-    return k % (act_kind == T_Q8_0 ? 32 : 256) == 0 && bytes <= 8*256*16;
+    return pad256h(k) + pad256h(nd*4) + ((nbs*2 + 15) & ~15);
 }
 
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const act_q8 & act, const mmvq_rope * rope, hipStream_t stream) {
+// the activation must be the n = 1 image act_q8_carve lays out: qs | pad | d | pad | bsums, contiguous
+bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind) {
+    return k % (act_kind == T_Q8_0 ? 32 : 256) == 0 && act_image_bytes(k, act_kind) <= 4*512*16;
+}
+bool mul_mat_vec_q_fused_prologue_supported(int64_t k) { return k % 256 == 0 && k <= 16*1024; }
+
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream) {
     fused_mmvq_args a = {};
-    a.n_groups = n_groups; a.k = (int) k; a.act_kind = act.kind;
+    a.n_groups = n_groups; a.k = (int) k; a.act_kind = in.act_kind;
+    // share the persistent workgroups among the groups in proportion to their rows (never more than one row pair per wave)
+    static int n_cu = 0, wpc = 2;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+        if (const char * e = getenv("GGML_MI355X_MMVQ_WPC")) wpc = atoi(e) > 0 ? atoi(e) : 2;
+    }
+    int64_t rows_total = 0;
+    for (int i = 0; i < n_groups; i++) rows_total += (int64_t) groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1);
+    const int budget = n_cu*(groups[0].epi == EPI_GLU ? 1 : wpc);   // the dual (GLU) kernels need > 128 VGPRs: one workgroup per CU
     int blocks = 0;
     for (int i = 0; i < n_groups; i++) {
         a.g[i] = groups[i];
-        blocks += (int)((groups[i].m + 7)/8);
+        const int max_wg = (int)(((groups[i].m + 1)/2 + FW - 1)/FW);
+        int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1) + rows_total - 1)/rows_total);
+        share = share < 1 ? 1 : (share > max_wg ? max_wg : share);
+        blocks += share;
         a.block_end[i] = blocks;
     }
-    const int64_t nbs = act.kind == T_Q8_0 ? k/32 : k/16;
-    a.act = (const char *) act.qs;
-    a.off_d = (int)((const char *) act.d - (const char *) act.qs);
-    a.off_bs = (int)((const char *) act.bsums - (const char *) act.qs);
-    const size_t bytes = (size_t) a.off_bs + ((nbs*2 + 15) & ~15);
+    const int64_t nd = in.act_kind == T_Q8_0 ? k/32 : k/256;
+    a.off_d = (int) pad256h(k);
+    a.off_bs = (int)(pad256h(k) + pad256h(nd*4));
+    const size_t bytes = act_image_bytes(k, in.act_kind);
     a.act_chunks = (int)(bytes/16);
+    if (in.mode == PRO_Q8) {
+        a.act = (const char *) in.act.qs;
+        if ((const char *) in.act.d - (const char *) in.act.qs != a.off_d || (const char *) in.act.bsums - (const char *) in.act.qs != a.off_bs) {
+            fprintf(stderr, "mul_mat_vec_q_fused: activation is not a contiguous n = 1 image\n"); abort();
+        }
+    } else {
+        a.x = in.x; a.norm_w = in.norm_w; a.eps = in.eps;
+    }
     if (rope) {
         a.rope.pos = rope->pos; a.rope.ff = rope->freq_factors; a.rope.n_dims = rope->p.n_dims; a.rope.head_dim = rope->head_dim;
         a.rope.n_ctx_orig = rope->p.n_ctx_orig; a.rope.freq_scale = rope->p.freq_scale; a.rope.ext_factor = rope->p.ext_factor;
@@ -448,15 +521,18 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
         a.rope.corr_lo = fmaxf(0.0f, start); a.rope.corr_hi = fminf((float)(rope->p.n_dims - 1), end);
     }
     const dim3 grid((unsigned) blocks);
+    const size_t lds = bytes + 32;     // + FW floats for the RMS reduction
     int ta = groups[0].type, tb = groups[0].type;
     for (int i = 1; i < n_groups; i++) if (groups[i].type != ta) tb = groups[i].type;
     if (tb < ta) { const int t = ta; ta = tb; tb = t; }
     const bool glu = groups[0].epi == EPI_GLU;
-    const int nact = a.act_chunks <= 2*256 ? 2 : (a.act_chunks <= 4*256 ? 4 : 8);
+    const int mode = in.mode;
+    const int na = mode == PRO_Q8 ? (a.act_chunks <= 512 ? 1 : (a.act_chunks <= 1024 ? 2 : 4)) : (k <= 4096 ? 2 : 8);
+#define MI_L(TA_, TB_, GLU_, PRO_, NA_) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_>), grid, dim3(FW*64), lds, stream, a)
 #define MI_LAUNCH(TA_, TB_, GLU_) do { \
-        if      (nact == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, 2>), grid, dim3(256), bytes, stream, a); \
-        else if (nact == 4) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, 4>), grid, dim3(256), bytes, stream, a); \
-        else                hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, 8>), grid, dim3(256), bytes, stream, a); } while (0)
+        if (mode == PRO_Q8)         { if (na == 1) MI_L(TA_, TB_, GLU_, PRO_Q8, 1); else if (na == 2) MI_L(TA_, TB_, GLU_, PRO_Q8, 2); else MI_L(TA_, TB_, GLU_, PRO_Q8, 4); } \
+        else if (mode == PRO_NORM)  { if (na == 2) MI_L(TA_, TB_, GLU_, PRO_NORM, 2); else MI_L(TA_, TB_, GLU_, PRO_NORM, 8); } \
+        else                        { if (na == 2) MI_L(TA_, TB_, GLU_, PRO_QUANT, 2); else MI_L(TA_, TB_, GLU_, PRO_QUANT, 8); } } while (0)
 #define MI_SINGLE(T_) if (ta == T_ && tb == T_) { if (glu) MI_LAUNCH(T_, T_, true); else MI_LAUNCH(T_, T_, false); return; }
     MI_SINGLE(T_Q4_K) MI_SINGLE(T_Q6_K) MI_SINGLE(T_Q5_K) MI_SINGLE(T_Q8_0) MI_SINGLE(T_Q4_0) MI_SINGLE(T_MXFP4)
     if (ta == T_Q4_K && tb == T_Q5_K) { MI_LAUNCH(T_Q4_K, T_Q5_K, false); return; }
@@ -464,6 +540,7 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
     if (ta == T_Q5_K && tb == T_Q6_K) { MI_LAUNCH(T_Q5_K, T_Q6_K, false); return; }
 #undef MI_SINGLE
 #undef MI_LAUNCH
+#undef MI_L
     fprintf(stderr, "mul_mat_vec_q_fused: type pair (%d, %d) has no kernel (check mul_mat_vec_q_fused_can_group)\n", ta, tb);
     abort();
 }

@@ -117,12 +117,27 @@ struct mmvq_group {
     size_t row_stride; int m; int type;
     float * dst; int epi;
     const float * res;                 // EPI_ADD: dst[row] = W.x + res[row]
+    // optional f16 store of the result (the KV-cache write that follows wk / wv in the graph):
+    //   st_mode 1: row store     st16[st_idx[0]*st_row_elems + row]   (SET_ROWS of one K row)
+    //   st_mode 2: element store st16[st_idx[row]]                    (SET_ROWS on the transposed-V [1, N] view)
+    uint16_t * st16; const int64_t * st_idx; int64_t st_row_elems; int st_mode;
 };
 struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; };   // EPI_ROPE (NORM pairs)
+
+// where the activation vector comes from
+enum mmvq_prologue { PRO_Q8 = 0, PRO_QUANT = 1, PRO_NORM = 2 };
+struct mmvq_input {
+    int mode;
+    act_q8 act;            // PRO_Q8: one quantized column laid out by act_q8_carve(…, n = 1) (one contiguous image)
+    const float * x;       // PRO_QUANT / PRO_NORM: the f32 vector (16-byte aligned, k % 256 == 0)
+    const float * norm_w;  // PRO_NORM: y = (x * rsqrt(mean(x^2) + eps)) * norm_w, then quantized — RMS_NORM -> MUL folded in
+    float eps;
+    int act_kind;
+};
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
+bool mul_mat_vec_q_fused_prologue_supported(int64_t k);        // PRO_QUANT / PRO_NORM limits
 bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);   // may these two weight types share one grouped launch
-// `act` must be a single quantized column laid out by act_q8_carve(…, n = 1) (one contiguous image)
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const act_q8 & act, const mmvq_rope * rope, hipStream_t stream);
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream);
 
 // ---- test / bench support ------------------------------------------------------------------
 // raw streaming read of `bytes` (16 B/lane, nontemporal) — measures the achievable HBM rate on the box
