@@ -23,7 +23,7 @@ ARCH = "gfx950"
 INC = ["-I", str(ROOT / "include"), "-I", str(ROOT / "include" / "ggml-compat"), "-I", str(CSRC)]
 COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-function",
           "-Wno-missing-field-initializers"]
-HIPFLAGS = [f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"]
+HIPFLAGS = [f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"] + os.environ.get("MI_EXTRA_HIPFLAGS", "").split()
 
 KERNEL_SRCS = ["quantize_act.hip", "mmvq.hip", "mmq.hip", "mm_dense.hip", "elem.hip", "decode_fused.hip"]
 

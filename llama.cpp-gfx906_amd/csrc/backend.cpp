@@ -451,7 +451,8 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             if (kind < 0) continue;
             const struct ggml_tensor * b = n->src[1];
             const int64_t rows = n->op == GGML_OP_MUL_MAT ? b->ne[1] : b->ne[1]*b->ne[2];
-            const size_t s = act_q8_bytes(kind, b->ne[0], rows);
+            size_t s = act_q8_bytes(kind, b->ne[0], rows);
+            if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows);
             if (s > need) need = s;
         }
     }
@@ -483,16 +484,17 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
         for (int64_t i13 = 0; i13 < b->ne[3]; i13++) {
             for (int64_t i12 = 0; i12 < b->ne[2]; i12++) {
                 const char * bp = (const char *) b->data + i12*b->nb[2] + i13*b->nb[3];
-                const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
                 const char * W = (const char *) a->data + (i12/r2)*a->nb[2] + (i13/r3)*a->nb[3];
                 float * d = (float *) ((char *) dst->data + i12*dst->nb[2] + i13*dst->nb[3]);
                 prof_begin(c, (int) a->type, M, K, N, (uint64_t) M*ggml_row_size(a->type, K));
                 if (N <= MMVQ_MAX_N) {
+                    const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
                     mul_mat_vec_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
                     c->cnt.mmvq_launches++;
                 } else {
-                    mul_mat_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
-                    c->cnt.mmq_launches++;
+                    c->aq.valid = false;   // the scratch is reused for the bf16 activations
+                    mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, d, dst->nb[1], c->stream);
+                    c->cnt.mmq_launches++; c->cnt.kernels_launched++;
                 }
                 prof_end(c);
                 c->cnt.kernels_launched++;

@@ -111,9 +111,14 @@ static __device__ __forceinline__ int2v ld_b64(const void * p) {
     const u32x2_u t = *(const u32x2_u *) p;
     return int2v{ (int) t.x, (int) t.y };
 }
-// 16-byte aligned, streamed-once weight bytes: nontemporal (MI355X_MICROARCH.md "nt-weights")
+// 16-byte aligned weight bytes. Measured on the tg128 bench (profiles/r01_*): plain loads 500 tok/s vs nontemporal 482,
+// so plain is the default; -DMI_NT_WEIGHTS switches the streamed-once hint back on for experiments.
 static __device__ __forceinline__ int4v ld_b128_nt(const void * p) {
+#ifdef MI_NT_WEIGHTS
     return __builtin_nontemporal_load((const int4v *) p);
+#else
+    return *(const int4v *) p;
+#endif
 }
 
 } // namespace mi355x
