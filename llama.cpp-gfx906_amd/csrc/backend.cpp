@@ -454,6 +454,9 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             size_t s = act_q8_bytes(kind, b->ne[0], rows);
             if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows);
             if (s > need) need = s;
+        } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16 && n->src[1]->type == GGML_TYPE_F32 && n->src[1]->ne[1] > MMVQ_MAX_N) {
+            const size_t s = (size_t) ggml_nelements(n->src[1])*2 + 256;     // f16 copy of src1 for the matrix-core attention products
+            if (s > need) need = s;
         }
     }
     return need;
@@ -511,6 +514,12 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
     p.ne10 = b->ne[0]; p.ne11 = b->ne[1]; p.ne12 = b->ne[2]; p.ne13 = b->ne[3];
     p.nb10 = b->nb[0]; p.nb11 = b->nb[1]; p.nb12 = b->nb[2]; p.nb13 = b->nb[3];
     p.dst = (float *) dst->data; p.nb1 = dst->nb[1]; p.nb2 = dst->nb[2]; p.nb3 = dst->nb[3];
+    if (mul_mat_dense_mfma_supported(p) && mul_mat_dense_mfma_scratch_bytes(p) <= c->scratch_size) {
+        c->aq.valid = false;   // scratch reused
+        mul_mat_dense_mfma(p, c->scratch, c->stream);
+        c->cnt.kernels_launched += 2;
+        return;
+    }
     mul_mat_dense(p, c->stream);
     c->cnt.kernels_launched++;
 }

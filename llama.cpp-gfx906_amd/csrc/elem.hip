@@ -42,6 +42,21 @@ static __device__ __forceinline__ void st_elem(char * p, int type, float v) {
     }
 }
 
+// linear index -> 4-D coordinates over (e0, e1, e2, *). 64-bit division is ~10x the cost of 32-bit on the VALU and these kernels
+// are tiny, so the 32-bit path is taken whenever the element count allows (always, on the decode/prefill path).
+struct idx4 { int64_t i0, i1, i2, i3; };
+static __device__ __forceinline__ idx4 unravel(int64_t i, int64_t e0, int64_t e1, int64_t e2) {
+    idx4 r;
+    if ((e0 | e1 | e2 | i) < (1ll << 31)) {
+        uint32_t u = (uint32_t) i; const uint32_t a = (uint32_t) e0, b = (uint32_t) e1, c = (uint32_t) e2;
+        r.i0 = u % a; u /= a; r.i1 = u % b; u /= b; r.i2 = u % c; r.i3 = u / c;
+    } else {
+        r.i0 = i % e0; r.i1 = (i / e0) % e1; r.i2 = (i / (e0*e1)) % e2; r.i3 = i / (e0*e1*e2);
+    }
+    return r;
+}
+static __device__ __forceinline__ int64_t wrap(int64_t i, int64_t e) { return e == 1 ? 0 : (i < e ? i : ((i | e) < (1ll << 31) ? (int64_t)((uint32_t) i % (uint32_t) e) : i % e)); }
+
 // block-wide sum / max for 256-thread workgroups (4 waves)
 static __device__ __forceinline__ float block_sum(float v, float * sh) {
     v = wave_sum(v);
@@ -72,7 +87,7 @@ template <bool HAS_W, bool HAS_ADD>
 __global__ void __launch_bounds__(256) k_rms_norm(const td src, const td w, const td add, const td dst, float eps) {
     __shared__ float sh[4];
     const int64_t row = blockIdx.x;
-    const int64_t i1 = row % src.ne1, i2 = (row / src.ne1) % src.ne2, i3 = row / (src.ne1*src.ne2);
+    const idx4 rx = unravel(row, src.ne1, src.ne2, 1ll << 30); const int64_t i1 = rx.i0, i2 = rx.i1, i3 = rx.i2;
     const char * x = src.data + i1*src.nb1 + i2*src.nb2 + i3*src.nb3;
     char * y = dst.data + i1*dst.nb1 + i2*dst.nb2 + i3*dst.nb3;
     float ss = 0.0f;
@@ -89,12 +104,13 @@ __global__ void __launch_bounds__(256) k_rms_norm(const td src, const td w, cons
     const float mean = ss / (float) src.ne0;
     const float scale = 1.0f/sqrtf(mean + eps);
     const char * wp = nullptr; const char * ap = nullptr;
-    if (HAS_W)   wp = w.data   + (i1 % w.ne1)*w.nb1     + (i2 % w.ne2)*w.nb2     + (i3 % w.ne3)*w.nb3;
-    if (HAS_ADD) ap = add.data + (i1 % add.ne1)*add.nb1 + (i2 % add.ne2)*add.nb2 + (i3 % add.ne3)*add.nb3;
+    if (HAS_W)   wp = w.data   + wrap(i1, w.ne1)*w.nb1     + wrap(i2, w.ne2)*w.nb2     + wrap(i3, w.ne3)*w.nb3;
+    if (HAS_ADD) ap = add.data + wrap(i1, add.ne1)*add.nb1 + wrap(i2, add.ne2)*add.nb2 + wrap(i3, add.ne3)*add.nb3;
+    const bool w_full = !HAS_W || w.ne0 == src.ne0, a_full = !HAS_ADD || add.ne0 == src.ne0;   // no wrap needed (the model case)
     for (int64_t i = threadIdx.x; i < src.ne0; i += blockDim.x) {
         float v = *(const float *) (x + i*4) * scale;
-        if (HAS_W)   v *= *(const float *) (wp + (i % w.ne0)*4);
-        if (HAS_ADD) v += *(const float *) (ap + (i % add.ne0)*4);
+        if (HAS_W)   v *= *(const float *) (wp + (w_full ? i : wrap(i, w.ne0))*4);
+        if (HAS_ADD) v += *(const float *) (ap + (a_full ? i : wrap(i, add.ne0))*4);
         *(float *) (y + i*4) = v;
     }
 }
@@ -119,9 +135,9 @@ template <int OP>
 __global__ void __launch_bounds__(256) k_bin_bcast(const td a, const td b, const td dst, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t i0 = i % dst.ne0, i1 = (i / dst.ne0) % dst.ne1, i2 = (i / (dst.ne0*dst.ne1)) % dst.ne2, i3 = i / (dst.ne0*dst.ne1*dst.ne2);
+    const idx4 ix = unravel(i, dst.ne0, dst.ne1, dst.ne2); const int64_t i0 = ix.i0, i1 = ix.i1, i2 = ix.i2, i3 = ix.i3;
     const float x = ld_elem(a.data + i0*a.nb0 + i1*a.nb1 + i2*a.nb2 + i3*a.nb3, a.type);
-    const float y = ld_elem(b.data + (i0 % b.ne0)*b.nb0 + (i1 % b.ne1)*b.nb1 + (i2 % b.ne2)*b.nb2 + (i3 % b.ne3)*b.nb3, b.type);
+    const float y = ld_elem(b.data + wrap(i0, b.ne0)*b.nb0 + wrap(i1, b.ne1)*b.nb1 + wrap(i2, b.ne2)*b.nb2 + wrap(i3, b.ne3)*b.nb3, b.type);
     float r;
     if (OP == BIN_ADD) r = x + y; else if (OP == BIN_MUL) r = x*y; else if (OP == BIN_DIV) r = x/y; else r = x - y;
     st_elem(dst.data + i0*dst.nb0 + i1*dst.nb1 + i2*dst.nb2 + i3*dst.nb3, dst.type, r);
@@ -143,7 +159,7 @@ void bin_bcast(int op, const tensor_desc & a, const tensor_desc & b, const tenso
 __global__ void __launch_bounds__(256) k_add_id(const td a, const td bias, const td ids, const td dst, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t i0 = i % dst.ne0, iu = (i / dst.ne0) % dst.ne1, it = i / (dst.ne0*dst.ne1);
+    const idx4 ix = unravel(i, dst.ne0, dst.ne1, 1ll << 30); const int64_t i0 = ix.i0, iu = ix.i1, it = ix.i2;
     const int e = *(const int32_t *) (ids.data + iu*ids.nb0 + it*ids.nb1);
     const float x = *(const float *) (a.data + i0*a.nb0 + iu*a.nb1 + it*a.nb2);
     const float y = *(const float *) (bias.data + i0*bias.nb0 + (int64_t) e*bias.nb1);
@@ -159,7 +175,7 @@ void add_id(const tensor_desc & a, const tensor_desc & bias, const tensor_desc &
 __global__ void __launch_bounds__(256) k_scale(const td src, const td dst, float s, float b, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t i0 = i % dst.ne0, i1 = (i / dst.ne0) % dst.ne1, i2 = (i / (dst.ne0*dst.ne1)) % dst.ne2, i3 = i / (dst.ne0*dst.ne1*dst.ne2);
+    const idx4 ix = unravel(i, dst.ne0, dst.ne1, dst.ne2); const int64_t i0 = ix.i0, i1 = ix.i1, i2 = ix.i2, i3 = ix.i3;
     const float x = *(const float *) (src.data + i0*src.nb0 + i1*src.nb1 + i2*src.nb2 + i3*src.nb3);
     *(float *) (dst.data + i0*dst.nb0 + i1*dst.nb1 + i2*dst.nb2 + i3*dst.nb3) = x*s + b;
 }
@@ -174,8 +190,8 @@ void scale(const tensor_desc & src, const tensor_desc & dst, float s, float b, h
 __global__ void __launch_bounds__(256) k_cpy(const td src, const td dst, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t s0 = i % src.ne0, s1 = (i / src.ne0) % src.ne1, s2 = (i / (src.ne0*src.ne1)) % src.ne2, s3 = i / (src.ne0*src.ne1*src.ne2);
-    const int64_t d0 = i % dst.ne0, d1 = (i / dst.ne0) % dst.ne1, d2 = (i / (dst.ne0*dst.ne1)) % dst.ne2, d3 = i / (dst.ne0*dst.ne1*dst.ne2);
+    const idx4 sx = unravel(i, src.ne0, src.ne1, src.ne2), dx = unravel(i, dst.ne0, dst.ne1, dst.ne2);
+    const int64_t s0 = sx.i0, s1 = sx.i1, s2 = sx.i2, s3 = sx.i3, d0 = dx.i0, d1 = dx.i1, d2 = dx.i2, d3 = dx.i3;
     const char * sp = src.data + s0*src.nb0 + s1*src.nb1 + s2*src.nb2 + s3*src.nb3;
     char * dp = dst.data + d0*dst.nb0 + d1*dst.nb1 + d2*dst.nb2 + d3*dst.nb3;
     if (src.type == dst.type) {
@@ -196,8 +212,8 @@ void cpy(const tensor_desc & src, const tensor_desc & dst, hipStream_t stream) {
 __global__ void __launch_bounds__(256) k_set_rows(const td src, const td idx, const td dst, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t i0 = i % src.ne0, i1 = (i / src.ne0) % src.ne1, i2 = (i / (src.ne0*src.ne1)) % src.ne2, i3 = i / (src.ne0*src.ne1*src.ne2);
-    const int64_t r = *(const int64_t *) (idx.data + i1*idx.nb0 + (i2 % idx.ne1)*idx.nb1 + (i3 % idx.ne2)*idx.nb2);
+    const idx4 ix = unravel(i, src.ne0, src.ne1, src.ne2); const int64_t i0 = ix.i0, i1 = ix.i1, i2 = ix.i2, i3 = ix.i3;
+    const int64_t r = *(const int64_t *) (idx.data + i1*idx.nb0 + wrap(i2, idx.ne1)*idx.nb1 + wrap(i3, idx.ne2)*idx.nb2);
     const float v = *(const float *) (src.data + i0*src.nb0 + i1*src.nb1 + i2*src.nb2 + i3*src.nb3);
     st_elem(dst.data + i0*dst.nb0 + r*dst.nb1 + i2*dst.nb2 + i3*dst.nb3, dst.type, v);
 }
@@ -212,7 +228,7 @@ void set_rows(const tensor_desc & src, const tensor_desc & idx, const tensor_des
 __global__ void __launch_bounds__(256) k_get_rows(const td src, const td idx, const td dst, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t i0 = i % dst.ne0, i10 = (i / dst.ne0) % dst.ne1, i11 = (i / (dst.ne0*dst.ne1)) % dst.ne2, i12 = i / (dst.ne0*dst.ne1*dst.ne2);
+    const idx4 ix = unravel(i, dst.ne0, dst.ne1, dst.ne2); const int64_t i0 = ix.i0, i10 = ix.i1, i11 = ix.i2, i12 = ix.i3;
     const int64_t r = *(const int32_t *) (idx.data + i10*idx.nb0 + i11*idx.nb1 + i12*idx.nb2);
     const float v = ld_elem(src.data + i0*src.nb0 + r*src.nb1 + i11*src.nb2 + i12*src.nb3, src.type);
     st_elem(dst.data + i0*dst.nb0 + i10*dst.nb1 + i11*dst.nb2 + i12*dst.nb3, dst.type, v);
@@ -288,7 +304,7 @@ static __device__ __forceinline__ float silu_f(float x) { return x/(1.0f + expf(
 __global__ void __launch_bounds__(256) k_unary(int op, const td src, const td dst, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t i0 = i % dst.ne0, i1 = (i / dst.ne0) % dst.ne1, i2 = (i / (dst.ne0*dst.ne1)) % dst.ne2, i3 = i / (dst.ne0*dst.ne1*dst.ne2);
+    const idx4 ix = unravel(i, dst.ne0, dst.ne1, dst.ne2); const int64_t i0 = ix.i0, i1 = ix.i1, i2 = ix.i2, i3 = ix.i3;
     const float x = ld_elem(src.data + i0*src.nb0 + i1*src.nb1 + i2*src.nb2 + i3*src.nb3, src.type);
     float r;
     switch (op) {
@@ -323,7 +339,7 @@ enum { G_REGLU, G_GEGLU, G_SWIGLU, G_SWIGLU_OAI, G_GEGLU_ERF, G_GEGLU_QUICK };
 __global__ void __launch_bounds__(256) k_glu(int op, const td a, const td b, const td dst, int64_t n, float alpha, float limit) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= n) return;
-    const int64_t i0 = i % dst.ne0, i1 = (i / dst.ne0) % dst.ne1, i2 = (i / (dst.ne0*dst.ne1)) % dst.ne2, i3 = i / (dst.ne0*dst.ne1*dst.ne2);
+    const idx4 ix = unravel(i, dst.ne0, dst.ne1, dst.ne2); const int64_t i0 = ix.i0, i1 = ix.i1, i2 = ix.i2, i3 = ix.i3;
     const float x = ld_elem(a.data + i0*a.nb0 + i1*a.nb1 + i2*a.nb2 + i3*a.nb3, a.type);
     const float g = ld_elem(b.data + i0*b.nb0 + i1*b.nb1 + i2*b.nb2 + i3*b.nb3, b.type);
     float r;
@@ -381,7 +397,7 @@ __global__ void __launch_bounds__(256) k_rope(const td src, const int32_t * pos,
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
     if (i >= npairs) return;
     const int64_t half = src.ne0/2;
-    const int64_t ip = i % half, i1 = (i / half) % src.ne1, i2 = (i / (half*src.ne1)) % src.ne2, i3 = i / (half*src.ne1*src.ne2);
+    const idx4 ix = unravel(i, half, src.ne1, src.ne2); const int64_t ip = ix.i0, i1 = ix.i1, i2 = ix.i2, i3 = ix.i3;
     const char * x = src.data + i1*src.nb1 + i2*src.nb2 + i3*src.nb3;
     char * y = dst.data + i1*dst.nb1 + i2*dst.nb2 + i3*dst.nb3;
     const int64_t i0 = 2*ip;
@@ -423,10 +439,10 @@ __global__ void __launch_bounds__(256) k_soft_max(const td src, const td mask, c
                                                    float m0, float m1, int n_head_log2, bool has_mask) {
     __shared__ float sh[4];
     const int64_t row = blockIdx.x;
-    const int64_t i1 = row % src.ne1, i2 = (row / src.ne1) % src.ne2, i3 = row / (src.ne1*src.ne2);
+    const idx4 rx = unravel(row, src.ne1, src.ne2, 1ll << 30); const int64_t i1 = rx.i0, i2 = rx.i1, i3 = rx.i2;
     const char * x = src.data + i1*src.nb1 + i2*src.nb2 + i3*src.nb3;
     char * y = dst.data + i1*dst.nb1 + i2*dst.nb2 + i3*dst.nb3;
-    const char * mp = has_mask ? mask.data + i1*mask.nb1 + (i2 % mask.ne2)*mask.nb2 + (i3 % mask.ne3)*mask.nb3 : nullptr;
+    const char * mp = has_mask ? mask.data + i1*mask.nb1 + wrap(i2, mask.ne2)*mask.nb2 + wrap(i3, mask.ne3)*mask.nb3 : nullptr;
     float slope = 1.0f;
     if (max_bias > 0.0f) {
         const int h = (int) i2;

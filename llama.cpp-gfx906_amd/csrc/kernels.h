@@ -64,6 +64,10 @@ struct mm_dense_args {
     float * dst; size_t nb1, nb2, nb3;
 };
 void mul_mat_dense(const mm_dense_args & p, hipStream_t stream);
+// matrix-core form for more than 8 columns of f16 x f32 (prefill attention): f32 b is converted to f16 in `scratch`
+bool   mul_mat_dense_mfma_supported(const mm_dense_args & p);
+size_t mul_mat_dense_mfma_scratch_bytes(const mm_dense_args & p);
+void   mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t stream);
 
 // ---- element kernels ---------------------------------------------
 struct tensor_desc {           // a strided 4-D view, ggml convention (ne = elements, nb = bytes)

@@ -29,14 +29,19 @@ static __device__ __forceinline__ uint32_t bf16_rne(float f) {   // finite input
 }
 static __device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return bf16_rne(a) | (bf16_rne(b) << 16); }
 
-// ---- f32 -> bf16 activation pre-pass ([n][k] f32 rows, arbitrary row stride -> dense [n][k] bf16) ----
-__global__ void __launch_bounds__(256) k_act_to_bf16(const float * __restrict__ x, size_t row_stride, uint16_t * __restrict__ y, int64_t k) {
-    const int64_t row = blockIdx.y;
+// ---- f32 -> bf16 / f16 activation pre-pass: strided f32 rows -> dense [batch][n][k] 16-bit ----
+struct act16_args { const char * x; size_t nb1, nb2, nb3; int64_t k, n, ne2; uint16_t * y; };
+template <bool F16>
+__global__ void __launch_bounds__(256) k_act_to_16(const act16_args p) {
+    const int64_t row = blockIdx.y, bz = blockIdx.z;
+    const int64_t i2 = bz % p.ne2, i3 = bz / p.ne2;
     const int64_t i0 = ((int64_t) blockIdx.x*256 + threadIdx.x)*4;
-    if (i0 >= k) return;
-    const float4v v = __builtin_bit_cast(float4v, ld_b128((const char *) x + row*row_stride + i0*4));
-    uint2 o; o.x = pack_bf16(v.x, v.y); o.y = pack_bf16(v.z, v.w);
-    *(uint2 *) (y + row*k + i0) = o;
+    if (i0 >= p.k) return;
+    const float4v v = __builtin_bit_cast(float4v, ld_b128(p.x + row*p.nb1 + i2*p.nb2 + i3*p.nb3 + i0*4));
+    uint2 o;
+    if (F16) { o.x = (uint32_t) f32_to_f16_bits(v.x) | ((uint32_t) f32_to_f16_bits(v.y) << 16); o.y = (uint32_t) f32_to_f16_bits(v.z) | ((uint32_t) f32_to_f16_bits(v.w) << 16); }
+    else     { o.x = pack_bf16(v.x, v.y); o.y = pack_bf16(v.z, v.w); }
+    *(uint2 *) (p.y + (bz*p.n + row)*p.k + i0) = o;
 }
 
 // ---- dequantize 32 consecutive elements [c32*32, c32*32 + 32) of one weight row (reference semantics) ----
@@ -148,15 +153,29 @@ template <> __device__ __forceinline__ void dequant32<T_Q6_K>(const char * row, 
 // ---- the tiled kernel ----
 constexpr int MQ_BM = 128, MQ_BN = 128, MQ_BK = 64, MQ_LD = MQ_BK*2 + 16;   // LDS row stride in bytes (padded)
 
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+struct mmq_args {
+    const char * W; size_t w_row_stride, w_nb2, w_nb3; int m, k;
+    const uint16_t * X; int n;                 // dense [batch][n][k] 16-bit
+    char * dst; size_t dst_nb1, dst_nb2, dst_nb3;
+    int ne12, r2, r3;                          // batch = blockIdx.z = i13*ne12 + i12; weights broadcast: i02 = i12/r2, i03 = i13/r3
+};
+
+// TYPE = a block format (bf16 MFMA on dequantized weights) or T_F16 (f16 MFMA, weights copied as they are: the attention
+// products K.q and V.kq of build_attn_mha, src/llama-graph.cpp:1285,1320, when more than 8 tokens are in flight)
 template <int TYPE>
-__global__ void __launch_bounds__(256) k_mmq(const char * __restrict__ W, size_t w_row_stride, int m, int k,
-                                             const uint16_t * __restrict__ X /* [n][k] bf16 */, int n,
-                                             float * __restrict__ dst, size_t dst_col_stride) {
+__global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     __shared__ __attribute__((aligned(16))) char lds_w[MQ_BM*MQ_LD];
     __shared__ __attribute__((aligned(16))) char lds_x[MQ_BN*MQ_LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y*MQ_BM, n0 = blockIdx.x*MQ_BN;   // the n-tiles of one weight tile are dispatched together (Infinity-Cache reuse of W)
     const int wm = wave & 1, wn = wave >> 1;             // wave tile: weight rows wm*64.., tokens wn*64..
+    const int m = p.m, n = p.n, k = p.k;
+    const int i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
+    const char * W = p.W + (size_t)(i12/p.r2)*p.w_nb2 + (size_t)(i13/p.r3)*p.w_nb3;
+    const uint16_t * X = p.X + (size_t) blockIdx.z*n*k;
+    char * dst = p.dst + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -170,51 +189,56 @@ __global__ void __launch_bounds__(256) k_mmq(const char * __restrict__ W, size_t
     const int srow = tid >> 1, shalf = tid & 1;
     const int wrow = min(m0 + srow, m - 1);
     const int xrow = min(n0 + srow, n - 1);
-    const char * wrow_p = W + (size_t) wrow*w_row_stride;
+    const char * wrow_p = W + (size_t) wrow*p.w_row_stride;
     const uint16_t * xrow_p = X + (size_t) xrow*k;
 
     for (int k0 = 0; k0 < k; k0 += MQ_BK) {
-        // ---- stage: dequantize 32 weights, copy 32 activations ----
+        // ---- stage: dequantize (or copy) 32 weights, copy 32 activations ----
         const int kc = k0 + 32*shalf;
-        float wv[32];
-        int4v xv[4];
+        int4v wpk[4], xv[4];
         if (kc < k) {
-            dequant32<TYPE>(wrow_p, kc >> 5, wv);
+            if (TYPE == T_F16) {
+#pragma unroll
+                for (int i = 0; i < 4; i++) wpk[i] = ld_b128(wrow_p + (size_t) kc*2 + 16*i);
+            } else {
+                float wv[32];
+                dequant32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kc >> 5, wv);
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    wpk[i].x = (int) pack_bf16(wv[8*i + 0], wv[8*i + 1]); wpk[i].y = (int) pack_bf16(wv[8*i + 2], wv[8*i + 3]);
+                    wpk[i].z = (int) pack_bf16(wv[8*i + 4], wv[8*i + 5]); wpk[i].w = (int) pack_bf16(wv[8*i + 6], wv[8*i + 7]);
+                }
+            }
 #pragma unroll
             for (int i = 0; i < 4; i++) xv[i] = ld_b128((const char *) (xrow_p + kc) + 16*i);
         } else {
 #pragma unroll
-            for (int i = 0; i < 32; i++) wv[i] = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 4; i++) xv[i] = int4v{ 0, 0, 0, 0 };
+            for (int i = 0; i < 4; i++) { wpk[i] = int4v{ 0, 0, 0, 0 }; xv[i] = int4v{ 0, 0, 0, 0 }; }
         }
         __syncthreads();   // previous step's operand reads are done
         {
             char * wp = lds_w + srow*MQ_LD + shalf*64;
             char * xp = lds_x + srow*MQ_LD + shalf*64;
 #pragma unroll
-            for (int i = 0; i < 4; i++) {
-                int4v pk;
-                pk.x = (int) pack_bf16(wv[8*i + 0], wv[8*i + 1]); pk.y = (int) pack_bf16(wv[8*i + 2], wv[8*i + 3]);
-                pk.z = (int) pack_bf16(wv[8*i + 4], wv[8*i + 5]); pk.w = (int) pack_bf16(wv[8*i + 6], wv[8*i + 7]);
-                *(int4v *) (wp + 16*i) = pk;
-                *(int4v *) (xp + 16*i) = xv[i];
-            }
+            for (int i = 0; i < 4; i++) { *(int4v *) (wp + 16*i) = wpk[i]; *(int4v *) (xp + 16*i) = xv[i]; }
         }
         __syncthreads();
         // ---- MFMA: A = activations (rows = tokens), B = weights (cols = weight rows) ----
 #pragma unroll
         for (int kk = 0; kk < MQ_BK/16; kk++) {
-            bf16x8 a[2], b[2];
+            int4v a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                a[i] = __builtin_bit_cast(bf16x8, *(const int4v *) (lds_x + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16));
-                b[i] = __builtin_bit_cast(bf16x8, *(const int4v *) (lds_w + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16));
+                a[i] = *(const int4v *) (lds_x + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+                b[i] = *(const int4v *) (lds_w + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)
 #pragma unroll
-                for (int j = 0; j < 2; j++) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < 2; j++) {
+                    if (TYPE == T_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
+                    else               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+                }
         }
     }
     // ---- store: D[row = token][col = weight row]; col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) ----
@@ -226,7 +250,7 @@ __global__ void __launch_bounds__(256) k_mmq(const char * __restrict__ W, size_t
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = n0 + wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
-                if (col < m && row < n) *(float *) ((char *) dst + (size_t) row*dst_col_stride + (size_t) col*4) = acc[i][j][r];
+                if (col < m && row < n) *(float *) (dst + (size_t) row*p.dst_nb1 + (size_t) col*4) = acc[i][j][r];
             }
         }
     }
@@ -238,9 +262,11 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
                const float * x, size_t x_row_stride, int64_t n, void * scratch, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
     if (m == 0 || n == 0) return;
     uint16_t * xb = (uint16_t *) scratch;
-    hipLaunchKernelGGL(k_act_to_bf16, dim3((unsigned)((k + 1023)/1024), (unsigned) n), dim3(256), 0, stream, x, x_row_stride, xb, k);
-    const dim3 grid((unsigned)((n + MQ_BN - 1)/MQ_BN), (unsigned)((m + MQ_BM - 1)/MQ_BM));
-#define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), 0, stream, (const char *) W, w_row_stride, (int) m, (int) k, xb, (int) n, dst, dst_col_stride_bytes)
+    act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
+    hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
+    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1 };
+    const dim3 grid((unsigned)((n + MQ_BN - 1)/MQ_BN), (unsigned)((m + MQ_BM - 1)/MQ_BM), 1);
+#define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), 0, stream, a)
     switch (type_a) {
         case T_Q4_0:  MI_MMQ(T_Q4_0);  break;
         case T_Q8_0:  MI_MMQ(T_Q8_0);  break;
@@ -251,6 +277,25 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         default: fprintf(stderr, "mmq: unsupported type %d\n", type_a); abort();
     }
 #undef MI_MMQ
+}
+
+// f16 x f32 with ggml broadcast on the matrix cores (n > 8 columns): a rows contiguous f16, b rows contiguous f32
+bool mul_mat_dense_mfma_supported(const mm_dense_args & p) {
+    return p.type_a == T_F16 && p.type_b == T_F32 && p.nb00 == 2 && p.nb10 == 4 && p.ne11 > MMVQ_MAX_N && p.ne00 % 32 == 0 &&
+           p.ne12*p.ne13 <= 65535 && p.ne01 < (1ll << 30) && p.ne11 < (1ll << 30);
+}
+size_t mul_mat_dense_mfma_scratch_bytes(const mm_dense_args & p) { return (size_t) p.ne10*p.ne11*p.ne12*p.ne13*2 + 256; }
+
+void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t stream) {
+    if (p.ne01 == 0 || p.ne11 == 0 || p.ne12*p.ne13 == 0) return;
+    uint16_t * xb = (uint16_t *) scratch;
+    const int64_t nbatch = p.ne12*p.ne13;
+    act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
+    hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((p.ne10 + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
+    mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
+                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03) };
+    const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
+    hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), 0, stream, a);
 }
 
 } // namespace mi355x
