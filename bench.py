@@ -110,15 +110,21 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: no GPU visible (the product has no CPU fallback)")
-    torch.cuda.set_device(local_rank)
+    n_dev = torch.cuda.device_count()
+    transport = os.environ.get("BENCH_TRANSPORT", "nccl")     # "gloo": debug path — ranks may share a GPU, hand-off staged through host memory
+    dev_index = local_rank if transport == "nccl" else local_rank % n_dev
+    torch.cuda.set_device(dev_index)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if transport == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group("gloo")
 
     import __graft_entry__ as ge
     pkg = ge.load_package()
     gg, ls, lsp = pkg.ggml, pkg.llama_synth, pkg.layer_split
 
-    be = gg.Backend(local_rank)
+    be = gg.Backend(dev_index)
     cfg = ls.MODELS[args.model]
     K, W = args.steps, args.warmup
     ranges = lsp.layer_ranges(cfg["n_layer"], world)
@@ -203,8 +209,9 @@ def main():
                 result["cpu_baseline"] = {"value": None, "unit": "tok/s", "cores": 0, "kind": "port", "sample": f"failed: {e}"}
     else:
         n_embd = cfg["n_embd"]
-        recv_buf = [torch.empty(n_embd, dtype=torch.float32, device="cuda") for _ in range(lsp.N_BUF)]
-        send_buf = [torch.empty(n_embd, dtype=torch.float32, device="cuda") for _ in range(lsp.N_BUF)]
+        buf_dev = "cuda" if transport == "nccl" else "cpu"
+        recv_buf = [torch.empty(n_embd, dtype=torch.float32, device=buf_dev) for _ in range(lsp.N_BUF)]
+        send_buf = [torch.empty(n_embd, dtype=torch.float32, device=buf_dev) for _ in range(lsp.N_BUF)]
         recv_work = [None] * lsp.N_BUF; send_work = [None] * lsp.N_BUF
         tcur = torch.cuda.current_stream()
 
@@ -237,7 +244,7 @@ def main():
         sync_all(); t0 = time.perf_counter()
         lsp.run_steps(tr, K, stage, 0, n_seq)
         sync_all(); dt = time.perf_counter() - t0
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=buf_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         result.update(value=K / dt, ms_per_step=dt / K * 1e3)
