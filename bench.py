@@ -218,14 +218,14 @@ def main():
         def post_recv(j):
             recv_work[j % lsp.N_BUF] = dist.irecv(recv_buf[j % lsp.N_BUF], src=rank - 1)
         def wait_recv(j):
-            recv_work[j % lsp.N_BUF].wait(); tcur.synchronize()
+            recv_work[j % lsp.N_BUF].wait(); recv_work[j % lsp.N_BUF] = None; tcur.synchronize()
         def send(j):
             b = j % lsp.N_BUF
             send_work[b] = dist.isend(send_buf[b], dst=rank + 1)
         def flush():
-            for w in send_work:
+            for i, w in enumerate(send_work):
                 if w is not None:
-                    w.wait()
+                    w.wait(); send_work[i] = None      # a Work is waited exactly once (gloo blocks on a second wait)
             tcur.synchronize()
         tr = lsp.Transport(rank, world, post_recv, wait_recv, send, flush)
         pos = [0] * n_seq
@@ -239,10 +239,16 @@ def main():
                      dev_result_out=send_buf[b].data_ptr() if rank < world - 1 else None,
                      want_host=has_out, sync=True)
             pos[seq] += 1
+        log(f"[rank {rank}] warm-up: {W} pipeline steps")
         lsp.run_steps(tr, W, stage, 0, n_seq)
         m.kv_clear()
+        log(f"[rank {rank}] warm-up done")
+        if os.environ.get("BENCH_DEBUG"):
+            import faulthandler; faulthandler.dump_traceback_later(int(os.environ["BENCH_DEBUG"]), exit=True)
         sync_all(); t0 = time.perf_counter()
+        log(f"[rank {rank}] timed region: {K} pipeline steps")
         lsp.run_steps(tr, K, stage, 0, n_seq)
+        log(f"[rank {rank}] timed steps done")
         sync_all(); dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64, device=buf_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
