@@ -282,13 +282,22 @@ struct fused_mmvq_args {
     int off_d, off_bs;                    // byte offsets of d / bsums inside the image
     const float * x; const float * norm_w; float eps;
     fused_rope rope;
+#ifdef MI_STAMPS
+    unsigned long long * stamps;          // [workgroup][8] 100 MHz wall-clock stamps (tools/stamp_timeline.py), NULL = off
+#endif
 };
 
-static __device__ __forceinline__ void rope_pair(const fused_rope & r, int row_in_head, float & x0, float & x1) {
+#ifdef MI_STAMPS
+#define MI_STAMP(i_) do { if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x*8 + (i_)] = wall_clock64(); } while (0)
+#else
+#define MI_STAMP(i_) do { } while (0)
+#endif
+
+static __device__ __forceinline__ void rope_pair(const fused_rope & r, int pos, int row_in_head, float & x0, float & x1) {
     // NORM rope on the pair (2i, 2i+1) — same formulas as elem.hip k_rope<false>
     if (row_in_head >= r.n_dims) return;
     const int ip = row_in_head >> 1;
-    const float theta_base = (float) r.pos[0]*powf(r.theta_scale, (float) ip);
+    const float theta_base = (float) pos*powf(r.theta_scale, (float) ip);
     const float theta_extrap = theta_base/(r.ff ? r.ff[ip] : 1.0f);
     float theta_interp = r.freq_scale*theta_extrap, theta = theta_interp, mscale = r.attn_factor;
     if (r.ext_factor != 0.0f) {
@@ -306,15 +315,40 @@ static __device__ __forceinline__ void rope_pair(const fused_rope & r, int row_i
 // PERSISTENT grouped mat-vec. A launch has about (CUs x 2) workgroups of 8 waves; each workgroup belongs to one group (weight
 // tensor) and its waves walk that tensor's row pairs with a grid stride, so that
 //   * the activation is prepared ONCE per workgroup (copy / quantize / rms-norm + quantize into LDS) instead of once per 8 rows,
-//   * the packed-weight stream never stops: loads run two steps ahead across row boundaries, and the DPP reduction + epilogue of
-//     one row pair overlaps the loads of the next.
-// Order of issue: (1) activation loads (L2-resident, a few KB), (2) the first two steps of weight loads (HBM), (3) prologue into
+//   * the packed-weight stream never stops: loads run D steps ahead across row boundaries in a STATIC ring of register sets (the
+//     loop is unrolled D times; a rotating copy w0 = w1 makes the compiler wait for every outstanding load at the top of each step,
+//     measured: tools/stamp_timeline.py), and the DPP reduction + epilogue of one row pair overlaps the loads of the next.
+// Order of issue: (1) activation loads (L2-resident, a few KB), (2) the first D steps of weight loads (HBM), (3) prologue into
 // LDS + barrier — the compiler's counted vmcnt wait covers only (1) — (4) integer dots, (5) reduction + epilogue per row pair.
 // Every load is unconditional (clamped address) so that the number of outstanding loads is the same on every path.
 //   PRO  : where the activation comes from (mmvq_prologue)
 //   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*2048)
 constexpr int FW = 8;            // waves per workgroup
-template <int TYPE, bool GLU, int PRO, int NA>
+
+// what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers)
+struct pair_out { float s0, s1; int row0; int pos0; long long idx0; };
+static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, pair_out o) {
+    float s0 = o.s0, s1 = o.s1;
+    const int row0 = o.row0;
+    if (g.epi == EPI_ADD) {
+        s0 += g.res[row0];
+        if (row0 + 1 < g.m) s1 += g.res[row0 + 1];
+    } else if (g.epi == EPI_ROPE) {
+        rope_pair(rope, o.pos0, row0 % rope.head_dim, s0, s1);   // m is even on this path
+    }
+    g.dst[row0] = s0;
+    if (row0 + 1 < g.m) g.dst[row0 + 1] = s1;
+    if (g.st_mode == 1) {
+        uint16_t * q = g.st16 + o.idx0*g.st_row_elems + row0;
+        q[0] = f32_to_f16_bits(s0);
+        if (row0 + 1 < g.m) q[1] = f32_to_f16_bits(s1);
+    } else if (g.st_mode == 2) {
+        g.st16[g.st_idx[row0]] = f32_to_f16_bits(s0);
+        if (row0 + 1 < g.m) g.st16[g.st_idx[row0 + 1]] = f32_to_f16_bits(s1);
+    }
+}
+
+template <int TYPE, bool GLU, int PRO, int NA, int D>
 static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fused_mmvq_args & p, char * smem, int wg_in_group, int nwg_group,
                                                   int lane, int wave) {
     typedef mmvq_t<TYPE> T;
@@ -324,8 +358,10 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     const int slot = lane % LPB, ibl = lane / LPB;
     const int P = (g.m + R - 1)/R;                       // row pairs in this group
     const int stride = nwg_group*FW;
-    int p_cur = wg_in_group*FW + wave;
+    const int p_first = wg_in_group*FW + wave;
+    int p_cur = p_first;
 
+    MI_STAMP(0);
     // ---- (1) activation loads ----
     int4v areg[PRO == PRO_Q8 ? NA : 1];
     float4v xv[PRO != PRO_Q8 ? NA : 1], wv[PRO == PRO_NORM ? NA : 1];
@@ -338,28 +374,46 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int c = min(wave + FW*i, nchunk - 1);
-            xv[i] = *(const float4v *) (p.x + c*256 + lane*4);
-            if (PRO == PRO_NORM) wv[i] = *(const float4v *) (p.norm_w + c*256 + lane*4);
-        }
+        for (int i = 0; i < NA; i++) xv[i] = *(const float4v *) (p.x + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+    }
+    // wave-uniform epilogue operands, fetched now (scalar loads) instead of at the end of the first row pair
+    const int pos0 = g.epi == EPI_ROPE ? p.rope.pos[0] : 0;
+    const long long idx0 = g.st_mode == 1 ? (long long) g.st_idx[0] : 0;
+    // A CU's L1 returns data in request order across all its waves: a load that hits L2 (the activation, just written) queued
+    // behind one that goes to HBM (weights, norm weights) of ANY wave comes back with HBM latency — 1-4 us instead of ~0.5 us,
+    // and the whole prologue hangs on it (measured, tools/stamp_timeline.py: the second workgroup on a CU saw its activation 2 us
+    // after the first). So: every wave issues its activation loads, the workgroup meets at a barrier (issue order = request
+    // order), and only then are norm weights and the weight stream requested. The asm statements are compiler barriers too.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (PRO == PRO_NORM) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + min(wave + FW*i, nchunk - 1)*256 + lane*4);
     }
 
-    // ---- (2) weight prefetch: the first two steps of this wave's stream ----
-    // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch
+    // ---- (2) weight prefetch: the first D steps of this wave's stream ----
+    // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch.
+    // Past the end of the stream the loads go to the wave's own first block (an L1 hit), not to a line every wave would share.
     int p_pf = p_cur, it_pf = 0;
-    typename T::wfrag w0[R], w1[R], u0[R], u1[R];
-#define MI_FETCH(WDST, UDST) { \
-        const int pp = min(p_pf, P - 1); \
-        const int ibf = min(it_pf*BPW + ibl, nb - 1); \
+    typename T::wfrag w[D][R], u[GLU ? D : 1][R];
+#define MI_FETCH(d_) { \
+        const bool live = p_pf < P; \
+        const int pp = live ? p_pf : min(p_first, P - 1); \
+        const int ibf = live ? min(it_pf*BPW + ibl, nb - 1) : 0; \
         _Pragma("unroll") for (int r = 0; r < R; r++) { \
             const size_t off = (size_t) min(pp*R + r, g.m - 1)*g.row_stride; \
-            WDST[r] = T::load_w(g.W + off, ibf, slot); \
-            if (GLU) UDST[r] = T::load_w(g.W2 + off, ibf, slot); \
+            w[d_][r] = T::load_w(g.W + off, ibf, slot); \
+            if (GLU) u[GLU ? d_ : 0][r] = T::load_w(g.W2 + off, ibf, slot); \
         } \
         if (++it_pf == iters) { it_pf = 0; p_pf += stride; } }
-    MI_FETCH(w0, u0)
-    MI_FETCH(w1, u1)
+    // A wave blocks at a load it cannot queue (the CU's request queue is finite) and then cannot run its share of the prologue
+    // either, so the D steps are not issued in one burst: one step now, the others between the phases of the prologue (FENCE keeps
+    // the compiler from hoisting them back up). HBM then has work from the first 0.2 us on and the prologue math starts as soon as
+    // the activation is there.
+#define MI_FENCE asm volatile("" ::: "memory")
+    MI_FETCH(0)
+    MI_FENCE;
 
     // ---- (3) prologue: build the quantized activation image in LDS ----
     int8_t * l_qs = (int8_t *) smem; float * l_d = (float *) (smem + p.off_d); int16_t * l_bs = (int16_t *) (smem + p.off_bs);
@@ -377,11 +431,16 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
 #pragma unroll
             for (int i = 0; i < NA; i++) if (wave + FW*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
             ss = wave_sum(ss);
+            MI_STAMP(4);
             if (lane == 0) red[wave] = ss;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
             scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
+            MI_STAMP(7);
+            MI_FENCE;
+            MI_FETCH(1)
+            MI_FENCE;
         }
 #pragma unroll
         for (int i = 0; i < NA; i++) {
@@ -391,61 +450,70 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
                 if (PRO == PRO_NORM) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
                 quant_store_chunk256<ACT>(v, c, lane, l_qs, l_d, l_bs);
             }
+            if (i == 0) {     // the steps must be fetched in ring order: set d holds stream step d
+                MI_STAMP(5);
+                MI_FENCE;
+                if (PRO == PRO_QUANT) { MI_FETCH(1) }
+                else if (D > 2)       { MI_FETCH(2) }
+                MI_FENCE;
+            }
         }
     }
+    MI_FENCE;
+    if (PRO == PRO_Q8) { MI_FETCH(1) }
+    if (D > 2 && PRO != PRO_NORM) { MI_FETCH(2) }
+    if (D > 3) { MI_FETCH(3) }
+    MI_FENCE;
+    MI_STAMP(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     act_view av;
     av.qs = l_qs; av.d = l_d; av.bs = l_bs;
+    MI_STAMP(1);
 
-    // ---- (4)+(5) stream ----
-    while (p_cur < P) {
-        float acc[R] = { 0.0f, 0.0f }, acu[R] = { 0.0f, 0.0f };
-        for (int it = 0; it < iters; it++) {
-            typename T::wfrag wn[R], un[R];
-            MI_FETCH(wn, un)
-            const int ib = it*BPW + ibl;
-            if (ib < nb) {
-                const typename T::afrag a = T::load_a(av, ib, slot);
+    // ---- (4)+(5) stream: D steps per trip, each consuming one register set and refilling it for D steps later ----
+    const int my_pairs = p_cur < P ? (P - 1 - p_cur)/stride + 1 : 0;
+    const int total = my_pairs*iters;
+    int it = 0;
+    float acc[R] = { 0.0f, 0.0f }, acu[R] = { 0.0f, 0.0f };
+#ifdef MI_STAMPS
+    bool first_pair = true;
+#endif
+    for (int s = 0; s < total; s += D) {
 #pragma unroll
-                for (int r = 0; r < R; r++) { acc[r] += T::dot(w0[r], a, slot); if (GLU) acu[r] += T::dot(u0[r], a, slot); }
-            }
+        for (int d = 0; d < D; d++) {
+            if (s + d < total) {        // wave-uniform
+                const int ib = it*BPW + ibl;
+                if (ib < nb) {
+                    const typename T::afrag a = T::load_a(av, ib, slot);
 #pragma unroll
-            for (int r = 0; r < R; r++) { w0[r] = w1[r]; w1[r] = wn[r]; if (GLU) { u0[r] = u1[r]; u1[r] = un[r]; } }
-        }
-        float s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
-        if (GLU) {
-            const float u0s = wave_sum(acu[0]), u1s = wave_sum(acu[1]);
-            s0 = (s0/(1.0f + expf(-s0)))*u0s;      // silu(gate)*up, as elem.hip k_glu
-            s1 = (s1/(1.0f + expf(-s1)))*u1s;
-        }
-        const int row0 = p_cur*R;
-        if (lane == 0) {
-            if (g.epi == EPI_ADD) {
-                s0 += g.res[row0];
-                if (row0 + 1 < g.m) s1 += g.res[row0 + 1];
-            } else if (g.epi == EPI_ROPE) {
-                rope_pair(p.rope, row0 % p.rope.head_dim, s0, s1);   // m is even on this path
-            }
-            g.dst[row0] = s0;
-            if (row0 + 1 < g.m) g.dst[row0 + 1] = s1;
-            if (g.st_mode == 1) {
-                uint16_t * o = g.st16 + g.st_idx[0]*g.st_row_elems + row0;
-                o[0] = f32_to_f16_bits(s0);
-                if (row0 + 1 < g.m) o[1] = f32_to_f16_bits(s1);
-            } else if (g.st_mode == 2) {
-                g.st16[g.st_idx[row0]] = f32_to_f16_bits(s0);
-                if (row0 + 1 < g.m) g.st16[g.st_idx[row0 + 1]] = f32_to_f16_bits(s1);
+                    for (int r = 0; r < R; r++) { acc[r] += T::dot(w[d][r], a, slot); if (GLU) acu[r] += T::dot(u[GLU ? d : 0][r], a, slot); }
+                }
+                MI_FETCH(d)
+                if (++it == iters) {
+#ifdef MI_STAMPS
+                    if (first_pair) { MI_STAMP(2); first_pair = false; }
+#endif
+                    float s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
+                    if (GLU) {
+                        const float u0s = wave_sum(acu[0]), u1s = wave_sum(acu[1]);
+                        s0 = (s0/(1.0f + expf(-s0)))*u0s;      // silu(gate)*up, as elem.hip k_glu
+                        s1 = (s1/(1.0f + expf(-s1)))*u1s;
+                    }
+                    if (lane == 0) finish_pair(g, p.rope, pair_out{ s0, s1, p_cur*R, pos0, idx0 });
+                    it = 0; p_cur += stride;
+                    acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
+                }
             }
         }
-        p_cur += stride;
     }
+    MI_STAMP(3);
 #undef MI_FETCH
 }
 
 // One instantiation per {weight type or pair of types} x {GLU} x {prologue} x {activation size class}: a single kernel switching
 // over all six formats at run time allocates registers for the fattest path (227 VGPRs -> 2 waves/SIMD), which starves the HBM stream.
-template <int TA, int TB, bool GLU, int PRO, int NA>
+template <int TA, int TB, bool GLU, int PRO, int NA, int D>
 __global__ void __launch_bounds__(512, 2) k_mmvq_fused(const fused_mmvq_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -454,9 +522,35 @@ __global__ void __launch_bounds__(512, 2) k_mmvq_fused(const fused_mmvq_args p) 
     const int first = gi ? p.block_end[gi - 1] : 0;
     const int blk = (int) blockIdx.x - first, nwg = p.block_end[gi] - first;
     const mmvq_group & g = p.g[gi];
-    if (TA == TB || g.type == TA) fused_body<TA, GLU, PRO, NA>(g, p, smem, blk, nwg, lane, wave);
-    else                          fused_body<TB, GLU, PRO, NA>(g, p, smem, blk, nwg, lane, wave);
+    if (TA == TB || g.type == TA) fused_body<TA, GLU, PRO, NA, D>(g, p, smem, blk, nwg, lane, wave);
+    else                          fused_body<TB, GLU, PRO, NA, D>(g, p, smem, blk, nwg, lane, wave);
 }
+
+#ifdef MI_STAMPS
+// debug build only (-DMI_STAMPS): every grouped mat-vec launch gets the next slot of a device buffer; slots are baked into captured graphs
+static unsigned long long * g_stamp_buf = nullptr;
+static int g_stamp_slots = 0, g_stamp_next = 0;
+constexpr int STAMP_MAX_WG = 1024;
+struct stamp_meta { int blocks, k, rows, type_a, type_b, mode, glu; long long bytes; };
+static stamp_meta g_stamp_meta[4096];
+extern "C" int mi355x_stamps_enable(int n_slots) {
+    if (g_stamp_buf) { (void) hipFree(g_stamp_buf); g_stamp_buf = nullptr; }
+    g_stamp_slots = n_slots > 4096 ? 4096 : n_slots; g_stamp_next = 0;
+    if (g_stamp_slots <= 0) return 0;
+    if (hipMalloc(&g_stamp_buf, (size_t) g_stamp_slots*STAMP_MAX_WG*8*8) != hipSuccess) return -1;
+    (void) hipMemset(g_stamp_buf, 0, (size_t) g_stamp_slots*STAMP_MAX_WG*8*8);
+    return 0;
+}
+extern "C" int mi355x_stamps_used(void) { return g_stamp_next; }
+extern "C" int mi355x_stamps_read(int slot, unsigned long long * out, int * meta, long long * bytes) {
+    if (!g_stamp_buf || slot < 0 || slot >= g_stamp_slots) return -1;
+    const stamp_meta & m = g_stamp_meta[slot];
+    (void) hipMemcpy(out, g_stamp_buf + (size_t) slot*STAMP_MAX_WG*8, (size_t) m.blocks*8*8, hipMemcpyDeviceToHost);
+    meta[0] = m.blocks; meta[1] = m.k; meta[2] = m.rows; meta[3] = m.type_a; meta[4] = m.type_b; meta[5] = m.mode; meta[6] = m.glu;
+    *bytes = m.bytes;
+    return 0;
+}
+#endif
 
 static float rope_corr_dim_h(int n_dims, int n_ctx_orig, float n_rot, float base) {
     return n_dims*logf(n_ctx_orig/(n_rot*2*(float) M_PI))/(2*logf(base));
@@ -479,16 +573,17 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
     fused_mmvq_args a = {};
     a.n_groups = n_groups; a.k = (int) k; a.act_kind = in.act_kind;
     // share the persistent workgroups among the groups in proportion to their rows (never more than one row pair per wave)
-    static int n_cu = 0, wpc = 2;
+    static int n_cu = 0, wpc = 1, glu_wpc = 1;   // measured (tools/stamp_timeline.py): the second workgroup on a CU runs its prologue ~2x slower
     if (n_cu == 0) {
         int dev = 0; hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
         if (n_cu <= 0) n_cu = 256;
-        if (const char * e = getenv("GGML_MI355X_MMVQ_WPC")) wpc = atoi(e) > 0 ? atoi(e) : 2;
+        if (const char * e = getenv("GGML_MI355X_MMVQ_WPC")) wpc = atoi(e) > 0 ? atoi(e) : 1;
+        if (const char * e = getenv("GGML_MI355X_GLU_WPC")) glu_wpc = atoi(e) > 0 ? atoi(e) : 1;
     }
     int64_t rows_total = 0;
     for (int i = 0; i < n_groups; i++) rows_total += (int64_t) groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1);
-    const int budget = n_cu*(groups[0].epi == EPI_GLU ? 1 : wpc);   // the dual (GLU) kernels need > 128 VGPRs: one workgroup per CU
+    const int budget = n_cu*(groups[0].epi == EPI_GLU ? glu_wpc : wpc);   // the dual (GLU) kernels need > 128 VGPRs: one workgroup per CU
     int blocks = 0;
     for (int i = 0; i < n_groups; i++) {
         a.g[i] = groups[i];
@@ -527,8 +622,31 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
     if (tb < ta) { const int t = ta; ta = tb; tb = t; }
     const bool glu = groups[0].epi == EPI_GLU;
     const int mode = in.mode;
+#ifdef MI_STAMPS
+    a.stamps = nullptr;
+    if (g_stamp_buf && g_stamp_next < g_stamp_slots && blocks <= STAMP_MAX_WG) {
+        stamp_meta & sm = g_stamp_meta[g_stamp_next];
+        sm.blocks = blocks; sm.k = (int) k; sm.rows = (int) rows_total; sm.type_a = ta; sm.type_b = tb; sm.mode = mode; sm.glu = glu;
+        sm.bytes = 0;
+        for (int i = 0; i < n_groups; i++) sm.bytes += (long long) groups[i].m*groups[i].row_stride*(groups[i].epi == EPI_GLU ? 2 : 1);
+        a.stamps = g_stamp_buf + (size_t) g_stamp_next*STAMP_MAX_WG*8;
+        g_stamp_next++;
+    }
+#endif
     const int na = mode == PRO_Q8 ? (a.act_chunks <= 512 ? 1 : (a.act_chunks <= 1024 ? 2 : 4)) : (k <= 4096 ? 2 : 8);
-#define MI_L(TA_, TB_, GLU_, PRO_, NA_) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_>), grid, dim3(FW*64), lds, stream, a)
+    // prefetch depth: measured on Llama-3-8B Q4_K_M tg128 (profiles/r01_g_*): D = 2 503 tok/s, D = 4 (3 for the dual GLU stream)
+    // 482-486 — a CU's request queue is finite and a wave that cannot queue a load cannot run its share of the prologue either.
+    // The deeper rings are compiled only with -DMI_MMVQ_DEEP (then GGML_MI355X_MMVQ_DEPTH=4 selects them).
+#ifdef MI_MMVQ_DEEP
+    static int depth_env = -1;
+    if (depth_env < 0) { const char * e = getenv("GGML_MI355X_MMVQ_DEPTH"); depth_env = e ? atoi(e) : 0; }
+    const bool deep = depth_env > 2;
+#define MI_L(TA_, TB_, GLU_, PRO_, NA_) do { \
+        if (deep) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, (GLU_ ? 3 : 4)>), grid, dim3(FW*64), lds, stream, a); \
+        else      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a); } while (0)
+#else
+#define MI_L(TA_, TB_, GLU_, PRO_, NA_) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a)
+#endif
 #define MI_LAUNCH(TA_, TB_, GLU_) do { \
         if (mode == PRO_Q8)         { if (na == 1) MI_L(TA_, TB_, GLU_, PRO_Q8, 1); else if (na == 2) MI_L(TA_, TB_, GLU_, PRO_Q8, 2); else MI_L(TA_, TB_, GLU_, PRO_Q8, 4); } \
         else if (mode == PRO_NORM)  { if (na == 2) MI_L(TA_, TB_, GLU_, PRO_NORM, 2); else MI_L(TA_, TB_, GLU_, PRO_NORM, 8); } \

@@ -44,19 +44,27 @@ __global__ void __launch_bounds__(256) k_act_to_16(const act16_args p) {
     *(uint2 *) (p.y + (bz*p.n + row)*p.k + i0) = o;
 }
 
-// ---- dequantize 32 consecutive elements [c32*32, c32*32 + 32) of one weight row (reference semantics) ----
-static __device__ __forceinline__ void k4_sc_m(const uint8_t * q, int j, float & sc, float & m) {   // quants.py:479-501
-    if (j < 4) { sc = (float)(q[j] & 63); m = (float)(q[j + 4] & 63); }
-    else { sc = (float)((q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4)); m = (float)((q[j + 4] >> 4) | ((q[j] >> 6) << 4)); }
+// ---- 32 consecutive elements [c32*32, c32*32 + 32) of one weight row, in two steps so that the loads of the NEXT k-step can
+//      be in flight while the matrix cores work on the current one: load_raw32 (global loads only), decode32 (reference dequant) ----
+struct raw32 { int4v v[5]; uint32_t s; };
+
+static __device__ __forceinline__ void k4_sc_m(const uint32_t (&hw)[4], int j, float & sc, float & m) {   // quants.py:479-501
+    // the 12 scale bytes are hw[1..3]; byte i = (hw[1 + i/4] >> 8*(i%4)) & 0xFF
+    auto byte = [&](int i) -> uint32_t { const uint32_t w = i < 4 ? hw[1] : (i < 8 ? hw[2] : hw[3]); return (w >> (8*(i & 3))) & 0xFF; };
+    if (j < 4) { sc = (float)(byte(j) & 63); m = (float)(byte(j + 4) & 63); }
+    else { sc = (float)((byte(j + 4) & 0xF) | ((byte(j - 4) >> 6) << 4)); m = (float)((byte(j + 4) >> 4) | ((byte(j) >> 6) << 4)); }
 }
 
-template <int TYPE> static __device__ __forceinline__ void dequant32(const char * row, int c32, float (&o)[32]);
+template <int TYPE> static __device__ __forceinline__ raw32 load_raw32(const char * row, int c32);
+template <int TYPE> static __device__ __forceinline__ void decode32(const raw32 & r, int c32, float (&o)[32]);
 
-template <> __device__ __forceinline__ void dequant32<T_Q4_0>(const char * row, int c32, float (&o)[32]) {
-    const char * b = row + (size_t) c32*18;
-    const float d = f16_bits_to_f32(ld_u16(b));
-    const int4v q = ld_b128(b + 2);
-    const uint32_t w[4] = { (uint32_t) q.x, (uint32_t) q.y, (uint32_t) q.z, (uint32_t) q.w };
+// Q4_0 — quants.py:241-251
+template <> __device__ __forceinline__ raw32 load_raw32<T_Q4_0>(const char * row, int c32) {
+    raw32 r; const char * b = row + (size_t) c32*18; r.s = ld_u16(b); r.v[0] = ld_b128(b + 2); return r;
+}
+template <> __device__ __forceinline__ void decode32<T_Q4_0>(const raw32 & r, int, float (&o)[32]) {
+    const float d = f16_bits_to_f32((uint16_t) r.s);
+    const uint32_t w[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t byte = (w[j >> 2] >> (8*(j & 3))) & 0xFF;
@@ -64,21 +72,24 @@ template <> __device__ __forceinline__ void dequant32<T_Q4_0>(const char * row, 
         o[j + 16] = (float)((int)(byte >> 4) - 8)*d;
     }
 }
-template <> __device__ __forceinline__ void dequant32<T_Q8_0>(const char * row, int c32, float (&o)[32]) {
-    const char * b = row + (size_t) c32*34;
-    const float d = f16_bits_to_f32(ld_u16(b));
-    const int4v q0 = ld_b128(b + 2), q1 = ld_b128(b + 18);
-    const uint32_t w[8] = { (uint32_t) q0.x, (uint32_t) q0.y, (uint32_t) q0.z, (uint32_t) q0.w, (uint32_t) q1.x, (uint32_t) q1.y, (uint32_t) q1.z, (uint32_t) q1.w };
+// Q8_0 — quants.py:396-401
+template <> __device__ __forceinline__ raw32 load_raw32<T_Q8_0>(const char * row, int c32) {
+    raw32 r; const char * b = row + (size_t) c32*34; r.s = ld_u16(b); r.v[0] = ld_b128(b + 2); r.v[1] = ld_b128(b + 18); return r;
+}
+template <> __device__ __forceinline__ void decode32<T_Q8_0>(const raw32 & r, int, float (&o)[32]) {
+    const float d = f16_bits_to_f32((uint16_t) r.s);
+    const uint32_t w[8] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w, (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w };
 #pragma unroll
     for (int j = 0; j < 32; j++) o[j] = (float)(int8_t)((w[j >> 2] >> (8*(j & 3))) & 0xFF)*d;
 }
-template <> __device__ __forceinline__ void dequant32<T_MXFP4>(const char * row, int c32, float (&o)[32]) {
-    const char * b = row + (size_t) c32*17;
-    const float d = e8m0_to_f32_half(*(const uint8_t *) b);
-    const int4v q = ld_b128(b + 1);
-    const uint32_t w[4] = { (uint32_t) q.x, (uint32_t) q.y, (uint32_t) q.z, (uint32_t) q.w };
-    // kvalues (quants.py:659): magnitude table by the low 3 bits, sign by bit 3
-    const uint64_t mag = 0x0C08060403020100ull;
+// MXFP4 — quants.py:656-700
+template <> __device__ __forceinline__ raw32 load_raw32<T_MXFP4>(const char * row, int c32) {
+    raw32 r; const char * b = row + (size_t) c32*17; r.s = *(const uint8_t *) b; r.v[0] = ld_b128(b + 1); return r;
+}
+template <> __device__ __forceinline__ void decode32<T_MXFP4>(const raw32 & r, int, float (&o)[32]) {
+    const float d = e8m0_to_f32_half(r.s);
+    const uint32_t w[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
+    const uint64_t mag = 0x0C08060403020100ull;   // kvalues (quants.py:659): magnitude by the low 3 bits, sign by bit 3
 #pragma unroll
     for (int j = 0; j < 16; j++) {
         const uint32_t byte = (w[j >> 2] >> (8*(j & 3))) & 0xFF;
@@ -88,38 +99,36 @@ template <> __device__ __forceinline__ void dequant32<T_MXFP4>(const char * row,
         o[j + 16] = ((hi & 8) ? -vh : vh)*d;
     }
 }
-template <> __device__ __forceinline__ void dequant32<T_Q4_K>(const char * row, int c32, float (&o)[32]) {
+// Q4_K — quants.py:504-522
+template <> __device__ __forceinline__ raw32 load_raw32<T_Q4_K>(const char * row, int c32) {
+    raw32 r; const int sb = c32 & 7; const char * b = row + (size_t)(c32 >> 3)*144;
+    r.v[0] = *(const int4v *) b; r.v[1] = *(const int4v *) (b + 16 + 32*(sb >> 1)); r.v[2] = *(const int4v *) (b + 32 + 32*(sb >> 1)); r.s = 0; return r;
+}
+template <> __device__ __forceinline__ void decode32<T_Q4_K>(const raw32 & r, int c32, float (&o)[32]) {
     const int sb = c32 & 7;
-    const char * b = row + (size_t)(c32 >> 3)*144;
-    const int4v hdr = *(const int4v *) b;
-    const uint32_t hw[4] = { (uint32_t) hdr.x, (uint32_t) hdr.y, (uint32_t) hdr.z, (uint32_t) hdr.w };
+    const uint32_t hw[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
     const float d = f16_bits_to_f32((uint16_t)(hw[0] & 0xFFFF)), dmin = f16_bits_to_f32((uint16_t)(hw[0] >> 16));
-    uint8_t sc8[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) sc8[i] = (uint8_t)((hw[1 + (i >> 2)] >> (8*(i & 3))) & 0xFF);
-    float sc, m; k4_sc_m(sc8, sb, sc, m);
+    float sc, m; k4_sc_m(hw, sb, sc, m);
     const float d1 = d*sc, m1 = dmin*m;
-    const int4v q0 = *(const int4v *) (b + 16 + 32*(sb >> 1)), q1 = *(const int4v *) (b + 32 + 32*(sb >> 1));
-    const uint32_t w[8] = { (uint32_t) q0.x, (uint32_t) q0.y, (uint32_t) q0.z, (uint32_t) q0.w, (uint32_t) q1.x, (uint32_t) q1.y, (uint32_t) q1.z, (uint32_t) q1.w };
+    const uint32_t w[8] = { (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w, (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w };
     const int sh = (sb & 1)*4;
 #pragma unroll
     for (int j = 0; j < 32; j++) o[j] = d1*(float)((w[j >> 2] >> (8*(j & 3) + sh)) & 0xF) - m1;
 }
-template <> __device__ __forceinline__ void dequant32<T_Q5_K>(const char * row, int c32, float (&o)[32]) {
+// Q5_K — quants.py:527-549
+template <> __device__ __forceinline__ raw32 load_raw32<T_Q5_K>(const char * row, int c32) {
+    raw32 r; const int sb = c32 & 7; const char * b = row + (size_t)(c32 >> 3)*176;
+    r.v[0] = *(const int4v *) b; r.v[1] = *(const int4v *) (b + 16); r.v[2] = *(const int4v *) (b + 32);
+    r.v[3] = *(const int4v *) (b + 48 + 32*(sb >> 1)); r.v[4] = *(const int4v *) (b + 64 + 32*(sb >> 1)); r.s = 0; return r;
+}
+template <> __device__ __forceinline__ void decode32<T_Q5_K>(const raw32 & r, int c32, float (&o)[32]) {
     const int sb = c32 & 7;
-    const char * b = row + (size_t)(c32 >> 3)*176;
-    const int4v hdr = *(const int4v *) b;
-    const uint32_t hw[4] = { (uint32_t) hdr.x, (uint32_t) hdr.y, (uint32_t) hdr.z, (uint32_t) hdr.w };
+    const uint32_t hw[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
     const float d = f16_bits_to_f32((uint16_t)(hw[0] & 0xFFFF)), dmin = f16_bits_to_f32((uint16_t)(hw[0] >> 16));
-    uint8_t sc8[12];
-#pragma unroll
-    for (int i = 0; i < 12; i++) sc8[i] = (uint8_t)((hw[1 + (i >> 2)] >> (8*(i & 3))) & 0xFF);
-    float sc, m; k4_sc_m(sc8, sb, sc, m);
+    float sc, m; k4_sc_m(hw, sb, sc, m);
     const float d1 = d*sc, m1 = dmin*m;
-    const int4v h0 = *(const int4v *) (b + 16), h1 = *(const int4v *) (b + 32);
-    const uint32_t qh[8] = { (uint32_t) h0.x, (uint32_t) h0.y, (uint32_t) h0.z, (uint32_t) h0.w, (uint32_t) h1.x, (uint32_t) h1.y, (uint32_t) h1.z, (uint32_t) h1.w };
-    const int4v q0 = *(const int4v *) (b + 48 + 32*(sb >> 1)), q1 = *(const int4v *) (b + 64 + 32*(sb >> 1));
-    const uint32_t w[8] = { (uint32_t) q0.x, (uint32_t) q0.y, (uint32_t) q0.z, (uint32_t) q0.w, (uint32_t) q1.x, (uint32_t) q1.y, (uint32_t) q1.z, (uint32_t) q1.w };
+    const uint32_t qh[8] = { (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w, (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w };
+    const uint32_t w[8]  = { (uint32_t) r.v[3].x, (uint32_t) r.v[3].y, (uint32_t) r.v[3].z, (uint32_t) r.v[3].w, (uint32_t) r.v[4].x, (uint32_t) r.v[4].y, (uint32_t) r.v[4].z, (uint32_t) r.v[4].w };
     const int sh = (sb & 1)*4;
 #pragma unroll
     for (int j = 0; j < 32; j++) {
@@ -128,19 +137,21 @@ template <> __device__ __forceinline__ void dequant32<T_Q5_K>(const char * row, 
         o[j] = d1*(float)(lo | (hb << 4)) - m1;
     }
 }
-template <> __device__ __forceinline__ void dequant32<T_Q6_K>(const char * row, int c32, float (&o)[32]) {
-    // chunk c of a 256-superblock: half n = c>>2, quarter p = c&3: elements 128n + 32p + l (quants.py:554-572)
-    const int c = c32 & 7, n = c >> 2, pq = c & 3;
-    const char * b = row + (size_t)(c32 >> 3)*210;       // 2-byte aligned only
-    const float d = f16_bits_to_f32(ld_u16(b + 208));
+// Q6_K — quants.py:554-572. chunk c of a 256-superblock: half n = c>>2, quarter pq = c&3: elements 128n + 32pq + l
+template <> __device__ __forceinline__ raw32 load_raw32<T_Q6_K>(const char * row, int c32) {
+    raw32 r; const int c = c32 & 7, n = c >> 2, pq = c & 3; const char * b = row + (size_t)(c32 >> 3)*210;   // 2-byte aligned only
     const char * ql = b + 64*n + 32*(pq & 1);
-    const int4v a0 = ld_b128(ql), a1 = ld_b128(ql + 16);
-    const int4v g0 = ld_b128(b + 128 + 32*n), g1 = ld_b128(b + 128 + 32*n + 16);
-    const uint32_t w[8] = { (uint32_t) a0.x, (uint32_t) a0.y, (uint32_t) a0.z, (uint32_t) a0.w, (uint32_t) a1.x, (uint32_t) a1.y, (uint32_t) a1.z, (uint32_t) a1.w };
-    const uint32_t qh[8] = { (uint32_t) g0.x, (uint32_t) g0.y, (uint32_t) g0.z, (uint32_t) g0.w, (uint32_t) g1.x, (uint32_t) g1.y, (uint32_t) g1.z, (uint32_t) g1.w };
+    r.v[0] = ld_b128(ql); r.v[1] = ld_b128(ql + 16); r.v[2] = ld_b128(b + 128 + 32*n); r.v[3] = ld_b128(b + 128 + 32*n + 16);
+    r.s = (uint32_t) ld_u16(b + 208) | ((uint32_t) ld_u16(b + 192 + 8*n + 2*pq) << 16);
+    return r;
+}
+template <> __device__ __forceinline__ void decode32<T_Q6_K>(const raw32 & r, int c32, float (&o)[32]) {
+    const int pq = c32 & 3;
+    const float d = f16_bits_to_f32((uint16_t)(r.s & 0xFFFF));
+    const float s0 = d*(float)(int8_t)((r.s >> 16) & 0xFF), s1 = d*(float)(int8_t)(r.s >> 24);
+    const uint32_t w[8]  = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w, (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w };
+    const uint32_t qh[8] = { (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w, (uint32_t) r.v[3].x, (uint32_t) r.v[3].y, (uint32_t) r.v[3].z, (uint32_t) r.v[3].w };
     const int sh = (pq >> 1)*4, hs = 2*pq;
-    const int8_t * scp = (const int8_t *) (b + 192 + 8*n + 2*pq);
-    const float s0 = d*(float) scp[0], s1 = d*(float) scp[1];
 #pragma unroll
     for (int l = 0; l < 32; l++) {
         const uint32_t lo = (w[l >> 2] >> (8*(l & 3) + sh)) & 0xF;
@@ -166,8 +177,8 @@ struct mmq_args {
 // products K.q and V.kq of build_attn_mha, src/llama-graph.cpp:1285,1320, when more than 8 tokens are in flight)
 template <int TYPE>
 __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
-    __shared__ __attribute__((aligned(16))) char lds_w[MQ_BM*MQ_LD];
-    __shared__ __attribute__((aligned(16))) char lds_x[MQ_BN*MQ_LD];
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
+    constexpr int TILE = MQ_BM*MQ_LD;                                // bytes of one operand tile (BM == BN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int m0 = blockIdx.y*MQ_BM, n0 = blockIdx.x*MQ_BN;   // the n-tiles of one weight tile are dispatched together (Infinity-Cache reuse of W)
     const int wm = wave & 1, wn = wave >> 1;             // wave tile: weight rows wm*64.., tokens wn*64..
@@ -187,50 +198,64 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
 
     // staging roles: thread -> (row = tid/2, half = tid&1): 32 of the 64 k of that row
     const int srow = tid >> 1, shalf = tid & 1;
-    const int wrow = min(m0 + srow, m - 1);
-    const int xrow = min(n0 + srow, n - 1);
-    const char * wrow_p = W + (size_t) wrow*p.w_row_stride;
-    const uint16_t * xrow_p = X + (size_t) xrow*k;
+    const char * wrow_p = W + (size_t) min(m0 + srow, m - 1)*p.w_row_stride;
+    const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*k;
+    const int nsteps = (k + MQ_BK - 1)/MQ_BK;
 
-    for (int k0 = 0; k0 < k; k0 += MQ_BK) {
-        // ---- stage: dequantize (or copy) 32 weights, copy 32 activations ----
-        const int kc = k0 + 32*shalf;
-        int4v wpk[4], xv[4];
+    // register stage: raw weight bytes + 32 activations of the NEXT k-step (addresses clamped, results discarded past k)
+    raw32 rw; int4v xv[4]; int4v wf[4];
+    auto fetch = [&](int step) {
+        const int kc = min(step*MQ_BK + 32*shalf, k - 32);
+        if (TYPE == T_F16) {
+#pragma unroll
+            for (int i = 0; i < 4; i++) wf[i] = ld_b128(wrow_p + (size_t) kc*2 + 16*i);
+        } else {
+            rw = load_raw32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kc >> 5);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) xv[i] = ld_b128((const char *) (xrow_p + kc) + 16*i);
+    };
+    auto commit = [&](int step, int buf) {       // decode the staged registers into LDS buffer `buf`
+        const int kc = step*MQ_BK + 32*shalf;
+        int4v wpk[4];
         if (kc < k) {
             if (TYPE == T_F16) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) wpk[i] = ld_b128(wrow_p + (size_t) kc*2 + 16*i);
+                for (int i = 0; i < 4; i++) wpk[i] = wf[i];
             } else {
                 float wv[32];
-                dequant32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kc >> 5, wv);
+                decode32<TYPE == T_F16 ? T_Q8_0 : TYPE>(rw, kc >> 5, wv);
 #pragma unroll
                 for (int i = 0; i < 4; i++) {
                     wpk[i].x = (int) pack_bf16(wv[8*i + 0], wv[8*i + 1]); wpk[i].y = (int) pack_bf16(wv[8*i + 2], wv[8*i + 3]);
                     wpk[i].z = (int) pack_bf16(wv[8*i + 4], wv[8*i + 5]); wpk[i].w = (int) pack_bf16(wv[8*i + 6], wv[8*i + 7]);
                 }
             }
-#pragma unroll
-            for (int i = 0; i < 4; i++) xv[i] = ld_b128((const char *) (xrow_p + kc) + 16*i);
         } else {
 #pragma unroll
             for (int i = 0; i < 4; i++) { wpk[i] = int4v{ 0, 0, 0, 0 }; xv[i] = int4v{ 0, 0, 0, 0 }; }
         }
-        __syncthreads();   // previous step's operand reads are done
-        {
-            char * wp = lds_w + srow*MQ_LD + shalf*64;
-            char * xp = lds_x + srow*MQ_LD + shalf*64;
+        char * wp = lds + buf*2*TILE + srow*MQ_LD + shalf*64;
+        char * xp = wp + TILE;
 #pragma unroll
-            for (int i = 0; i < 4; i++) { *(int4v *) (wp + 16*i) = wpk[i]; *(int4v *) (xp + 16*i) = xv[i]; }
-        }
-        __syncthreads();
+        for (int i = 0; i < 4; i++) { *(int4v *) (wp + 16*i) = wpk[i]; *(int4v *) (xp + 16*i) = xv[i]; }
+    };
+
+    fetch(0);
+    commit(0, 0);
+    __syncthreads();
+    for (int step = 0; step < nsteps; step++) {
+        const int buf = step & 1;
+        if (step + 1 < nsteps) fetch(step + 1);          // global loads in flight during the MFMAs below
+        const char * lw = lds + buf*2*TILE, * lx = lw + TILE;
         // ---- MFMA: A = activations (rows = tokens), B = weights (cols = weight rows) ----
 #pragma unroll
         for (int kk = 0; kk < MQ_BK/16; kk++) {
             int4v a[2], b[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                a[i] = *(const int4v *) (lds_x + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
-                b[i] = *(const int4v *) (lds_w + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+                a[i] = *(const int4v *) (lx + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+                b[i] = *(const int4v *) (lw + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -240,6 +265,8 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
                     else               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
                 }
         }
+        if (step + 1 < nsteps) commit(step + 1, buf ^ 1);  // the other buffer was last read at step-1: every wave passed the barrier since
+        __syncthreads();
     }
     // ---- store: D[row = token][col = weight row]; col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) ----
 #pragma unroll
@@ -256,6 +283,8 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     }
 }
 
+constexpr size_t MQ_LDS_BYTES = 4*(size_t) MQ_BM*MQ_LD;
+
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n) { return (size_t) n*k*2 + 256; }
 
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
@@ -266,7 +295,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
     hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1 };
     const dim3 grid((unsigned)((n + MQ_BN - 1)/MQ_BN), (unsigned)((m + MQ_BM - 1)/MQ_BM), 1);
-#define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), 0, stream, a)
+#define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), MQ_LDS_BYTES, stream, a)
     switch (type_a) {
         case T_Q4_0:  MI_MMQ(T_Q4_0);  break;
         case T_Q8_0:  MI_MMQ(T_Q8_0);  break;
@@ -295,7 +324,7 @@ void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t str
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
                    (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03) };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
-    hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), 0, stream, a);
+    hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
 }
 
 } // namespace mi355x
