@@ -477,6 +477,8 @@ static act_q8 get_act(mi_backend_ctx * c, const void * x, int64_t k, int64_t n_i
     return q;
 }
 
+static constexpr int ACT_KIND_BF16 = -16;   // aq.kind of the dense bf16 copy the MFMA prefill kernel reads
+
 static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
     const struct ggml_tensor * a = dst->src[0];
     const struct ggml_tensor * b = dst->src[1];
@@ -495,9 +497,13 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
                     mul_mat_vec_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
                     c->cnt.mmvq_launches++;
                 } else {
-                    c->aq.valid = false;   // the scratch is reused for the bf16 activations
-                    mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, d, dst->nb[1], c->stream);
-                    c->cnt.mmq_launches++; c->cnt.kernels_launched++;
+                    // the scratch holds the bf16 copy of the activations; wq/wk/wv and gate/up read the same ones: convert once
+                    const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == bp && c->aq.k == K && c->aq.n_inner == N &&
+                                       c->aq.s_inner == b->nb[1];
+                    mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, ready, d, dst->nb[1], c->stream);
+                    if (ready) c->cnt.act_quant_reused++;
+                    else c->aq = { bp, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
+                    c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 0 : 1;
                 }
                 prof_end(c);
                 c->cnt.kernels_launched++;

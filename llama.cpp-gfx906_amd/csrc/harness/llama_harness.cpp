@@ -31,7 +31,7 @@
 extern "C" {
 
 // llama_ftype values (include/llama.h) for the configs of BASELINE.json
-enum { MI_FTYPE_Q4_0 = 2, MI_FTYPE_Q8_0 = 7, MI_FTYPE_Q4_K_M = 15, MI_FTYPE_Q5_K_M = 17, MI_FTYPE_Q6_K = 18 };
+enum { MI_FTYPE_Q4_0 = 2, MI_FTYPE_Q8_0 = 7, MI_FTYPE_Q4_K_M = 15, MI_FTYPE_Q5_K_M = 17, MI_FTYPE_Q6_K = 18, MI_FTYPE_MXFP4_MOE = 38 };   // llama_ftype ids (include/llama.h)
 
 struct mi_llama_hparams {
     int32_t n_embd, n_ff, n_layer, n_head, n_head_kv, n_embd_head, n_vocab;
@@ -45,6 +45,8 @@ struct mi_llama_hparams {
     int32_t layer_begin, layer_end;   // this instance holds layers [begin, end) — layer split (src/llama-model.cpp:1949-1972)
     int32_t has_output;               // holds output_norm + output (the last device, src/llama-model.cpp:1972)
     int32_t n_seq_max;                // independent sequences, each with its own KV cache stream (llama_context_params.n_seq_max, kv_unified = false)
+    int32_t n_expert, n_expert_used;  // > 0: the FFN is build_moe_ffn (src/llama-graph.cpp:811-1023); n_ff is then the expert width
+    int32_t arch;                     // 0 = llm_build_llama (dense or Mixtral-style MoE), 1 = llm_build_openai_moe_iswa (gpt-oss; src/llama-model.cpp:17610-17738)
 };
 
 struct mi_llama;
@@ -125,15 +127,27 @@ layer_types types_for_layer(const mi_llama_hparams & hp, int il) {
     if (hp.ftype == MI_FTYPE_Q4_K_M || hp.ftype == MI_FTYPE_Q5_K_M) {
         if (use_more_bits(il, hp.n_layer)) { t.wv = GGML_TYPE_Q6_K; t.down = GGML_TYPE_Q6_K; }   // :302-303, :358-364
         if (hp.is_70b && t.wv == GGML_TYPE_Q4_K) t.wv = GGML_TYPE_Q5_K;                          // :305-310
+        if (hp.n_expert == 8) {                                                                   // the 8-expert bumps, :311-322 and :383-389
+            t.wv = t.wk = GGML_TYPE_Q8_0;
+            if (hp.ftype == MI_FTYPE_Q4_K_M) t.wo = GGML_TYPE_Q5_K;
+        }
+    }
+    if (hp.ftype == MI_FTYPE_MXFP4_MOE) {                                                         // :229-236: 3-D tensors MXFP4, the rest Q8_0
+        t.wq = t.wk = t.wv = t.wo = GGML_TYPE_Q8_0;
+        t.gate = t.up = t.down = hp.n_expert > 0 ? GGML_TYPE_MXFP4 : GGML_TYPE_Q8_0;
     }
     return t;
 }
 enum ggml_type output_type(const mi_llama_hparams & hp) {   // :205-227
-    return hp.ftype == MI_FTYPE_Q8_0 ? GGML_TYPE_Q8_0 : GGML_TYPE_Q6_K;
+    return hp.ftype == MI_FTYPE_Q8_0 || hp.ftype == MI_FTYPE_MXFP4_MOE ? GGML_TYPE_Q8_0 : GGML_TYPE_Q6_K;
 }
 
 struct layer {
-    ggml_tensor * attn_norm, * wq, * wk, * wv, * wo, * ffn_norm, * ffn_gate, * ffn_up, * ffn_down;
+    ggml_tensor * attn_norm, * wq, * wk, * wv, * wo, * ffn_norm, * ffn_gate, * ffn_up, * ffn_down;   // ffn_*: [n_embd, n_ff(, n_expert)]
+    ggml_tensor * ffn_gate_inp = nullptr;                                                            // router, F32 [n_embd, n_expert]
+    // gpt-oss only (src/llama-model.cpp:5436-5462): projection biases, attention sinks, router and expert biases
+    ggml_tensor * bq = nullptr, * bk = nullptr, * bv = nullptr, * bo = nullptr, * sinks = nullptr;
+    ggml_tensor * gate_inp_b = nullptr, * gate_b = nullptr, * up_b = nullptr, * down_b = nullptr;
     std::vector<ggml_tensor *> k_cache, v_cache;   // one per sequence stream
 };
 
@@ -160,7 +174,8 @@ struct mi_llama {
     std::map<std::tuple<int, int, int>, graph_inst> graphs;   // (seq, n_tokens, n_kv) -> graph: the reuse of src/llama-context.cpp:728
     int64_t tick = 0;
     std::vector<int> n_past;                            // cells [0, n_past[s]) of sequence s are in use
-    uint64_t weight_bytes = 0;                          // bytes of every MUL_MAT weight held here (= algorithmic bytes / token)
+    uint64_t weight_bytes = 0;                          // bytes of every dense MUL_MAT weight held here (all of them are read per token)
+    uint64_t expert_bytes = 0;                          // bytes of the MUL_MAT_ID expert stacks (n_expert_used/n_expert of them are read per token)
     uint64_t seed;
     // pinned staging for the per-step inputs (set_inputs: src/llama-graph.cpp:16-58)
     ggml_backend_buffer_t hbuf = nullptr;
@@ -179,12 +194,73 @@ ggml_tensor * new_weight(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t
     return t;
 }
 
+ggml_tensor * new_experts(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t ne1, int64_t ne2, const char * name) {
+    ggml_tensor * t = ggml_new_tensor_3d(m->wctx, type, ne0, ne1, ne2);
+    ggml_set_name(t, name);
+    m->expert_bytes += ggml_nbytes(t);
+    return t;
+}
+ggml_tensor * new_f32(mi_llama * m, int64_t ne0, int64_t ne1, const char * name) {   // biases, sinks, router: not part of the byte model
+    ggml_tensor * t = ggml_new_tensor_2d(m->wctx, GGML_TYPE_F32, ne0, ne1);
+    ggml_set_name(t, name);
+    return t;
+}
+
 void upload_random(mi_llama * m, ggml_tensor * t, float sigma, uint64_t seed, std::vector<uint8_t> & tmp) {
     const size_t nb = ggml_nbytes(t);
     tmp.resize(nb);
-    if (t->type == GGML_TYPE_F32) fill_f32((float *) tmp.data(), nb/4, 0.5f, 1.5f, seed);      // norm weights ~ 1
-    else fill_random_blocks(t->type, tmp.data(), nb, sigma, seed);
+    if (t->type == GGML_TYPE_F32) {
+        const char * nm = t->name;
+        if (strstr(nm, "ffn_gate_inp.weight"))      fill_f32((float *) tmp.data(), nb/4, -1.7320508f*sigma, 1.7320508f*sigma, seed);   // router: std sigma
+        else if (strstr(nm, ".bias"))               fill_f32((float *) tmp.data(), nb/4, -0.1f, 0.1f, seed);
+        else if (strstr(nm, "attn_sinks"))          fill_f32((float *) tmp.data(), nb/4, -1.0f, 1.0f, seed);
+        else                                        fill_f32((float *) tmp.data(), nb/4, 0.5f, 1.5f, seed);                              // norm weights ~ 1
+    } else {
+        fill_random_blocks(t->type, tmp.data(), nb, sigma, seed);
+    }
     ggml_backend_tensor_set(t, tmp.data(), 0, nb);
+}
+
+// build_moe_ffn (src/llama-graph.cpp:811-1023) for the two gatings the configs use: SOFTMAX + norm_w (llm_build_llama's MoE branch,
+// src/llama-model.cpp:6082-6092) and SOFTMAX_WEIGHT + biases + SWIGLU_OAI (gpt-oss, src/llama-model.cpp:17700-17711)
+ggml_tensor * build_moe_ffn(ggml_context * ctx0, ggml_cgraph * gf, const mi_llama_hparams & hp, const layer & L, ggml_tensor * cur) {
+    const int64_t n_embd = cur->ne[0], n_tokens = cur->ne[1], n_expert = hp.n_expert, n_used = hp.n_expert_used;
+    const bool oai = hp.arch == 1;
+    ggml_tensor * logits = ggml_mul_mat(ctx0, L.ffn_gate_inp, cur);                             // [n_expert, n_tokens]   :838
+    if (L.gate_inp_b) logits = ggml_add(ctx0, logits, L.gate_inp_b);                            // :845
+    ggml_tensor * probs = oai ? logits : ggml_soft_max(ctx0, logits);                           // :850-866
+    ggml_tensor * selected = ggml_top_k(ctx0, probs, (int) n_used);                             // [n_used, n_tokens] I32   :883
+    ggml_tensor * weights = ggml_get_rows(ctx0, ggml_reshape_3d(ctx0, probs, 1, n_expert, n_tokens), selected);   // [1, n_used, n_tokens]   :887
+    if (oai) {                                                                                  // :891-896
+        weights = ggml_reshape_2d(ctx0, weights, n_used, n_tokens);
+        weights = ggml_soft_max(ctx0, weights);
+        weights = ggml_reshape_3d(ctx0, weights, 1, n_used, n_tokens);
+    } else {                                                                                    // norm_w, :898-908
+        weights = ggml_reshape_2d(ctx0, weights, n_used, n_tokens);
+        ggml_tensor * wsum = ggml_sum_rows(ctx0, weights);
+        weights = ggml_div(ctx0, weights, wsum);
+        weights = ggml_reshape_3d(ctx0, weights, 1, n_used, n_tokens);
+    }
+    cur = ggml_reshape_3d(ctx0, cur, n_embd, 1, n_tokens);                                      // :914
+    ggml_tensor * up = ggml_mul_mat_id(ctx0, L.ffn_up, cur, selected);                          // [n_ff, n_used, n_tokens]   :923
+    if (L.up_b) up = ggml_add_id(ctx0, up, L.up_b, selected);                                   // :927
+    ggml_tensor * gate = ggml_mul_mat_id(ctx0, L.ffn_gate, cur, selected);                      // :933
+    if (L.gate_b) gate = ggml_add_id(ctx0, gate, L.gate_b, selected);                           // :940
+    ggml_tensor * act = oai ? ggml_swiglu_oai(ctx0, gate, up, 1.702f, 7.0f)                     // :961-968
+                            : ggml_swiglu_split(ctx0, gate, up);                                // :947
+    ggml_tensor * experts = ggml_mul_mat_id(ctx0, L.ffn_down, act, selected);                   // [n_embd, n_used, n_tokens]   :981
+    if (L.down_b) experts = ggml_add_id(ctx0, experts, L.down_b, selected);                     // :985
+    experts = ggml_mul(ctx0, experts, weights);                                                 // :990
+    ggml_tensor * moe_out = nullptr;                                                            // :996-1012: views ordered before the adds
+    std::vector<ggml_tensor *> views;
+    for (int64_t i = 0; i < n_used; i++) {
+        views.push_back(ggml_view_2d(ctx0, experts, n_embd, n_tokens, experts->nb[2], i*experts->nb[1]));
+        ggml_build_forward_expand(gf, views.back());
+    }
+    moe_out = views[0];
+    for (int64_t i = 1; i < n_used; i++) moe_out = ggml_add(ctx0, moe_out, views[i]);
+    if (n_used == 1) moe_out = ggml_cont(ctx0, moe_out);                                        // :1014-1017
+    return moe_out;
 }
 
 // llm_build_llama for n_tokens tokens attending to n_kv cache cells
@@ -224,8 +300,11 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
 
         // self-attention
         ggml_tensor * Qcur = ggml_mul_mat(ctx0, L.wq, cur);
+        if (L.bq) Qcur = ggml_add(ctx0, Qcur, L.bq);                  // src/llama-model.cpp:17636-17639
         ggml_tensor * Kcur = ggml_mul_mat(ctx0, L.wk, cur);
+        if (L.bk) Kcur = ggml_add(ctx0, Kcur, L.bk);
         ggml_tensor * Vcur = ggml_mul_mat(ctx0, L.wv, cur);
+        if (L.bv) Vcur = ggml_add(ctx0, Vcur, L.bv);
         Qcur = ggml_reshape_3d(ctx0, Qcur, hd, n_head,    n_tokens);
         Kcur = ggml_reshape_3d(ctx0, Kcur, hd, n_head_kv, n_tokens);
         Vcur = ggml_reshape_3d(ctx0, Vcur, hd, n_head_kv, n_tokens);
@@ -257,12 +336,14 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
             ggml_tensor * kq = ggml_mul_mat(ctx0, k, q);
             ggml_mul_mat_set_prec(kq, GGML_PREC_F32);
             kq = ggml_soft_max_ext(ctx0, kq, g.kq_mask, kq_scale, 0.0f);
+            if (L.sinks) ggml_soft_max_add_sinks(kq, L.sinks);       // build_attn_with_sinks, src/llama-graph.cpp:1313
             ggml_tensor * kqv = ggml_mul_mat(ctx0, v, kq);
             cur = ggml_permute(ctx0, kqv, 0, 2, 1, 3);
             cur = ggml_cont_2d(ctx0, cur, cur->ne[0]*cur->ne[1], cur->ne[2]*cur->ne[3]);
             ggml_build_forward_expand(g.gf, cur);
         }
         cur = ggml_mul_mat(ctx0, L.wo, cur);
+        if (L.bo) cur = ggml_add(ctx0, cur, L.bo);                    // src/llama-graph.cpp:1479-1481
 
         if (last_layer) {   // src/llama-model.cpp:6052-6055
             cur   = ggml_get_rows(ctx0, cur,   g.out_ids);
@@ -273,10 +354,14 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
         // feed-forward: build_norm + build_ffn(LLM_FFN_SILU, LLM_FFN_PAR)
         cur = ggml_rms_norm(ctx0, ffn_inp, hp.f_norm_rms_eps);
         cur = ggml_mul(ctx0, cur, L.ffn_norm);
-        ggml_tensor * tmp = ggml_mul_mat(ctx0, L.ffn_up, cur);
-        cur = ggml_mul_mat(ctx0, L.ffn_gate, cur);
-        cur = ggml_swiglu_split(ctx0, cur, tmp);
-        cur = ggml_mul_mat(ctx0, L.ffn_down, cur);
+        if (hp.n_expert > 0) {
+            cur = build_moe_ffn(ctx0, g.gf, hp, L, cur);              // src/llama-model.cpp:6075-6093 / :17700-17711
+        } else {
+            ggml_tensor * tmp = ggml_mul_mat(ctx0, L.ffn_up, cur);
+            cur = ggml_mul_mat(ctx0, L.ffn_gate, cur);
+            cur = ggml_swiglu_split(ctx0, cur, tmp);
+            cur = ggml_mul_mat(ctx0, L.ffn_down, cur);
+        }
         cur = ggml_add(ctx0, cur, ffn_inp);
         inpL = cur;
     }
@@ -333,9 +418,29 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
         snprintf(name, sizeof(name), "blk.%d.attn_v.weight", il);      L.wv = new_weight(m, t.wv, n_embd, n_embd_v_gqa, name);
         snprintf(name, sizeof(name), "blk.%d.attn_output.weight", il); L.wo = new_weight(m, t.wo, hd*hp.n_head, n_embd, name);
         snprintf(name, sizeof(name), "blk.%d.ffn_norm.weight", il);    L.ffn_norm = new_weight(m, GGML_TYPE_F32, n_embd, 1, name);
-        snprintf(name, sizeof(name), "blk.%d.ffn_gate.weight", il);    L.ffn_gate = new_weight(m, t.gate, n_embd, n_ff, name);
-        snprintf(name, sizeof(name), "blk.%d.ffn_up.weight", il);      L.ffn_up = new_weight(m, t.up, n_embd, n_ff, name);
-        snprintf(name, sizeof(name), "blk.%d.ffn_down.weight", il);    L.ffn_down = new_weight(m, t.down, n_ff, n_embd, name);
+        if (hp.n_expert > 0) {      // src/llama-model.cpp:2230-2247 (llama MoE), :5450-5462 (gpt-oss)
+            snprintf(name, sizeof(name), "blk.%d.ffn_gate_inp.weight", il);  L.ffn_gate_inp = new_f32(m, n_embd, hp.n_expert, name);
+            snprintf(name, sizeof(name), "blk.%d.ffn_gate_exps.weight", il); L.ffn_gate = new_experts(m, t.gate, n_embd, n_ff, hp.n_expert, name);
+            snprintf(name, sizeof(name), "blk.%d.ffn_up_exps.weight", il);   L.ffn_up = new_experts(m, t.up, n_embd, n_ff, hp.n_expert, name);
+            snprintf(name, sizeof(name), "blk.%d.ffn_down_exps.weight", il); L.ffn_down = new_experts(m, t.down, n_ff, n_embd, hp.n_expert, name);
+        } else {
+            snprintf(name, sizeof(name), "blk.%d.ffn_gate.weight", il);    L.ffn_gate = new_weight(m, t.gate, n_embd, n_ff, name);
+            snprintf(name, sizeof(name), "blk.%d.ffn_up.weight", il);      L.ffn_up = new_weight(m, t.up, n_embd, n_ff, name);
+            snprintf(name, sizeof(name), "blk.%d.ffn_down.weight", il);    L.ffn_down = new_weight(m, t.down, n_ff, n_embd, name);
+        }
+        if (hp.arch == 1) {         // gpt-oss: src/llama-model.cpp:5436-5462
+            snprintf(name, sizeof(name), "blk.%d.attn_q.bias", il);          L.bq = new_f32(m, hd*hp.n_head, 1, name);
+            snprintf(name, sizeof(name), "blk.%d.attn_k.bias", il);          L.bk = new_f32(m, n_embd_k_gqa, 1, name);
+            snprintf(name, sizeof(name), "blk.%d.attn_v.bias", il);          L.bv = new_f32(m, n_embd_v_gqa, 1, name);
+            snprintf(name, sizeof(name), "blk.%d.attn_output.bias", il);     L.bo = new_f32(m, n_embd, 1, name);
+            snprintf(name, sizeof(name), "blk.%d.attn_sinks.weight", il);    L.sinks = new_f32(m, hp.n_head, 1, name);
+            if (hp.n_expert > 0) {
+                snprintf(name, sizeof(name), "blk.%d.ffn_gate_inp.bias", il);    L.gate_inp_b = new_f32(m, hp.n_expert, 1, name);
+                snprintf(name, sizeof(name), "blk.%d.ffn_gate_exps.bias", il);   L.gate_b = new_f32(m, n_ff, hp.n_expert, name);
+                snprintf(name, sizeof(name), "blk.%d.ffn_up_exps.bias", il);     L.up_b = new_f32(m, n_ff, hp.n_expert, name);
+                snprintf(name, sizeof(name), "blk.%d.ffn_down_exps.bias", il);   L.down_b = new_f32(m, n_embd, hp.n_expert, name);
+            }
+        }
         // KV cache on the layer's device, F16 (src/llama-kv-cache-unified.cpp:114-132)
         for (int sq = 0; sq < std::max(1, hp.n_seq_max); sq++) {
             L.k_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_k_gqa, kv_size));
@@ -389,7 +494,10 @@ GGML_API void mi_llama_free(struct mi_llama * m) {
     delete m;
 }
 
-GGML_API uint64_t mi_llama_weight_bytes(const struct mi_llama * m) { return m->weight_bytes; }
+// algorithmic weight bytes per decoded token: every dense matrix + the used fraction of the expert stacks
+GGML_API uint64_t mi_llama_weight_bytes(const struct mi_llama * m) {
+    return m->weight_bytes + (m->hp.n_expert > 0 ? m->expert_bytes*(uint64_t) m->hp.n_expert_used/(uint64_t) m->hp.n_expert : 0);
+}
 GGML_API int      mi_llama_n_past(const struct mi_llama * m, int seq) { return m->n_past[seq]; }
 GGML_API void     mi_llama_kv_clear(struct mi_llama * m) { for (auto & p : m->n_past) p = 0; }   // llama_memory_clear(mem, false): metadata only (llama-bench.cpp:1974)
 GGML_API int      mi_llama_n_result(const struct mi_llama * m) { return (int) m->logits.size(); }

@@ -27,7 +27,12 @@ static __device__ __forceinline__ uint32_t bf16_rne(float f) {   // finite input
     uint32_t u = __builtin_bit_cast(uint32_t, f);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-static __device__ __forceinline__ uint32_t pack_bf16(float a, float b) { return bf16_rne(a) | (bf16_rne(b) << 16); }
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float  f32x2_t  __attribute__((ext_vector_type(2)));
+// one v_cvt_pk_bf16_f32 (round to nearest even), not the ~8 integer operations of the bit formula
+static __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{ a, b }, bf16x2_t));
+}
 
 // ---- f32 -> bf16 / f16 activation pre-pass: strided f32 rows -> dense [batch][n][k] 16-bit ----
 struct act16_args { const char * x; size_t nb1, nb2, nb3; int64_t k, n, ne2; uint16_t * y; };
@@ -171,6 +176,7 @@ struct mmq_args {
     const uint16_t * X; int n;                 // dense [batch][n][k] 16-bit
     char * dst; size_t dst_nb1, dst_nb2, dst_nb3;
     int ne12, r2, r3;                          // batch = blockIdx.z = i13*ne12 + i12; weights broadcast: i02 = i12/r2, i03 = i13/r3
+    int ksplit, mtiles;                        // ksplit = 2: blockIdx.y = half*mtiles + m-tile; both halves atomically add into a zeroed dst
 };
 
 // TYPE = a block format (bf16 MFMA on dequantized weights) or T_F16 (f16 MFMA, weights copied as they are: the attention
@@ -180,7 +186,8 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
     constexpr int TILE = MQ_BM*MQ_LD;                                // bytes of one operand tile (BM == BN)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y*MQ_BM, n0 = blockIdx.x*MQ_BN;   // the n-tiles of one weight tile are dispatched together (Infinity-Cache reuse of W)
+    const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;
+    const int m0 = ((int) blockIdx.y - khalf*p.mtiles)*MQ_BM, n0 = blockIdx.x*MQ_BN;   // the n-tiles of one weight tile are dispatched together
     const int wm = wave & 1, wn = wave >> 1;             // wave tile: weight rows wm*64.., tokens wn*64..
     const int m = p.m, n = p.n, k = p.k;
     const int i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
@@ -200,7 +207,10 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     const int srow = tid >> 1, shalf = tid & 1;
     const char * wrow_p = W + (size_t) min(m0 + srow, m - 1)*p.w_row_stride;
     const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*k;
-    const int nsteps = (k + MQ_BK - 1)/MQ_BK;
+    // split-K: each half walks k/2 (a multiple of 256, so block boundaries stay aligned); steps are counted from step0
+    const int nsteps_all = (k + MQ_BK - 1)/MQ_BK;
+    const int step0 = khalf*(nsteps_all/2);
+    const int nsteps = p.ksplit > 1 ? nsteps_all/2 : nsteps_all;
 
     // register stage: raw weight bytes + 32 activations of the NEXT k-step (addresses clamped, results discarded past k)
     raw32 rw; int4v xv[4]; int4v wf[4];
@@ -241,12 +251,12 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
         for (int i = 0; i < 4; i++) { *(int4v *) (wp + 16*i) = wpk[i]; *(int4v *) (xp + 16*i) = xv[i]; }
     };
 
-    fetch(0);
-    commit(0, 0);
+    fetch(step0);
+    commit(step0, 0);
     __syncthreads();
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
-        if (step + 1 < nsteps) fetch(step + 1);          // global loads in flight during the MFMAs below
+        if (step + 1 < nsteps) fetch(step0 + step + 1);  // global loads in flight during the MFMAs below
         const char * lw = lds + buf*2*TILE, * lx = lw + TILE;
         // ---- MFMA: A = activations (rows = tokens), B = weights (cols = weight rows) ----
 #pragma unroll
@@ -265,7 +275,7 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
                     else               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
                 }
         }
-        if (step + 1 < nsteps) commit(step + 1, buf ^ 1);  // the other buffer was last read at step-1: every wave passed the barrier since
+        if (step + 1 < nsteps) commit(step0 + step + 1, buf ^ 1);  // the other buffer was last read at step-1: every wave passed the barrier since
         __syncthreads();
     }
     // ---- store: D[row = token][col = weight row]; col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) ----
@@ -277,7 +287,11 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = n0 + wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
-                if (col < m && row < n) *(float *) (dst + (size_t) row*p.dst_nb1 + (size_t) col*4) = acc[i][j][r];
+                if (col < m && row < n) {
+                    float * o = (float *) (dst + (size_t) row*p.dst_nb1 + (size_t) col*4);
+                    if (p.ksplit > 1) atomicAdd(o, acc[i][j][r]);   // two addends on a zeroed element: the sum does not depend on their order
+                    else              *o = acc[i][j][r];
+                }
             }
         }
     }
@@ -288,13 +302,23 @@ constexpr size_t MQ_LDS_BYTES = 4*(size_t) MQ_BM*MQ_LD;
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n) { return (size_t) n*k*2 + 256; }
 
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
-               const float * x, size_t x_row_stride, int64_t n, void * scratch, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
+               const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
     if (m == 0 || n == 0) return;
     uint16_t * xb = (uint16_t *) scratch;
-    act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
-    hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
-    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1 };
-    const dim3 grid((unsigned)((n + MQ_BN - 1)/MQ_BN), (unsigned)((m + MQ_BM - 1)/MQ_BM), 1);
+    if (!scratch_ready) {
+        act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
+        hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
+    }
+    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0 };
+    const int ntiles = (int)((n + MQ_BN - 1)/MQ_BN), mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
+    a.mtiles = mtiles;
+    // a grid that leaves the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k; dst rows must be
+    // dense for the memset
+    if ((int64_t) ntiles*mtiles <= 160 && k % 512 == 0 && k >= 2048 && dst_col_stride_bytes == (size_t) m*4) {
+        a.ksplit = 2;
+        MI_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t) m*n*4, stream));
+    }
+    const dim3 grid((unsigned) ntiles, (unsigned)(mtiles*a.ksplit), 1);
 #define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), MQ_LDS_BYTES, stream, a)
     switch (type_a) {
         case T_Q4_0:  MI_MMQ(T_Q4_0);  break;
@@ -322,7 +346,7 @@ void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t str
     act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
     hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((p.ne10 + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
-                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03) };
+                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0 };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
     hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
 }

@@ -13,14 +13,14 @@ import numpy as np
 from . import ggml_ctypes as gg
 
 # llama_ftype ids (include/llama.h) used by BASELINE.json's configs
-FTYPE = {"Q4_0": 2, "Q8_0": 7, "Q4_K_M": 15, "Q5_K_M": 17, "Q6_K": 18}
+FTYPE = {"Q4_0": 2, "Q8_0": 7, "Q4_K_M": 15, "Q5_K_M": 17, "Q6_K": 18, "MXFP4_MOE": 38}
 
 
 class hparams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_embd", "n_ff", "n_layer", "n_head", "n_head_kv", "n_embd_head", "n_vocab", "n_ctx",
                                          "ftype", "rope_type", "n_ctx_orig", "has_rope_freqs", "is_70b")] + \
                [(n, C.c_float) for n in ("rope_freq_base", "rope_freq_scale", "f_norm_rms_eps")] + \
-               [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max")]
+               [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max", "n_expert", "n_expert_used", "arch")]
 
 
 # model shapes used by the configs
@@ -34,6 +34,18 @@ MODELS = {
     # stories15M (tinyllama): 288/768/6/6/6/48/32000 — BASELINE.json configs[0] shape
     "stories15m": dict(n_embd=288, n_ff=768, n_layer=6, n_head=6, n_head_kv=6, n_embd_head=48, n_vocab=32000,
                        rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
+    # Mixtral-8x7B: 4096/14336/32/32/8/128/32000, 8 experts top-2 (llm_build_llama's MoE branch)
+    "mixtral-8x7b": dict(n_embd=4096, n_ff=14336, n_layer=32, n_head=32, n_head_kv=8, n_embd_head=128, n_vocab=32000,
+                         rope_freq_base=1000000.0, n_ctx_orig=32768, is_70b=0, n_expert=8, n_expert_used=2),
+    # gpt-oss-20b: n_embd=2880, n_ff_exp=2880, 24 layers, 64/8 heads x 64, 32 experts top-4, vocab 201088 (llm_build_openai_moe_iswa;
+    # the sliding window of its even layers is 128 tokens = the bench context, so the full causal mask is the same mask)
+    "gpt-oss-20b": dict(n_embd=2880, n_ff=2880, n_layer=24, n_head=64, n_head_kv=8, n_embd_head=64, n_vocab=201088,
+                        rope_freq_base=150000.0, n_ctx_orig=4096, is_70b=0, n_expert=32, n_expert_used=4, arch=1, rope_type=2),
+    # small MoE models for graph-level parity tests
+    "tiny-moe": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
+                     rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=8, n_expert_used=2),
+    "tiny-oai": dict(n_embd=128, n_ff=128, n_layer=2, n_head=8, n_head_kv=2, n_embd_head=32, n_vocab=512,
+                     rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=8, n_expert_used=4, arch=1, rope_type=2),
     # small model for graph-level parity tests (oracle finishes in seconds)
     "tiny": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                  rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
@@ -78,7 +90,8 @@ class SynthLlama:
             setattr(hp, k, cfg[k])
         hp.n_ctx = (n_ctx + 31) // 32 * 32
         hp.ftype = FTYPE[ftype]
-        hp.rope_type = rope_type
+        hp.rope_type = cfg.get("rope_type", rope_type)
+        hp.n_expert, hp.n_expert_used, hp.arch = cfg.get("n_expert", 0), cfg.get("n_expert_used", 0), cfg.get("arch", 0)
         hp.has_rope_freqs = int(has_rope_freqs)
         hp.rope_freq_base = cfg["rope_freq_base"]; hp.rope_freq_scale = 1.0; hp.f_norm_rms_eps = 1e-5
         hp.layer_begin, hp.layer_end, hp.has_output = layer_begin, layer_end, int(has_output)
