@@ -453,6 +453,11 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             const int64_t rows = n->op == GGML_OP_MUL_MAT ? b->ne[1] : b->ne[1]*b->ne[2];
             size_t s = act_q8_bytes(kind, b->ne[0], rows);
             if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows);
+            if (n->op == GGML_OP_MUL_MAT_ID) {
+                const struct ggml_tensor * ids = n->src[2];
+                const size_t sg = mul_mat_q_id_scratch_bytes(b->ne[0], b->ne[1], ids->ne[1], ids->ne[0], n->src[0]->ne[2]);
+                if (sg > s) s = sg;
+            }
             if (s > need) need = s;
         } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16 && n->src[1]->type == GGML_TYPE_F32 && n->src[1]->ne[1] > MMVQ_MAX_N) {
             const size_t s = (size_t) ggml_nelements(n->src[1])*2 + 256;     // f16 copy of src1 for the matrix-core attention products
@@ -537,6 +542,17 @@ static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
     const int kind = act_kind_for((int) as->type);
     const int64_t K = as->ne[0], M = as->ne[1];
     const int64_t n_used = ids->ne[0], n_tokens = ids->ne[1], n_b = b->ne[1];
+    // many tokens: sort the (token, slot) pairs by expert on the device and run the MFMA tile kernel per expert; the mat-vec kernel
+    // below would read every expert matrix once per pair
+    if (n_used*n_tokens > 4*MMVQ_MAX_N && mul_mat_q_id_supported(as->ne[2], n_used, n_tokens) && dst->nb[0] == sizeof(float)) {
+        c->aq.valid = false;   // the scratch is reused
+        mul_mat_q_id((int) as->type, as->data, as->nb[1], as->nb[2], M, K, (const float *) b->data, b->nb[1], b->nb[2], n_b,
+                     (const int32_t *) ids->data, ids->nb[0], ids->nb[1], n_used, n_tokens, as->ne[2],
+                     c->scratch, (float *) dst->data, dst->nb[1], dst->nb[2], c->stream);
+        c->cnt.mmq_launches++; c->cnt.kernels_launched += 3;
+        c->cnt.weight_bytes += (uint64_t) as->ne[2]*M*ggml_row_size(as->type, K);
+        return;
+    }
     const act_q8 q = get_act(c, b->data, K, n_b, n_tokens, b->nb[1], b->nb[2], kind);
     mul_mat_vec_q_id((int) as->type, as->data, as->nb[1], as->nb[2], M, K, q,
                      (const int32_t *) ids->data, ids->nb[0], ids->nb[1], n_used, n_tokens, n_b,

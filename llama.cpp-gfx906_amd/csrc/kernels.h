@@ -58,6 +58,16 @@ size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n);
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
 
+// ---- MUL_MAT_ID for many tokens (src/llama-graph.cpp:569-595): (token, slot) pairs sorted by expert on the device, then the tiled
+// MFMA kernel per (expert, 128 pairs). b: f32 [k, n_b, n_tokens] (n_b = 1 or n_used); ids: i32 [n_used, n_tokens] (strided);
+// dst: f32 [m, n_used, n_tokens]. No host round trip, so the launch sequence can be captured in a hipGraph.
+bool   mul_mat_q_id_supported(int64_t n_expert, int64_t n_used, int64_t n_tokens);
+size_t mul_mat_q_id_scratch_bytes(int64_t k, int64_t n_b, int64_t n_tokens, int64_t n_used, int64_t n_expert);
+void   mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
+                    const float * b, size_t b_nb1, size_t b_nb2, int64_t n_b,
+                    const int32_t * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert,
+                    void * scratch, float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream);
+
 // ---- dense f16/f32 x f32 mat-mul with ggml broadcast (attention K.Q and V.KQ; tests/test-backend-ops.cpp:5791-5813)
 struct mm_dense_args {
     const void * a; int type_a; int64_t ne00, ne01, ne02, ne03; size_t nb00, nb01, nb02, nb03;

@@ -177,6 +177,9 @@ struct mmq_args {
     char * dst; size_t dst_nb1, dst_nb2, dst_nb3;
     int ne12, r2, r3;                          // batch = blockIdx.z = i13*ne12 + i12; weights broadcast: i02 = i12/r2, i03 = i13/r3
     int ksplit, mtiles;                        // ksplit = 2: blockIdx.y = half*mtiles + m-tile; both halves atomically add into a zeroed dst
+    // MUL_MAT_ID (grouped by expert): blockIdx.x walks the tile table k_moe_sort wrote; a tile = up to 128 (token, slot) pairs of ONE expert
+    const int * moe;                           // NULL, or [0] = n_tiles, then {expert, first, count}[max_tiles], then sorted pair ids
+    int moe_max_tiles, n_used, n_b;            // pair = token*n_used + slot; X row of a pair = token*n_b + slot % n_b
 };
 
 // TYPE = a block format (bf16 MFMA on dequantized weights) or T_F16 (f16 MFMA, weights copied as they are: the attention
@@ -194,6 +197,14 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     const char * W = p.W + (size_t)(i12/p.r2)*p.w_nb2 + (size_t)(i13/p.r3)*p.w_nb3;
     const uint16_t * X = p.X + (size_t) blockIdx.z*n*k;
     char * dst = p.dst + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
+    int moe_first = 0, moe_cnt = 0;
+    const int * moe_pairs = nullptr;
+    if (p.moe) {                               // workgroup-uniform
+        if ((int) blockIdx.x >= p.moe[0]) return;
+        const int * t = p.moe + 1 + 3*blockIdx.x;
+        W = p.W + (size_t) t[0]*p.w_nb2; moe_first = t[1]; moe_cnt = t[2];
+        moe_pairs = p.moe + 1 + 3*p.moe_max_tiles;
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -207,6 +218,10 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     const int srow = tid >> 1, shalf = tid & 1;
     const char * wrow_p = W + (size_t) min(m0 + srow, m - 1)*p.w_row_stride;
     const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*k;
+    if (p.moe) {
+        const int pair = moe_pairs[moe_first + min(srow, moe_cnt - 1)];
+        xrow_p = p.X + (size_t)((pair/p.n_used)*p.n_b + (pair % p.n_used) % p.n_b)*k;
+    }
     // split-K: each half walks k/2 (a multiple of 256, so block boundaries stay aligned); steps are counted from step0
     const int nsteps_all = (k + MQ_BK - 1)/MQ_BK;
     const int step0 = khalf*(nsteps_all/2);
@@ -287,7 +302,13 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = n0 + wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
-                if (col < m && row < n) {
+                if (p.moe) {
+                    const int rt = row - n0;
+                    if (col < m && rt < moe_cnt) {
+                        const int pair = moe_pairs[moe_first + rt];
+                        *(float *) (p.dst + (size_t)(pair/p.n_used)*p.dst_nb2 + (size_t)(pair % p.n_used)*p.dst_nb1 + (size_t) col*4) = acc[i][j][r];
+                    }
+                } else if (col < m && row < n) {
                     float * o = (float *) (dst + (size_t) row*p.dst_nb1 + (size_t) col*4);
                     if (p.ksplit > 1) atomicAdd(o, acc[i][j][r]);   // two addends on a zeroed element: the sum does not depend on their order
                     else              *o = acc[i][j][r];
@@ -309,7 +330,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
-    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0 };
+    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, 0, 0, 0 };
     const int ntiles = (int)((n + MQ_BN - 1)/MQ_BN), mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     a.mtiles = mtiles;
     // a grid that leaves the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k; dst rows must be
@@ -332,6 +353,73 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
 #undef MI_MMQ
 }
 
+// ---- MUL_MAT_ID for many tokens: pairs (token, slot) sorted by expert, then the tiled kernel above per (expert, 128 pairs) ----
+// one workgroup: counts per expert, tile table, counting sort of the pair ids. Which position a pair gets inside its expert's
+// range is not deterministic (LDS atomics) and does not matter: every pair's result row is computed independently.
+struct moe_sort_args { const char * ids; size_t ids_nb0, ids_nb1; int n_used, n_tokens, n_expert, max_tiles; int * out; };
+__global__ void __launch_bounds__(256) k_moe_sort(const moe_sort_args p) {
+    __shared__ int cnt[256], off[256], cur[256];
+    const int tid = threadIdx.x, n_pairs = p.n_used*p.n_tokens;
+    if (tid < 256) { cnt[tid] = 0; cur[tid] = 0; }
+    __syncthreads();
+    for (int i = tid; i < n_pairs; i += 256) {
+        const int e = *(const int32_t *) (p.ids + (size_t)(i % p.n_used)*p.ids_nb0 + (size_t)(i/p.n_used)*p.ids_nb1);
+        atomicAdd(&cnt[e], 1);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int o = 0, nt = 0;
+        int * tiles = p.out + 1;
+        for (int e = 0; e < p.n_expert; e++) {
+            off[e] = o;
+            for (int r = 0; r < cnt[e]; r += MQ_BN) { tiles[3*nt] = e; tiles[3*nt + 1] = o + r; tiles[3*nt + 2] = min(MQ_BN, cnt[e] - r); nt++; }
+            o += cnt[e];
+        }
+        p.out[0] = nt;
+    }
+    __syncthreads();
+    int * pairs = p.out + 1 + 3*p.max_tiles;
+    for (int i = tid; i < n_pairs; i += 256) {
+        const int e = *(const int32_t *) (p.ids + (size_t)(i % p.n_used)*p.ids_nb0 + (size_t)(i/p.n_used)*p.ids_nb1);
+        pairs[off[e] + atomicAdd(&cur[e], 1)] = i;
+    }
+}
+
+static int moe_max_tiles(int64_t n_pairs, int64_t n_expert) { return (int)(n_pairs/MQ_BN + n_expert); }
+bool mul_mat_q_id_supported(int64_t n_expert, int64_t n_used, int64_t n_tokens) { return n_expert <= 256 && n_used*n_tokens < (1 << 24); }
+size_t mul_mat_q_id_scratch_bytes(int64_t k, int64_t n_b, int64_t n_tokens, int64_t n_used, int64_t n_expert) {
+    return (((size_t) k*n_b*n_tokens*2 + 255) & ~(size_t) 255) + (size_t)(1 + 3*moe_max_tiles(n_used*n_tokens, n_expert) + n_used*n_tokens)*4 + 256;
+}
+
+void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
+                  const float * b, size_t b_nb1, size_t b_nb2, int64_t n_b,
+                  const int32_t * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert,
+                  void * scratch, float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream) {
+    if (m == 0 || n_used*n_tokens == 0) return;
+    uint16_t * xb = (uint16_t *) scratch;
+    int * table = (int *) ((char *) scratch + (((size_t) k*n_b*n_tokens*2 + 255) & ~(size_t) 255));
+    const int max_tiles = moe_max_tiles(n_used*n_tokens, n_expert);
+    act16_args pa = { (const char *) b, b_nb1, b_nb2, 0, k, n_b, n_tokens, xb };     // dense [token][n_b][k] bf16
+    hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
+    moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, max_tiles, table };
+    hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
+    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0,
+                   table, max_tiles, (int) n_used, (int) n_b };
+    a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
+    const dim3 grid((unsigned) max_tiles, (unsigned) a.mtiles, 1);
+#define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), MQ_LDS_BYTES, stream, a)
+    switch (type_a) {
+        case T_Q4_0:  MI_MMQ(T_Q4_0);  break;
+        case T_Q8_0:  MI_MMQ(T_Q8_0);  break;
+        case T_Q4_K:  MI_MMQ(T_Q4_K);  break;
+        case T_Q5_K:  MI_MMQ(T_Q5_K);  break;
+        case T_Q6_K:  MI_MMQ(T_Q6_K);  break;
+        case T_MXFP4: MI_MMQ(T_MXFP4); break;
+        default: fprintf(stderr, "mmq_id: unsupported type %d\n", type_a); abort();
+    }
+#undef MI_MMQ
+}
+
 // f16 x f32 with ggml broadcast on the matrix cores (n > 8 columns): a rows contiguous f16, b rows contiguous f32
 bool mul_mat_dense_mfma_supported(const mm_dense_args & p) {
     return p.type_a == T_F16 && p.type_b == T_F32 && p.nb00 == 2 && p.nb10 == 4 && p.ne11 > MMVQ_MAX_N && p.ne00 % 32 == 0 &&
@@ -346,7 +434,7 @@ void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t str
     act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
     hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((p.ne10 + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
-                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0 };
+                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, 0, 0, 0 };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
     hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
 }
