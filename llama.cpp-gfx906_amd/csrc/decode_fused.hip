@@ -634,19 +634,24 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
     }
 #endif
     const int na = mode == PRO_Q8 ? (a.act_chunks <= 512 ? 1 : (a.act_chunks <= 1024 ? 2 : 4)) : (k <= 4096 ? 2 : 8);
-    // prefetch depth: measured on Llama-3-8B Q4_K_M tg128 (profiles/r01_g_*): D = 2 503 tok/s, D = 4 (3 for the dual GLU stream)
-    // 482-486 — a CU's request queue is finite and a wave that cannot queue a load cannot run its share of the prologue either.
-    // The deeper rings are compiled only with -DMI_MMVQ_DEEP (then GGML_MI355X_MMVQ_DEPTH=4 selects them).
-#ifdef MI_MMVQ_DEEP
+    // prefetch depth: measured on Llama-3-8B Q4_K_M tg128 (profiles/r01_g_*): D = 2 everywhere 503 tok/s, D = 4 (3 for the dual GLU
+    // stream) everywhere 482-486 — a CU's request queue is finite and a wave that cannot queue a load cannot run its share of the
+    // prologue either. Only long single-tensor streams (>= 16 steps per wave: the lm_head, 31 row pairs per wave) take the deep ring;
+    // GGML_MI355X_MMVQ_DEPTH=2|4 forces one for experiments (the GLU kernels exist with D = 2 only).
     static int depth_env = -1;
     if (depth_env < 0) { const char * e = getenv("GGML_MI355X_MMVQ_DEPTH"); depth_env = e ? atoi(e) : 0; }
-    const bool deep = depth_env > 2;
+    int64_t max_steps = 0;
+    for (int i = 0; i < n_groups; i++) {
+        const int nwg_i = a.block_end[i] - (i ? a.block_end[i - 1] : 0);
+        const int64_t pairs = (groups[i].m + 1)/2, per_wave = (pairs + (int64_t) nwg_i*FW - 1)/((int64_t) nwg_i*FW);
+        const int64_t nblk = k/(in.act_kind == T_Q8_0 ? 32 : 256);
+        const int64_t it = in.act_kind == T_Q8_0 ? (nblk + 63)/64 : (nblk + 7)/8;      // <= the steps per row pair of every type
+        if (per_wave*it > max_steps) max_steps = per_wave*it;
+    }
+    const bool deep = depth_env ? depth_env > 2 : max_steps >= 16;
 #define MI_L(TA_, TB_, GLU_, PRO_, NA_) do { \
-        if (deep) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, (GLU_ ? 3 : 4)>), grid, dim3(FW*64), lds, stream, a); \
-        else      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a); } while (0)
-#else
-#define MI_L(TA_, TB_, GLU_, PRO_, NA_) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a)
-#endif
+        if (deep && !GLU_) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a); \
+        else               hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a); } while (0)
 #define MI_LAUNCH(TA_, TB_, GLU_) do { \
         if (mode == PRO_Q8)         { if (na == 1) MI_L(TA_, TB_, GLU_, PRO_Q8, 1); else if (na == 2) MI_L(TA_, TB_, GLU_, PRO_Q8, 2); else MI_L(TA_, TB_, GLU_, PRO_Q8, 4); } \
         else if (mode == PRO_NORM)  { if (na == 2) MI_L(TA_, TB_, GLU_, PRO_NORM, 2); else MI_L(TA_, TB_, GLU_, PRO_NORM, 8); } \

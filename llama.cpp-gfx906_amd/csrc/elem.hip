@@ -489,8 +489,35 @@ __global__ void __launch_bounds__(256) k_hbm_read(const int4v * p, size_t n16, u
     }
     if (acc == 0x12345678) *sink = acc;   // never true in practice; keeps the loads alive
 }
+// the same bytes with the Q4_K mat-vec's load shape and no arithmetic: 8 lanes per 144-byte block, each loading the block's 16-byte
+// header (the same 16 bytes for the 8 lanes) and its own 16 bytes of nibbles; 2 rows x 2 k-steps in flight per wave; rows of 2304 bytes
+// (k = 4096) walked with a grid stride — what the streaming phase of the decode kernels can reach at most
+__global__ void __launch_bounds__(512) k_hbm_read_q4k(const char * p, int n_pairs, unsigned * sink) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, slot = lane & 7, ibl = lane >> 3;
+    const int stride = gridDim.x*8;
+    int acc = 0;
+    for (int pr = blockIdx.x*8 + wave; pr < n_pairs; pr += stride) {
+        int4v h[2][2], q[2][2];
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const char * b = p + (size_t)(pr*2 + r)*2304 + (size_t)(it*8 + ibl)*144;
+                h[it][r] = *(const int4v *) b;
+                q[it][r] = *(const int4v *) (b + 16 + 16*slot);
+            }
+#pragma unroll
+        for (int it = 0; it < 2; it++)
+#pragma unroll
+            for (int r = 0; r < 2; r++) acc ^= h[it][r].x ^ h[it][r].w ^ q[it][r].x ^ q[it][r].y ^ q[it][r].z ^ q[it][r].w;
+    }
+    if (acc == 0x12345678) *sink = acc;
+}
 void hbm_read_probe(const void * p, size_t bytes, unsigned * sink, hipStream_t stream) {
-    hipLaunchKernelGGL(k_hbm_read, dim3(256*8), dim3(256), 0, stream, (const int4v *) p, bytes/16, sink);
+    static int mode = -1;
+    if (mode < 0) { const char * e = getenv("GGML_MI355X_PROBE_MODE"); mode = e ? atoi(e) : 0; }
+    if (mode == 1) hipLaunchKernelGGL(k_hbm_read_q4k, dim3(256), dim3(512), 0, stream, (const char *) p, (int)(bytes/4608), sink);
+    else           hipLaunchKernelGGL(k_hbm_read, dim3(256*8), dim3(256), 0, stream, (const int4v *) p, bytes/16, sink);
 }
 
 } // namespace mi355x
