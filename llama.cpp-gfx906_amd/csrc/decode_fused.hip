@@ -327,24 +327,25 @@ constexpr int FW = 8;            // waves per workgroup
 
 // what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers)
 struct pair_out { float s0, s1; int row0; int pos0; long long idx0; };
-static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, pair_out o) {
+static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, pair_out o, const int rows) {
     float s0 = o.s0, s1 = o.s1;
     const int row0 = o.row0;
+    const int m = rows > 1 ? g.m : row0 + 1;      // rows == 1: the unit has no second row
     if (g.epi == EPI_ADD) {
         s0 += g.res[row0];
-        if (row0 + 1 < g.m) s1 += g.res[row0 + 1];
+        if (row0 + 1 < m) s1 += g.res[row0 + 1];
     } else if (g.epi == EPI_ROPE) {
         rope_pair(rope, o.pos0, row0 % rope.head_dim, s0, s1);   // m is even on this path
     }
     g.dst[row0] = s0;
-    if (row0 + 1 < g.m) g.dst[row0 + 1] = s1;
+    if (row0 + 1 < m) g.dst[row0 + 1] = s1;
     if (g.st_mode == 1) {
         uint16_t * q = g.st16 + o.idx0*g.st_row_elems + row0;
         q[0] = f32_to_f16_bits(s0);
-        if (row0 + 1 < g.m) q[1] = f32_to_f16_bits(s1);
+        if (row0 + 1 < m) q[1] = f32_to_f16_bits(s1);
     } else if (g.st_mode == 2) {
         g.st16[g.st_idx[row0]] = f32_to_f16_bits(s0);
-        if (row0 + 1 < g.m) g.st16[g.st_idx[row0 + 1]] = f32_to_f16_bits(s1);
+        if (row0 + 1 < m) g.st16[g.st_idx[row0 + 1]] = f32_to_f16_bits(s1);
     }
 }
 
@@ -352,7 +353,9 @@ template <int TYPE, bool GLU, int PRO, int NA, int D>
 static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fused_mmvq_args & p, char * smem, int wg_in_group, int nwg_group,
                                                   int lane, int wave) {
     typedef mmvq_t<TYPE> T;
-    constexpr int R = 2, LPB = T::LPB, BPW = 64/LPB, ACT = T::ACT;
+    // rows per unit of work: a pair for single-tensor groups; ONE row (of gate and of up) for the dual GLU stream, so that n_ff = 14336
+    // rows split evenly over 2048 waves (7 each; as pairs it was 4 for half the waves and 3 for the rest — tools/stamp_timeline.py)
+    constexpr int R = GLU ? 1 : 2, LPB = T::LPB, BPW = 64/LPB, ACT = T::ACT;
     const int nb = p.k / T::QK;
     const int iters = (nb + BPW - 1)/BPW;
     const int slot = lane % LPB, ibl = lane / LPB;
@@ -475,7 +478,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     const int my_pairs = p_cur < P ? (P - 1 - p_cur)/stride + 1 : 0;
     const int total = my_pairs*iters;
     int it = 0;
-    float acc[R] = { 0.0f, 0.0f }, acu[R] = { 0.0f, 0.0f };
+    float acc[2] = { 0.0f, 0.0f }, acu[2] = { 0.0f, 0.0f };
 #ifdef MI_STAMPS
     bool first_pair = true;
 #endif
@@ -494,13 +497,9 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
 #ifdef MI_STAMPS
                     if (first_pair) { MI_STAMP(2); first_pair = false; }
 #endif
-                    float s0 = wave_sum(acc[0]), s1 = wave_sum(acc[1]);
-                    if (GLU) {
-                        const float u0s = wave_sum(acu[0]), u1s = wave_sum(acu[1]);
-                        s0 = (s0/(1.0f + expf(-s0)))*u0s;      // silu(gate)*up, as elem.hip k_glu
-                        s1 = (s1/(1.0f + expf(-s1)))*u1s;
-                    }
-                    if (lane == 0) finish_pair(g, p.rope, pair_out{ s0, s1, p_cur*R, pos0, idx0 });
+                    float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
+                    if (GLU) s0 = (s0/(1.0f + expf(-s0)))*wave_sum(acu[0]);      // silu(gate)*up, as elem.hip k_glu
+                    if (lane == 0) finish_pair(g, p.rope, pair_out{ s0, s1, p_cur*R, pos0, idx0 }, R);
                     it = 0; p_cur += stride;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
                 }
@@ -587,7 +586,7 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
     int blocks = 0;
     for (int i = 0; i < n_groups; i++) {
         a.g[i] = groups[i];
-        const int max_wg = (int)(((groups[i].m + 1)/2 + FW - 1)/FW);
+        const int max_wg = groups[i].epi == EPI_GLU ? (int)((groups[i].m + FW - 1)/FW) : (int)(((groups[i].m + 1)/2 + FW - 1)/FW);   // units: rows (GLU) or row pairs
         int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1) + rows_total - 1)/rows_total);
         share = share < 1 ? 1 : (share > max_wg ? max_wg : share);
         blocks += share;
@@ -650,8 +649,9 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
     }
     const bool deep = depth_env ? depth_env > 2 : max_steps >= 16;
 #define MI_L(TA_, TB_, GLU_, PRO_, NA_) do { \
-        if (deep && !GLU_) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a); \
-        else               hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, GLU_, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a); } while (0)
+        if (GLU_)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, true,  PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a);   /* one-row units: 4 steps = the bytes 2 steps of pairs held */ \
+        else if (deep) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a); \
+        else           hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a); } while (0)
 #define MI_LAUNCH(TA_, TB_, GLU_) do { \
         if (mode == PRO_Q8)         { if (na == 1) MI_L(TA_, TB_, GLU_, PRO_Q8, 1); else if (na == 2) MI_L(TA_, TB_, GLU_, PRO_Q8, 2); else MI_L(TA_, TB_, GLU_, PRO_Q8, 4); } \
         else if (mode == PRO_NORM)  { if (na == 2) MI_L(TA_, TB_, GLU_, PRO_NORM, 2); else MI_L(TA_, TB_, GLU_, PRO_NORM, 8); } \
