@@ -42,9 +42,9 @@ def cpu_baseline(model_cfg, ftype, budget_s=20.0):
     sys.path.insert(0, str(ROOT / "oracle"))
     import oracle as orc
     native = orc.build(native=True, out_dir=Path(os.environ.get("TMPDIR", "/tmp")))
+    cores = orc.cpu_budget(cap=64)          # affinity mask / cgroup quota, at most 64 threads (a GPU box shares a 256-thread host)
+    os.environ["OMP_NUM_THREADS"] = str(cores)
     L = orc.lib(native)
-    cores = len(os.sched_getaffinity(0))
-    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
     rng = np.random.default_rng(0)
     c = model_cfg
     assert ftype == "Q4_K_M"

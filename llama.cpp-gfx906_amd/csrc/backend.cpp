@@ -286,6 +286,12 @@ static void prof_end(mi_backend_ctx * c) {
     if (!c->profiling) return;
     MI_CHECK(hipEventRecord(c->prof.back().e1, c->stream));
 }
+// the grouped mat-vec module launches (possibly several graph nodes later, possibly several launches merged into one): it calls back
+static void prof_hook_pre(void * ctx, int type, uint64_t wbytes, int n_merged, int64_t k) {
+    // m < 0: grouped launch, |m| = KiB of weights; n = launches merged into this kernel
+    prof_begin((mi_backend_ctx *) ctx, type, -(int64_t)(wbytes/1024), k, n_merged, wbytes);
+}
+static void prof_hook_post(void * ctx, int, uint64_t, int, int64_t) { prof_end((mi_backend_ctx *) ctx); }
 
 
 static ggml_guid_t mi_guid(void) {
@@ -747,11 +753,10 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     } else if (mul_mat_vec_q_fused_prologue_supported(K)) {
         in.mode = PRO_QUANT; in.x = (const float *) b->data;
     } else {
+        mul_mat_vec_q_fused_flush(c->stream);     // the quantizer below reads what a held-back launch writes
         in.mode = PRO_Q8; in.act = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);
     }
-    if (c->profiling) prof_begin(c, grp[0].type, nc == 1 && grp[0].epi != EPI_GLU ? grp[0].m : -(int64_t)(wbytes/1024), K, 1, wbytes);   // m < 0: grouped launch, |m| = KiB of weights
-    mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream);
-    if (c->profiling) prof_end(c);
+    mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream);     // may be held back as a position of the per-layer chain (profile events: prof_hook_*)
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++; c->cnt.weight_bytes += wbytes;
     return last;
 }
@@ -821,13 +826,18 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     bool fresh_aq = false;   // this step produced the cached quantized activations itself
     if (c->use_fusion) {
         int f = 0;
-        if (node->op == GGML_OP_MUL_MAT) { const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0; if (!f) f = try_fused_attn(c, g, i); }
-        else if (node->op == GGML_OP_SET_ROWS) f = try_fused_kv_store(c, g, i);
+        if (node->op == GGML_OP_MUL_MAT) {
+            const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0;
+            if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
+        } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
         if (f) {
             consumed = f;
             goto done;
         }
     }
+    // held-back grouped launches (decode_fused.hip: the per-layer chain) go out before anything else touches the stream; only an
+    // RMS_NORM may still be absorbed into the next grouped launch's prologue
+    if (node->op != GGML_OP_RMS_NORM) mul_mat_vec_q_fused_flush(c->stream);
     switch (node->op) {
         case GGML_OP_MUL_MAT:    op_mul_mat(c, node); break;
         case GGML_OP_MUL_MAT_ID: op_mul_mat_id(c, node); break;
@@ -854,6 +864,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                             const int l = try_fused_mmv(c, g, jn, node, w);
                             if (l >= 0) { consumed = l - i + 1; break; }
                         }
+                        mul_mat_vec_q_fused_flush(c->stream);
                         if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&
                             act_kind_for((int) mm->src[0]->type) > 0 && rms_norm_mul_quant_supported(node->ne[0]) && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 &&
                             w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] && s0->nb[0] == 4 &&
@@ -877,6 +888,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                     }
                 }
             }
+            mul_mat_vec_q_fused_flush(c->stream);
             rms_norm(desc(s0), desc(node), op_f32(node, 0), c->stream);
             c->cnt.kernels_launched++;
         } break;
@@ -939,6 +951,7 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
         }
     }
     for (int i = 0; i < g->n_nodes; ) i += compute_node(c, g, i);
+    mul_mat_vec_q_fused_flush(c->stream);
     c->aq.valid = false;
 }
 
@@ -1271,7 +1284,11 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
     GGML_ASSERT(ggml_backend_is_mi355x(backend));
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     if (strcmp(key, "graphs") == 0) { c->use_graphs = value != 0; return 0; }
-    if (strcmp(key, "profile") == 0) { c->profiling = value != 0; return 0; }
+    if (strcmp(key, "profile") == 0) {
+        c->profiling = value != 0;
+        mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
+        return 0;
+    }
     if (strcmp(key, "fusion") == 0) {
         c->use_fusion = value != 0;
         MI_CHECK(hipStreamSynchronize(c->stream));

@@ -325,20 +325,31 @@ static __device__ __forceinline__ void rope_pair(const fused_rope & r, int pos, 
 //   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*2048)
 constexpr int FW = 8;            // waves per workgroup
 
-// what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers)
+// what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers).
+// CHAIN: the rows are handed to the next phase of the same launch, which runs on other CUs behind other L2s: stores and loads of
+// handed-over bytes bypass the caches that are not coherent (agent-scope relaxed atomics lower to `sc1` accesses).
 struct pair_out { float s0, s1; int row0; int pos0; long long idx0; };
+template <bool CHAIN>
+static __device__ __forceinline__ float ld_handoff(const float * p) {
+    return CHAIN ? __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : *p;
+}
+template <bool CHAIN>
+static __device__ __forceinline__ void st_handoff(float * p, float v) {
+    if (CHAIN) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); else *p = v;
+}
+template <bool CHAIN>
 static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, pair_out o, const int rows) {
     float s0 = o.s0, s1 = o.s1;
     const int row0 = o.row0;
     const int m = rows > 1 ? g.m : row0 + 1;      // rows == 1: the unit has no second row
     if (g.epi == EPI_ADD) {
-        s0 += g.res[row0];
-        if (row0 + 1 < m) s1 += g.res[row0 + 1];
+        s0 += ld_handoff<CHAIN>(g.res + row0);
+        if (row0 + 1 < m) s1 += ld_handoff<CHAIN>(g.res + row0 + 1);
     } else if (g.epi == EPI_ROPE) {
         rope_pair(rope, o.pos0, row0 % rope.head_dim, s0, s1);   // m is even on this path
     }
-    g.dst[row0] = s0;
-    if (row0 + 1 < m) g.dst[row0 + 1] = s1;
+    st_handoff<CHAIN>(g.dst + row0, s0);
+    if (row0 + 1 < m) st_handoff<CHAIN>(g.dst + row0 + 1, s1);
     if (g.st_mode == 1) {
         uint16_t * q = g.st16 + o.idx0*g.st_row_elems + row0;
         q[0] = f32_to_f16_bits(s0);
@@ -349,9 +360,12 @@ static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const f
     }
 }
 
-template <int TYPE, bool GLU, int PRO, int NA, int D>
+// hand-off between two phases of one launch (k_mmvq_chain): phase n waits until `target` workgroups have added to `ctr`
+struct chain_wait { unsigned * ctr; unsigned target; unsigned * err; };
+
+template <int TYPE, bool GLU, int PRO, int NA, int D, bool CHAIN = false>
 static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fused_mmvq_args & p, char * smem, int wg_in_group, int nwg_group,
-                                                  int lane, int wave) {
+                                                  int lane, int wave, const chain_wait cw = chain_wait{ nullptr, 0, nullptr }) {
     typedef mmvq_t<TYPE> T;
     // rows per unit of work: a pair for single-tensor groups; ONE row (of gate and of up) for the dual GLU stream, so that n_ff = 14336
     // rows split evenly over 2048 waves (7 each; as pairs it was 4 for half the waves and 3 for the rest — tools/stamp_timeline.py)
@@ -365,37 +379,9 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     int p_cur = p_first;
 
     MI_STAMP(0);
-    // ---- (1) activation loads ----
     int4v areg[PRO == PRO_Q8 ? NA : 1];
     float4v xv[PRO != PRO_Q8 ? NA : 1], wv[PRO == PRO_NORM ? NA : 1];
     const int nchunk = p.k >> 8;
-    if (PRO == PRO_Q8) {
-#pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int idx = min((int) threadIdx.x + i*(FW*64), p.act_chunks - 1);
-            areg[i] = *(const int4v *) (p.act + (size_t) idx*16);
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < NA; i++) xv[i] = *(const float4v *) (p.x + min(wave + FW*i, nchunk - 1)*256 + lane*4);
-    }
-    // wave-uniform epilogue operands, fetched now (scalar loads) instead of at the end of the first row pair
-    const int pos0 = g.epi == EPI_ROPE ? p.rope.pos[0] : 0;
-    const long long idx0 = g.st_mode == 1 ? (long long) g.st_idx[0] : 0;
-    // A CU's L1 returns data in request order across all its waves: a load that hits L2 (the activation, just written) queued
-    // behind one that goes to HBM (weights, norm weights) of ANY wave comes back with HBM latency — 1-4 us instead of ~0.5 us,
-    // and the whole prologue hangs on it (measured, tools/stamp_timeline.py: the second workgroup on a CU saw its activation 2 us
-    // after the first). So: every wave issues its activation loads, the workgroup meets at a barrier (issue order = request
-    // order), and only then are norm weights and the weight stream requested. The asm statements are compiler barriers too.
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (PRO == PRO_NORM) {
-#pragma unroll
-        for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + min(wave + FW*i, nchunk - 1)*256 + lane*4);
-    }
-
-    // ---- (2) weight prefetch: the first D steps of this wave's stream ----
     // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch.
     // Past the end of the stream the loads go to the wave's own first block (an L1 hit), not to a line every wave would share.
     int p_pf = p_cur, it_pf = 0;
@@ -410,13 +396,68 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
             if (GLU) u[GLU ? d_ : 0][r] = T::load_w(g.W2 + off, ibf, slot); \
         } \
         if (++it_pf == iters) { it_pf = 0; p_pf += stride; } }
+#define MI_FENCE asm volatile("" ::: "memory")
+    // wave-uniform epilogue operands, fetched now (scalar loads) instead of at the end of the first row pair
+    const int pos0 = g.epi == EPI_ROPE ? p.rope.pos[0] : 0;
+    const long long idx0 = g.st_mode == 1 ? (long long) g.st_idx[0] : 0;
+
+    if (CHAIN) {
+        // A phase of k_mmvq_chain. What does not depend on the previous phase is requested BEFORE the hand-off wait: the norm
+        // weights and the whole ring of weight steps — they arrive while the wait, the activation round trip and the prologue
+        // arithmetic run, which between separate launches is time HBM spends idle.
+        if (PRO == PRO_NORM) {
+#pragma unroll
+            for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+        }
+#pragma unroll
+        for (int d = 0; d < D; d++) MI_FETCH(d)
+        MI_FENCE;
+        if (cw.target && threadIdx.x == 0) {       // one relaxed sc1 poll loop per workgroup; bounded, so a lost hand-off cannot hang the GPU
+            int spins = 0;
+            while (__hip_atomic_load(cw.ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < cw.target) {
+                if (++spins > (1 << 23)) { __hip_atomic_store(cw.err, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
+            }
+        }
+        __syncthreads();                           // every wave loads the handed-over bytes only behind the polling wave's barrier
+        MI_FENCE;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const float * px = p.x + min(wave + FW*i, nchunk - 1)*256 + lane*4;
+            xv[i].x = ld_handoff<true>(px); xv[i].y = ld_handoff<true>(px + 1); xv[i].z = ld_handoff<true>(px + 2); xv[i].w = ld_handoff<true>(px + 3);
+        }
+    } else {
+    // ---- (1) activation loads ----
+    if (PRO == PRO_Q8) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = min((int) threadIdx.x + i*(FW*64), p.act_chunks - 1);
+            areg[i] = *(const int4v *) (p.act + (size_t) idx*16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NA; i++) xv[i] = *(const float4v *) (p.x + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+    }
+    // A CU's L1 returns data in request order across all its waves: a load that hits L2 (the activation, just written) queued
+    // behind one that goes to HBM (weights, norm weights) of ANY wave comes back with HBM latency — 1-4 us instead of ~0.5 us,
+    // and the whole prologue hangs on it (measured, tools/stamp_timeline.py: the second workgroup on a CU saw its activation 2 us
+    // after the first). So: every wave issues its activation loads, the workgroup meets at a barrier (issue order = request
+    // order), and only then are norm weights and the weight stream requested. The asm statements are compiler barriers too.
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (PRO == PRO_NORM) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+    }
+
+    // ---- (2) weight prefetch: the first D steps of this wave's stream ----
     // A wave blocks at a load it cannot queue (the CU's request queue is finite) and then cannot run its share of the prologue
     // either, so the D steps are not issued in one burst: one step now, the others between the phases of the prologue (FENCE keeps
     // the compiler from hoisting them back up). HBM then has work from the first 0.2 us on and the prologue math starts as soon as
     // the activation is there.
-#define MI_FENCE asm volatile("" ::: "memory")
     MI_FETCH(0)
     MI_FENCE;
+    }
 
     // ---- (3) prologue: build the quantized activation image in LDS ----
     int8_t * l_qs = (int8_t *) smem; float * l_d = (float *) (smem + p.off_d); int16_t * l_bs = (int16_t *) (smem + p.off_bs);
@@ -442,7 +483,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
             scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
             MI_STAMP(7);
             MI_FENCE;
-            MI_FETCH(1)
+            if (!CHAIN) { MI_FETCH(1) }
             MI_FENCE;
         }
 #pragma unroll
@@ -456,16 +497,20 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
             if (i == 0) {     // the steps must be fetched in ring order: set d holds stream step d
                 MI_STAMP(5);
                 MI_FENCE;
-                if (PRO == PRO_QUANT) { MI_FETCH(1) }
-                else if (D > 2)       { MI_FETCH(2) }
+                if (!CHAIN) {
+                    if (PRO == PRO_QUANT) { MI_FETCH(1) }
+                    else if (D > 2)       { MI_FETCH(2) }
+                }
                 MI_FENCE;
             }
         }
     }
     MI_FENCE;
-    if (PRO == PRO_Q8) { MI_FETCH(1) }
-    if (D > 2 && PRO != PRO_NORM) { MI_FETCH(2) }
-    if (D > 3) { MI_FETCH(3) }
+    if (!CHAIN) {
+        if (PRO == PRO_Q8) { MI_FETCH(1) }
+        if (D > 2 && PRO != PRO_NORM) { MI_FETCH(2) }
+        if (D > 3) { MI_FETCH(3) }
+    }
     MI_FENCE;
     MI_STAMP(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -499,7 +544,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
 #endif
                     float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
                     if (GLU) s0 = (s0/(1.0f + expf(-s0)))*wave_sum(acu[0]);      // silu(gate)*up, as elem.hip k_glu
-                    if (lane == 0) finish_pair(g, p.rope, pair_out{ s0, s1, p_cur*R, pos0, idx0 }, R);
+                    if (lane == 0) finish_pair<CHAIN>(g, p.rope, pair_out{ s0, s1, p_cur*R, pos0, idx0 }, R);
                     it = 0; p_cur += stride;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
                 }
@@ -523,6 +568,54 @@ __global__ void __launch_bounds__(512, 2) k_mmvq_fused(const fused_mmvq_args p) 
     const mmvq_group & g = p.g[gi];
     if (TA == TB || g.type == TA) fused_body<TA, GLU, PRO, NA, D>(g, p, smem, blk, nwg, lane, wave);
     else                          fused_body<TB, GLU, PRO, NA, D>(g, p, smem, blk, nwg, lane, wave);
+}
+
+// ---- several grouped mat-vec launches of one decode layer as ONE launch ----
+// Positions are fixed (the order llm_build_llama emits them, src/llama-model.cpp:6042-6100): 0 quantize + wo + residual,
+// 1 norm + gate/up + SwiGLU, 2 quantize + down + residual, 3 norm + QKV + RoPE + KV store of the NEXT layer (or norm + lm_head);
+// a launch runs the contiguous positions [first, last]. Between positions the rows are handed over through `sc1` stores / loads
+// and one agent-scope counter per position (MI355X guide, "inter-workgroup visibility": every storing wave waits for its stores,
+// the workgroup meets at a barrier, one lane adds to the counter; the consumer polls it with one lane, then a workgroup barrier,
+// then `sc1` loads). What a separate launch pays for — dispatch, end-of-kernel, and HBM idling until the first weights arrive —
+// is replaced by the counter round trip with the next position's weights already in flight.
+// One workgroup per CU and the whole grid resident (grid <= CU count), or the wait could never be satisfied; the poll is bounded.
+struct chain_args { int first, last; unsigned * sync; fused_mmvq_args ph[4]; };      // sync: [0..3] per-position counters, [6] finished, [7] error
+
+template <int TA, int TB>
+__global__ void __launch_bounds__(512, 1) k_mmvq_chain(const chain_args c) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned prev_total = 0;
+#define MI_PHASE(POS_, GLU_, PRO_, NA_, D_) \
+    if (c.first <= POS_ && POS_ <= c.last) { \
+        const fused_mmvq_args & p = c.ph[POS_]; \
+        const int total = p.block_end[p.n_groups - 1]; \
+        const chain_wait cw = { c.sync + (POS_ > 0 ? POS_ - 1 : 0), POS_ > c.first ? prev_total : 0u, c.sync + 7 }; \
+        if ((int) blockIdx.x < total) { \
+            int gi = 0; \
+            while (gi < p.n_groups - 1 && (int) blockIdx.x >= p.block_end[gi]) gi++; \
+            const int first_b = gi ? p.block_end[gi - 1] : 0; \
+            const mmvq_group & g = p.g[gi]; \
+            if (TA == TB || g.type == TA) fused_body<TA, GLU_, PRO_, NA_, D_, true>(g, p, smem, (int) blockIdx.x - first_b, p.block_end[gi] - first_b, lane, wave, cw); \
+            else                          fused_body<TB, GLU_, PRO_, NA_, D_, true>(g, p, smem, (int) blockIdx.x - first_b, p.block_end[gi] - first_b, lane, wave, cw); \
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      /* every storing wave: its stores have left */ \
+            __syncthreads();                                       /* also: the LDS image is free for the next position */ \
+            if (threadIdx.x == 0 && POS_ < c.last) __hip_atomic_fetch_add(c.sync + POS_, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        } \
+        prev_total = (unsigned) total; \
+    }
+    MI_PHASE(0, false, PRO_QUANT, 2, 2)
+    MI_PHASE(1, true,  PRO_NORM,  2, 4)
+    MI_PHASE(2, false, PRO_QUANT, 8, 2)
+    MI_PHASE(3, false, PRO_NORM,  2, 2)
+#undef MI_PHASE
+    // the last workgroup to finish re-arms the counters for the next launch that uses this slot (a graph replay)
+    if (threadIdx.x == 0) {
+        const unsigned done = __hip_atomic_fetch_add(c.sync + 6, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (done == gridDim.x - 1) {
+            for (int i = 0; i < 7; i++) __hip_atomic_store(c.sync + i, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 #ifdef MI_STAMPS
@@ -568,8 +661,16 @@ bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind) {
 }
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k) { return k % 256 == 0 && k <= 16*1024; }
 
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream) {
-    fused_mmvq_args a = {};
+static struct { mmvq_launch_hook pre = nullptr, post = nullptr; void * ctx = nullptr; } g_hook;
+void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx) { g_hook.pre = pre; g_hook.post = post; g_hook.ctx = ctx; }
+
+// a grouped launch, prepared: either run at once or held back as a position of a chained launch
+struct fused_launch { fused_mmvq_args a; int blocks; size_t lds; int ta, tb; bool glu; int mode, na; bool deep; int64_t k; uint64_t wbytes; };
+static void fused_launch_now(const fused_launch & L, hipStream_t stream);
+
+static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope) {
+    fused_launch L = {};
+    fused_mmvq_args & a = L.a;
     a.n_groups = n_groups; a.k = (int) k; a.act_kind = in.act_kind;
     // share the persistent workgroups among the groups in proportion to their rows (never more than one row pair per wave)
     static int n_cu = 0, wpc = 1, glu_wpc = 1;   // measured (tools/stamp_timeline.py): the second workgroup on a CU runs its prologue ~2x slower
@@ -587,7 +688,7 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
     for (int i = 0; i < n_groups; i++) {
         a.g[i] = groups[i];
         const int max_wg = groups[i].epi == EPI_GLU ? (int)((groups[i].m + FW - 1)/FW) : (int)(((groups[i].m + 1)/2 + FW - 1)/FW);   // units: rows (GLU) or row pairs
-        int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1) + rows_total - 1)/rows_total);
+        int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1))/rows_total);   // rounded down: the grid never exceeds the budget (one workgroup per CU)
         share = share < 1 ? 1 : (share > max_wg ? max_wg : share);
         blocks += share;
         a.block_end[i] = blocks;
@@ -614,7 +715,6 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
         const float end   = ceilf (rope_corr_dim_h(rope->p.n_dims, rope->p.n_ctx_orig, rope->p.beta_slow, rope->p.freq_base));
         a.rope.corr_lo = fmaxf(0.0f, start); a.rope.corr_hi = fminf((float)(rope->p.n_dims - 1), end);
     }
-    const dim3 grid((unsigned) blocks);
     const size_t lds = bytes + 32;     // + FW floats for the RMS reduction
     int ta = groups[0].type, tb = groups[0].type;
     for (int i = 1; i < n_groups; i++) if (groups[i].type != ta) tb = groups[i].type;
@@ -648,6 +748,23 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
         if (per_wave*it > max_steps) max_steps = per_wave*it;
     }
     const bool deep = depth_env ? depth_env > 2 : max_steps >= 16;
+    L.blocks = blocks; L.lds = lds; L.ta = ta; L.tb = tb; L.glu = glu; L.mode = mode; L.na = na; L.deep = deep; L.k = k;
+    for (int i = 0; i < n_groups; i++) L.wbytes += (uint64_t) groups[i].m*groups[i].row_stride*(groups[i].epi == EPI_GLU ? 2 : 1);
+    return L;
+}
+
+static void fused_launch_kernel(const fused_launch & L, hipStream_t stream);
+static void fused_launch_now(const fused_launch & L, hipStream_t stream) {
+    if (g_hook.pre) g_hook.pre(g_hook.ctx, L.ta, L.wbytes, 1, L.k);
+    fused_launch_kernel(L, stream);
+    if (g_hook.post) g_hook.post(g_hook.ctx, L.ta, L.wbytes, 1, L.k);
+}
+static void fused_launch_kernel(const fused_launch & L, hipStream_t stream) {
+    const fused_mmvq_args & a = L.a;
+    const dim3 grid((unsigned) L.blocks);
+    const size_t lds = L.lds;
+    const int ta = L.ta, tb = L.tb, mode = L.mode, na = L.na;
+    const bool glu = L.glu, deep = L.deep;
 #define MI_L(TA_, TB_, GLU_, PRO_, NA_) do { \
         if (GLU_)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, true,  PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a);   /* one-row units: 4 steps = the bytes 2 steps of pairs held */ \
         else if (deep) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a); \
@@ -666,6 +783,80 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
 #undef MI_L
     fprintf(stderr, "mul_mat_vec_q_fused: type pair (%d, %d) has no kernel (check mul_mat_vec_q_fused_can_group)\n", ta, tb);
     abort();
+}
+
+// ---- the chain queue: grouped launches that follow each other in a decode layer are held back and sent as ONE k_mmvq_chain ----
+// (every caller that puts anything else on the stream calls mul_mat_vec_q_fused_flush first; backend.cpp does so per graph node)
+static int chain_position(const fused_launch & L) {      // which fixed position of k_mmvq_chain this launch fits, or -1
+    const bool types_ok = (L.ta == T_Q4_K || L.ta == T_Q6_K) && (L.tb == T_Q4_K || L.tb == T_Q6_K);
+    if (!types_ok || L.deep) return -1;
+    if (!L.glu && L.mode == PRO_QUANT && L.na == 2) return 0;
+    if ( L.glu && L.mode == PRO_NORM  && L.na == 2) return 1;
+    if (!L.glu && L.mode == PRO_QUANT && L.na == 8) return 2;
+    if (!L.glu && L.mode == PRO_NORM  && L.na == 2) return 3;
+    return -1;
+}
+static struct {
+    fused_launch q[4]; int pos[4]; int n = 0;
+    unsigned * sync = nullptr; int next_slot = 0; int enabled = -1; int n_cu = 0;
+} g_chain;
+constexpr int CHAIN_SLOTS = 8192;
+
+int mul_mat_vec_q_fused_pending(uint64_t * wbytes) {
+    uint64_t b = 0;
+    for (int i = 0; i < g_chain.n; i++) b += g_chain.q[i].wbytes;
+    if (wbytes) *wbytes = b;
+    return g_chain.n;
+}
+
+void mul_mat_vec_q_fused_flush(hipStream_t stream) {
+    if (g_chain.n == 0) return;
+    if (g_chain.n == 1) { g_chain.n = 0; fused_launch_now(g_chain.q[0], stream); return; }
+    chain_args c = {};
+    c.first = g_chain.pos[0]; c.last = g_chain.pos[g_chain.n - 1];
+    size_t lds = 0; int blocks = 0;
+    for (int i = 0; i < g_chain.n; i++) {
+        c.ph[g_chain.pos[i]] = g_chain.q[i].a;
+        if (g_chain.q[i].lds > lds) lds = g_chain.q[i].lds;
+        if (g_chain.q[i].blocks > blocks) blocks = g_chain.q[i].blocks;
+    }
+    c.sync = g_chain.sync + (size_t)(g_chain.next_slot++ % CHAIN_SLOTS)*8;
+    uint64_t wb = 0;
+    for (int i = 0; i < g_chain.n; i++) wb += g_chain.q[i].wbytes;
+    const int n_merged = g_chain.n;
+    g_chain.n = 0;
+    if (g_hook.pre) g_hook.pre(g_hook.ctx, T_Q4_K, wb, n_merged, 0);
+    hipLaunchKernelGGL((k_mmvq_chain<T_Q4_K, T_Q6_K>), dim3((unsigned) blocks), dim3(FW*64), lds, stream, c);
+    if (g_hook.post) g_hook.post(g_hook.ctx, T_Q4_K, wb, n_merged, 0);
+}
+
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream) {
+    const fused_launch L = fused_prepare(groups, n_groups, k, in, rope);
+    if (g_chain.enabled < 0) {
+        const char * e = getenv("GGML_MI355X_CHAIN");
+        g_chain.enabled = e ? atoi(e) : 0;     // opt-in: measured 446 tok/s chained vs 512 unchained (Llama-3-8B Q4_K_M tg128) — the sc1 hand-off
+                                               // (per-row 4-byte sc1 stores, their acks before the counter add, sc1 reloads) costs more than
+                                               // the kernel boundary + weight wait it removes; parity-tested, kept as the base for round 2
+        int dev = 0; hipDeviceProp_t prop;
+        g_chain.n_cu = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+        if (g_chain.enabled) {      // counters: zeroed once; every chained launch re-arms its own slot when its last workgroup finishes
+            if (hipMalloc(&g_chain.sync, (size_t) CHAIN_SLOTS*8*sizeof(unsigned)) != hipSuccess ||
+                hipMemset(g_chain.sync, 0, (size_t) CHAIN_SLOTS*8*sizeof(unsigned)) != hipSuccess) { (void) hipGetLastError(); g_chain.enabled = 0; }
+        }
+    }
+    int pos = g_chain.enabled ? chain_position(L) : -1;
+#ifdef MI_STAMPS
+    pos = -1;                                        // the timeline tool looks at separate launches
+#endif
+    if (pos >= 0 && (L.blocks > g_chain.n_cu || L.blocks > 1024)) pos = -1;      // the whole grid must be resident: one workgroup per CU
+    if (pos < 0) {
+        mul_mat_vec_q_fused_flush(stream);
+        fused_launch_now(L, stream);
+        return;
+    }
+    if (g_chain.n > 0 && pos != g_chain.pos[g_chain.n - 1] + 1) mul_mat_vec_q_fused_flush(stream);     // not the next position: a new chain starts here
+    g_chain.q[g_chain.n] = L; g_chain.pos[g_chain.n] = pos; g_chain.n++;
+    if (pos == 3) mul_mat_vec_q_fused_flush(stream);                                                    // the last position closes the chain
 }
 
 // which weight types may share one grouped launch (the mixtures llama_tensor_get_type produces, src/llama-quant.cpp:178-434)

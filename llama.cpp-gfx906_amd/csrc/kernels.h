@@ -155,6 +155,13 @@ bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k);        // PRO_QUANT / PRO_NORM limits
 bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);   // may these two weight types share one grouped launch
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream);
+// Launches that fit a position of the per-layer chain (decode_fused.hip: k_mmvq_chain) are held back until the chain is complete
+// or broken. EVERY other use of the stream must call flush first; `pending` tells how many launches (and weight bytes) are held.
+void mul_mat_vec_q_fused_flush(hipStream_t stream);
+// called right before / after every kernel this module puts on the stream (type of the first group, weight bytes, launches merged, k)
+typedef void (*mmvq_launch_hook)(void * ctx, int type, uint64_t weight_bytes, int n_merged, int64_t k);
+void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx);
+int  mul_mat_vec_q_fused_pending(uint64_t * weight_bytes);
 
 // ---- test / bench support ------------------------------------------------------------------
 // raw streaming read of `bytes` (16 B/lane, nontemporal) — measures the achievable HBM rate on the box

@@ -47,10 +47,26 @@ def build(native: bool = False, out_dir: Path | None = None) -> Path:
 _lib = None
 
 
+def cpu_budget(cap: int = 16) -> int:
+    """Threads worth starting: the affinity mask, the cgroup CPU quota when one is set, and `cap` (a GPU box hands each job about 16
+    CPUs of a 256-thread host; OpenMP's default of one spinning thread per visible CPU made small oracle calls ~100x slower there)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except Exception:
+        pass
+    return max(1, min(n, cap))
+
+
 def lib(path: Path | None = None):
     global _lib
     if _lib is not None and path is None:
         return _lib
+    # before libgomp initialises: a bounded team that sleeps between the many small parallel regions of a test run
+    os.environ.setdefault("OMP_NUM_THREADS", str(cpu_budget()))
+    os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
     p = Path(path) if path else build()
     L = ctypes.CDLL(str(p))
     c_i64, c_int, c_vp = ctypes.c_int64, ctypes.c_int, ctypes.c_void_p
