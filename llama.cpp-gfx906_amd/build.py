@@ -25,7 +25,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-paramet
           "-Wno-missing-field-initializers"]
 HIPFLAGS = [f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"] + os.environ.get("MI_EXTRA_HIPFLAGS", "").split()
 
-KERNEL_SRCS = ["quantize_act.hip", "mmvq.hip", "mmq.hip", "mm_dense.hip", "elem.hip", "decode_fused.hip"]
+KERNEL_SRCS = ["quantize_act.hip", "mmvq.hip", "mmq.hip", "mm_dense.hip", "elem.hip", "decode_fused.hip", "attn_prefill.hip"]
 
 
 def run(cmd):

@@ -787,7 +787,8 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     const struct ggml_tensor * k = kq->src[0]; const struct ggml_tensor * q = kq->src[1];
     if (k->type != GGML_TYPE_F16 || q->type != GGML_TYPE_F32 || k->ne[3] != 1 || q->ne[3] != 1) return 0;
     const int64_t hd = k->ne[0], n_kv = k->ne[1], n_head_kv = k->ne[2], T = q->ne[1], n_head = q->ne[2];
-    if (T > 8 || !attn_decode_supported(hd, n_kv) || n_head % n_head_kv != 0) return 0;
+    const bool prefill = T > 8;      // many tokens: the matrix-core kernel with online softmax (attn_prefill.hip)
+    if (n_head % n_head_kv != 0 || !(prefill ? attn_prefill_supported(hd, n_kv) : attn_decode_supported(hd, n_kv))) return 0;
     if (k->nb[0] != 2 || q->nb[0] != 4 || k->nb[1] % 16 || k->nb[2] % 16 || (uintptr_t) k->data % 16 || q->nb[1] % 16 || q->nb[2] % 16 || (uintptr_t) q->data % 16) return 0;
     const int j1 = next_real(g, i); if (j1 < 0) return 0;
     struct ggml_tensor * sm = g->nodes[j1];
@@ -807,6 +808,16 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     if (pm->op != GGML_OP_PERMUTE || pm->src[0] != kqv || !is_internal(c, pm)) return 0;
     if (pm->ne[0] != hd || pm->ne[1] != n_head || pm->ne[2] != T || pm->ne[3] != 1) return 0;
     if (ct->type != GGML_TYPE_F32 || !ggml_is_contiguous(ct) || ggml_nelements(ct) != hd*n_head*T) return 0;
+    if (prefill) {
+        if (mask && (mask->ne[1] < T || ((uintptr_t) mask->data % 16) || mask->nb[1] % 16)) return 0;
+        if (v->nb[1] % 8 || v->nb[2] % 8 || ((uintptr_t) v->data % 8)) return 0;
+        attn_prefill(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2],
+                     mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, mask && mask->type == GGML_TYPE_F16,
+                     sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
+                     hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream);
+        c->cnt.kernels_launched++;
+        return j3 - i + 1;
+    }
     attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2],
                 mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, mask && mask->type == GGML_TYPE_F16,
                 sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,

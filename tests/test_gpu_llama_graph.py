@@ -181,6 +181,41 @@ def test_synthetic_moe_matches_oracle(model, ftype):
         m.free()
 
 
+@pytest.mark.parametrize("model,n_prompt", [("tiny", 40), ("tiny-hd128", 33), ("tiny-hd128", 64)])
+def test_prefill_attention_on_matrix_cores(model, n_prompt):
+    """More than 8 tokens per step: K.q -> soft_max -> V.kq runs as one matrix-core kernel with an online softmax (attn_prefill.hip)
+    instead of three kernels and a score matrix in memory; prompts that are not multiples of the 32-query tile, then single-token
+    steps that read the cache the prompt pass wrote. Also the fused path against the node-by-node one (fusion = 0)."""
+    be = backend()
+    outs = {}
+    for fusion in (1, 0):
+        be.set_option("graphs", 1); be.set_option("fusion", fusion)
+        m = ls.SynthLlama(be, model, "Q4_K_M", n_ctx=96, seed=6)
+        try:
+            if fusion:
+                W = read_weights(m)
+                rc = RefLlama(m.cfg, W, 96, "cpu"); re_ = RefLlama(m.cfg, W, 96, "exact")
+            res = []
+            rng = np.random.default_rng(5)
+            for toks in [list(rng.integers(0, 512, size=n_prompt)), [7], [8]]:
+                got = m.decode(toks)
+                res.append(got.copy())
+                if fusion:
+                    emb = np.stack([m.embedding(t) for t in toks])
+                    exp_c = rc.decode(emb); exp_e = re_.decode(emb)
+                    assert np.isfinite(got).all()
+                    # the prompt pass multiplies in bf16 on the matrix cores (weights and activations rounded to 8 bits of mantissa), so
+                    # only the reference's whole-graph gate applies to it (tests/test-backend-ops.cpp:4991-4993)
+                    if len(toks) <= 8:
+                        assert orc.nmse(exp_c, got) <= 1e-3, (len(toks), orc.nmse(exp_c, got))
+                    assert orc.nmse(exp_e, got) <= 2e-3, (len(toks), orc.nmse(exp_e, got))
+            outs[fusion] = np.stack(res)
+        finally:
+            m.free()
+    be.set_option("fusion", 1)
+    assert orc.nmse(outs[0], outs[1]) <= 5e-4
+
+
 def test_graph_replay_is_bitwise_neutral_and_fusion_stays_within_tolerance():
     """hipGraph replay must not change a bit. The decode fusions keep each op's arithmetic but the fused attention
     kernel sums V.p in a different lane order than the node-by-node kernels, so fusion on/off agree to f32 rounding,
