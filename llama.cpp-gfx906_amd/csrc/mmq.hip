@@ -117,8 +117,13 @@ template <> __device__ __forceinline__ void decode32<T_Q4_K>(const raw32 & r, in
     const float d1 = d*sc, m1 = dmin*m;
     const uint32_t w[8] = { (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w, (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w };
     const int sh = (sb & 1)*4;
+    // word-wise: one shift + mask per 4 nibbles, then v_cvt_f32_ubyte{0..3} straight from the masked word
 #pragma unroll
-    for (int j = 0; j < 32; j++) o[j] = d1*(float)((w[j >> 2] >> (8*(j & 3) + sh)) & 0xF) - m1;
+    for (int i = 0; i < 8; i++) {
+        const uint32_t q4 = (w[i] >> sh) & 0x0F0F0F0Fu;
+#pragma unroll
+        for (int b = 0; b < 4; b++) o[4*i + b] = d1*(float)((q4 >> (8*b)) & 0xFF) - m1;
+    }
 }
 // Q5_K — quants.py:527-549
 template <> __device__ __forceinline__ raw32 load_raw32<T_Q5_K>(const char * row, int c32) {
@@ -136,10 +141,10 @@ template <> __device__ __forceinline__ void decode32<T_Q5_K>(const raw32 & r, in
     const uint32_t w[8]  = { (uint32_t) r.v[3].x, (uint32_t) r.v[3].y, (uint32_t) r.v[3].z, (uint32_t) r.v[3].w, (uint32_t) r.v[4].x, (uint32_t) r.v[4].y, (uint32_t) r.v[4].z, (uint32_t) r.v[4].w };
     const int sh = (sb & 1)*4;
 #pragma unroll
-    for (int j = 0; j < 32; j++) {
-        const uint32_t lo = (w[j >> 2] >> (8*(j & 3) + sh)) & 0xF;
-        const uint32_t hb = (qh[j >> 2] >> (8*(j & 3) + sb)) & 1;
-        o[j] = d1*(float)(lo | (hb << 4)) - m1;
+    for (int i = 0; i < 8; i++) {      // word-wise: 4 quants per word = low nibbles | (bit sb of the qh bytes) << 4
+        const uint32_t q5 = ((w[i] >> sh) & 0x0F0F0F0Fu) | (((qh[i] >> sb) & 0x01010101u) << 4);
+#pragma unroll
+        for (int b = 0; b < 4; b++) o[4*i + b] = d1*(float)((q5 >> (8*b)) & 0xFF) - m1;
     }
 }
 // Q6_K — quants.py:554-572. chunk c of a 256-superblock: half n = c>>2, quarter pq = c&3: elements 128n + 32pq + l
@@ -158,11 +163,11 @@ template <> __device__ __forceinline__ void decode32<T_Q6_K>(const raw32 & r, in
     const uint32_t qh[8] = { (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w, (uint32_t) r.v[3].x, (uint32_t) r.v[3].y, (uint32_t) r.v[3].z, (uint32_t) r.v[3].w };
     const int sh = (pq >> 1)*4, hs = 2*pq;
 #pragma unroll
-    for (int l = 0; l < 32; l++) {
-        const uint32_t lo = (w[l >> 2] >> (8*(l & 3) + sh)) & 0xF;
-        const uint32_t hi = (qh[l >> 2] >> (8*(l & 3) + hs)) & 3;
-        const int q = (int)(lo | (hi << 4)) - 32;
-        o[l] = (l < 16 ? s0 : s1)*(float) q;
+    for (int i = 0; i < 8; i++) {      // word-wise: 4 quants per word = low nibbles | (2 bits of the qh bytes) << 4, each 0..63
+        const uint32_t q6 = ((w[i] >> sh) & 0x0F0F0F0Fu) | (((qh[i] >> hs) & 0x03030303u) << 4);
+        const float sc = i < 4 ? s0 : s1;
+#pragma unroll
+        for (int b = 0; b < 4; b++) o[4*i + b] = sc*(float)((int)((q6 >> (8*b)) & 0xFF) - 32);
     }
 }
 
@@ -184,13 +189,16 @@ struct mmq_args {
 
 // TYPE = a block format (bf16 MFMA on dequantized weights) or T_F16 (f16 MFMA, weights copied as they are: the attention
 // products K.q and V.kq of build_attn_mha, src/llama-graph.cpp:1285,1320, when more than 8 tokens are in flight)
-template <int TYPE>
-__global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
+// BN = tokens per workgroup tile: 128 (4 waves) or 256 (8 waves; the weight tile is dequantized by waves 0-3 only and reused by twice
+// as many MFMAs — with 128 tokens the dequantization VALU work, not the matrix cores, sets the pace: an ablation without any global
+// load still ran at 22 % of the bf16 peak)
+template <int TYPE, int BN = MQ_BN>
+__global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
-    constexpr int TILE = MQ_BM*MQ_LD;                                // bytes of one operand tile (BM == BN)
+    constexpr int WTILE = MQ_BM*MQ_LD, XTILE = BN*MQ_LD, STAGE = WTILE + XTILE;     // bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;
-    const int m0 = ((int) blockIdx.y - khalf*p.mtiles)*MQ_BM, n0 = blockIdx.x*MQ_BN;   // the n-tiles of one weight tile are dispatched together
+    const int m0 = ((int) blockIdx.y - khalf*p.mtiles)*MQ_BM, n0 = blockIdx.x*BN;   // the n-tiles of one weight tile are dispatched together
     const int wm = wave & 1, wn = wave >> 1;             // wave tile: weight rows wm*64.., tokens wn*64..
     const int m = p.m, n = p.n, k = p.k;
     const int i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
@@ -214,9 +222,11 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
 
-    // staging roles: thread -> (row = tid/2, half = tid&1): 32 of the 64 k of that row
+    // staging roles: thread -> (row = tid/2, half = tid&1): 32 of the 64 k of that row — every thread an activation row, the first 256
+    // threads (waves 0-3) also a weight row
     const int srow = tid >> 1, shalf = tid & 1;
-    const char * wrow_p = W + (size_t) min(m0 + srow, m - 1)*p.w_row_stride;
+    const bool w_role = BN == MQ_BM || tid < 2*MQ_BM;        // wave-uniform
+    const char * wrow_p = W + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*p.w_row_stride;
     const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*k;
     if (p.moe) {
         const int pair = moe_pairs[moe_first + min(srow, moe_cnt - 1)];
@@ -231,39 +241,49 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     raw32 rw; int4v xv[4]; int4v wf[4];
     auto fetch = [&](int step) {
         const int kc = min(step*MQ_BK + 32*shalf, k - 32);
-        if (TYPE == T_F16) {
+        if (w_role) {
+            if (TYPE == T_F16) {
 #pragma unroll
-            for (int i = 0; i < 4; i++) wf[i] = ld_b128(wrow_p + (size_t) kc*2 + 16*i);
-        } else {
-            rw = load_raw32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kc >> 5);
+                for (int i = 0; i < 4; i++) wf[i] = ld_b128(wrow_p + (size_t) kc*2 + 16*i);
+            } else {
+                rw = load_raw32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kc >> 5);
+            }
         }
 #pragma unroll
         for (int i = 0; i < 4; i++) xv[i] = ld_b128((const char *) (xrow_p + kc) + 16*i);
     };
     auto commit = [&](int step, int buf) {       // decode the staged registers into LDS buffer `buf`
         const int kc = step*MQ_BK + 32*shalf;
-        int4v wpk[4];
-        if (kc < k) {
-            if (TYPE == T_F16) {
+        char * wp = lds + buf*STAGE + (srow & (MQ_BM - 1))*MQ_LD + shalf*64;
+        char * xp = lds + buf*STAGE + WTILE + srow*MQ_LD + shalf*64;
+        if (kc >= k) {
 #pragma unroll
-                for (int i = 0; i < 4; i++) wpk[i] = wf[i];
-            } else {
-                float wv[32];
-                decode32<TYPE == T_F16 ? T_Q8_0 : TYPE>(rw, kc >> 5, wv);
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    wpk[i].x = (int) pack_bf16(wv[8*i + 0], wv[8*i + 1]); wpk[i].y = (int) pack_bf16(wv[8*i + 2], wv[8*i + 3]);
-                    wpk[i].z = (int) pack_bf16(wv[8*i + 4], wv[8*i + 5]); wpk[i].w = (int) pack_bf16(wv[8*i + 6], wv[8*i + 7]);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; i++) { wpk[i] = int4v{ 0, 0, 0, 0 }; xv[i] = int4v{ 0, 0, 0, 0 }; }
+            for (int i = 0; i < 4; i++) xv[i] = int4v{ 0, 0, 0, 0 };
         }
-        char * wp = lds + buf*2*TILE + srow*MQ_LD + shalf*64;
-        char * xp = wp + TILE;
 #pragma unroll
-        for (int i = 0; i < 4; i++) { *(int4v *) (wp + 16*i) = wpk[i]; *(int4v *) (xp + 16*i) = xv[i]; }
+        for (int i = 0; i < 4; i++) *(int4v *) (xp + 16*i) = xv[i];
+        if (w_role) {
+            int4v wpk[4];
+            if (kc < k) {
+                if (TYPE == T_F16) {
+#pragma unroll
+                    for (int i = 0; i < 4; i++) wpk[i] = wf[i];
+                } else {
+                    float wv[32];
+                    decode32<TYPE == T_F16 ? T_Q8_0 : TYPE>(rw, kc >> 5, wv);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        wpk[i].x = (int) pack_bf16(wv[8*i + 0], wv[8*i + 1]); wpk[i].y = (int) pack_bf16(wv[8*i + 2], wv[8*i + 3]);
+                        wpk[i].z = (int) pack_bf16(wv[8*i + 4], wv[8*i + 5]); wpk[i].w = (int) pack_bf16(wv[8*i + 6], wv[8*i + 7]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 4; i++) wpk[i] = int4v{ 0, 0, 0, 0 };
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) *(int4v *) (wp + 16*i) = wpk[i];
+        }
     };
 
     fetch(step0);
@@ -272,7 +292,7 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
         if (step + 1 < nsteps) fetch(step0 + step + 1);  // global loads in flight during the MFMAs below
-        const char * lw = lds + buf*2*TILE, * lx = lw + TILE;
+        const char * lw = lds + buf*STAGE, * lx = lw + WTILE;
         // ---- MFMA: A = activations (rows = tokens), B = weights (cols = weight rows) ----
 #pragma unroll
         for (int kk = 0; kk < MQ_BK/16; kk++) {
@@ -319,6 +339,18 @@ __global__ void __launch_bounds__(256) k_mmq(const mmq_args p) {
 }
 
 constexpr size_t MQ_LDS_BYTES = 4*(size_t) MQ_BM*MQ_LD;
+constexpr size_t MQ_LDS_BYTES_256 = 2*(size_t)(MQ_BM + 256)*MQ_LD;
+
+// 108 KB of dynamic LDS: more than the 64 KB a kernel gets without asking
+template <int T_>
+static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
+    static const bool once = [] {
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq<T_, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
+        return true;
+    }();
+    (void) once;
+    hipLaunchKernelGGL((k_mmq<T_, 256>), grid, dim3(512), MQ_LDS_BYTES_256, stream, a);
+}
 
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n) { return (size_t) n*k*2 + 256; }
 
@@ -331,16 +363,19 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
     mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, 0, 0, 0 };
-    const int ntiles = (int)((n + MQ_BN - 1)/MQ_BN), mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
+    const int mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     a.mtiles = mtiles;
-    // a grid that leaves the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k; dst rows must be
-    // dense for the memset
-    if ((int64_t) ntiles*mtiles <= 160 && k % 512 == 0 && k >= 2048 && dst_col_stride_bytes == (size_t) m*4) {
+    // 256-token tiles when they still fill the chip (m = 14336, n = 512: 224 workgroups); else 128-token tiles, and a grid that would
+    // leave the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k; dst rows must be dense for the memset
+    const bool wide = n >= 256 && (int64_t) mtiles*((n + 255)/256) >= 160;
+    const int ntiles = wide ? (int)((n + 255)/256) : (int)((n + MQ_BN - 1)/MQ_BN);
+    if (!wide && (int64_t) ntiles*mtiles <= 160 && k % 512 == 0 && k >= 2048 && dst_col_stride_bytes == (size_t) m*4) {
         a.ksplit = 2;
         MI_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t) m*n*4, stream));
     }
     const dim3 grid((unsigned) ntiles, (unsigned)(mtiles*a.ksplit), 1);
-#define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), MQ_LDS_BYTES, stream, a)
+#define MI_MMQ(T_) do { if (wide) launch_mmq_wide<T_>(grid, a, stream); \
+                        else      hipLaunchKernelGGL((k_mmq<T_, 128>), grid, dim3(256), MQ_LDS_BYTES, stream, a); } while (0)
     switch (type_a) {
         case T_Q4_0:  MI_MMQ(T_Q4_0);  break;
         case T_Q8_0:  MI_MMQ(T_Q8_0);  break;
