@@ -107,6 +107,18 @@ __global__ void __launch_bounds__(256) k_rms_norm(const td src, const td w, cons
     if (HAS_W)   wp = w.data   + wrap(i1, w.ne1)*w.nb1     + wrap(i2, w.ne2)*w.nb2     + wrap(i3, w.ne3)*w.nb3;
     if (HAS_ADD) ap = add.data + wrap(i1, add.ne1)*add.nb1 + wrap(i2, add.ne2)*add.nb2 + wrap(i3, add.ne3)*add.nb3;
     const bool w_full = !HAS_W || w.ne0 == src.ne0, a_full = !HAS_ADD || add.ne0 == src.ne0;   // no wrap needed (the model case)
+    if (vec && w_full && a_full && (!HAS_W || (uintptr_t) wp % 16 == 0) && (!HAS_ADD || (uintptr_t) ap % 16 == 0) && src.ne0 < (1ll << 30)) {
+        // the model case: 16-byte loads and stores, 32-bit indices (the scalar loop below cost 11.7 us for one 4096-float row)
+        const int n0 = (int) src.ne0;
+        for (int i = threadIdx.x*4; i < n0; i += blockDim.x*4) {
+            float4v v = *(const float4v *) (x + (size_t) i*4);
+            v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+            if (HAS_W)   { const float4v t = *(const float4v *) (wp + (size_t) i*4); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
+            if (HAS_ADD) { const float4v t = *(const float4v *) (ap + (size_t) i*4); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
+            *(float4v *) (y + (size_t) i*4) = v;
+        }
+        return;
+    }
     for (int64_t i = threadIdx.x; i < src.ne0; i += blockDim.x) {
         float v = *(const float *) (x + i*4) * scale;
         if (HAS_W)   v *= *(const float *) (wp + (w_full ? i : wrap(i, w.ne0))*4);

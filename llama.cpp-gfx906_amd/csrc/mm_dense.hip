@@ -18,7 +18,8 @@ static __device__ __forceinline__ float ld_a(const char * p, int type) {
          : *(const float *) p;
 }
 
-template <int NC, bool FAST>   // FAST: a contiguous f16 along k, b contiguous f32 along k
+template <int NC, int FAST>   // FAST 1: a contiguous f16 along k, b contiguous f32 along k; FAST 2: both contiguous f32, 16-byte aligned rows
+                               // (the MoE router: F32 [n_embd, n_expert] x the normed activation, src/llama-graph.cpp:838)
 __global__ void __launch_bounds__(256) k_mm_dense(const mm_dense_args p) {
     const int lane = threadIdx.x & 63;
     const int64_t i01 = (int64_t) blockIdx.x*4 + (threadIdx.x >> 6);
@@ -34,7 +35,18 @@ __global__ void __launch_bounds__(256) k_mm_dense(const mm_dense_args p) {
 #pragma unroll
     for (int c = 0; c < NC; c++) acc[c] = 0.0f;
 
-    if (FAST) {
+    if (FAST == 2) {
+        for (int k = lane*4; k < (int) K; k += 256) {   // K % 4 == 0; independent 16-byte loads, no type switch, 32-bit indices
+            const float4v av = *(const float4v *) (a + (size_t) k*4);
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                if (c0 + c < p.ne11) {
+                    const float4v bv = *(const float4v *) (b + (c0 + c)*p.nb11 + (size_t) k*4);
+                    acc[c] += (av.x*bv.x + av.y*bv.y) + (av.z*bv.z + av.w*bv.w);
+                }
+            }
+        }
+    } else if (FAST == 1) {
         for (int64_t k = lane*2; k < K; k += 128) {   // K is even on this path
             const uint32_t av = ld_u32(a + k*2);
             const float a0 = f16_bits_to_f32((uint16_t)(av & 0xFFFF)), a1 = f16_bits_to_f32((uint16_t)(av >> 16));
@@ -71,8 +83,12 @@ void mul_mat_dense(const mm_dense_args & p, hipStream_t stream) {
     const bool fast = p.type_a == T_F16 && p.type_b == T_F32 && p.nb00 == 2 && p.nb10 == 4 && (p.ne00 % 2 == 0);
     constexpr int NC = 8;
     const dim3 grid((unsigned)((p.ne01 + 3)/4), (unsigned)((p.ne11 + NC - 1)/NC), (unsigned)(p.ne12*p.ne13));
-    if (fast) hipLaunchKernelGGL((k_mm_dense<NC, true>),  grid, dim3(256), 0, stream, p);
-    else      hipLaunchKernelGGL((k_mm_dense<NC, false>), grid, dim3(256), 0, stream, p);
+    const bool fast32 = p.type_a == T_F32 && p.type_b == T_F32 && p.nb00 == 4 && p.nb10 == 4 && p.ne00 % 4 == 0 && p.ne00 < (1ll << 30) &&
+                        ((uintptr_t) p.a % 16) == 0 && ((uintptr_t) p.b % 16) == 0 && p.nb01 % 16 == 0 && p.nb02 % 16 == 0 && p.nb03 % 16 == 0 &&
+                        p.nb11 % 16 == 0 && p.nb12 % 16 == 0 && p.nb13 % 16 == 0;
+    if (fast)        hipLaunchKernelGGL((k_mm_dense<NC, 1>), grid, dim3(256), 0, stream, p);
+    else if (fast32) hipLaunchKernelGGL((k_mm_dense<NC, 2>), grid, dim3(256), 0, stream, p);
+    else             hipLaunchKernelGGL((k_mm_dense<NC, 0>), grid, dim3(256), 0, stream, p);
 }
 
 } // namespace mi355x
