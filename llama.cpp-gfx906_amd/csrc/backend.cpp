@@ -826,6 +826,70 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     return j3 - i + 1;
 }
 
+// GET_ROWS(probs, selected) -> [SUM_ROWS -> DIV | SOFT_MAX] -> MUL(experts, weights) -> ADD ... ADD (sum over the used experts)
+// [-> ADD residual], one token: the tail of build_moe_ffn (src/llama-graph.cpp:887-1012) as one kernel
+static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * gr = g->nodes[i];
+    const struct ggml_tensor * pr = gr->src[0]; const struct ggml_tensor * ids = gr->src[1];
+    if (gr->type != GGML_TYPE_F32 || pr->type != GGML_TYPE_F32 || ids->type != GGML_TYPE_I32) return 0;
+    const int64_t n_used = ids->ne[0];
+    if (gr->ne[0] != 1 || gr->ne[1] != n_used || gr->ne[2] != 1 || gr->ne[3] != 1 || n_used < 2 || n_used > 8) return 0;
+    if (pr->ne[0] != 1 || pr->ne[2] != 1 || pr->ne[3] != 1 || pr->nb[1] != 4 || ids->ne[1] != 1 || ids->nb[0] != 4) return 0;
+    if (!is_internal(c, gr)) return 0;
+    int j = next_real(g, i); if (j < 0) return 0;
+    int mode; const struct ggml_tensor * wsrc;      // wsrc: the tensor whose reshape is the MUL's weight operand
+    struct ggml_tensor * n1 = g->nodes[j];
+    if (n1->op == GGML_OP_SUM_ROWS && base_of(n1->src[0]) == gr && n1->src[0]->ne[0] == n_used && is_internal(c, n1)) {
+        const int j2 = next_real(g, j); if (j2 < 0) return 0;
+        struct ggml_tensor * dv = g->nodes[j2];
+        if (dv->op != GGML_OP_DIV || base_of(dv->src[0]) != gr || dv->src[1] != n1 || dv->ne[0] != n_used || ggml_nelements(dv) != n_used) return 0;
+        mode = 0; wsrc = dv; j = j2;
+    } else if (n1->op == GGML_OP_SOFT_MAX && base_of(n1->src[0]) == gr && !n1->src[1] && !n1->src[2] && op_f32(n1, 0) == 1.0f && op_f32(n1, 1) == 0.0f &&
+               n1->ne[0] == n_used && ggml_nelements(n1) == n_used) {
+        mode = 1; wsrc = n1;
+    } else return 0;
+    if (n_uses(c, wsrc) != 1 || (wsrc->flags & GGML_TENSOR_FLAG_OUTPUT)) return 0;
+    const int jm = next_real(g, j); if (jm < 0) return 0;
+    struct ggml_tensor * mul = g->nodes[jm];
+    if (mul->op != GGML_OP_MUL || mul->type != GGML_TYPE_F32) return 0;
+    const struct ggml_tensor * ex = base_of(mul->src[1]) == wsrc ? mul->src[0] : (base_of(mul->src[0]) == wsrc ? mul->src[1] : nullptr);
+    if (!ex || ex->type != GGML_TYPE_F32 || ex->ne[1] != n_used || ex->ne[2] != 1 || ex->ne[3] != 1 || ex->nb[0] != 4 || ex->ne[0] % 4 || ex->nb[1] % 16 ||
+        ((uintptr_t) ex->data % 16) || !ggml_are_same_shape(ex, mul) || (mul->flags & GGML_TENSOR_FLAG_OUTPUT) || n_uses(c, mul) != (int) n_used) return 0;
+    const int64_t n_embd = ex->ne[0];
+    // the adds: ((view0 + view1) + view2) + ...
+    int jl = jm; const struct ggml_tensor * prev = nullptr;
+    for (int64_t u = 1; u < n_used; u++) {
+        const int ja = next_real(g, jl); if (ja < 0) return 0;
+        struct ggml_tensor * ad = g->nodes[ja];
+        if (ad->op != GGML_OP_ADD || ad->type != GGML_TYPE_F32 || ad->ne[0] != n_embd || ggml_nelements(ad) != n_embd) return 0;
+        const struct ggml_tensor * a0 = ad->src[0]; const struct ggml_tensor * a1 = ad->src[1];
+        if (u == 1) { if (base_of(a0) != mul || a0->data != mul->data) return 0; }
+        else if (a0 != prev) return 0;
+        if (base_of(a1) != mul || (const char *) a1->data != (const char *) mul->data + u*mul->nb[1]) return 0;
+        if (u + 1 < n_used && !is_internal(c, ad)) return 0;
+        prev = ad; jl = ja;
+    }
+    struct ggml_tensor * out = g->nodes[jl];
+    const float * res = nullptr;
+    // + residual (src/llama-model.cpp:6096)
+    if (is_internal(c, out)) {
+        const int jr = next_real(g, jl);
+        if (jr > 0) {
+            struct ggml_tensor * ra = g->nodes[jr];
+            if (ra->op == GGML_OP_ADD && ra->type == GGML_TYPE_F32 && ggml_nelements(ra) == n_embd && ggml_is_contiguous(ra) && (ra->src[0] == out || ra->src[1] == out)) {
+                const struct ggml_tensor * r = ra->src[0] == out ? ra->src[1] : ra->src[0];
+                if (r->type == GGML_TYPE_F32 && ggml_nelements(r) == n_embd && ggml_is_contiguous(r) && ((uintptr_t) r->data % 16) == 0 && ((uintptr_t) ra->data % 16) == 0) {
+                    res = (const float *) r->data; out = ra; jl = jr;
+                }
+            }
+        }
+    }
+    if (!ggml_is_contiguous(out) || ((uintptr_t) out->data % 16)) return 0;
+    moe_combine((const float *) pr->data, (const int32_t *) ids->data, (int) n_used, mode, ex->data, ex->nb[1], n_embd, res, (float *) out->data, c->stream);
+    c->cnt.kernels_launched++;
+    return jl - i + 1;
+}
+
 // returns the number of graph nodes consumed (>= 1)
 static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * node = g->nodes[i];
@@ -841,6 +905,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0;
             if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
         } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
+        else if (node->op == GGML_OP_GET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_moe_combine(c, g, i); }
         if (f) {
             consumed = f;
             goto done;

@@ -491,6 +491,52 @@ void soft_max(const tensor_desc & src, const tensor_desc * mask, const float * s
                        mk(src), mask ? mk(*mask) : td{}, sinks, mk(dst), scale, max_bias, m0, m1, n_head_log2, mask != nullptr);
 }
 
+// ---- MoE combine, one token (decode): the tail of build_moe_ffn as ONE kernel (src/llama-graph.cpp:887-1012) ----
+//   weights = get_rows(probs, selected) -> (sum_rows, div | soft_max) ; experts * weights ; sum over the used experts ; + residual
+// mode 0: w_u = p_u / sum(p) (norm_w, llm_build_llama's MoE branch); mode 1: w = soft_max(selected logits) (SOFTMAX_WEIGHT, gpt-oss)
+struct moe_combine_args { const float * probs; const int32_t * ids; int n_used, mode; const char * experts; size_t e_nb1; int n_embd; const float * res; float * dst; };
+__global__ void __launch_bounds__(256) k_moe_combine(const moe_combine_args p) {
+    float w[8];
+    float pv[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) pv[u] = u < p.n_used ? p.probs[p.ids[u]] : 0.0f;
+    if (p.mode == 0) {
+        float sum = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (u < p.n_used) sum += pv[u];
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] = pv[u]/sum;
+    } else {
+        float mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (u < p.n_used) mx = fmaxf(mx, pv[u]);
+        float sum = 0.0f;
+#pragma unroll
+        for (int u = 0; u < 8; u++) { w[u] = u < p.n_used ? expf(pv[u] - mx) : 0.0f; sum += w[u]; }
+        const float inv = 1.0f/sum;
+#pragma unroll
+        for (int u = 0; u < 8; u++) w[u] *= inv;
+    }
+    const int i = (blockIdx.x*256 + threadIdx.x)*4;
+    if (i >= p.n_embd) return;
+    float4v acc = *(const float4v *) (p.experts + (size_t) i*4);
+    acc.x *= w[0]; acc.y *= w[0]; acc.z *= w[0]; acc.w *= w[0];
+#pragma unroll
+    for (int u = 1; u < 8; u++) {
+        if (u < p.n_used) {
+            const float4v e = *(const float4v *) (p.experts + (size_t) u*p.e_nb1 + (size_t) i*4);
+            acc.x += e.x*w[u]; acc.y += e.y*w[u]; acc.z += e.z*w[u]; acc.w += e.w*w[u];
+        }
+    }
+    if (p.res) { const float4v r = *(const float4v *) (p.res + i); acc.x += r.x; acc.y += r.y; acc.z += r.z; acc.w += r.w; }
+    *(float4v *) (p.dst + i) = acc;
+}
+void moe_combine(const float * probs, const int32_t * ids, int n_used, int mode, const void * experts, size_t e_nb1, int64_t n_embd,
+                 const float * res, float * dst, hipStream_t stream) {
+    moe_combine_args a = { probs, ids, n_used, mode, (const char *) experts, e_nb1, (int) n_embd, res, dst };
+    hipLaunchKernelGGL(k_moe_combine, dim3((unsigned)((n_embd/4 + 255)/256)), dim3(256), 0, stream, a);
+}
+
 // ---- HBM probe ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_hbm_read(const int4v * p, size_t n16, unsigned * sink) {
     int acc = 0;

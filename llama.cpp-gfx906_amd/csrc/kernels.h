@@ -96,6 +96,10 @@ void cpy(const tensor_desc & src, const tensor_desc & dst, hipStream_t stream); 
 void set_rows(const tensor_desc & src, const tensor_desc & idx, const tensor_desc & dst, hipStream_t stream);
 void get_rows(const tensor_desc & src, const tensor_desc & idx, const tensor_desc & dst, hipStream_t stream);
 void sum_rows(const tensor_desc & src, const tensor_desc & dst, hipStream_t stream);
+// one token: dst[i] = sum_u experts[u][i] * w_u (+ res[i]); w from probs[ids[u]] normalised (mode 0) or soft_max'ed (mode 1);
+// n_used <= 8, n_embd % 4 == 0, 16-byte aligned rows (elem.hip: k_moe_combine)
+void moe_combine(const float * probs, const int32_t * ids, int n_used, int mode, const void * experts, size_t e_nb1, int64_t n_embd,
+                 const float * res, float * dst, hipStream_t stream);
 void argsort(const tensor_desc & src, const tensor_desc & dst, int order, hipStream_t stream);
 void unary(int op, const tensor_desc & src, const tensor_desc & dst, hipStream_t stream);
 void glu(int glu_op, bool swapped, const tensor_desc & a, const tensor_desc * b, const tensor_desc & dst, float alpha, float limit, hipStream_t stream);
