@@ -890,6 +890,62 @@ static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int
     return jl - i + 1;
 }
 
+// MUL_MAT_ID for ONE token as grouped launches of the persistent mat-vec kernel, one group per used expert (the expert index is read
+// on the device): up + gate + SwiGLU of build_moe_ffn in one launch (src/llama-graph.cpp:923-947), any other one-token MUL_MAT_ID
+// (the down projection: one activation vector per expert, :981) in one launch with the f32 -> int8 quantization in its prologue
+static bool moe_mmv_ok(const struct ggml_tensor * n) {
+    if (n->op != GGML_OP_MUL_MAT_ID) return false;
+    const struct ggml_tensor * as = n->src[0]; const struct ggml_tensor * b = n->src[1]; const struct ggml_tensor * ids = n->src[2];
+    if (!ggml_is_quantized(as->type) || !mul_mat_vec_q_supported((int) as->type) || as->nb[0] != ggml_type_size(as->type) || as->ne[3] != 1) return false;
+    if (ids->type != GGML_TYPE_I32 || ids->ne[1] != 1 || ids->ne[2] != 1 || ids->nb[0] != 4 || ids->ne[0] < 1 || ids->ne[0] > MMVQ_MAX_GROUPS) return false;
+    if (b->type != GGML_TYPE_F32 || b->ne[2] != 1 || b->ne[3] != 1 || b->nb[0] != 4 || !(b->ne[1] == 1 || b->ne[1] == ids->ne[0])) return false;
+    if (((uintptr_t) b->data % 16) || (b->ne[1] > 1 && b->nb[1] % 16) || n->type != GGML_TYPE_F32 || n->nb[0] != 4) return false;
+    const int64_t K = as->ne[0];
+    return mul_mat_vec_q_fused_supported(K, act_kind_for((int) as->type)) && mul_mat_vec_q_fused_prologue_supported(K) && as->ne[1] < (1 << 30);
+}
+static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * up = g->nodes[i];
+    if (!moe_mmv_ok(up)) return 0;
+    const struct ggml_tensor * as = up->src[0]; const struct ggml_tensor * b = up->src[1]; const struct ggml_tensor * ids = up->src[2];
+    const int n_used = (int) ids->ne[0];
+    const int64_t K = as->ne[0], M = as->ne[1];
+    mmvq_input in = {};
+    in.act_kind = act_kind_for((int) as->type); in.mode = PRO_QUANT; in.x = (const float *) b->data;
+    mmvq_group grp[MMVQ_MAX_GROUPS];
+    // up, gate (in either order: the graph lists a node's sources depth-first), swiglu_split(gate, up)
+    const int j1 = next_real(g, i), j2 = j1 > 0 ? next_real(g, j1) : -1;
+    if (j2 > 0 && b->ne[1] == 1 && is_internal(c, up)) {
+        struct ggml_tensor * other = g->nodes[j1]; struct ggml_tensor * gl = g->nodes[j2];
+        if (moe_mmv_ok(other) && other->src[1] == b && other->src[2] == ids && other->src[0]->type == as->type && other->src[0]->ne[0] == K && other->src[0]->ne[1] == M &&
+            other->src[0]->nb[1] == as->nb[1] && other->src[0]->nb[2] == as->nb[2] && is_internal(c, other) &&
+            gl->op == GGML_OP_GLU && ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU && gl->op_params[1] == 0 &&
+            ((gl->src[0] == other && gl->src[1] == up) || (gl->src[0] == up && gl->src[1] == other)) &&
+            gl->type == GGML_TYPE_F32 && gl->nb[0] == 4 && gl->ne[0] == M && gl->ne[1] == n_used && ggml_nelements(gl) == M*n_used &&
+            !ranges_overlap(gl->data, ggml_nbytes(gl), b->data, ggml_nbytes(b))) {
+            const struct ggml_tensor * w_gate = gl->src[0]->src[0]; const struct ggml_tensor * w_up = gl->src[1]->src[0];     // out = silu(src0) * src1
+            for (int u = 0; u < n_used; u++) {
+                grp[u] = { (const char *) w_gate->data, (const char *) w_up->data, as->nb[1], (int) M, (int) as->type,
+                           (float *) ((char *) gl->data + (size_t) u*gl->nb[1]), EPI_GLU, nullptr, nullptr, nullptr, 0, 0,
+                           (const int32_t *) ids->data + u, as->nb[2], 0 };
+            }
+            mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
+            c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
+            c->cnt.weight_bytes += (uint64_t) 2*n_used*M*ggml_row_size(as->type, K);
+            return j2 - i + 1;
+        }
+    }
+    // a single one-token MUL_MAT_ID
+    if (ranges_overlap(up->data, ggml_nbytes(up), b->data, ggml_nbytes(b))) return 0;
+    for (int u = 0; u < n_used; u++) {
+        grp[u] = { (const char *) as->data, nullptr, as->nb[1], (int) M, (int) as->type, (float *) ((char *) up->data + (size_t) u*up->nb[1]), EPI_NONE,
+                   nullptr, nullptr, nullptr, 0, 0, (const int32_t *) ids->data + u, as->nb[2], b->ne[1] > 1 ? (int)((size_t) u*b->nb[1]/4) : 0 };
+    }
+    mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
+    c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
+    c->cnt.weight_bytes += (uint64_t) n_used*M*ggml_row_size(as->type, K);
+    return 1;
+}
+
 // returns the number of graph nodes consumed (>= 1)
 static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * node = g->nodes[i];
@@ -906,6 +962,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
         } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
         else if (node->op == GGML_OP_GET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_moe_combine(c, g, i); }
+        else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);
         if (f) {
             consumed = f;
             goto done;

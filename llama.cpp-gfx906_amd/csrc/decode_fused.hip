@@ -379,6 +379,10 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     int p_cur = p_first;
 
     MI_STAMP(0);
+    // an expert of a stack (MUL_MAT_ID, one token): the index is a device value, workgroup-uniform -> scalar load
+    const size_t eoff = g.eid ? (size_t) g.eid[0]*g.estride : 0;
+    const char * gW = g.W + eoff; const char * gW2 = GLU ? g.W2 + eoff : nullptr;
+    const float * gx = p.x + g.x_off;
     int4v areg[PRO == PRO_Q8 ? NA : 1];
     float4v xv[PRO != PRO_Q8 ? NA : 1], wv[PRO == PRO_NORM ? NA : 1];
     const int nchunk = p.k >> 8;
@@ -392,8 +396,8 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         const int ibf = live ? min(it_pf*BPW + ibl, nb - 1) : 0; \
         _Pragma("unroll") for (int r = 0; r < R; r++) { \
             const size_t off = (size_t) min(pp*R + r, g.m - 1)*g.row_stride; \
-            w[d_][r] = T::load_w(g.W + off, ibf, slot); \
-            if (GLU) u[GLU ? d_ : 0][r] = T::load_w(g.W2 + off, ibf, slot); \
+            w[d_][r] = T::load_w(gW + off, ibf, slot); \
+            if (GLU) u[GLU ? d_ : 0][r] = T::load_w(gW2 + off, ibf, slot); \
         } \
         if (++it_pf == iters) { it_pf = 0; p_pf += stride; } }
 #define MI_FENCE asm volatile("" ::: "memory")
@@ -422,7 +426,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         MI_FENCE;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const float * px = p.x + min(wave + FW*i, nchunk - 1)*256 + lane*4;
+            const float * px = gx + min(wave + FW*i, nchunk - 1)*256 + lane*4;
             xv[i].x = ld_handoff<true>(px); xv[i].y = ld_handoff<true>(px + 1); xv[i].z = ld_handoff<true>(px + 2); xv[i].w = ld_handoff<true>(px + 3);
         }
     } else {
@@ -435,7 +439,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NA; i++) xv[i] = *(const float4v *) (p.x + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+        for (int i = 0; i < NA; i++) xv[i] = *(const float4v *) (gx + min(wave + FW*i, nchunk - 1)*256 + lane*4);
     }
     // A CU's L1 returns data in request order across all its waves: a load that hits L2 (the activation, just written) queued
     // behind one that goes to HBM (weights, norm weights) of ANY wave comes back with HBM latency — 1-4 us instead of ~0.5 us,

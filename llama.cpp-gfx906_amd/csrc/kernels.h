@@ -137,7 +137,7 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
                   int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream);
 
 // grouped mat-vec (n = 1): up to MMVQ_MAX_GROUPS weight tensors that share one activation vector, each with an epilogue
-constexpr int MMVQ_MAX_GROUPS = 3;
+constexpr int MMVQ_MAX_GROUPS = 4;
 enum mmvq_epilogue { EPI_NONE = 0, EPI_ADD = 1, EPI_ROPE = 2, EPI_GLU = 3 };
 struct mmvq_group {
     const char * W; const char * W2;   // W2: the second weight tensor of EPI_GLU (dst = silu(W.x) * (W2.x))
@@ -148,6 +148,10 @@ struct mmvq_group {
     //   st_mode 1: row store     st16[st_idx[0]*st_row_elems + row]   (SET_ROWS of one K row)
     //   st_mode 2: element store st16[st_idx[row]]                    (SET_ROWS on the transposed-V [1, N] view)
     uint16_t * st16; const int64_t * st_idx; int64_t st_row_elems; int st_mode;
+    // MUL_MAT_ID for one token (src/llama-graph.cpp:569-595): the group's matrices are expert eid[0] of a stack (W += eid[0]*estride,
+    // W2 likewise); x_off: this group's activation vector starts x_off floats into the launch's x (the down projection reads one
+    // activation per used expert). eid == NULL: a plain weight tensor.
+    const int32_t * eid; size_t estride; int x_off;
 };
 struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; };   // EPI_ROPE (NORM pairs)
 
