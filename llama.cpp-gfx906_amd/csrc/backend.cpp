@@ -946,6 +946,40 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
     return 1;
 }
 
+// MUL_MAT(F32 router weights, x) [-> ADD bias] [-> SOFT_MAX] -> ARGSORT desc, one token (src/llama-graph.cpp:838-883)
+static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * lg = g->nodes[i];
+    const struct ggml_tensor * w = lg->src[0]; const struct ggml_tensor * x = lg->src[1];
+    if (w->type != GGML_TYPE_F32 || x->type != GGML_TYPE_F32 || lg->type != GGML_TYPE_F32) return 0;
+    const int64_t K = w->ne[0], E = w->ne[1];
+    if (E < 2 || E > 256 || K % 4 || K >= (1ll << 30) || w->ne[2] != 1 || w->ne[3] != 1 || w->nb[0] != 4 || w->nb[1] % 16 || ((uintptr_t) w->data % 16)) return 0;
+    if (!is_row_vec_f32(x) || x->ne[0] != K || !ggml_is_contiguous(lg) || ggml_nelements(lg) != E) return 0;
+    int j = next_real(g, i); if (j < 0) return 0;
+    const struct ggml_tensor * cur = lg; const float * bias = nullptr; float * logits_out = nullptr;
+    struct ggml_tensor * nd = g->nodes[j];
+    if (nd->op == GGML_OP_ADD && (nd->src[0] == cur || nd->src[1] == cur) && ggml_is_contiguous(nd) && ggml_nelements(nd) == E && is_internal(c, cur)) {
+        const struct ggml_tensor * bt = nd->src[0] == cur ? nd->src[1] : nd->src[0];
+        if (bt->type != GGML_TYPE_F32 || !ggml_is_contiguous(bt) || ggml_nelements(bt) != E) return 0;
+        bias = (const float *) bt->data; cur = nd;
+        j = next_real(g, j); if (j < 0) return 0;
+        nd = g->nodes[j];
+    }
+    float * probs_out = nullptr; bool softmax = false;
+    if (nd->op == GGML_OP_SOFT_MAX && nd->src[0] == cur && !nd->src[1] && !nd->src[2] && op_f32(nd, 0) == 1.0f && op_f32(nd, 1) == 0.0f &&
+        ggml_is_contiguous(nd) && ggml_nelements(nd) == E && is_internal(c, cur)) {
+        softmax = true; probs_out = (float *) nd->data; cur = nd;
+        j = next_real(g, j); if (j < 0) return 0;
+        nd = g->nodes[j];
+    } else {
+        logits_out = (float *) cur->data;      // the logits themselves are gathered later (SOFTMAX_WEIGHT gating)
+    }
+    if (nd->op != GGML_OP_ARGSORT || nd->src[0] != cur || nd->op_params[0] != GGML_SORT_ORDER_DESC || nd->type != GGML_TYPE_I32 ||
+        !ggml_is_contiguous(nd) || ggml_nelements(nd) != E) return 0;
+    moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream);
+    c->cnt.kernels_launched++;
+    return j - i + 1;
+}
+
 // returns the number of graph nodes consumed (>= 1)
 static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * node = g->nodes[i];
@@ -960,6 +994,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         if (node->op == GGML_OP_MUL_MAT) {
             const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0;
             if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
+            if (!f) f = try_fused_moe_route(c, g, i);
         } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
         else if (node->op == GGML_OP_GET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_moe_combine(c, g, i); }
         else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);

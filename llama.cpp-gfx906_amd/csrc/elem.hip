@@ -491,6 +491,54 @@ void soft_max(const tensor_desc & src, const tensor_desc * mask, const float * s
                        mk(src), mask ? mk(*mask) : td{}, sinks, mk(dst), scale, max_bias, m0, m1, n_head_log2, mask != nullptr);
 }
 
+// ---- MoE router, one token (decode): logits = W_r . x (+ bias) -> [soft_max] -> argsort descending, one workgroup
+// (src/llama-graph.cpp:838-883: build_lora_mm(gate_inp), ggml_add(gate_inp_b), ggml_soft_max, ggml_top_k = argsort + view)
+struct moe_route_args { const float * w; size_t w_nb1; const float * x; const float * bias; int k, n_expert, softmax; float * logits; float * probs; int32_t * sorted; };
+__global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
+    __shared__ float v[256];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 16 waves: the rows of 32 experts are 2 per wave
+    for (int e = wave; e < p.n_expert; e += 16) {
+        const char * row = (const char *) p.w + (size_t) e*p.w_nb1;
+        float acc = 0.0f, acc2 = 0.0f;
+        int i = lane*4;
+        for (; i + 256 < p.k; i += 512) {       // two independent 16-byte loads per operand in flight
+            const float4v a = *(const float4v *) (row + (size_t) i*4), b = *(const float4v *) (p.x + i);
+            const float4v a2 = *(const float4v *) (row + (size_t)(i + 256)*4), b2 = *(const float4v *) (p.x + i + 256);
+            acc  += (a.x*b.x + a.y*b.y) + (a.z*b.z + a.w*b.w);
+            acc2 += (a2.x*b2.x + a2.y*b2.y) + (a2.z*b2.z + a2.w*b2.w);
+        }
+        if (i < p.k) {
+            const float4v a = *(const float4v *) (row + (size_t) i*4), b = *(const float4v *) (p.x + i);
+            acc += (a.x*b.x + a.y*b.y) + (a.z*b.z + a.w*b.w);
+        }
+        acc += acc2;
+        acc = wave_sum(acc);
+        if (lane == 0) { if (p.bias) acc += p.bias[e]; v[e] = acc; if (p.logits) p.logits[e] = acc; }
+    }
+    __syncthreads();
+    const int e = threadIdx.x;
+    if (p.softmax) {
+        float mx = -INFINITY, sum = 0.0f;
+        for (int j = 0; j < p.n_expert; j++) mx = fmaxf(mx, v[j]);
+        for (int j = 0; j < p.n_expert; j++) sum += expf(v[j] - mx);
+        const float pe = e < p.n_expert ? expf(v[e] - mx)*(1.0f/sum) : 0.0f;
+        __syncthreads();
+        if (e < p.n_expert) { v[e] = pe; p.probs[e] = pe; }
+        __syncthreads();
+    }
+    if (e < p.n_expert) {      // rank = how many values sort before this one (descending, index breaks ties)
+        int rank = 0;
+        const float me = v[e];
+        for (int j = 0; j < p.n_expert; j++) rank += (v[j] > me) || (v[j] == me && j < e);
+        p.sorted[rank] = e;
+    }
+}
+void moe_route(const float * w, size_t w_nb1, const float * x, const float * bias, int64_t k, int64_t n_expert, bool softmax,
+               float * logits, float * probs, int32_t * sorted, hipStream_t stream) {
+    moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted };
+    hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(1024), 0, stream, a);
+}
+
 // ---- MoE combine, one token (decode): the tail of build_moe_ffn as ONE kernel (src/llama-graph.cpp:887-1012) ----
 //   weights = get_rows(probs, selected) -> (sum_rows, div | soft_max) ; experts * weights ; sum over the used experts ; + residual
 // mode 0: w_u = p_u / sum(p) (norm_w, llm_build_llama's MoE branch); mode 1: w = soft_max(selected logits) (SOFTMAX_WEIGHT, gpt-oss)
