@@ -744,13 +744,13 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     mmvq_input in = {};
     in.act_kind = kind;
     const bool cached = c->aq.valid && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == 1 && c->aq.n_outer == 1 && c->aq.kind == kind;
-    if (norm && n_mm == n_uses(c, b) && mul_mat_vec_q_fused_prologue_supported(K) && ((uintptr_t) normw->data % 16) == 0) {
+    if (norm && n_mm == n_uses(c, b) && mul_mat_vec_q_fused_prologue_supported(K, kind) && ((uintptr_t) normw->data % 16) == 0) {
         in.mode = PRO_NORM; in.x = (const float *) norm->src[0]->data; in.norm_w = (const float *) normw->data; in.eps = op_f32(norm, 0);
     } else if (norm) {
         return -1;      // the caller runs the norm (+ quantization) as its own kernel, then comes back without `norm`
     } else if (cached) {
         in.mode = PRO_Q8; in.act = c->aq.q; c->cnt.act_quant_reused++;
-    } else if (mul_mat_vec_q_fused_prologue_supported(K)) {
+    } else if (mul_mat_vec_q_fused_prologue_supported(K, kind)) {
         in.mode = PRO_QUANT; in.x = (const float *) b->data;
     } else {
         mul_mat_vec_q_fused_flush(c->stream);     // the quantizer below reads what a held-back launch writes
@@ -901,7 +901,7 @@ static bool moe_mmv_ok(const struct ggml_tensor * n) {
     if (b->type != GGML_TYPE_F32 || b->ne[2] != 1 || b->ne[3] != 1 || b->nb[0] != 4 || !(b->ne[1] == 1 || b->ne[1] == ids->ne[0])) return false;
     if (((uintptr_t) b->data % 16) || (b->ne[1] > 1 && b->nb[1] % 16) || n->type != GGML_TYPE_F32 || n->nb[0] != 4) return false;
     const int64_t K = as->ne[0];
-    return mul_mat_vec_q_fused_supported(K, act_kind_for((int) as->type)) && mul_mat_vec_q_fused_prologue_supported(K) && as->ne[1] < (1 << 30);
+    return mul_mat_vec_q_fused_supported(K, act_kind_for((int) as->type)) && mul_mat_vec_q_fused_prologue_supported(K, act_kind_for((int) as->type)) && as->ne[1] < (1 << 30);
 }
 static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * up = g->nodes[i];

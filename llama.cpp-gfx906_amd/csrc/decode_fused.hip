@@ -385,7 +385,10 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     const float * gx = p.x + g.x_off;
     int4v areg[PRO == PRO_Q8 ? NA : 1];
     float4v xv[PRO != PRO_Q8 ? NA : 1], wv[PRO == PRO_NORM ? NA : 1];
-    const int nchunk = p.k >> 8;
+    const int nchunk = (p.k + 255) >> 8;     // the last chunk may be partial (k % 32 == 0 with Q8_0 activations: gpt-oss's 2880)
+    // element offset of this lane's 4 floats in chunk slot i: clamped into the vector; `live` tells whether they exist
+#define MI_XOFF(i_) min(min(wave + FW*(i_), nchunk - 1)*256 + lane*4, p.k - 4)
+#define MI_XLIVE(i_) ((wave + FW*(i_))*256 + lane*4 < p.k)
     // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch.
     // Past the end of the stream the loads go to the wave's own first block (an L1 hit), not to a line every wave would share.
     int p_pf = p_cur, it_pf = 0;
@@ -411,7 +414,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         // arithmetic run, which between separate launches is time HBM spends idle.
         if (PRO == PRO_NORM) {
 #pragma unroll
-            for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+            for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + MI_XOFF(i));
         }
 #pragma unroll
         for (int d = 0; d < D; d++) MI_FETCH(d)
@@ -426,8 +429,9 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         MI_FENCE;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const float * px = gx + min(wave + FW*i, nchunk - 1)*256 + lane*4;
+            const float * px = gx + MI_XOFF(i);
             xv[i].x = ld_handoff<true>(px); xv[i].y = ld_handoff<true>(px + 1); xv[i].z = ld_handoff<true>(px + 2); xv[i].w = ld_handoff<true>(px + 3);
+            if (!MI_XLIVE(i)) xv[i] = float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
         }
     } else {
     // ---- (1) activation loads ----
@@ -439,7 +443,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         }
     } else {
 #pragma unroll
-        for (int i = 0; i < NA; i++) xv[i] = *(const float4v *) (gx + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+        for (int i = 0; i < NA; i++) { xv[i] = *(const float4v *) (gx + MI_XOFF(i)); if (!MI_XLIVE(i)) xv[i] = float4v{ 0.0f, 0.0f, 0.0f, 0.0f }; }
     }
     // A CU's L1 returns data in request order across all its waves: a load that hits L2 (the activation, just written) queued
     // behind one that goes to HBM (weights, norm weights) of ANY wave comes back with HBM latency — 1-4 us instead of ~0.5 us,
@@ -557,6 +561,8 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     }
     MI_STAMP(3);
 #undef MI_FETCH
+#undef MI_XOFF
+#undef MI_XLIVE
 }
 
 // One instantiation per {weight type or pair of types} x {GLU} x {prologue} x {activation size class}: a single kernel switching
@@ -663,7 +669,7 @@ static size_t act_image_bytes(int64_t k, int act_kind) {
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind) {
     return k % (act_kind == T_Q8_0 ? 32 : 256) == 0 && act_image_bytes(k, act_kind) <= 4*512*16;
 }
-bool mul_mat_vec_q_fused_prologue_supported(int64_t k) { return k % 256 == 0 && k <= 16*1024; }
+bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind) { return (k % 256 == 0 || (act_kind == T_Q8_0 && k % 32 == 0)) && k <= 16*1024; }
 
 static struct { mmvq_launch_hook pre = nullptr, post = nullptr; void * ctx = nullptr; } g_hook;
 void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx) { g_hook.pre = pre; g_hook.post = post; g_hook.ctx = ctx; }

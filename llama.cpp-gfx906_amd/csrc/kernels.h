@@ -170,7 +170,7 @@ struct mmvq_input {
     int act_kind;
 };
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
-bool mul_mat_vec_q_fused_prologue_supported(int64_t k);        // PRO_QUANT / PRO_NORM limits
+bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind);        // PRO_QUANT / PRO_NORM limits (k % 256, or k % 32 with Q8_0 activations)
 bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);   // may these two weight types share one grouped launch
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream);
 // Launches that fit a position of the per-layer chain (decode_fused.hip: k_mmvq_chain) are held back until the chain is complete
