@@ -98,6 +98,7 @@ def main():
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--ftype", default="Q4_K_M")
     ap.add_argument("--pp", type=int, default=512, help="prompt length for the extra pp measurement (0 = skip)")
+    ap.add_argument("--fa", type=int, default=0, help="1 = llama-bench -fa 1: FLASH_ATTN_EXT, V cache not transposed, n_kv padded to 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     args = ap.parse_args()
@@ -148,7 +149,8 @@ def main():
     steps_per_seq = (max(K, W) + n_seq - 1) // n_seq + 1
     n_ctx = max(32, (steps_per_seq + 31) // 32 * 32) if world > 1 else max(128, (K + 31) // 32 * 32)
     t0 = time.time()
-    m = ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, layer_begin=lb, layer_end=le, has_output=has_out, n_seq_max=n_seq)
+    m = ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, layer_begin=lb, layer_end=le, has_output=has_out, n_seq_max=n_seq,
+                      flash_attn=bool(args.fa))
     log(f"[rank {rank}] layers [{lb},{le}) output={has_out} weights {m.weight_bytes/1e9:.3f} GB, model ready in {time.time()-t0:.1f}s")
     rng = np.random.default_rng(1)   # llama-bench: std::rand() % n_vocab, default seed (tools/llama-bench/llama-bench.cpp:1798)
     tokens = rng.integers(0, cfg["n_vocab"], size=max(K, W) + 8).astype(np.int32)
@@ -219,7 +221,7 @@ def main():
         m.free()
 
         if args.pp > 0:
-            mp = ls.SynthLlama(be, args.model, args.ftype, n_ctx=args.pp, seed=1)
+            mp = ls.SynthLlama(be, args.model, args.ftype, n_ctx=args.pp, seed=1, flash_attn=bool(args.fa))
             ptoks = rng.integers(0, cfg["n_vocab"], size=args.pp).astype(np.int32)
             mp.decode(ptoks); mp.kv_clear()                       # warm-up prompt pass (llama-bench.cpp:1949-1971)
             reps = []
@@ -293,7 +295,7 @@ def main():
             "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 dot (4-6 bit weights x Q8 activations), f32 accumulate", "data": "synthetic",
             "config": {"workload": f"{args.model} {args.ftype}, llama-bench tg{K} protocol (BASELINE.json configs[1]): 1 token/step, sync per token, "
-                                   f"f16 KV cache, no flash-attn, n_ctx={n_ctx}",
+                                   f"f16 KV cache, {'flash-attn' if args.fa else 'no flash-attn'}, n_ctx={n_ctx}",
                        "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs, {world} sequences in flight, {'RCCL' if transport == 'nccl' else 'gloo (host memory)'} p2p hand-off"},
             "roofline": result.get("roofline"), "cpu_baseline": result.get("cpu_baseline"),
         }

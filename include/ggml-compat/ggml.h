@@ -379,7 +379,14 @@ GGML_API struct ggml_tensor * ggml_get_rows(struct ggml_context * ctx, struct gg
 GGML_API struct ggml_tensor * ggml_set_rows(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c); // src/llama-kv-cache-unified.cpp:1123
 GGML_API struct ggml_tensor * ggml_soft_max(struct ggml_context * ctx, struct ggml_tensor * a);
 GGML_API struct ggml_tensor * ggml_soft_max_ext(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * mask, float scale, float max_bias); // src/llama-graph.cpp:1312
-GGML_API void                 ggml_soft_max_add_sinks(struct ggml_tensor * a, struct ggml_tensor * sinks);              // src/llama-graph.cpp:1313
+GGML_API void                 ggml_soft_max_add_sinks(struct ggml_tensor * a, struct ggml_tensor * sinks);
+// q [hd, n_batch, n_head, ne3] (F32), k [hd, n_kv, n_head_kv, ne3], v [hd_v, n_kv, n_head_kv, ne3] (F16, NOT transposed), mask [n_kv, n_batch_pad] F16
+// -> [hd_v, n_head, n_batch, ne3] F32 (src/llama-graph.cpp:1261-1265; tests/test-backend-ops.cpp:4559)
+GGML_API struct ggml_tensor * ggml_flash_attn_ext(struct ggml_context * ctx, struct ggml_tensor * q, struct ggml_tensor * k, struct ggml_tensor * v,
+                                                   struct ggml_tensor * mask, float scale, float max_bias, float logit_softcap);
+GGML_API void                 ggml_flash_attn_ext_set_prec(struct ggml_tensor * a, enum ggml_prec prec);
+GGML_API void                 ggml_flash_attn_ext_add_sinks(struct ggml_tensor * a, struct ggml_tensor * sinks);
+GGML_API struct ggml_tensor * ggml_cast(struct ggml_context * ctx, struct ggml_tensor * a, enum ggml_type type);              // src/llama-graph.cpp:1313
 GGML_API struct ggml_tensor * ggml_rope_ext(struct ggml_context * ctx, struct ggml_tensor * a, struct ggml_tensor * b, struct ggml_tensor * c,
         int n_dims, int mode, int n_ctx_orig, float freq_base, float freq_scale, float ext_factor, float attn_factor, float beta_fast, float beta_slow); // src/llama-model.cpp:6030
 GGML_API struct ggml_tensor * ggml_argsort (struct ggml_context * ctx, struct ggml_tensor * a, enum ggml_sort_order order);

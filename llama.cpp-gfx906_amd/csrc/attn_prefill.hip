@@ -37,7 +37,9 @@ static __device__ __forceinline__ float xhalf(float v, int lane) {      // the v
     return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, v)));
 }
 
-template <int HD>
+// VT: transposed V cache (rows over cells). !VT: V rows are cells (FLASH_ATTN_EXT): the 8 cells of a k-slot group are then 8 two-byte
+// gathers per operand — correct, not fast; a transposing LDS read is the next step for that layout.
+template <int HD, bool VT = true>
 __global__ void __launch_bounds__(64) k_attn_prefill(const attn_pf_args p) {
     constexpr int NC = HD/16, NDT = HD/32;
     const int lane = threadIdx.x, ql = lane & 31, hf = lane >> 5;
@@ -63,7 +65,8 @@ __global__ void __launch_bounds__(64) k_attn_prefill(const attn_pf_args p) {
     float m = -INFINITY, l = 0.0f;     // running maximum (common to both halves) and this half's share of the denominator
 
     const char * kbase = p.k + (size_t) hk*p.k_nb2 + (size_t)(8*hf)*2;
-    const char * vbase = p.v + (size_t) hk*p.v_nb2 + (size_t) ql*p.v_nb1 + (size_t)(4*hf)*2;
+    const char * vbase = VT ? p.v + (size_t) hk*p.v_nb2 + (size_t) ql*p.v_nb1 + (size_t)(4*hf)*2
+                            : p.v + (size_t) hk*p.v_nb2 + (size_t) ql*2 + (size_t)(4*hf)*p.v_nb1;
     const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 : nullptr;
 
     for (int kv0 = 0; kv0 < p.n_kv; kv0 += 32) {
@@ -116,9 +119,18 @@ __global__ void __launch_bounds__(64) k_attn_prefill(const attn_pf_args p) {
                                (_Float16) pr[8*c2 + 4], (_Float16) pr[8*c2 + 5], (_Float16) pr[8*c2 + 6], (_Float16) pr[8*c2 + 7] };
 #pragma unroll
             for (int d = 0; d < NDT; d++) {
-                const char * vp = vbase + (size_t)(32*d)*p.v_nb1 + (size_t)(kv0 + 16*c2)*2;
-                const int2v lo = ld_b64(vp), hi = ld_b64(vp + 16);
-                const int4v va = { lo.x, lo.y, hi.x, hi.y };
+                int4v va;
+                if (VT) {
+                    const char * vp = vbase + (size_t)(32*d)*p.v_nb1 + (size_t)(kv0 + 16*c2)*2;
+                    const int2v lo = ld_b64(vp), hi = ld_b64(vp + 16);
+                    va = int4v{ lo.x, lo.y, hi.x, hi.y };
+                } else {
+                    const char * vp = vbase + (size_t)(32*d)*2 + (size_t)(kv0 + 16*c2)*p.v_nb1;      // cell kv0 + 16 c2 + 4 hf, dim 32 d + ql
+                    uint32_t hv[8];
+#pragma unroll
+                    for (int sl = 0; sl < 8; sl++) hv[sl] = ld_u16(vp + (size_t)(8*(sl >> 2) + (sl & 3))*p.v_nb1);
+                    va = int4v{ (int)(hv[0] | (hv[1] << 16)), (int)(hv[2] | (hv[3] << 16)), (int)(hv[4] | (hv[5] << 16)), (int)(hv[6] | (hv[7] << 16)) };
+                }
                 o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, va), pb, o[d], 0, 0, 0);
             }
         }
@@ -149,10 +161,15 @@ bool attn_prefill_supported(int64_t head_dim, int64_t n_kv) { return (head_dim =
 
 void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                   const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
-                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream) {
+                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans) {
     attn_pf_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
                        (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
     const dim3 grid((unsigned)((T + 31)/32), (unsigned) n_head);
+    if (!v_trans) {
+        if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128, false>), grid, dim3(64), 0, stream, a);
+        else                 hipLaunchKernelGGL((k_attn_prefill<64, false>),  grid, dim3(64), 0, stream, a);
+        return;
+    }
     if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128>), grid, dim3(64), 0, stream, a);
     else                 hipLaunchKernelGGL((k_attn_prefill<64>),  grid, dim3(64), 0, stream, a);
 }

@@ -368,6 +368,8 @@ static bool is_view_op(enum ggml_op op) {
 }
 static bool float_type(enum ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16 || t == GGML_TYPE_BF16; }
 
+static float op_f32(const struct ggml_tensor * t, int i) { float f; memcpy(&f, &t->op_params[i], 4); return f; }
+
 static bool mi_supports_op(const struct ggml_tensor * op) {
     const struct ggml_tensor * s0 = op->src[0];
     const struct ggml_tensor * s1 = op->src[1];
@@ -396,6 +398,15 @@ static bool mi_supports_op(const struct ggml_tensor * op) {
             if (s0->ne[0] % ggml_blck_size(s0->type) != 0) return false;
             if (s1->nb[0] != sizeof(float)) return false;
             return op->src[2]->type == GGML_TYPE_I32;
+        }
+        case GGML_OP_FLASH_ATTN_EXT: {     // f16 KV, head size 64 / 128, no ALiBi, no logit soft-cap (src/llama-graph.cpp:1245-1265)
+            const struct ggml_tensor * k = op->src[1]; const struct ggml_tensor * v = op->src[2]; const struct ggml_tensor * mask = op->src[3];
+            if (s0->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
+            if (s0->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1 || v->ne[0] != k->ne[0] || s0->ne[2] % k->ne[2] != 0) return false;
+            if (op_f32(op, 1) != 0.0f || op_f32(op, 2) != 0.0f) return false;
+            if (mask && (mask->type != GGML_TYPE_F16 || mask->ne[2] != 1 || mask->ne[3] != 1)) return false;
+            if (s0->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || s0->nb[1] % 16 || s0->nb[2] % 16 || k->nb[1] % 16 || k->nb[2] % 16 || v->nb[1] % 16 || v->nb[2] % 16) return false;
+            return s0->ne[1] <= 8 ? attn_decode_supported(k->ne[0], k->ne[1]) : attn_prefill_supported(k->ne[0], k->ne[1]);
         }
         case GGML_OP_RMS_NORM:
             return s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == sizeof(float);
@@ -440,7 +451,6 @@ static tensor_desc desc(const struct ggml_tensor * t) {
     for (int i = 0; i < 4; i++) { d.ne[i] = t->ne[i]; d.nb[i] = t->nb[i]; }
     return d;
 }
-static float op_f32(const struct ggml_tensor * t, int i) { float f; memcpy(&f, &t->op_params[i], 4); return f; }
 
 static bool ranges_overlap(const void * a, size_t na, const void * b, size_t nb) {
     const char * pa = (const char *) a; const char * pb = (const char *) b;
@@ -718,15 +728,18 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
                 ks->type == GGML_TYPE_F32 && vs->type == GGML_TYPE_F32 && ki->type == GGML_TYPE_I64 && vi->type == GGML_TYPE_I64 &&
                 ggml_is_contiguous(ki) && ggml_is_contiguous(vi) && ggml_is_contiguous(ks) && ggml_is_contiguous(vs) &&
                 ks->ne[1] == 1 && ks->ne[2] == 1 && ks->ne[3] == 1 && ks->ne[0] == chains[qk].grp.m && sk->nb[0] == 2 && sk->nb[1] % 2 == 0 &&
-                vs->ne[0] == 1 && vs->ne[1] == chains[qv].grp.m && vs->ne[2] == 1 && vs->ne[3] == 1 && sv->ne[0] == 1 && sv->nb[1] == 2 &&
-                ggml_nelements(vi) == chains[qv].grp.m && chains[qv].grp.epi == EPI_NONE &&
+                vs->ne[2] == 1 && vs->ne[3] == 1 && qv >= 0 && chains[qv].grp.epi == EPI_NONE &&
+                // V: element scatter on the transposed cache's [1, N] view (v_trans), or — with flash attention — a row like K (:1154)
+                ((vs->ne[0] == 1 && vs->ne[1] == chains[qv].grp.m && sv->ne[0] == 1 && sv->nb[1] == 2 && ggml_nelements(vi) == chains[qv].grp.m) ||
+                 (vs->ne[0] == chains[qv].grp.m && vs->ne[1] == 1 && sv->nb[0] == 2 && sv->nb[1] % 2 == 0 && ggml_nelements(vi) == 1)) &&
                 // the cache rows written must not be read by anything inside the launch (they are not: only weights and the activation are)
                 !ranges_overlap(sk->data, ggml_nbytes(sk), b->data, ggml_nbytes(b)) && !ranges_overlap(sv->data, ggml_nbytes(sv), b->data, ggml_nbytes(b));
             if (ok) {
                 chains[qk].grp.st16 = (uint16_t *) sk->data; chains[qk].grp.st_idx = (const int64_t *) ki->data;
                 chains[qk].grp.st_row_elems = (int64_t)(sk->nb[1]/2); chains[qk].grp.st_mode = 1;
                 chains[qv].grp.st16 = (uint16_t *) sv->data; chains[qv].grp.st_idx = (const int64_t *) vi->data;
-                chains[qv].grp.st_row_elems = 0; chains[qv].grp.st_mode = 2;
+                if (vs->ne[0] == 1) { chains[qv].grp.st_row_elems = 0; chains[qv].grp.st_mode = 2; }
+                else                { chains[qv].grp.st_row_elems = (int64_t)(sv->nb[1]/2); chains[qv].grp.st_mode = 1; }
                 last = j2;
             }
         }
@@ -1009,6 +1022,18 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     switch (node->op) {
         case GGML_OP_MUL_MAT:    op_mul_mat(c, node); break;
         case GGML_OP_MUL_MAT_ID: op_mul_mat_id(c, node); break;
+        case GGML_OP_FLASH_ATTN_EXT: {
+            const struct ggml_tensor * q = s0; const struct ggml_tensor * k = node->src[1]; const struct ggml_tensor * v = node->src[2];
+            const struct ggml_tensor * mask = node->src[3]; const struct ggml_tensor * sinks = node->src[4];
+            const int64_t hd = k->ne[0], n_kv = k->ne[1], T = q->ne[1];
+            GGML_ASSERT(node->nb[1] == (size_t) hd*4 && ((uintptr_t) q->data % 16) == 0 && ((uintptr_t) k->data % 16) == 0 && ((uintptr_t) v->data % 16) == 0);
+            GGML_ASSERT(!mask || (mask->ne[0] == n_kv && mask->ne[1] >= T && ((uintptr_t) mask->data % 16) == 0 && mask->nb[1] % 16 == 0));
+            if (T <= 8) attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
+                                    sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false);
+            else        attn_prefill(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
+                                     sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false);
+            c->cnt.kernels_launched++;
+        } break;
         case GGML_OP_RMS_NORM: {
             // fusion: RMS_NORM -> MUL(by weight) [-> ADD], when the intermediate has no other reader
             // (the pattern build_norm emits, src/llama-graph.cpp:597-630; pinned by tests/test-backend-ops.cpp:2856)

@@ -452,6 +452,34 @@ struct ggml_tensor * ggml_cpy(struct ggml_context * ctx, struct ggml_tensor * a,
     r->op = GGML_OP_CPY; r->src[0] = a; r->src[1] = b;
     return r;
 }
+struct ggml_tensor * ggml_cast(struct ggml_context * ctx, struct ggml_tensor * a, enum ggml_type type) {
+    ggml_tensor * r = ggml_new_tensor(ctx, type, GGML_MAX_DIMS, a->ne);
+    r->op = GGML_OP_CPY; r->src[0] = a; r->src[1] = r;
+    return r;
+}
+struct ggml_tensor * ggml_flash_attn_ext(struct ggml_context * ctx, struct ggml_tensor * q, struct ggml_tensor * k, struct ggml_tensor * v,
+                                         struct ggml_tensor * mask, float scale, float max_bias, float logit_softcap) {
+    GGML_ASSERT(q->ne[0] == k->ne[0] && k->ne[1] == v->ne[1] && k->ne[2] == v->ne[2] && q->ne[2] % k->ne[2] == 0);
+    if (mask) {
+        GGML_ASSERT(ggml_is_contiguous(mask));
+        GGML_ASSERT(mask->ne[0] == k->ne[1] && mask->ne[1] >= q->ne[1]);
+    }
+    if (max_bias > 0.0f) GGML_ASSERT(mask);
+    const int64_t ne[4] = { v->ne[0], q->ne[2], q->ne[1], q->ne[3] };
+    ggml_tensor * r = ggml_new_tensor(ctx, GGML_TYPE_F32, 4, ne);
+    set_f32(r, 0, scale); set_f32(r, 1, max_bias); set_f32(r, 2, logit_softcap);
+    r->op = GGML_OP_FLASH_ATTN_EXT; r->src[0] = q; r->src[1] = k; r->src[2] = v; r->src[3] = mask;
+    return r;
+}
+void ggml_flash_attn_ext_set_prec(struct ggml_tensor * a, enum ggml_prec prec) {
+    GGML_ASSERT(a->op == GGML_OP_FLASH_ATTN_EXT);
+    a->op_params[3] = (int32_t) prec;
+}
+void ggml_flash_attn_ext_add_sinks(struct ggml_tensor * a, struct ggml_tensor * sinks) {
+    if (!sinks) { a->src[4] = NULL; return; }
+    GGML_ASSERT(a->op == GGML_OP_FLASH_ATTN_EXT && a->src[4] == NULL && a->src[0]->ne[2] == sinks->ne[0] && sinks->type == GGML_TYPE_F32);
+    a->src[4] = sinks;
+}
 struct ggml_tensor * ggml_cont(struct ggml_context * ctx, struct ggml_tensor * a) {
     ggml_tensor * r = ggml_dup_tensor(ctx, a);
     r->op = GGML_OP_CONT; r->src[0] = a;

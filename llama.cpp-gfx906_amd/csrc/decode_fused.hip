@@ -172,7 +172,9 @@ static __device__ __forceinline__ float dot8_f16_f32(const int4v kv, const float
 
 // Latency is the enemy here (a few hundred KB, one dependent chain per workgroup): every phase issues its independent
 // 16-byte loads in batches of U before touching the data.
-template <int HD>
+// VT: V is the transposed cache [n_kv, hd] (rows over cells; the graph without flash attention). !VT: V rows are cells [hd, n_kv]
+// (FLASH_ATTN_EXT, src/llama-graph.cpp:1245-1265): v_nb1 is then the cell stride.
+template <int HD, bool VT = true>
 __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float * s = (float *) smem;                          // [n_kv] scores -> probabilities
@@ -226,6 +228,40 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     for (int j = threadIdx.x; j < p.n_kv; j += 256) s[j] *= inv;   // the unfused SOFT_MAX normalises before V.p
     __syncthreads();
 
+    if (!VT) {
+        // ---- out[d] = sum_j p[j]*V[j][d]: a thread owns 8 dims of every NGR-th cell; partial sums meet in LDS ----
+        constexpr int DCH = HD/8, NGR = 256/DCH, UV = 4;
+        float * red = (float *) (smem + (((size_t) p.n_kv*4 + 15) & ~(size_t) 15));     // [NGR][HD]
+        const int dch = threadIdx.x % DCH, cg = threadIdx.x / DCH;
+        const char * vb = p.v + (size_t) hk*p.v_nb2 + (size_t) dch*16;
+        float a8[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
+        for (int j0 = cg; j0 < p.n_kv; j0 += NGR*UV) {
+            int4v vr[UV]; float pj[UV];
+#pragma unroll
+            for (int u = 0; u < UV; u++) {
+                const int j = min(j0 + u*NGR, p.n_kv - 1);
+                vr[u] = *(const int4v *) (vb + (size_t) j*p.v_nb1);
+                pj[u] = j0 + u*NGR < p.n_kv ? s[j] : 0.0f;
+            }
+#pragma unroll
+            for (int u = 0; u < UV; u++) {
+                const uint32_t w0 = (uint32_t) vr[u].x, w1 = (uint32_t) vr[u].y, w2 = (uint32_t) vr[u].z, w3 = (uint32_t) vr[u].w;
+                a8[0] += pj[u]*f16_bits_to_f32((uint16_t) w0); a8[1] += pj[u]*f16_bits_to_f32((uint16_t)(w0 >> 16));
+                a8[2] += pj[u]*f16_bits_to_f32((uint16_t) w1); a8[3] += pj[u]*f16_bits_to_f32((uint16_t)(w1 >> 16));
+                a8[4] += pj[u]*f16_bits_to_f32((uint16_t) w2); a8[5] += pj[u]*f16_bits_to_f32((uint16_t)(w2 >> 16));
+                a8[6] += pj[u]*f16_bits_to_f32((uint16_t) w3); a8[7] += pj[u]*f16_bits_to_f32((uint16_t)(w3 >> 16));
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) red[cg*HD + dch*8 + i] = a8[i];
+        __syncthreads();
+        if (threadIdx.x < HD) {
+            float r = 0.0f;
+            for (int gq = 0; gq < NGR; gq++) r += red[gq*HD + threadIdx.x];
+            *(float *) ((char *) p.dst + (size_t) t*p.dst_nb1 + (size_t)(h*HD + threadIdx.x)*4) = r;
+        }
+        return;
+    }
     // ---- out[d] = sum_j V[d][j]*p[j]: 16 lanes per V row, 4 rows per wave, HD/16 row groups per workgroup ----
     constexpr int NG = HD/16;                            // row groups: d = g*16 + wave*4 + rw
     const int l16 = lane & 15, rw = lane >> 4;
@@ -249,15 +285,20 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     }
 }
 
-bool attn_decode_supported(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv % 8 == 0 && n_kv*4 <= 60*1024; }
+bool attn_decode_supported(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv % 8 == 0 && n_kv*4 <= 48*1024; }
 
 void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                  const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
-                 int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream) {
+                 int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans) {
     attn_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
                     (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
     const dim3 grid((unsigned) n_head, (unsigned) T);
-    const size_t lds = (size_t) n_kv*4;
+    const size_t lds = (((size_t) n_kv*4 + 15) & ~(size_t) 15) + (v_trans ? 0 : 8192);     // !v_trans: + [256/(hd/8)][hd] partial sums
+    if (!v_trans) {
+        if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, false>), grid, dim3(256), lds, stream, a);
+        else                 hipLaunchKernelGGL((k_attn_decode<64, false>),  grid, dim3(256), lds, stream, a);
+        return;
+    }
     if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128>), grid, dim3(256), lds, stream, a);
     else                 hipLaunchKernelGGL((k_attn_decode<64>),  grid, dim3(256), lds, stream, a);
 }

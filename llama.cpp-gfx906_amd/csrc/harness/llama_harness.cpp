@@ -47,6 +47,7 @@ struct mi_llama_hparams {
     int32_t n_seq_max;                // independent sequences, each with its own KV cache stream (llama_context_params.n_seq_max, kv_unified = false)
     int32_t n_expert, n_expert_used;  // > 0: the FFN is build_moe_ffn (src/llama-graph.cpp:811-1023); n_ff is then the expert width
     int32_t arch;                     // 0 = llm_build_llama (dense or Mixtral-style MoE), 1 = llm_build_openai_moe_iswa (gpt-oss; src/llama-model.cpp:17610-17738)
+    int32_t flash_attn;               // -fa 1: ggml_flash_attn_ext, V cache not transposed, n_kv padded to 256, F16 mask (src/llama-graph.cpp:1245-1265)
 };
 
 struct mi_llama;
@@ -282,7 +283,9 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
     g.inp_pos  = ggml_new_tensor_1d(ctx0, GGML_TYPE_I32, n_tokens);         ggml_set_input(g.inp_pos);  ggml_set_name(g.inp_pos, "inp_pos");
     g.kq_mask  = ggml_new_tensor_2d(ctx0, GGML_TYPE_F32, n_kv, GGML_PAD(n_tokens, GGML_KQ_MASK_PAD)); ggml_set_input(g.kq_mask);   // src/llama-graph.cpp:1421
     g.k_idxs   = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, n_tokens);                 ggml_set_input(g.k_idxs);   // :1195
-    g.v_idxs   = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, n_tokens*n_embd_v_gqa);    ggml_set_input(g.v_idxs);   // :1208 (v_trans)
+    g.v_idxs   = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, hp.flash_attn ? n_tokens : n_tokens*n_embd_v_gqa); ggml_set_input(g.v_idxs);   // :1208 (v_trans: per element)
+    // with flash attention the mask is cast to F16 once per graph (src/llama-graph.cpp:1423)
+    ggml_tensor * kq_mask_f16 = hp.flash_attn ? ggml_cast(ctx0, g.kq_mask, GGML_TYPE_F16) : nullptr;
     const int n_outputs = 1;                                                       // llama_batch_get_one: logits for the last token only
     g.out_ids  = ggml_new_tensor_1d(ctx0, GGML_TYPE_I32, n_outputs);                ggml_set_input(g.out_ids);
 
@@ -319,16 +322,33 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
             ggml_tensor * k_cur2 = ggml_reshape_2d(ctx0, Kcur, n_embd_k_gqa, n_tokens);
             ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, L.k_cache[seq], k_cur2, g.k_idxs));
             ggml_tensor * v_cur2 = ggml_reshape_2d(ctx0, Vcur, n_embd_v_gqa, n_tokens);
-            ggml_tensor * v_view = ggml_reshape_2d(ctx0, L.v_cache[seq], 1, n_embd_v_gqa*kv_size);     // the row becomes a single element
-            v_cur2 = ggml_reshape_2d(ctx0, v_cur2, 1, n_embd_v_gqa*n_tokens);
-            ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, v_view, v_cur2, g.v_idxs));
+            if (hp.flash_attn) {      // !v_trans: a row scatter like K (:1154)
+                ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, L.v_cache[seq], v_cur2, g.v_idxs));
+            } else {
+                ggml_tensor * v_view = ggml_reshape_2d(ctx0, L.v_cache[seq], 1, n_embd_v_gqa*kv_size);     // the row becomes a single element
+                v_cur2 = ggml_reshape_2d(ctx0, v_cur2, 1, n_embd_v_gqa*n_tokens);
+                ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, v_view, v_cur2, g.v_idxs));
+            }
         }
         // get_k / get_v (:1056-1106), v_trans layout
         ggml_tensor * k = ggml_view_4d(ctx0, L.k_cache[seq], hd, n_head_kv, n_kv, 1,
                 ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa*kv_size), 0);
-        ggml_tensor * v = ggml_view_4d(ctx0, L.v_cache[seq], n_kv, n_head_kv, hd, 1,
+        ggml_tensor * v = hp.flash_attn
+            ? ggml_view_4d(ctx0, L.v_cache[seq], hd, n_head_kv, n_kv, 1,      // !v_trans (:1087-1096)
+                ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa*kv_size), 0)
+            : ggml_view_4d(ctx0, L.v_cache[seq], n_kv, n_head_kv, hd, 1,
                 ggml_row_size(GGML_TYPE_F16, kv_size*hd), ggml_row_size(GGML_TYPE_F16, kv_size), ggml_row_size(GGML_TYPE_F16, kv_size*n_embd_v_gqa), 0);
-        {   // build_attn_mha, no flash attention (src/llama-graph.cpp:1283-1341)
+        if (hp.flash_attn) {   // build_attn_mha with flash attention (src/llama-graph.cpp:1245-1265, :1337): n_kv % 256 == 0 by the cache's padding
+            ggml_tensor * q = ggml_reshape_4d(ctx0, Qcur, Qcur->ne[0], Qcur->ne[1], Qcur->ne[2], 1);
+            q = ggml_permute(ctx0, q, 0, 2, 1, 3);
+            k = ggml_permute(ctx0, k, 0, 2, 1, 3);
+            v = ggml_permute(ctx0, v, 0, 2, 1, 3);
+            cur = ggml_flash_attn_ext(ctx0, q, k, v, kq_mask_f16, kq_scale, 0.0f, 0.0f);
+            ggml_flash_attn_ext_add_sinks(cur, L.sinks);
+            ggml_flash_attn_ext_set_prec(cur, GGML_PREC_F32);
+            cur = ggml_reshape_2d(ctx0, cur, cur->ne[0]*cur->ne[1], cur->ne[2]*cur->ne[3]);
+            ggml_build_forward_expand(g.gf, cur);
+        } else {   // build_attn_mha, no flash attention (src/llama-graph.cpp:1283-1341)
             ggml_tensor * q = ggml_reshape_4d(ctx0, Qcur, Qcur->ne[0], Qcur->ne[1], Qcur->ne[2], 1);
             q = ggml_permute(ctx0, q, 0, 2, 1, 3);
             k = ggml_permute(ctx0, k, 0, 2, 1, 3);
@@ -404,7 +424,7 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
     const int64_t n_embd = hp.n_embd, hd = hp.n_embd_head, n_ff = hp.n_ff;
     const int64_t n_embd_k_gqa = hd*hp.n_head_kv, n_embd_v_gqa = hd*hp.n_head_kv;
     const int kv_size = hp.n_ctx;
-    if (kv_size % KV_PAD != 0) { fprintf(stderr, "mi_llama: n_ctx must be a multiple of %d\n", KV_PAD); delete m; return nullptr; }
+    if (kv_size % (hp.flash_attn ? 256 : KV_PAD) != 0) { fprintf(stderr, "mi_llama: n_ctx must be a multiple of %d\n", hp.flash_attn ? 256 : KV_PAD); delete m; return nullptr; }
 
     m->wctx = ggml_init({ 0, NULL, true });
     m->kvctx = ggml_init({ 0, NULL, true });
@@ -522,7 +542,8 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
     if (seq < 0 || seq >= (int) m->n_past.size()) return -1;
     if (n_tokens <= 0 || m->n_past[seq] + n_tokens > hp.n_ctx) return 1;   // "could not find a KV slot" (src/llama-context.cpp:1006)
     const int head = m->n_past[seq];
-    const int n_kv = std::min(hp.n_ctx, std::max(KV_PAD, (int) GGML_PAD(head + n_tokens, KV_PAD)));   // get_n_kv (:1040-1050)
+    const int kv_pad = hp.flash_attn ? 256 : KV_PAD;                                                   // get_padding (:2407-2410)
+    const int n_kv = std::min(hp.n_ctx, std::max(kv_pad, (int) GGML_PAD(head + n_tokens, kv_pad)));   // get_n_kv (:1040-1050)
 
     auto key = std::make_tuple(seq, n_tokens, n_kv);
     auto it = m->graphs.find(key);
@@ -573,7 +594,11 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
         for (int i = 0; i < n_tokens; i++) p[i] = head + i;
         ggml_backend_tensor_set_async(m->backend, g.k_idxs, p, 0, ggml_nbytes(g.k_idxs));
     }
-    {   // v_trans: one index per element (set_input_v_idxs :1252-1267)
+    if (hp.flash_attn) {   // V rows are cells: one index per token (set_input_v_idxs :1240-1250)
+        int64_t * p = (int64_t *) stage((size_t) n_tokens*8);
+        for (int i = 0; i < n_tokens; i++) p[i] = head + i;
+        ggml_backend_tensor_set_async(m->backend, g.v_idxs, p, 0, ggml_nbytes(g.v_idxs));
+    } else {   // v_trans: one index per element (set_input_v_idxs :1252-1267)
         int64_t * p = (int64_t *) stage((size_t) n_tokens*n_embd_v_gqa*8);
         for (int i = 0; i < n_tokens; i++)
             for (int64_t j = 0; j < n_embd_v_gqa; j++) p[(int64_t) i*n_embd_v_gqa + j] = j*kv_size + head + i;

@@ -133,6 +133,8 @@ def base():
     _sig(L, "ggml_view_4d", T, [vp, T, i64, i64, i64, i64, sz, sz, sz, sz])
     _sig(L, "ggml_permute", T, [vp, T, ci, ci, ci, ci])
     _sig(L, "ggml_soft_max_ext", T, [vp, T, T, cf, cf]); _sig(L, "ggml_soft_max_add_sinks", None, [T, T])
+    _sig(L, "ggml_flash_attn_ext", T, [vp, T, T, T, T, cf, cf, cf]); _sig(L, "ggml_flash_attn_ext_add_sinks", None, [T, T])
+    _sig(L, "ggml_flash_attn_ext_set_prec", None, [T, C.c_int]); _sig(L, "ggml_cast", T, [vp, T, C.c_int])
     _sig(L, "ggml_rope_ext", T, [vp, T, T, T, ci, ci, ci, cf, cf, cf, cf, cf, cf])
     _sig(L, "ggml_argsort", T, [vp, T, ci]); _sig(L, "ggml_top_k", T, [vp, T, ci])
     _sig(L, "ggml_swiglu_oai", T, [vp, T, T, cf, cf]); _sig(L, "ggml_glu_split", T, [vp, T, T, ci])

@@ -20,7 +20,7 @@ class hparams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_embd", "n_ff", "n_layer", "n_head", "n_head_kv", "n_embd_head", "n_vocab", "n_ctx",
                                          "ftype", "rope_type", "n_ctx_orig", "has_rope_freqs", "is_70b")] + \
                [(n, C.c_float) for n in ("rope_freq_base", "rope_freq_scale", "f_norm_rms_eps")] + \
-               [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max", "n_expert", "n_expert_used", "arch")]
+               [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max", "n_expert", "n_expert_used", "arch", "flash_attn")]
 
 
 # model shapes used by the configs
@@ -82,7 +82,7 @@ def harness():
 
 class SynthLlama:
     def __init__(self, backend: gg.Backend, model="llama3-8b", ftype="Q4_K_M", n_ctx=128, seed=1, layer_begin=0, layer_end=None,
-                 has_output=None, rope_type=0, has_rope_freqs=False, n_seq_max=1, **over):
+                 has_output=None, rope_type=0, has_rope_freqs=False, n_seq_max=1, flash_attn=False, **over):
         cfg = dict(MODELS[model]); cfg.update(over)
         self.cfg = cfg
         n_layer = cfg["n_layer"]
@@ -91,7 +91,9 @@ class SynthLlama:
         hp = hparams()
         for k in ("n_embd", "n_ff", "n_layer", "n_head", "n_head_kv", "n_embd_head", "n_vocab", "n_ctx_orig", "is_70b"):
             setattr(hp, k, cfg[k])
-        hp.n_ctx = (n_ctx + 31) // 32 * 32
+        pad = 256 if flash_attn else 32       # the KV cache's padding (src/llama-kv-cache-unified.cpp:2407-2410)
+        hp.n_ctx = (n_ctx + pad - 1) // pad * pad
+        hp.flash_attn = int(flash_attn)
         hp.ftype = FTYPE[ftype]
         hp.rope_type = cfg.get("rope_type", rope_type)
         hp.n_expert, hp.n_expert_used, hp.arch = cfg.get("n_expert", 0), cfg.get("n_expert_used", 0), cfg.get("arch", 0)

@@ -216,6 +216,36 @@ def test_prefill_attention_on_matrix_cores(model, n_prompt):
     assert orc.nmse(outs[0], outs[1]) <= 5e-4
 
 
+@pytest.mark.parametrize("model", ["tiny", "tiny-hd128"])
+def test_flash_attention_graph(model):
+    """-fa 1: FLASH_ATTN_EXT, V cache rows = cells written by a row scatter, F16 mask, n_kv padded to 256 (src/llama-graph.cpp:1245-1265,
+    src/llama-kv-cache-unified.cpp:1154, :2407-2410) against the oracle graph and against the same model without flash attention."""
+    be = backend()
+    be.set_option("graphs", 1); be.set_option("fusion", 1)
+    outs = {}
+    for fa in (True, False):
+        m = ls.SynthLlama(be, model, "Q4_K_M", n_ctx=256, seed=8, flash_attn=fa)
+        try:
+            if fa:
+                W = read_weights(m)
+                re_ = RefLlama(m.cfg, W, 256, "exact"); rc = RefLlama(m.cfg, W, 256, "cpu")
+            res = []
+            for toks in [[5, 9, 200, 17, 3, 44, 101], [7], [8], list(range(20, 60)), [2]]:
+                got = m.decode(toks)
+                res.append(got.copy())
+                if fa:
+                    emb = np.stack([m.embedding(t) for t in toks])
+                    exp_c = rc.decode(emb); exp_e = re_.decode(emb)
+                    assert np.isfinite(got).all()
+                    if len(toks) <= 8:
+                        assert orc.nmse(exp_c, got) <= 1e-3, (len(toks), orc.nmse(exp_c, got))
+                    assert orc.nmse(exp_e, got) <= 2e-3, (len(toks), orc.nmse(exp_e, got))
+            outs[fa] = np.stack(res)
+        finally:
+            m.free()
+    assert orc.nmse(outs[False], outs[True]) <= 5e-4
+
+
 def test_graph_replay_is_bitwise_neutral_and_fusion_stays_within_tolerance():
     """hipGraph replay must not change a bit. The decode fusions keep each op's arithmetic but the fused attention
     kernel sums V.p in a different lane order than the node-by-node kernels, so fusion on/off agree to f32 rounding,

@@ -335,3 +335,48 @@ def test_mul_mat_f32_f16_generic_strided():
             got = run(ctx, L.ggml_mul_mat(ctx.ctx, a, b), [(a, a_ if ta == gg.F32 else a_.astype(np.float16)), (b, b_)])
         aa = a_ if ta == gg.F32 else a_.astype(np.float16).astype(np.float32)
         assert orc.nmse(ref.mul_mat_dense(aa, b_), got) <= 5e-4
+
+
+@pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,T,sinks", [(128, 8, 2, 256, 1, False), (128, 8, 2, 512, 3, True), (64, 4, 4, 256, 8, False),
+                                                            (128, 8, 2, 256, 33, False), (64, 8, 2, 512, 64, True), (128, 4, 1, 256, 40, False)])
+def test_flash_attn_ext(hd, n_head, n_head_kv, n_kv, T, sinks):
+    """FLASH_ATTN_EXT as build_attn_mha emits it with -fa (src/llama-graph.cpp:1245-1265; tests/test-backend-ops.cpp:4559, NMSE 5e-4):
+    q F32 permuted view, K and V F16 views of the cache with rows = cells (V NOT transposed), F16 mask padded in the token dimension,
+    GQA broadcast, optional attention sinks; result [hd, n_head, T]. T <= 8 runs the decode kernel, more the matrix-core one."""
+    rng = np.random.default_rng(100 + T)
+    kv_size = n_kv + 64
+    kc = rng.uniform(-1, 1, size=(1, 1, kv_size, hd * n_head_kv)).astype(np.float16)
+    vc = rng.uniform(-1, 1, size=(1, 1, kv_size, hd * n_head_kv)).astype(np.float16)
+    q_ = rng.uniform(-1, 1, size=(1, T, n_head, hd)).astype(np.float32)
+    Tp = (T + 63) // 64 * 64
+    mask = np.full((1, 1, Tp, n_kv), -np.inf, np.float32)
+    for t in range(T):
+        mask[0, 0, t, : n_kv - T + t + 1] = 0.0          # causal: the T tokens are the last T cells
+    sk = rng.uniform(-1, 1, size=(n_head,)).astype(np.float32)
+    scale = 1.0 / np.sqrt(hd)
+    with gg.Context() as ctx:
+        k_l = ctx.new_tensor(gg.F16, (hd * n_head_kv, kv_size)); v_l = ctx.new_tensor(gg.F16, (hd * n_head_kv, kv_size))
+        q_cur = ctx.new_tensor(gg.F32, (hd, n_head, T)); m_ = ctx.new_tensor(gg.F16, (n_kv, Tp)); s_ = ctx.new_tensor(gg.F32, (n_head,))
+        k = L.ggml_view_3d(ctx.ctx, k_l, hd, n_head_kv, n_kv, hd * 2, hd * n_head_kv * 2, 0)
+        v = L.ggml_view_3d(ctx.ctx, v_l, hd, n_head_kv, n_kv, hd * 2, hd * n_head_kv * 2, 0)
+        q = L.ggml_permute(ctx.ctx, q_cur, 0, 2, 1, 3); k = L.ggml_permute(ctx.ctx, k, 0, 2, 1, 3); v = L.ggml_permute(ctx.ctx, v, 0, 2, 1, 3)
+        fa = L.ggml_flash_attn_ext(ctx.ctx, q, k, v, m_, float(scale), 0.0, 0.0)
+        if sinks:
+            L.ggml_flash_attn_ext_add_sinks(fa, s_)
+        L.ggml_flash_attn_ext_set_prec(fa, 10)
+        be = backend(); assert be.supports_op(fa); ctx.alloc(be)
+        gg.tensor_set(k_l, kc); gg.tensor_set(v_l, vc); gg.tensor_set(q_cur, q_); gg.tensor_set(m_, mask.astype(np.float16)); gg.tensor_set(s_, sk.reshape(1, 1, 1, -1))
+        be.compute(gg.graph_of(ctx, fa))
+        got = gg.tensor_get(fa)                                                     # [1, T, n_head, hd]
+    K = kc[0, 0, :n_kv].reshape(n_kv, n_head_kv, hd).astype(np.float64); V = vc[0, 0, :n_kv].reshape(n_kv, n_head_kv, hd).astype(np.float64)
+    exp = np.zeros((T, n_head, hd))
+    for h in range(n_head):
+        hk = h // (n_head // n_head_kv)
+        s = q_[0, :, h, :].astype(np.float16).astype(np.float64) @ K[:, hk, :].T * scale + mask[0, 0, :T].astype(np.float64)
+        mx = s.max(-1, keepdims=True)
+        if sinks:
+            mx = np.maximum(mx, sk[h])
+        p = np.exp(s - mx); den = p.sum(-1, keepdims=True) + (np.exp(sk[h] - mx) if sinks else 0.0)
+        exp[:, h, :] = (p / den) @ V[:, hk, :]
+    assert got[0].shape == exp.shape
+    assert orc.nmse(exp, got[0]) <= 5e-4, orc.nmse(exp, got[0])
