@@ -404,7 +404,7 @@ static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const f
 // hand-off between two phases of one launch (k_mmvq_chain): phase n waits until `target` workgroups have added to `ctr`
 struct chain_wait { unsigned * ctr; unsigned target; unsigned * err; };
 
-template <int TYPE, bool GLU, int PRO, int NA, int D, bool CHAIN = false>
+template <int TYPE, bool GLU, int PRO, int NA, int D, bool CHAIN = false, int FWT = 8>
 static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fused_mmvq_args & p, char * smem, int wg_in_group, int nwg_group,
                                                   int lane, int wave, const chain_wait cw = chain_wait{ nullptr, 0, nullptr }) {
     typedef mmvq_t<TYPE> T;
@@ -415,8 +415,8 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     const int iters = (nb + BPW - 1)/BPW;
     const int slot = lane % LPB, ibl = lane / LPB;
     const int P = (g.m + R - 1)/R;                       // row pairs in this group
-    const int stride = nwg_group*FW;
-    const int p_first = wg_in_group*FW + wave;
+    const int stride = nwg_group*FWT;
+    const int p_first = wg_in_group*FWT + wave;
     int p_cur = p_first;
 
     MI_STAMP(0);
@@ -428,8 +428,8 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     float4v xv[PRO != PRO_Q8 ? NA : 1], wv[PRO == PRO_NORM ? NA : 1];
     const int nchunk = (p.k + 255) >> 8;     // the last chunk may be partial (k % 32 == 0 with Q8_0 activations: gpt-oss's 2880)
     // element offset of this lane's 4 floats in chunk slot i: clamped into the vector; `live` tells whether they exist
-#define MI_XOFF(i_) min(min(wave + FW*(i_), nchunk - 1)*256 + lane*4, p.k - 4)
-#define MI_XLIVE(i_) ((wave + FW*(i_))*256 + lane*4 < p.k)
+#define MI_XOFF(i_) min(min(wave + FWT*(i_), nchunk - 1)*256 + lane*4, p.k - 4)
+#define MI_XLIVE(i_) ((wave + FWT*(i_))*256 + lane*4 < p.k)
     // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch.
     // Past the end of the stream the loads go to the wave's own first block (an L1 hit), not to a line every wave would share.
     int p_pf = p_cur, it_pf = 0;
@@ -479,7 +479,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     if (PRO == PRO_Q8) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int idx = min((int) threadIdx.x + i*(FW*64), p.act_chunks - 1);
+            const int idx = min((int) threadIdx.x + i*(FWT*64), p.act_chunks - 1);
             areg[i] = *(const int4v *) (p.act + (size_t) idx*16);
         }
     } else {
@@ -496,7 +496,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     asm volatile("" ::: "memory");
     if (PRO == PRO_NORM) {
 #pragma unroll
-        for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + min(wave + FW*i, nchunk - 1)*256 + lane*4);
+        for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (p.norm_w + min(wave + FWT*i, nchunk - 1)*256 + lane*4);
     }
 
     // ---- (2) weight prefetch: the first D steps of this wave's stream ----
@@ -513,22 +513,23 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
     if (PRO == PRO_Q8) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int idx = threadIdx.x + i*(FW*64);
+            const int idx = threadIdx.x + i*(FWT*64);
             if (idx < p.act_chunks) *(int4v *) (smem + (size_t) idx*16) = areg[i];
         }
     } else {
         float scale = 1.0f;
         if (PRO == PRO_NORM) {
-            float * red = (float *) (smem + p.off_bs + (((p.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15));   // FW floats after the image
+            float * red = (float *) (smem + p.off_bs + (((p.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15));   // FWT floats after the image
             float ss = 0.0f;
 #pragma unroll
-            for (int i = 0; i < NA; i++) if (wave + FW*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
+            for (int i = 0; i < NA; i++) if (wave + FWT*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
             ss = wave_sum(ss);
             MI_STAMP(4);
             if (lane == 0) red[wave] = ss;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+            if (FWT == 16) ss += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
             scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
             MI_STAMP(7);
             MI_FENCE;
@@ -537,7 +538,7 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
         }
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int c = wave + FW*i;
+            const int c = wave + FWT*i;
             if (c < nchunk) {   // wave-uniform
                 float4v v = xv[i];
                 if (PRO == PRO_NORM) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
@@ -608,8 +609,11 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
 
 // One instantiation per {weight type or pair of types} x {GLU} x {prologue} x {activation size class}: a single kernel switching
 // over all six formats at run time allocates registers for the fattest path (227 VGPRs -> 2 waves/SIMD), which starves the HBM stream.
-template <int TA, int TB, bool GLU, int PRO, int NA, int D>
-__global__ void __launch_bounds__(512, 2) k_mmvq_fused(const fused_mmvq_args p) {
+// FWT = waves per workgroup: 8, or 16 for launches with more row pairs than 8 waves x CUs but no more than 16 x CUs (norm + QKV:
+// 3072 pairs) — ONE 1024-thread workgroup per CU shares one prologue (two 8-wave workgroups on a CU ran the second one's prologue
+// ~2x slower), every wave owns a single pair, and the prologue has one 256-chunk per wave instead of two
+template <int TA, int TB, bool GLU, int PRO, int NA, int D, int FWT = 8>
+__global__ void __launch_bounds__(FWT*64, FWT == 8 ? 2 : 1) k_mmvq_fused(const fused_mmvq_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int gi = 0;
@@ -617,8 +621,8 @@ __global__ void __launch_bounds__(512, 2) k_mmvq_fused(const fused_mmvq_args p) 
     const int first = gi ? p.block_end[gi - 1] : 0;
     const int blk = (int) blockIdx.x - first, nwg = p.block_end[gi] - first;
     const mmvq_group & g = p.g[gi];
-    if (TA == TB || g.type == TA) fused_body<TA, GLU, PRO, NA, D>(g, p, smem, blk, nwg, lane, wave);
-    else                          fused_body<TB, GLU, PRO, NA, D>(g, p, smem, blk, nwg, lane, wave);
+    if (TA == TB || g.type == TA) fused_body<TA, GLU, PRO, NA, D, false, FWT>(g, p, smem, blk, nwg, lane, wave);
+    else                          fused_body<TB, GLU, PRO, NA, D, false, FWT>(g, p, smem, blk, nwg, lane, wave);
 }
 
 // ---- several grouped mat-vec launches of one decode layer as ONE launch ----
@@ -716,7 +720,7 @@ static struct { mmvq_launch_hook pre = nullptr, post = nullptr; void * ctx = nul
 void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx) { g_hook.pre = pre; g_hook.post = post; g_hook.ctx = ctx; }
 
 // a grouped launch, prepared: either run at once or held back as a position of a chained launch
-struct fused_launch { fused_mmvq_args a; int blocks; size_t lds; int ta, tb; bool glu; int mode, na; bool deep; int64_t k; uint64_t wbytes; };
+struct fused_launch { fused_mmvq_args a; int blocks; size_t lds; int ta, tb; bool glu; int mode, na; bool deep; int64_t k; uint64_t wbytes; int fw; };
 static void fused_launch_now(const fused_launch & L, hipStream_t stream);
 
 static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope) {
@@ -734,6 +738,12 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
     }
     int64_t rows_total = 0;
     for (int i = 0; i < n_groups; i++) rows_total += (int64_t) groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1);
+    // 16 waves per workgroup: more than one row pair per wave at 8 waves x CUs, at most one at 16 (the in-prologue-norm launches only)
+    static int fw16_env = -1;
+    if (fw16_env < 0) { const char * e = getenv("GGML_MI355X_MMVQ_FW16"); fw16_env = e ? atoi(e) : 1; }
+    const int FW = (fw16_env && groups[0].epi != EPI_GLU && in.mode == PRO_NORM && k <= 4096 && k % 256 == 0 &&
+                    (rows_total + 1)/2 > (int64_t) n_cu*8 && (rows_total + 1)/2 <= (int64_t) n_cu*16 + 64) ? 16 : 8;
+    L.fw = FW;
     const int budget = n_cu*(groups[0].epi == EPI_GLU ? glu_wpc : wpc);   // the dual (GLU) kernels need > 128 VGPRs: one workgroup per CU
     int blocks = 0;
     for (int i = 0; i < n_groups; i++) {
@@ -766,7 +776,7 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         const float end   = ceilf (rope_corr_dim_h(rope->p.n_dims, rope->p.n_ctx_orig, rope->p.beta_slow, rope->p.freq_base));
         a.rope.corr_lo = fmaxf(0.0f, start); a.rope.corr_hi = fminf((float)(rope->p.n_dims - 1), end);
     }
-    const size_t lds = bytes + 32;     // + FW floats for the RMS reduction
+    const size_t lds = bytes + 64;     // + FW floats for the RMS reduction
     int ta = groups[0].type, tb = groups[0].type;
     for (int i = 1; i < n_groups; i++) if (groups[i].type != ta) tb = groups[i].type;
     if (tb < ta) { const int t = ta; ta = tb; tb = t; }
@@ -783,7 +793,7 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         g_stamp_next++;
     }
 #endif
-    const int na = mode == PRO_Q8 ? (a.act_chunks <= 512 ? 1 : (a.act_chunks <= 1024 ? 2 : 4)) : (k <= 4096 ? 2 : 8);
+    const int na = mode == PRO_Q8 ? (a.act_chunks <= 512 ? 1 : (a.act_chunks <= 1024 ? 2 : 4)) : (FW == 16 ? 1 : (k <= 4096 ? 2 : 8));
     // prefetch depth: measured on Llama-3-8B Q4_K_M tg128 (profiles/r01_g_*): D = 2 everywhere 503 tok/s, D = 4 (3 for the dual GLU
     // stream) everywhere 482-486 — a CU's request queue is finite and a wave that cannot queue a load cannot run its share of the
     // prologue either. Only long single-tensor streams (>= 16 steps per wave: the lm_head, 31 row pairs per wave) take the deep ring;
@@ -816,12 +826,14 @@ static void fused_launch_kernel(const fused_launch & L, hipStream_t stream) {
     const size_t lds = L.lds;
     const int ta = L.ta, tb = L.tb, mode = L.mode, na = L.na;
     const bool glu = L.glu, deep = L.deep;
+    constexpr int FW = 8;
 #define MI_L(TA_, TB_, GLU_, PRO_, NA_) do { \
         if (GLU_)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, true,  PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a);   /* one-row units: 4 steps = the bytes 2 steps of pairs held */ \
         else if (deep) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_, NA_, 4>), grid, dim3(FW*64), lds, stream, a); \
         else           hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_, NA_, 2>), grid, dim3(FW*64), lds, stream, a); } while (0)
-#define MI_LAUNCH(TA_, TB_, GLU_) do { \
-        if (mode == PRO_Q8)         { if (na == 1) MI_L(TA_, TB_, GLU_, PRO_Q8, 1); else if (na == 2) MI_L(TA_, TB_, GLU_, PRO_Q8, 2); else MI_L(TA_, TB_, GLU_, PRO_Q8, 4); } \
+ #define MI_LAUNCH(TA_, TB_, GLU_) do { \
+        if (L.fw == 16) { hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 1, 2, 16>), grid, dim3(1024), lds, stream, a); } \
+        else if (mode == PRO_Q8)         { if (na == 1) MI_L(TA_, TB_, GLU_, PRO_Q8, 1); else if (na == 2) MI_L(TA_, TB_, GLU_, PRO_Q8, 2); else MI_L(TA_, TB_, GLU_, PRO_Q8, 4); } \
         else if (mode == PRO_NORM)  { if (na == 2) MI_L(TA_, TB_, GLU_, PRO_NORM, 2); else MI_L(TA_, TB_, GLU_, PRO_NORM, 8); } \
         else                        { if (na == 2) MI_L(TA_, TB_, GLU_, PRO_QUANT, 2); else MI_L(TA_, TB_, GLU_, PRO_QUANT, 8); } } while (0)
 #define MI_SINGLE(T_) if (ta == T_ && tb == T_) { if (glu) MI_LAUNCH(T_, T_, true); else MI_LAUNCH(T_, T_, false); return; }
@@ -840,7 +852,7 @@ static void fused_launch_kernel(const fused_launch & L, hipStream_t stream) {
 // (every caller that puts anything else on the stream calls mul_mat_vec_q_fused_flush first; backend.cpp does so per graph node)
 static int chain_position(const fused_launch & L) {      // which fixed position of k_mmvq_chain this launch fits, or -1
     const bool types_ok = (L.ta == T_Q4_K || L.ta == T_Q6_K) && (L.tb == T_Q4_K || L.tb == T_Q6_K);
-    if (!types_ok || L.deep) return -1;
+    if (!types_ok || L.deep || L.fw != 8) return -1;
     if (!L.glu && L.mode == PRO_QUANT && L.na == 2) return 0;
     if ( L.glu && L.mode == PRO_NORM  && L.na == 2) return 1;
     if (!L.glu && L.mode == PRO_QUANT && L.na == 8) return 2;
