@@ -536,23 +536,26 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
             if (!CHAIN) { MI_FETCH(1) }
             MI_FENCE;
         }
+        // all chunks of this wave are quantized first (independent chains the scheduler can interleave; a chunk past the end is
+        // quantized too — its lanes hold a clamped duplicate — and simply not stored), then stored
+        uint32_t qp[NA]; float qd[NA]; int qb[NA];
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            float4v v = xv[i];
+            if (PRO == PRO_NORM) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
+            qp[i] = quant_chunk256<ACT>(v, qd[i], qb[i]);
+        }
+        MI_STAMP(5);
+        MI_FENCE;
+        if (!CHAIN) {     // the steps must be fetched in ring order: set d holds stream step d
+            if (PRO == PRO_QUANT) { MI_FETCH(1) }
+            else if (D > 2)       { MI_FETCH(2) }
+        }
+        MI_FENCE;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int c = wave + FWT*i;
-            if (c < nchunk) {   // wave-uniform
-                float4v v = xv[i];
-                if (PRO == PRO_NORM) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
-                quant_store_chunk256<ACT>(v, c, lane, l_qs, l_d, l_bs);
-            }
-            if (i == 0) {     // the steps must be fetched in ring order: set d holds stream step d
-                MI_STAMP(5);
-                MI_FENCE;
-                if (!CHAIN) {
-                    if (PRO == PRO_QUANT) { MI_FETCH(1) }
-                    else if (D > 2)       { MI_FETCH(2) }
-                }
-                MI_FENCE;
-            }
+            if (c < nchunk) store_chunk256<ACT>(qp[i], qd[i], qb[i], c, lane, l_qs, l_d, l_bs);
         }
     }
     MI_FENCE;

@@ -32,19 +32,37 @@ static __device__ __forceinline__ uint32_t quant_frag_q8_K(float4v v, float & d_
     if (fabsf(v.z) > amax) { amax = fabsf(v.z); mx = v.z; }
     if (fabsf(v.w) > amax) { amax = fabsf(v.w); mx = v.w; }
     const float wmax = wave_max(amax);
-    if (wmax == 0.0f) { d_out = 0.0f; bsum16_out = 0; return 0u; }
+    // branch-free (an all-zero block takes the same instructions with a stand-in scale and is zeroed at the end): several chunks
+    // quantized back to back can then be interleaved by the scheduler instead of running as dependent chains one after the other
+    const bool zero = wmax == 0.0f;
     const unsigned long long ball = __ballot(amax == wmax);
     const int first = __builtin_ctzll(ball);
-    const float maxv = readlane_f(mx, first);
+    const float maxv = zero ? 1.0f : readlane_f(mx, first);
     const float iscale = -127.0f/maxv;
     int q0 = __float2int_rn(iscale*v.x), q1 = __float2int_rn(iscale*v.y), q2 = __float2int_rn(iscale*v.z), q3 = __float2int_rn(iscale*v.w);
     q0 = min(127, q0); q1 = min(127, q1); q2 = min(127, q2); q3 = min(127, q3);
     int s = q0 + q1 + q2 + q3;
     s += dpp_i<0xB1>(s);
     s += dpp_i<0x4E>(s);
-    bsum16_out = s;
-    d_out = 1.0f/iscale;
-    return pack4_i8(q0, q1, q2, q3);
+    bsum16_out = zero ? 0 : s;
+    d_out = zero ? 0.0f : 1.0f/iscale;
+    return zero ? 0u : pack4_i8(q0, q1, q2, q3);
+}
+
+// the two halves of quant_store_chunk256, so that a caller can quantize several chunks first and store them afterwards
+template <int ACT>
+static __device__ __forceinline__ uint32_t quant_chunk256(float4v v, float & dd, int & bsum) {
+    return ACT == T_Q8_0 ? quant_frag_q8_0(v, dd, bsum) : quant_frag_q8_K(v, dd, bsum);
+}
+template <int ACT>
+static __device__ __forceinline__ void store_chunk256(uint32_t p, float dd, int bsum, int c, int lane, int8_t * qs, float * d, int16_t * bs) {
+    *(uint32_t *) (qs + c*256 + lane*4) = p;
+    if (ACT == T_Q8_0) {
+        if ((lane & 7) == 0) { d[c*8 + (lane >> 3)] = dd; bs[c*8 + (lane >> 3)] = (int16_t) bsum; }
+    } else {
+        if ((lane & 3) == 0) bs[c*16 + (lane >> 2)] = (int16_t) bsum;
+        if (lane == 0) d[c] = dd;
+    }
 }
 
 // quantize the 256-element chunk `c` of one row held as 4 floats per lane and store it
