@@ -268,6 +268,8 @@ struct mi_backend_ctx {
     // "profile" option: every quantized mat-mul launch is bracketed by a hipEvent pair on this stream (eager mode)
     struct prof_rec { int type; int64_t m, k, n; uint64_t bytes; hipEvent_t e0, e1; };
     bool profiling = false;
+    bool prof_in_graph = false;      // option "profile" = 2: the event pairs are captured into the hipGraphs as event-record nodes
+    bool prof_suspend = false;       //   ... and eager passes (before a graph's capture) are not recorded
     std::vector<prof_rec> prof;
     std::vector<hipEvent_t> ev_pool;
 };
@@ -277,13 +279,13 @@ static hipEvent_t prof_event(mi_backend_ctx * c) {
     hipEvent_t e; MI_CHECK(hipEventCreate(&e)); return e;
 }
 static void prof_begin(mi_backend_ctx * c, int type, int64_t m, int64_t k, int64_t n, uint64_t bytes) {
-    if (!c->profiling) return;
+    if (!c->profiling || c->prof_suspend) return;
     mi_backend_ctx::prof_rec r = { type, m, k, n, bytes, prof_event(c), prof_event(c) };
     MI_CHECK(hipEventRecord(r.e0, c->stream));
     c->prof.push_back(r);
 }
 static void prof_end(mi_backend_ctx * c) {
-    if (!c->profiling) return;
+    if (!c->profiling || c->prof_suspend) return;
     MI_CHECK(hipEventRecord(c->prof.back().e1, c->stream));
 }
 // the grouped mat-vec module launches (possibly several graph nodes later, possibly several launches merged into one): it calls back
@@ -1214,7 +1216,8 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
 
     // hipGraph path: launch-bound decode graphs (~10^3 tiny kernels per token) are captured the second time their
     // signature is seen, then replayed while the signature is unchanged.
-    const bool try_graph = c->use_graphs && !c->profiling && g->n_nodes >= 8;
+    const bool try_graph = c->use_graphs && (!c->profiling || c->prof_in_graph) && g->n_nodes >= 8;
+    c->prof_suspend = try_graph && c->prof_in_graph;     // only what is captured gets recorded in that mode
     if (try_graph) {
         graph_entry & e = graph_lookup(c, g);
         if (e.exec) {
@@ -1225,7 +1228,9 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
         if (e.seen >= 2) {
             hipGraph_t graph = nullptr;
             MI_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            c->prof_suspend = false;
             run_nodes(c, g);
+            c->prof_suspend = c->prof_in_graph;
             MI_CHECK(hipStreamEndCapture(c->stream, &graph));
             hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
             MI_CHECK(hipGraphDestroy(graph));
@@ -1234,6 +1239,7 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
                 MI_CHECK(hipGraphLaunch(e.exec, c->stream));
                 return GGML_STATUS_SUCCESS;
             }
+            fprintf(stderr, "ggml-mi355x: hipGraphInstantiate failed (%s): staying eager\n", hipGetErrorString(err));
             (void) hipGetLastError();
             e.exec = nullptr;
             c->use_graphs = false;   // instantiate failed: stay eager
@@ -1478,7 +1484,13 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     if (strcmp(key, "graphs") == 0) { c->use_graphs = value != 0; return 0; }
     if (strcmp(key, "profile") == 0) {
-        c->profiling = value != 0;
+        // 1: eager, an event pair around every quantized mat-mul launch; 2: the same pairs captured into the hipGraphs (what the
+        // replayed token really costs per launch, without the eager launch gaps); either way the graphs are rebuilt
+        MI_CHECK(hipStreamSynchronize(c->stream));
+        drop_graphs(c);
+        for (auto & r : c->prof) { c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1); }
+        c->prof.clear();
+        c->profiling = value != 0; c->prof_in_graph = value == 2; c->prof_suspend = false;
         mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
         return 0;
     }
@@ -1501,8 +1513,8 @@ int ggml_backend_mi355x_get_profile(ggml_backend_t backend, struct ggml_backend_
     int n = 0;
     for (auto & r : c->prof) {
         float ms = 0.0f;
-        MI_CHECK(hipEventElapsedTime(&ms, r.e0, r.e1));
-        c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1);
+        if (hipEventElapsedTime(&ms, r.e0, r.e1) != hipSuccess) { (void) hipGetLastError(); continue; }     // a captured pair whose graph never ran
+        if (!c->prof_in_graph) { c->ev_pool.push_back(r.e0); c->ev_pool.push_back(r.e1); }
         int j = 0;
         for (; j < n; j++) if (out[j].type == r.type && out[j].m == r.m && out[j].k == r.k && out[j].n == r.n) break;
         if (j == n) {
@@ -1512,7 +1524,7 @@ int ggml_backend_mi355x_get_profile(ggml_backend_t backend, struct ggml_backend_
         }
         out[j].launches++; out[j].total_ms += ms;
     }
-    c->prof.clear();
+    if (!c->prof_in_graph) c->prof.clear();      // captured pairs stay with their graphs until the option changes
     return n;
 }
 
