@@ -927,26 +927,52 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
     mmvq_input in = {};
     in.act_kind = act_kind_for((int) as->type); in.mode = PRO_QUANT; in.x = (const float *) b->data;
     mmvq_group grp[MMVQ_MAX_GROUPS];
-    // up, gate (in either order: the graph lists a node's sources depth-first), swiglu_split(gate, up)
-    const int j1 = next_real(g, i), j2 = j1 > 0 ? next_real(g, j1) : -1;
-    if (j2 > 0 && b->ne[1] == 1 && is_internal(c, up)) {
-        struct ggml_tensor * other = g->nodes[j1]; struct ggml_tensor * gl = g->nodes[j2];
-        if (moe_mmv_ok(other) && other->src[1] == b && other->src[2] == ids && other->src[0]->type == as->type && other->src[0]->ne[0] == K && other->src[0]->ne[1] == M &&
-            other->src[0]->nb[1] == as->nb[1] && other->src[0]->nb[2] == as->nb[2] && is_internal(c, other) &&
-            gl->op == GGML_OP_GLU && ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU && gl->op_params[1] == 0 &&
-            ((gl->src[0] == other && gl->src[1] == up) || (gl->src[0] == up && gl->src[1] == other)) &&
-            gl->type == GGML_TYPE_F32 && gl->nb[0] == 4 && gl->ne[0] == M && gl->ne[1] == n_used && ggml_nelements(gl) == M*n_used &&
-            !ranges_overlap(gl->data, ggml_nbytes(gl), b->data, ggml_nbytes(b))) {
-            const struct ggml_tensor * w_gate = gl->src[0]->src[0]; const struct ggml_tensor * w_up = gl->src[1]->src[0];     // out = silu(src0) * src1
-            for (int u = 0; u < n_used; u++) {
-                grp[u] = { (const char *) w_gate->data, (const char *) w_up->data, as->nb[1], (int) M, (int) as->type,
-                           (float *) ((char *) gl->data + (size_t) u*gl->nb[1]), EPI_GLU, nullptr, nullptr, nullptr, 0, 0,
-                           (const int32_t *) ids->data + u, as->nb[2], 0 };
+    // up, gate (in either order: the graph lists a node's sources depth-first), each optionally followed by its ADD_ID bias, then
+    // swiglu_split(gate, up) or swiglu_oai(gate, up) (src/llama-graph.cpp:923-968)
+    if (b->ne[1] == 1 && is_internal(c, up)) {
+        auto bias_of = [&](struct ggml_tensor * mm, int & j) -> struct ggml_tensor * {      // the ADD_ID that consumes mm, if it is next
+            const int jn = next_real(g, j);
+            if (jn < 0) return nullptr;
+            struct ggml_tensor * ad = g->nodes[jn];
+            if (ad->op != GGML_OP_ADD_ID || ad->src[0] != mm || ad->src[2] != ids || ad->type != GGML_TYPE_F32 || !is_internal(c, ad)) return nullptr;
+            const struct ggml_tensor * bt = ad->src[1];
+            if (bt->type != GGML_TYPE_F32 || bt->ne[0] != M || bt->nb[0] != 4 || bt->nb[1] != (size_t) M*4 || bt->ne[1] != as->ne[2]) return nullptr;
+            j = jn;
+            return ad;
+        };
+        int j = i;
+        struct ggml_tensor * a_b = bias_of(up, j);
+        const int jo = next_real(g, j);
+        struct ggml_tensor * other = jo > 0 ? g->nodes[jo] : nullptr;
+        if (other && moe_mmv_ok(other) && other->src[1] == b && other->src[2] == ids && other->src[0]->type == as->type && other->src[0]->ne[0] == K &&
+            other->src[0]->ne[1] == M && other->src[0]->nb[1] == as->nb[1] && other->src[0]->nb[2] == as->nb[2] && is_internal(c, other)) {
+            j = jo;
+            struct ggml_tensor * o_b = bias_of(other, j);
+            const int jg = next_real(g, j);
+            struct ggml_tensor * gl = jg > 0 ? g->nodes[jg] : nullptr;
+            struct ggml_tensor * a_out = a_b ? a_b : up; struct ggml_tensor * o_out = o_b ? o_b : other;
+            if (gl && gl->op == GGML_OP_GLU && gl->op_params[1] == 0 && (!a_b) == (!o_b) &&
+                (ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU || ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU_OAI) &&
+                ((gl->src[0] == o_out && gl->src[1] == a_out) || (gl->src[0] == a_out && gl->src[1] == o_out)) &&
+                gl->type == GGML_TYPE_F32 && gl->nb[0] == 4 && gl->ne[0] == M && gl->ne[1] == n_used && ggml_nelements(gl) == M*n_used &&
+                !ranges_overlap(gl->data, ggml_nbytes(gl), b->data, ggml_nbytes(b))) {
+                // out = act(src0) * src1: src0 is the gate side
+                const bool a_is_gate = gl->src[0] == a_out;
+                const struct ggml_tensor * mm_gate = a_is_gate ? up : other; const struct ggml_tensor * mm_up = a_is_gate ? other : up;
+                const struct ggml_tensor * bg = a_is_gate ? a_b : o_b; const struct ggml_tensor * bu = a_is_gate ? o_b : a_b;
+                const bool oai = ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU_OAI;
+                for (int u = 0; u < n_used; u++) {
+                    grp[u] = { (const char *) mm_gate->src[0]->data, (const char *) mm_up->src[0]->data, as->nb[1], (int) M, (int) as->type,
+                               (float *) ((char *) gl->data + (size_t) u*gl->nb[1]), EPI_GLU, nullptr, nullptr, nullptr, 0, 0,
+                               (const int32_t *) ids->data + u, as->nb[2], 0,
+                               bg ? (const float *) bg->src[1]->data : nullptr, bu ? (const float *) bu->src[1]->data : nullptr,
+                               oai ? op_f32(gl, 2) : 0.0f, oai ? op_f32(gl, 3) : 0.0f };
+                }
+                mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
+                c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
+                c->cnt.weight_bytes += (uint64_t) 2*n_used*M*ggml_row_size(as->type, K);
+                return jg - i + 1;
             }
-            mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
-            c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
-            c->cnt.weight_bytes += (uint64_t) 2*n_used*M*ggml_row_size(as->type, K);
-            return j2 - i + 1;
         }
     }
     // a single one-token MUL_MAT_ID

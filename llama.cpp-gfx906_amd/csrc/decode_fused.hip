@@ -596,7 +596,19 @@ static __device__ __forceinline__ void fused_body(const mmvq_group & g, const fu
                     if (first_pair) { MI_STAMP(2); first_pair = false; }
 #endif
                     float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
-                    if (GLU) s0 = (s0/(1.0f + expf(-s0)))*wave_sum(acu[0]);      // silu(gate)*up, as elem.hip k_glu
+                    if (GLU) {
+                        float up_s = wave_sum(acu[0]);
+                        if (g.b_gate) {     // + bias rows of this group's expert (ADD_ID), wave-uniform addresses
+                            const size_t brow = (size_t)(g.eid ? g.eid[0] : 0)*g.m + p_cur;
+                            s0 += g.b_gate[brow]; up_s += g.b_up[brow];
+                        }
+                        if (g.glu_alpha != 0.0f) {      // swiglu_oai, as elem.hip k_glu
+                            const float xc = fminf(s0, g.glu_limit), gc = fmaxf(fminf(up_s, g.glu_limit), -g.glu_limit);
+                            s0 = (xc/(1.0f + expf(-xc*g.glu_alpha)))*(gc + 1.0f);
+                        } else {
+                            s0 = (s0/(1.0f + expf(-s0)))*up_s;      // silu(gate)*up, as elem.hip k_glu
+                        }
+                    }
                     if (lane == 0) finish_pair<CHAIN>(g, p.rope, pair_out{ s0, s1, p_cur*R, pos0, idx0 }, R);
                     it = 0; p_cur += stride;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;

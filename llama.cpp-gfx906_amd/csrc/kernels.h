@@ -156,6 +156,9 @@ struct mmvq_group {
     // W2 likewise); x_off: this group's activation vector starts x_off floats into the launch's x (the down projection reads one
     // activation per used expert). eid == NULL: a plain weight tensor.
     const int32_t * eid; size_t estride; int x_off;
+    // EPI_GLU variants of gpt-oss's expert FFN (src/llama-graph.cpp:927-968): per-expert biases added to the two products (ADD_ID,
+    // row `eid[0]` of [m, n_expert] f32 tensors) and swiglu_oai(alpha, limit) instead of swiglu when glu_alpha != 0
+    const float * b_gate; const float * b_up; float glu_alpha, glu_limit;
 };
 struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; };   // EPI_ROPE (NORM pairs)
 
