@@ -211,12 +211,12 @@ def main():
             # gfx950 correction prescribes; tools/pmc_traffic.py) — it cannot be collected inside this run, so the committed summary
             # of the same workload is quoted, and only when its kernel matches the dominant launch found live
             try:
-                pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_f_pmc_fetch_size_summary.json")
+                pmc_file = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_l_pmc_fetch_size_summary.json")
                 if args.model == "llama3-8b" and args.ftype == "Q4_K_M" and os.path.exists(pmc_file):
                     for e in json.load(open(pmc_file)):
                         t = e.get("hbm_read_bytes_per_launch_corrected")
                         if "k_mmvq_fused" in e["kernel"] and t and abs(t - top["bytes_per_launch"]) <= 0.05 * top["bytes_per_launch"]:
-                            roof["traffic"] = int(t); roof["traffic_source"] = "profiles/r01_f_pmc_fetch_size_summary.json (" + e["kernel"] + ")"
+                            roof["traffic"] = int(t); roof["traffic_source"] = "profiles/r01_l_pmc_fetch_size_summary.json (" + e["kernel"] + ")"
                             break
             except Exception:
                 pass
