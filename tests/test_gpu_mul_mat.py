@@ -136,6 +136,8 @@ def test_prefill_width_matches_decode_width():
 @pytest.mark.parametrize("name,m,k,n", [
     ("q4_K", 256, 1024, 512), ("q6_K", 200, 512, 130), ("q5_K", 129, 768, 64), ("q8_0", 130, 2880, 33),
     ("q4_0", 77, 96, 17), ("mxfp4", 288, 2880, 100), ("q4_K", 1024, 4096, 9), ("q8_0", 64, 32, 12),
+    # enough weight tiles for the 256-token tile variant (>= 160 workgroups), ragged in both directions
+    ("q4_K", 10240, 512, 512), ("q6_K", 10300, 256, 300), ("mxfp4", 10240, 96, 257), ("q5_K", 10250, 256, 512),
 ])
 def test_mul_mat_prefill_mfma(name, m, k, n):
     rng = np.random.default_rng(m + k + n)
