@@ -380,3 +380,72 @@ def test_flash_attn_ext(hd, n_head, n_head_kv, n_kv, T, sinks):
         exp[:, h, :] = (p / den) @ V[:, hk, :]
     assert got[0].shape == exp.shape
     assert orc.nmse(exp, got[0]) <= 5e-4, orc.nmse(exp, got[0])
+
+
+@pytest.mark.parametrize("types", [("q4_K", "q4_K", "q6_K"), ("q4_K", "q4_K", "q4_K"), ("q8_0", "q8_0", "q8_0")])
+def test_norm_qkv_group_at_model_size(types):
+    """RMS_NORM -> MUL(w) -> three mat-vecs that all read the product, at Llama-3-8B's sizes (4096 -> 4096 / 1024 / 1024): with fusion on
+    this is ONE grouped launch with the norm in its prologue and — 3072 row pairs on 256 CUs — the 16-wave workgroup variant;
+    against the oracle evaluation of the separate ops, and bit-for-bit against the node-by-node path's quantized arithmetic."""
+    rng = np.random.default_rng(21)
+    k = 4096
+    ms = (4096, 1024, 1024)
+    x = rng.standard_normal((1, 1, 1, k)).astype(np.float32)
+    wn = rng.uniform(0.5, 1.5, size=(1, 1, 1, k)).astype(np.float32)
+    ws = [orc.random_blocks(rng, QTYPES[t], (m,), k, scale=1.0 / np.sqrt(k)) for t, m in zip(types, ms)]
+    res = {}
+    for fusion in (1, 0):
+        be = backend(); be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            xt = ctx.new_tensor(gg.F32, (k, 1)); wt = ctx.new_tensor(gg.F32, (k,))
+            mats = [ctx.new_tensor(QTYPES[t], (k, m)) for t, m in zip(types, ms)]
+            nm = L.ggml_mul(ctx.ctx, L.ggml_rms_norm(ctx.ctx, xt, 1e-5), wt)
+            outs = [L.ggml_mul_mat(ctx.ctx, a, nm) for a in mats]
+            assert ctx.alloc(be)
+            gg.tensor_set(xt, x); gg.tensor_set(wt, wn)
+            for a, w in zip(mats, ws):
+                gg.tensor_set(a, w)
+            be.compute(gg.graph_of(ctx, *outs))
+            res[fusion] = [gg.tensor_get(o)[0, 0, 0].copy() for o in outs]
+        be.set_option("fusion", 1)
+    h = (ref.rms_norm(x[0, 0], 1e-5) * wn[0, 0, 0]).astype(np.float32)
+    for i, (t, m) in enumerate(zip(types, ms)):
+        cpu = orc.mul_mat_2d(ws[i], QTYPES[t], h, "cpu")[0]; exact = orc.mul_mat_2d(ws[i], QTYPES[t], h, "exact")[0]
+        assert orc.nmse(exact, res[1][i]) <= 5e-4 and orc.nmse(cpu, res[1][i]) <= 5e-4
+        assert np.abs(res[1][i] - cpu).max() <= 2e-5 * (np.abs(cpu).max() + 1e-30)
+        assert np.abs(res[1][i] - res[0][i]).max() <= 2e-5 * (np.abs(cpu).max() + 1e-30)
+
+
+@pytest.mark.parametrize("t_ff,t_down", [("q4_K", "q6_K"), ("q4_K", "q4_K"), ("q8_0", "q8_0")])
+def test_ffn_at_model_size(t_ff, t_down):
+    """build_ffn at Llama-3-8B's sizes (src/llama-graph.cpp:632-774): norm -> gate / up (4096 -> 14336) -> swiglu -> down (14336 -> 4096)
+    -> + residual. With fusion on: the dual-stream GLU launch (one-row units, 7 rows per wave) and the down launch with the f32 -> int8
+    quantization of 14336 activations in its prologue and the residual in its epilogue."""
+    rng = np.random.default_rng(22)
+    k, ff = 4096, 14336
+    x = rng.standard_normal((1, 1, 1, k)).astype(np.float32)
+    wn = rng.uniform(0.5, 1.5, size=(1, 1, 1, k)).astype(np.float32)
+    wg = orc.random_blocks(rng, QTYPES[t_ff], (ff,), k, scale=1.0 / np.sqrt(k)); wu = orc.random_blocks(rng, QTYPES[t_ff], (ff,), k, scale=1.0 / np.sqrt(k))
+    wd = orc.random_blocks(rng, QTYPES[t_down], (k,), ff, scale=1.0 / np.sqrt(ff))
+    res = {}
+    for fusion in (1, 0):
+        be = backend(); be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            xt = ctx.new_tensor(gg.F32, (k, 1)); wt = ctx.new_tensor(gg.F32, (k,))
+            g_ = ctx.new_tensor(QTYPES[t_ff], (k, ff)); u_ = ctx.new_tensor(QTYPES[t_ff], (k, ff)); d_ = ctx.new_tensor(QTYPES[t_down], (ff, k))
+            nm = L.ggml_mul(ctx.ctx, L.ggml_rms_norm(ctx.ctx, xt, 1e-5), wt)
+            up = L.ggml_mul_mat(ctx.ctx, u_, nm); gate = L.ggml_mul_mat(ctx.ctx, g_, nm)
+            act = L.ggml_swiglu_split(ctx.ctx, gate, up)
+            out = L.ggml_add(ctx.ctx, L.ggml_mul_mat(ctx.ctx, d_, act), xt)
+            assert ctx.alloc(be)
+            gg.tensor_set(xt, x); gg.tensor_set(wt, wn); gg.tensor_set(g_, wg); gg.tensor_set(u_, wu); gg.tensor_set(d_, wd)
+            be.compute(gg.graph_of(ctx, out))
+            res[fusion] = gg.tensor_get(out)[0, 0, 0].copy()
+        be.set_option("fusion", 1)
+    h = (ref.rms_norm(x[0, 0], 1e-5) * wn[0, 0, 0]).astype(np.float32)
+    outs = {}
+    for mode in ("cpu", "exact"):
+        a = ref.swiglu(orc.mul_mat_2d(wg, QTYPES[t_ff], h, mode), orc.mul_mat_2d(wu, QTYPES[t_ff], h, mode)).astype(np.float32)
+        outs[mode] = orc.mul_mat_2d(wd, QTYPES[t_down], a, mode)[0] + x[0, 0, 0]
+    assert orc.nmse(outs["exact"], res[1]) <= 5e-4 and orc.nmse(outs["cpu"], res[1]) <= 5e-4
+    assert orc.nmse(res[0], res[1]) <= 1e-6
