@@ -493,7 +493,11 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
 
     // pinned staging for per-step inputs
     ggml_backend_buffer_type_t hbt = ggml_backend_dev_host_buffer_type(ggml_backend_get_device(backend));
-    m->hsize = 128u << 20;
+    {   // 4 slots, each large enough for the inputs of one decode of up to n_ctx tokens: embeddings, mask, K / V indices, positions
+        const size_t nc = (size_t) hp.n_ctx;
+        const size_t slot = nc*hp.n_embd*4 + nc*GGML_PAD(nc, GGML_KQ_MASK_PAD)*4 + nc*(size_t) n_embd_v_gqa*8 + nc*16 + (64u << 10);
+        m->hsize = 4*((slot + 4095) & ~(size_t) 4095);
+    }
     if (hbt) {
         m->hbuf = ggml_backend_buft_alloc_buffer(hbt, m->hsize);
         if (m->hbuf) m->hbase = (uint8_t *) ggml_backend_buffer_get_base(m->hbuf);
