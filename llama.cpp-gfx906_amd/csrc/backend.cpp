@@ -1164,6 +1164,8 @@ done:
 }
 
 static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
+    // the grouped mat-vec module keeps its launch hooks per host thread: (re)install this backend's for the thread that computes
+    mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
     c->aq.valid = false;
     c->uses.clear();
     if (c->use_fusion) {

@@ -16,6 +16,8 @@
 //
 // Every fused kernel is checked against the unfused node-by-node execution (tests/test_gpu_llama_graph.py) and,
 // through it, against the oracle.
+#include <atomic>
+#include <mutex>
 #include "mmvq_core.h"
 #include "quant_core.h"
 
@@ -731,7 +733,9 @@ bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind) {
 }
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind) { return (k % 256 == 0 || (act_kind == T_Q8_0 && k % 32 == 0)) && k <= 16*1024; }
 
-static struct { mmvq_launch_hook pre = nullptr, post = nullptr; void * ctx = nullptr; } g_hook;
+// per host thread: one backend (stream) is driven by one thread at a time, different backends concurrently from different threads
+// (tests/test-thread-safety.cpp)
+static thread_local struct { mmvq_launch_hook pre = nullptr, post = nullptr; void * ctx = nullptr; } g_hook;
 void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx) { g_hook.pre = pre; g_hook.post = post; g_hook.ctx = ctx; }
 
 // a grouped launch, prepared: either run at once or held back as a position of a chained launch
@@ -874,35 +878,33 @@ static int chain_position(const fused_launch & L) {      // which fixed position
     if (!L.glu && L.mode == PRO_NORM  && L.na == 2) return 3;
     return -1;
 }
-static struct {
-    fused_launch q[4]; int pos[4]; int n = 0;
-    unsigned * sync = nullptr; int next_slot = 0; int enabled = -1; int n_cu = 0;
-} g_chain;
+static thread_local struct { fused_launch q[4]; int pos[4]; int n = 0; } g_chain_q;      // the held-back launches of this thread's stream
+static struct { unsigned * sync = nullptr; std::atomic<int> next_slot{0}; int enabled = -1; int n_cu = 0; std::mutex init; } g_chain;
 constexpr int CHAIN_SLOTS = 8192;
 
 int mul_mat_vec_q_fused_pending(uint64_t * wbytes) {
     uint64_t b = 0;
-    for (int i = 0; i < g_chain.n; i++) b += g_chain.q[i].wbytes;
+    for (int i = 0; i < g_chain_q.n; i++) b += g_chain_q.q[i].wbytes;
     if (wbytes) *wbytes = b;
-    return g_chain.n;
+    return g_chain_q.n;
 }
 
 void mul_mat_vec_q_fused_flush(hipStream_t stream) {
-    if (g_chain.n == 0) return;
-    if (g_chain.n == 1) { g_chain.n = 0; fused_launch_now(g_chain.q[0], stream); return; }
+    if (g_chain_q.n == 0) return;
+    if (g_chain_q.n == 1) { g_chain_q.n = 0; fused_launch_now(g_chain_q.q[0], stream); return; }
     chain_args c = {};
-    c.first = g_chain.pos[0]; c.last = g_chain.pos[g_chain.n - 1];
+    c.first = g_chain_q.pos[0]; c.last = g_chain_q.pos[g_chain_q.n - 1];
     size_t lds = 0; int blocks = 0;
-    for (int i = 0; i < g_chain.n; i++) {
-        c.ph[g_chain.pos[i]] = g_chain.q[i].a;
-        if (g_chain.q[i].lds > lds) lds = g_chain.q[i].lds;
-        if (g_chain.q[i].blocks > blocks) blocks = g_chain.q[i].blocks;
+    for (int i = 0; i < g_chain_q.n; i++) {
+        c.ph[g_chain_q.pos[i]] = g_chain_q.q[i].a;
+        if (g_chain_q.q[i].lds > lds) lds = g_chain_q.q[i].lds;
+        if (g_chain_q.q[i].blocks > blocks) blocks = g_chain_q.q[i].blocks;
     }
-    c.sync = g_chain.sync + (size_t)(g_chain.next_slot++ % CHAIN_SLOTS)*8;
+    c.sync = g_chain.sync + (size_t)(g_chain.next_slot.fetch_add(1) % CHAIN_SLOTS)*8;
     uint64_t wb = 0;
-    for (int i = 0; i < g_chain.n; i++) wb += g_chain.q[i].wbytes;
-    const int n_merged = g_chain.n;
-    g_chain.n = 0;
+    for (int i = 0; i < g_chain_q.n; i++) wb += g_chain_q.q[i].wbytes;
+    const int n_merged = g_chain_q.n;
+    g_chain_q.n = 0;
     if (g_hook.pre) g_hook.pre(g_hook.ctx, T_Q4_K, wb, n_merged, 0);
     hipLaunchKernelGGL((k_mmvq_chain<T_Q4_K, T_Q6_K>), dim3((unsigned) blocks), dim3(FW*64), lds, stream, c);
     if (g_hook.post) g_hook.post(g_hook.ctx, T_Q4_K, wb, n_merged, 0);
@@ -911,15 +913,20 @@ void mul_mat_vec_q_fused_flush(hipStream_t stream) {
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream) {
     const fused_launch L = fused_prepare(groups, n_groups, k, in, rope);
     if (g_chain.enabled < 0) {
-        const char * e = getenv("GGML_MI355X_CHAIN");
-        g_chain.enabled = e ? atoi(e) : 0;     // opt-in: measured 446 tok/s chained vs 512 unchained (Llama-3-8B Q4_K_M tg128) — the sc1 hand-off
-                                               // (per-row 4-byte sc1 stores, their acks before the counter add, sc1 reloads) costs more than
-                                               // the kernel boundary + weight wait it removes; parity-tested, kept as the base for round 2
-        int dev = 0; hipDeviceProp_t prop;
-        g_chain.n_cu = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
-        if (g_chain.enabled) {      // counters: zeroed once; every chained launch re-arms its own slot when its last workgroup finishes
-            if (hipMalloc(&g_chain.sync, (size_t) CHAIN_SLOTS*8*sizeof(unsigned)) != hipSuccess ||
-                hipMemset(g_chain.sync, 0, (size_t) CHAIN_SLOTS*8*sizeof(unsigned)) != hipSuccess) { (void) hipGetLastError(); g_chain.enabled = 0; }
+        std::lock_guard<std::mutex> lock(g_chain.init);
+        if (g_chain.enabled < 0) {
+            // opt-in: measured 446 tok/s chained vs 512 unchained (Llama-3-8B Q4_K_M tg128) — the sc1 hand-off (per-row 4-byte sc1 stores,
+            // their acks before the counter add, sc1 reloads) costs more than the kernel boundary + weight wait it removes;
+            // parity-tested, kept as the base for round 2
+            const char * e = getenv("GGML_MI355X_CHAIN");
+            int enabled = e ? atoi(e) : 0;
+            int dev = 0; hipDeviceProp_t prop;
+            g_chain.n_cu = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 0;
+            if (enabled) {      // counters: zeroed once; every chained launch re-arms its own slot when its last workgroup finishes
+                if (hipMalloc(&g_chain.sync, (size_t) CHAIN_SLOTS*8*sizeof(unsigned)) != hipSuccess ||
+                    hipMemset(g_chain.sync, 0, (size_t) CHAIN_SLOTS*8*sizeof(unsigned)) != hipSuccess) { (void) hipGetLastError(); enabled = 0; }
+            }
+            g_chain.enabled = enabled;
         }
     }
     int pos = g_chain.enabled ? chain_position(L) : -1;
@@ -932,8 +939,8 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
         fused_launch_now(L, stream);
         return;
     }
-    if (g_chain.n > 0 && pos != g_chain.pos[g_chain.n - 1] + 1) mul_mat_vec_q_fused_flush(stream);     // not the next position: a new chain starts here
-    g_chain.q[g_chain.n] = L; g_chain.pos[g_chain.n] = pos; g_chain.n++;
+    if (g_chain_q.n > 0 && pos != g_chain_q.pos[g_chain_q.n - 1] + 1) mul_mat_vec_q_fused_flush(stream);     // not the next position: a new chain starts here
+    g_chain_q.q[g_chain_q.n] = L; g_chain_q.pos[g_chain_q.n] = pos; g_chain_q.n++;
     if (pos == 3) mul_mat_vec_q_fused_flush(stream);                                                    // the last position closes the chain
 }
 

@@ -293,3 +293,38 @@ def test_decode_refuses_when_cache_is_full():
     with pytest.raises(RuntimeError):
         m.decode([1])
     m.free()
+
+
+def test_two_backends_from_two_threads():
+    """tests/test-thread-safety.cpp: different contexts driven concurrently from different threads. Each thread owns a backend (its own
+    stream, scratch, hipGraph cache) on the same device and a model of its own; the results must equal the single-threaded ones."""
+    import threading
+    seqs = {0: [[3, 4, 5, 6, 9, 11, 200]] + [[t] for t in range(10, 40)], 1: [list(range(50, 90))] + [[t] for t in range(100, 130)]}
+
+    def run(idx, out):
+        be = gg.Backend(0)
+        try:
+            m = ls.SynthLlama(be, "tiny" if idx == 0 else "tiny-moe", "Q4_K_M", n_ctx=96, seed=11 + idx)
+            out[idx] = np.stack([m.decode(t).copy() for t in seqs[idx]])
+            m.free()
+        finally:
+            be.free()
+
+    single = {}
+    for i in (0, 1):
+        run(i, single)
+    multi = {}
+    errs = []
+    def guarded(i):
+        try:
+            run(i, multi)
+        except Exception as e:   # noqa: BLE001
+            errs.append(e)
+    ths = [threading.Thread(target=guarded, args=(i,)) for i in (0, 1)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+    for i in (0, 1):
+        assert np.array_equal(single[i], multi[i])
