@@ -423,7 +423,9 @@ static bool mi_supports_op(const struct ggml_tensor * op) {
             return (float_type(st) && float_type(dt)) || (st == GGML_TYPE_I32 && dt == GGML_TYPE_I32);
         }
         case GGML_OP_SET_ROWS:
-            return s0->type == GGML_TYPE_F32 && s1->type == GGML_TYPE_I64 && float_type(op->type);
+            if (s0->type != GGML_TYPE_F32 || s1->type != GGML_TYPE_I64) return false;
+            if (op->type == GGML_TYPE_Q8_0 || op->type == GGML_TYPE_Q4_0) return s0->ne[0] % 32 == 0 && op->nb[0] == ggml_type_size(op->type);   // quantized KV cache rows
+            return float_type(op->type);
         case GGML_OP_GET_ROWS:
             return (float_type(s0->type) || s0->type == GGML_TYPE_I32) && s1->type == GGML_TYPE_I32 && s0->nb[0] == ggml_type_size(s0->type);
         case GGML_OP_SUM_ROWS:

@@ -229,9 +229,58 @@ __global__ void __launch_bounds__(256) k_set_rows(const td src, const td idx, co
     const float v = *(const float *) (src.data + i0*src.nb0 + i1*src.nb1 + i2*src.nb2 + i3*src.nb3);
     st_elem(dst.data + i0*dst.nb0 + r*dst.nb1 + i2*dst.nb2 + i3*dst.nb3, dst.type, v);
 }
+// quantized destination (a quantized KV cache: -ctk q8_0 / q4_0; tests/test-backend-ops.cpp:5333-5343): one thread per 32-element
+// block, the reference row quantizers restated operation for operation (gguf-py/gguf/quants.py:222-238 Q4_0, :381-393 Q8_0 —
+// oracle/ggml_oracle.c quantize_row_q4_0_ref / quantize_row_q8_0_ref, pinned bit-exactly by tests/golden/quant_*.npz)
+template <int TYPE>
+__global__ void __launch_bounds__(256) k_set_rows_q(const td src, const td idx, const td dst, int64_t n_blocks) {
+    const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
+    if (i >= n_blocks) return;
+    const int64_t nb0 = src.ne0/32;
+    const idx4 ix = unravel(i, nb0, src.ne1, src.ne2); const int64_t ib = ix.i0, i1 = ix.i1, i2 = ix.i2, i3 = ix.i3;
+    const int64_t r = *(const int64_t *) (idx.data + i1*idx.nb0 + wrap(i2, idx.ne1)*idx.nb1 + wrap(i3, idx.ne2)*idx.nb2);
+    const char * x = src.data + (ib*32)*src.nb0 + i1*src.nb1 + i2*src.nb2 + i3*src.nb3;
+    float v[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) v[j] = *(const float *) (x + j*src.nb0);
+    uint8_t * out = (uint8_t *) (dst.data + r*dst.nb1 + i2*dst.nb2 + i3*dst.nb3) + ib*(TYPE == T_Q8_0 ? 34 : 18);
+    if (TYPE == T_Q8_0) {
+        float amax = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { const float a = fabsf(v[j]); if (a > amax) amax = a; }
+        const float d = amax/127.0f;
+        const float id = d != 0.0f ? 1.0f/d : 0.0f;
+        const uint16_t dh = f32_to_f16_bits(d);
+        out[0] = (uint8_t) dh; out[1] = (uint8_t)(dh >> 8);
+#pragma unroll
+        for (int j = 0; j < 32; j++) out[2 + j] = (uint8_t)(int8_t) roundf(v[j]*id);
+    } else {
+        float amax = 0.0f, mx = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { if (amax < fabsf(v[j])) { amax = fabsf(v[j]); mx = v[j]; } }
+        float d = mx/-8.0f;
+        // keep the product in a register of its own: fused into the f16 conversion (v_fma_mixlo_f16 with a +0 addend) a zero block's
+        // d = 0 / -8 = -0.0 came out as +0.0, one bit off the reference's bytes
+        asm volatile("" : "+v"(d));
+        const float id = d != 0.0f ? 1.0f/d : 0.0f;
+        const uint16_t dh = f32_to_f16_bits(d);
+        out[0] = (uint8_t) dh; out[1] = (uint8_t)(dh >> 8);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            const int v0 = (int)(v[j]*id + 8.5f), v1 = (int)(v[16 + j]*id + 8.5f);
+            out[2 + j] = (uint8_t)((v0 < 15 ? v0 : 15) | ((v1 < 15 ? v1 : 15) << 4));
+        }
+    }
+}
 void set_rows(const tensor_desc & src, const tensor_desc & idx, const tensor_desc & dst, hipStream_t stream) {
     const int64_t n = src.ne[0]*src.ne[1]*src.ne[2]*src.ne[3];
     if (n == 0) return;
+    if (dst.type == T_Q8_0 || dst.type == T_Q4_0) {
+        const int64_t nblk = n/32;
+        if (dst.type == T_Q8_0) hipLaunchKernelGGL((k_set_rows_q<T_Q8_0>), dim3((unsigned)((nblk + 255)/256)), dim3(256), 0, stream, mk(src), mk(idx), mk(dst), nblk);
+        else                    hipLaunchKernelGGL((k_set_rows_q<T_Q4_0>), dim3((unsigned)((nblk + 255)/256)), dim3(256), 0, stream, mk(src), mk(idx), mk(dst), nblk);
+        return;
+    }
     hipLaunchKernelGGL(k_set_rows, dim3((unsigned)((n + 255)/256)), dim3(256), 0, stream, mk(src), mk(idx), mk(dst), n);
 }
 

@@ -449,3 +449,33 @@ def test_ffn_at_model_size(t_ff, t_down):
         outs[mode] = orc.mul_mat_2d(wd, QTYPES[t_down], a, mode)[0] + x[0, 0, 0]
     assert orc.nmse(outs["exact"], res[1]) <= 5e-4 and orc.nmse(outs["cpu"], res[1]) <= 5e-4
     assert orc.nmse(res[0], res[1]) <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["q8_0", "q4_0"])
+@pytest.mark.parametrize("ne0,rows,r,b", [(256, 5, 1, 1), (256, 11, 7, 3), (96, 3, 2, 7), (1024, 64, 5, 1)])
+def test_set_rows_quantized_dst(name, ne0, rows, r, b):
+    """SET_ROWS into a quantized destination (a q8_0 / q4_0 KV cache; tests/test-backend-ops.cpp:5333-5343): the written rows must be
+    byte-identical to the reference row quantizer's output (oracle quantize_row_*_ref, pinned by the golden vectors); rows that are
+    not addressed keep their bytes."""
+    rng = np.random.default_rng(ne0 + rows + r)
+    qt = QTYPES[name]
+    rb = orc.row_size(qt, ne0)
+    dst0 = orc.random_blocks(rng, qt, (1, b, rows), ne0)                      # [1, b, rows, row_bytes]
+    src = rng.uniform(-1, 1, size=(1, b, r, ne0)).astype(np.float32)
+    src[0, 0, 0, :32] = 0.0                                                  # a zero block
+    idx = np.stack([rng.permutation(rows)[:r] for _ in range(b)]).astype(np.int64).reshape(1, 1, b, r)
+    with gg.Context() as ctx:
+        d = ctx.new_tensor(qt, (ne0, rows, b)); s_ = ctx.new_tensor(gg.F32, (ne0, r, b)); i_ = ctx.new_tensor(gg.I64, (r, b))
+        o = L.ggml_set_rows(ctx.ctx, d, s_, i_)
+        be = backend(); assert be.supports_op(o); ctx.alloc(be)
+        gg.tensor_set(d, dst0); gg.tensor_set(s_, src); gg.tensor_set(i_, idx)
+        be.compute(gg.graph_of(ctx, o))
+        got = gg.tensor_get(d)
+    exp = dst0.copy().reshape(1, b, rows, rb)
+    q = orc.quantize(src.reshape(-1, ne0), qt).reshape(b, r, rb)
+    for ib in range(b):
+        for ir in range(r):
+            exp[0, ib, idx[0, 0, ib, ir]] = q[ib, ir]
+    g2 = got.reshape(exp.shape)
+    bad = np.argwhere(g2 != exp)
+    assert bad.size == 0, (len(bad), bad[:6].tolist(), [int(g2[tuple(b)]) for b in bad[:6]], [int(exp[tuple(b)]) for b in bad[:6]], idx.tolist())
