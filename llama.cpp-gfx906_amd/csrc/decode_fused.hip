@@ -761,7 +761,8 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
     static int fw16_env = -1;
     if (fw16_env < 0) { const char * e = getenv("GGML_MI355X_MMVQ_FW16"); fw16_env = e ? atoi(e) : 1; }
     const int FW = (fw16_env && groups[0].epi != EPI_GLU && in.mode == PRO_NORM && k <= 4096 && k % 256 == 0 &&
-                    (rows_total + 1)/2 > (int64_t) n_cu*8 && ((rows_total + 1)/2 <= (int64_t) n_cu*16 + 64 || fw16_env == 2)) ? 16 : 8;
+                    (rows_total + 1)/2 > (int64_t) n_cu*8 &&
+                    ((rows_total + 1)/2 <= (int64_t) n_cu*16 + 64 || (rows_total + 1)/2 >= (int64_t) n_cu*64)) ? 16 : 8;   // or a long stream (lm_head: 101 -> 96 us)
     L.fw = FW;
     const int budget = n_cu*(groups[0].epi == EPI_GLU ? glu_wpc : wpc);   // the dual (GLU) kernels need > 128 VGPRs: one workgroup per CU
     int blocks = 0;
