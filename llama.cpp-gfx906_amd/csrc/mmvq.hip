@@ -20,6 +20,7 @@
 //     n == 1 (k + k/16 bytes), or read through L1/L2 for 2 <= n <= 8.
 //   * per-lane partial sums are reduced with DPP row operations + v_readlane (dev_common.h).
 #include "mmvq_core.h"
+#include <algorithm>
 
 namespace mi355x {
 
@@ -117,6 +118,121 @@ __global__ void __launch_bounds__(256) k_mmvq(const mmvq_args p) {
     }
 }
 
+static size_t lds_bytes_for(int act_kind, int64_t k) {
+    const int nd = act_kind == T_Q8_0 ? 32 : 256, nbs = act_kind == T_Q8_0 ? 32 : 16;
+    return ((k + 15) & ~15) + (((k/nd)*4 + 15) & ~15) + (((k/nbs)*2 + 15) & ~15);
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// 2 <= n <= 8 columns: persistent workgroups of 8 waves (one per CU), the n quantized activation columns staged into LDS once per
+// workgroup, each wave walking row pairs with a grid stride and its weight loads two k-steps ahead in a static ring of register
+// sets (the structure of decode_fused.hip's single-column kernel; the simple kernel above reads the activations through L1/L2 at
+// every step and waits for every load it issues: 29-58 us at n = 8 for a 4096 x 14336 matrix, tools/op_perf.py)
+// ------------------------------------------------------------------------------------------------
+template <int TYPE, int NCOLS>
+__global__ void __launch_bounds__(512, 1) k_mmvq_cols(const mmvq_args p) {
+    typedef mmvq_t<TYPE> T;
+    constexpr int LPB = T::LPB, BPW = 64/LPB, R = 2, D = 2, FW = 8;
+    constexpr int ND  = T::ACT == T_Q8_0 ? 32 : 256, NBS = T::ACT == T_Q8_0 ? 32 : 16;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int slot = lane % LPB, ibl = lane / LPB;
+    const int nb = (int)(p.k / T::QK);
+    const int iters = (nb + BPW - 1)/BPW;
+    const int P = (int)((p.m + R - 1)/R);
+    const int stride = gridDim.x*FW;
+    const int p_first = blockIdx.x*FW + wave;
+
+    // weight prefetch first (HBM), then the activation images (L2) — the images are small and the barrier below waits for them anyway
+    int p_pf = p_first, it_pf = 0;
+    typename T::wfrag w[D][R];
+#define MV_FETCH(d_) { \
+        const bool live = p_pf < P; \
+        const int pp = live ? p_pf : min(p_first, P - 1); \
+        const int ibf = live ? min(it_pf*BPW + ibl, nb - 1) : 0; \
+        _Pragma("unroll") for (int r = 0; r < R; r++) \
+            w[d_][r] = T::load_w(p.W + (size_t) min((int64_t) pp*R + r, p.m - 1)*p.w_row_stride, ibf, slot); \
+        if (++it_pf == iters) { it_pf = 0; p_pf += stride; } }
+    const size_t qs_b = ((size_t) p.k + 15) & ~(size_t) 15, d_b = (((size_t) p.k/ND)*4 + 15) & ~(size_t) 15, bs_b = (((size_t) p.k/NBS)*2 + 15) & ~(size_t) 15;
+    const size_t img = qs_b + d_b + bs_b;
+    act_view av[NCOLS];
+#pragma unroll
+    for (int c = 0; c < NCOLS; c++) {
+        char * base = smem + (size_t) c*img;
+        const char * g_qs = (const char *) (p.a_qs + (size_t) c*p.k); const char * g_d = (const char *) (p.a_d + (size_t) c*(p.k/ND));
+        const char * g_bs = (const char *) (p.a_bs + (size_t) c*(p.k/NBS));
+        for (size_t i = (size_t) threadIdx.x*16; i < qs_b; i += 512*16) *(int4v *) (base + i) = ld_b128(g_qs + i);
+        for (size_t i = (size_t) threadIdx.x*4;  i < d_b;  i += 512*4)  *(uint32_t *) (base + qs_b + i) = ld_u32(g_d + i);      // up to 12 bytes past the column: the next column or the region's 256-byte pad
+        for (size_t i = (size_t) threadIdx.x*4;  i < bs_b; i += 512*4)  *(uint32_t *) (base + qs_b + d_b + i) = ld_u32(g_bs + i);
+        av[c].qs = (const int8_t *) base; av[c].d = (const float *) (base + qs_b); av[c].bs = (const int16_t *) (base + qs_b + d_b);
+    }
+    asm volatile("" ::: "memory");
+#pragma unroll
+    for (int d = 0; d < D; d++) MV_FETCH(d)
+    __syncthreads();
+
+    const int my_pairs = p_first < P ? (P - 1 - p_first)/stride + 1 : 0;
+    const int total = my_pairs*iters;
+    int it = 0, p_cur = p_first;
+    float acc[NCOLS][R];
+#pragma unroll
+    for (int c = 0; c < NCOLS; c++)
+#pragma unroll
+        for (int r = 0; r < R; r++) acc[c][r] = 0.0f;
+    for (int s = 0; s < total; s += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (s + d < total) {        // wave-uniform
+                const int ib = it*BPW + ibl;
+                if (ib < nb) {
+#pragma unroll
+                    for (int c = 0; c < NCOLS; c++) {
+                        const typename T::afrag a = T::load_a(av[c], ib, slot);
+#pragma unroll
+                        for (int r = 0; r < R; r++) acc[c][r] += T::dot(w[d][r], a, slot);
+                    }
+                }
+                MV_FETCH(d)
+                if (++it == iters) {
+                    const int64_t row0 = (int64_t) p_cur*R;
+#pragma unroll
+                    for (int c = 0; c < NCOLS; c++) {
+#pragma unroll
+                        for (int r = 0; r < R; r++) {
+                            const float sum = wave_sum(acc[c][r]);
+                            if (lane == 0 && row0 + r < p.m) *(float *) ((char *) p.dst + (size_t) c*p.dst_col_stride + (size_t)(row0 + r)*4) = sum;
+                            acc[c][r] = 0.0f;
+                        }
+                    }
+                    it = 0; p_cur += stride;
+                }
+            }
+        }
+    }
+#undef MV_FETCH
+}
+
+template <int TYPE, int NCOLS>
+static bool launch_mmvq_cols(const mmvq_args & a, int act_kind, hipStream_t stream) {
+    const size_t lds = (size_t) NCOLS*lds_bytes_for(act_kind, a.k);
+    if (lds > 150*1024 || a.k % 16 != 0 || a.m >= (1ll << 30)) return false;
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        n_cu = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
+    }
+    static size_t lds_set = 0;
+    if (lds > lds_set) {
+        if (hipFuncSetAttribute((const void *) k_mmvq_cols<TYPE, NCOLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 152*1024) != hipSuccess) { (void) hipGetLastError(); return false; }
+        lds_set = 152*1024;
+    }
+    const int64_t pairs = (a.m + 1)/2;
+    const int blocks = (int) std::min<int64_t>(n_cu, (pairs + 7)/8);
+    hipLaunchKernelGGL((k_mmvq_cols<TYPE, NCOLS>), dim3((unsigned) blocks), dim3(512), lds, stream, a);
+    return true;
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
@@ -125,11 +241,6 @@ bool mul_mat_vec_q_supported(int type_a) {
         case T_Q4_0: case T_Q8_0: case T_Q4_K: case T_Q5_K: case T_Q6_K: case T_MXFP4: return true;
         default: return false;
     }
-}
-
-static size_t lds_bytes_for(int act_kind, int64_t k) {
-    const int nd = act_kind == T_Q8_0 ? 32 : 256, nbs = act_kind == T_Q8_0 ? 32 : 16;
-    return ((k + 15) & ~15) + (((k/nd)*4 + 15) & ~15) + (((k/nbs)*2 + 15) & ~15);
 }
 
 template <int TYPE, int NCOLS, bool IDS>
@@ -142,6 +253,14 @@ static void launch_mmvq_n(const mmvq_args & a, int act_kind, int64_t n_pairs, hi
             hipLaunchKernelGGL((k_mmvq<TYPE, 1, R, true, IDS>), grid, dim3(256), lds, stream, a);
             return;
         }
+    }
+    // measured (tools/op_perf.py, m = 4096, k = 14336): faster for the 32-element block formats (Q8_0 n = 8: 57.7 -> 30.4 us, Q4_0 35.9 ->
+    // 27.4) but not for the K-quants, whose n dot chains per block are VALU-bound either way (Q4_K n = 8: 29.5 -> 35.5 us with 2 waves
+    // per SIMD; 16 waves per workgroup spill) — those keep the simple kernel until the int8 MFMA kernel exists
+    if (NCOLS > 1 && !IDS && (TYPE == T_Q8_0 || TYPE == T_Q4_0)) {
+        static int use_cols = -1;
+        if (use_cols < 0) { const char * e = getenv("GGML_MI355X_MMVQ_COLS"); use_cols = e ? atoi(e) : 1; }
+        if (use_cols && launch_mmvq_cols<TYPE, (NCOLS > 1 ? NCOLS : 2)>(a, act_kind, stream)) return;
     }
     hipLaunchKernelGGL((k_mmvq<TYPE, NCOLS, R, false, IDS>), grid, dim3(256), 0, stream, a);
 }
