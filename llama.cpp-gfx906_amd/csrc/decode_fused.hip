@@ -355,17 +355,20 @@ static __device__ __forceinline__ void rope_pair(const fused_rope & r, int pos, 
     x1 = a*s + b*c;
 }
 
-// PERSISTENT grouped mat-vec. A launch has about (CUs x 2) workgroups of 8 waves; each workgroup belongs to one group (weight
-// tensor) and its waves walk that tensor's row pairs with a grid stride, so that
+// PERSISTENT grouped mat-vec. A launch has ONE workgroup of 8 (or 16) waves per CU; each workgroup belongs to one group (weight
+// tensor) and its waves walk that tensor's row pairs (single rows for the dual GLU stream) with a grid stride, so that
 //   * the activation is prepared ONCE per workgroup (copy / quantize / rms-norm + quantize into LDS) instead of once per 8 rows,
 //   * the packed-weight stream never stops: loads run D steps ahead across row boundaries in a STATIC ring of register sets (the
 //     loop is unrolled D times; a rotating copy w0 = w1 makes the compiler wait for every outstanding load at the top of each step,
 //     measured: tools/stamp_timeline.py), and the DPP reduction + epilogue of one row pair overlaps the loads of the next.
-// Order of issue: (1) activation loads (L2-resident, a few KB), (2) the first D steps of weight loads (HBM), (3) prologue into
-// LDS + barrier — the compiler's counted vmcnt wait covers only (1) — (4) integer dots, (5) reduction + epilogue per row pair.
+// Order of issue: (1) activation loads by every wave, workgroup barrier (a CU returns loads in request order: nothing HBM-bound
+// may be queued in front of them), (2) norm weights, then the D steps of weight loads one at a time BETWEEN the phases of
+// (3) the prologue into LDS (a wave that cannot queue a load cannot do its share of the prologue either) + barrier,
+// (4) integer dots, (5) reduction + epilogue per row pair.
 // Every load is unconditional (clamped address) so that the number of outstanding loads is the same on every path.
 //   PRO  : where the activation comes from (mmvq_prologue)
-//   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*2048)
+//   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*256*waves)
+//   D    : ring depth (2; 4 for the one-row GLU units and for long single-tensor streams)
 constexpr int FW = 8;            // waves per workgroup
 
 // what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers).
