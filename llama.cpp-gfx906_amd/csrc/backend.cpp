@@ -472,7 +472,7 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             const struct ggml_tensor * b = n->src[1];
             const int64_t rows = n->op == GGML_OP_MUL_MAT ? b->ne[1] : b->ne[1]*b->ne[2];
             size_t s = act_q8_bytes(kind, b->ne[0], rows);
-            if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows);
+            if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows, n->src[0]->ne[1]);
             if (n->op == GGML_OP_MUL_MAT_ID) {
                 const struct ggml_tensor * ids = n->src[2];
                 const size_t sg = mul_mat_q_id_scratch_bytes(b->ne[0], b->ne[1], ids->ne[1], ids->ne[0], n->src[0]->ne[2]);

@@ -181,7 +181,8 @@ struct mmq_args {
     const uint16_t * X; int n;                 // dense [batch][n][k] 16-bit
     char * dst; size_t dst_nb1, dst_nb2, dst_nb3;
     int ne12, r2, r3;                          // batch = blockIdx.z = i13*ne12 + i12; weights broadcast: i02 = i12/r2, i03 = i13/r3
-    int ksplit, mtiles;                        // ksplit = 2: blockIdx.y = half*mtiles + m-tile; both halves atomically add into a zeroed dst
+    int ksplit, mtiles;                        // ksplit = 2 | 4: blockIdx.y = part*mtiles + m-tile; parts 0,1 atomically add into a zeroed dst,
+    char * dst2;                               //   parts 2,3 into the zeroed plane dst2 (same layout): never more than two addends per element
     // MUL_MAT_ID (grouped by expert): blockIdx.x walks the tile table k_moe_sort wrote; a tile = up to 128 (token, slot) pairs of ONE expert
     const int * moe;                           // NULL, or [0] = n_tiles, then {expert, first, count}[max_tiles], then sorted pair ids
     int moe_max_tiles, n_used, n_b;            // pair = token*n_used + slot; X row of a pair = token*n_b + slot % n_b
@@ -197,14 +198,14 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
     constexpr int WTILE = MQ_BM*MQ_LD, XTILE = BN*MQ_LD, STAGE = WTILE + XTILE;     // bytes
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;
+    const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;      // which part of k
     const int m0 = ((int) blockIdx.y - khalf*p.mtiles)*MQ_BM, n0 = blockIdx.x*BN;   // the n-tiles of one weight tile are dispatched together
     const int wm = wave & 1, wn = wave >> 1;             // wave tile: weight rows wm*64.., tokens wn*64..
     const int m = p.m, n = p.n, k = p.k;
     const int i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
     const char * W = p.W + (size_t)(i12/p.r2)*p.w_nb2 + (size_t)(i13/p.r3)*p.w_nb3;
     const uint16_t * X = p.X + (size_t) blockIdx.z*n*k;
-    char * dst = p.dst + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
+    char * dst = (khalf >= 2 ? p.dst2 : p.dst) + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
     int moe_first = 0, moe_cnt = 0;
     const int * moe_pairs = nullptr;
     if (p.moe) {                               // workgroup-uniform
@@ -234,8 +235,8 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
     }
     // split-K: each half walks k/2 (a multiple of 256, so block boundaries stay aligned); steps are counted from step0
     const int nsteps_all = (k + MQ_BK - 1)/MQ_BK;
-    const int step0 = khalf*(nsteps_all/2);
-    const int nsteps = p.ksplit > 1 ? nsteps_all/2 : nsteps_all;
+    const int nsteps = p.ksplit > 1 ? nsteps_all/p.ksplit : nsteps_all;
+    const int step0 = khalf*nsteps;
 
     // register stage: raw weight bytes + 32 activations of the NEXT k-step (addresses clamped, results discarded past k)
     raw32 rw; int4v xv[4]; int4v wf[4];
@@ -352,7 +353,16 @@ static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
     hipLaunchKernelGGL((k_mmq<T_, 256>), grid, dim3(512), MQ_LDS_BYTES_256, stream, a);
 }
 
-size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n) { return (size_t) n*k*2 + 256; }
+static size_t mmq_x_bytes(int64_t k, int64_t n) { return ((size_t) n*k*2 + 255) & ~(size_t) 255; }
+size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m) { return mmq_x_bytes(k, n) + (size_t) m*n*4 + 512; }     // bf16 copy of x | second plane of a 4-way split-K
+
+__global__ void __launch_bounds__(256) k_add_plane(float * dst, const float * plane, int64_t n4) {
+    const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
+    if (i >= n4) return;
+    float4v a = ((const float4v *) dst)[i]; const float4v b = ((const float4v *) plane)[i];
+    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    ((float4v *) dst)[i] = a;
+}
 
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
@@ -362,14 +372,24 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
-    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, 0, 0, 0 };
+    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, 0, 0 };
     const int mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     a.mtiles = mtiles;
     // 256-token tiles when they still fill the chip (m = 14336, n = 512: 224 workgroups); else 128-token tiles, and a grid that would
     // leave the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k; dst rows must be dense for the memset
-    const bool wide = n >= 256 && (int64_t) mtiles*((n + 255)/256) >= 160;
+    const int64_t wtiles = (int64_t) mtiles*((n + 255)/256);
+    const bool dense_dst = dst_col_stride_bytes == (size_t) m*4;
+    // a long-k matrix with few rows (ffn_down: m = 4096, k = 14336): 256-token tiles and k in four parts — parts 0,1 add into dst, parts
+    // 2,3 into a second plane (two addends per element each: order-independent), one pass adds the planes
+    const bool wide4 = n >= 256 && wtiles < 160 && wtiles*4 >= 160 && k % 1024 == 0 && k >= 8192 && dense_dst && (m*n) % 4 == 0;
+    const bool wide = (n >= 256 && wtiles >= 160) || wide4;
     const int ntiles = wide ? (int)((n + 255)/256) : (int)((n + MQ_BN - 1)/MQ_BN);
-    if (!wide && (int64_t) ntiles*mtiles <= 160 && k % 512 == 0 && k >= 2048 && dst_col_stride_bytes == (size_t) m*4) {
+    float * plane = (float *) ((char *) scratch + mmq_x_bytes(k, n));
+    if (wide4) {
+        a.ksplit = 4; a.dst2 = (char *) plane;
+        MI_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t) m*n*4, stream));
+        MI_HIP_CHECK(hipMemsetAsync(plane, 0, (size_t) m*n*4, stream));
+    } else if (!wide && (int64_t) ntiles*mtiles <= 160 && k % 512 == 0 && k >= 2048 && dense_dst) {
         a.ksplit = 2;
         MI_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t) m*n*4, stream));
     }
@@ -386,6 +406,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         default: fprintf(stderr, "mmq: unsupported type %d\n", type_a); abort();
     }
 #undef MI_MMQ
+    if (wide4) hipLaunchKernelGGL(k_add_plane, dim3((unsigned)((m*n/4 + 255)/256)), dim3(256), 0, stream, dst, plane, m*n/4);
 }
 
 // ---- MUL_MAT_ID for many tokens: pairs (token, slot) sorted by expert, then the tiled kernel above per (expert, 128 pairs) ----
@@ -438,7 +459,7 @@ void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expe
     hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
     moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, max_tiles, table };
     hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
-    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0,
+    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr,
                    table, max_tiles, (int) n_used, (int) n_b };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     const dim3 grid((unsigned) max_tiles, (unsigned) a.mtiles, 1);
@@ -469,7 +490,7 @@ void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t str
     act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
     hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((p.ne10 + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
-                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, 0, 0, 0 };
+                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, 0, 0, 0 };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
     hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
 }

@@ -138,6 +138,8 @@ def test_prefill_width_matches_decode_width():
     ("q4_0", 77, 96, 17), ("mxfp4", 288, 2880, 100), ("q4_K", 1024, 4096, 9), ("q8_0", 64, 32, 12),
     # enough weight tiles for the 256-token tile variant (>= 160 workgroups), ragged in both directions
     ("q4_K", 10240, 512, 512), ("q6_K", 10300, 256, 300), ("mxfp4", 10240, 96, 257), ("q5_K", 10250, 256, 512),
+    # long k, few rows (ffn_down-like): 256-token tiles with k split four ways into two planes
+    ("q4_K", 5120, 8192, 512), ("q6_K", 5000, 8192, 300),
 ])
 def test_mul_mat_prefill_mfma(name, m, k, n):
     rng = np.random.default_rng(m + k + n)
