@@ -1023,6 +1023,37 @@ static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i
     return j - i + 1;
 }
 
+// Prefill: MUL_MAT(gate) ; MUL_MAT(up) -> GLU(swiglu) on the same many-token activations (build_ffn, src/llama-graph.cpp:646-691) as one
+// matrix-core kernel (mmq.hip DUAL): neither product is written, the GLU kernel is gone and the activation tile is staged once.
+static int try_fused_prefill_glu(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    static const bool on = !getenv("GGML_MI355X_PREFILL_GLU") || atoi(getenv("GGML_MI355X_PREFILL_GLU")) != 0;
+    if (!on) return 0;
+    struct ggml_tensor * n = g->nodes[i];
+    const struct ggml_tensor * a = n->src[0]; const struct ggml_tensor * b = n->src[1];
+    if (!ggml_is_quantized(a->type) || b->type != GGML_TYPE_F32 || b->ne[1] <= MMVQ_MAX_N || b->ne[2] != 1 || b->ne[3] != 1 || a->ne[2] != 1 || a->ne[3] != 1 ||
+        b->nb[0] != 4 || !mul_mat_q_glu_supported(a->ne[1], b->ne[1]) || !is_internal(c, n)) return 0;
+    const int j = next_real(g, i); if (j < 0) return 0;
+    struct ggml_tensor * nx = g->nodes[j];
+    if (nx->op != GGML_OP_MUL_MAT || nx->src[1] != b || nx->src[0]->type != a->type || !ggml_are_same_shape(nx->src[0], a) || nx->src[0]->nb[1] != a->nb[1] ||
+        !is_internal(c, nx)) return 0;
+    const int j2 = next_real(g, j); if (j2 < 0) return 0;
+    struct ggml_tensor * gl = g->nodes[j2];
+    if (gl->op != GGML_OP_GLU || ggml_get_glu_op(gl) != GGML_GLU_OP_SWIGLU || gl->op_params[1] != 0 || gl->src[1] == NULL || gl->type != GGML_TYPE_F32 ||
+        !ggml_is_contiguous(gl) || !((gl->src[0] == nx && gl->src[1] == n) || (gl->src[0] == n && gl->src[1] == nx))) return 0;
+    const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
+    if (mul_mat_q_scratch_bytes(K, N, M) > c->scratch_size) return 0;
+    const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1];
+    prof_begin(c, (int) a->type, 2*M, K, N, (uint64_t) 2*M*ggml_row_size(a->type, K));
+    mul_mat_q_glu((int) a->type, gl->src[0]->src[0]->data, gl->src[1]->src[0]->data, a->nb[1], M, K, (const float *) b->data, b->nb[1], N,
+                  c->scratch, ready, (float *) gl->data, gl->nb[1], c->stream);
+    prof_end(c);
+    if (ready) c->cnt.act_quant_reused++;
+    else c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
+    c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 1 : 2;
+    c->cnt.weight_bytes += (uint64_t) 2*M*ggml_row_size(a->type, K);
+    return j2 - i + 1;
+}
+
 // returns the number of graph nodes consumed (>= 1)
 static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * node = g->nodes[i];
@@ -1038,6 +1069,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0;
             if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
             if (!f) f = try_fused_moe_route(c, g, i);
+            if (!f) f = try_fused_prefill_glu(c, g, i);
         } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
         else if (node->op == GGML_OP_GET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_moe_combine(c, g, i); }
         else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);

@@ -58,6 +58,12 @@ size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m);
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
 
+// gate / up + SwiGLU for many tokens in one kernel: dst[n][m] = silu(Wg.x) * (Wu.x) (both weight tensors of one type and shape);
+// supported when the 256-token tiles fill the chip
+bool mul_mat_q_glu_supported(int64_t m, int64_t n);
+void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_stride, int64_t m, int64_t k,
+                   const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
+
 // ---- MUL_MAT_ID for many tokens (src/llama-graph.cpp:569-595): (token, slot) pairs sorted by expert on the device, then the tiled
 // MFMA kernel per (expert, 128 pairs). b: f32 [k, n_b, n_tokens] (n_b = 1 or n_used); ids: i32 [n_used, n_tokens] (strided);
 // dst: f32 [m, n_used, n_tokens]. No host round trip, so the launch sequence can be captured in a hipGraph.

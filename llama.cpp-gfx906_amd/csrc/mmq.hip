@@ -183,6 +183,7 @@ struct mmq_args {
     int ne12, r2, r3;                          // batch = blockIdx.z = i13*ne12 + i12; weights broadcast: i02 = i12/r2, i03 = i13/r3
     int ksplit, mtiles;                        // ksplit = 2 | 4: blockIdx.y = part*mtiles + m-tile; parts 0,1 atomically add into a zeroed dst,
     char * dst2;                               //   parts 2,3 into the zeroed plane dst2 (same layout): never more than two addends per element
+    const char * W2;                           // DUAL kernel: the second weight tensor (dst = silu(W.x) * (W2.x), build_ffn's gate / up + swiglu)
     // MUL_MAT_ID (grouped by expert): blockIdx.x walks the tile table k_moe_sort wrote; a tile = up to 128 (token, slot) pairs of ONE expert
     const int * moe;                           // NULL, or [0] = n_tiles, then {expert, first, count}[max_tiles], then sorted pair ids
     int moe_max_tiles, n_used, n_b;            // pair = token*n_used + slot; X row of a pair = token*n_b + slot % n_b
@@ -193,10 +194,14 @@ struct mmq_args {
 // BN = tokens per workgroup tile: 128 (4 waves) or 256 (8 waves; the weight tile is dequantized by waves 0-3 only and reused by twice
 // as many MFMAs — with 128 tokens the dequantization VALU work, not the matrix cores, sets the pace: an ablation without any global
 // load still ran at 22 % of the bf16 peak)
-template <int TYPE, int BN = MQ_BN>
+// DUAL (BN = 256 only): two weight tensors against the same activations and their SwiGLU in the epilogue — waves 0-3 dequantize the
+// gate tile, waves 4-7 the up tile (every wave has dequantization work now), every wave multiplies its 64 x 64 token / row tile with
+// both: 32 MFMAs per k-step and wave against one 64-element dequantization, one result tensor instead of two plus a GLU kernel
+template <int TYPE, int BN = MQ_BN, bool DUAL = false>
 __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
-    constexpr int WTILE = MQ_BM*MQ_LD, XTILE = BN*MQ_LD, STAGE = WTILE + XTILE;     // bytes
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile [| W2 tile] | X tile)
+    constexpr int WTILE = MQ_BM*MQ_LD, XTILE = BN*MQ_LD, WT = DUAL ? 2 : 1, STAGE = WT*WTILE + XTILE;     // bytes
+    static_assert(!DUAL || BN == 256, "the dual kernel has 8 waves");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;      // which part of k
     const int m0 = ((int) blockIdx.y - khalf*p.mtiles)*MQ_BM, n0 = blockIdx.x*BN;   // the n-tiles of one weight tile are dispatched together
@@ -215,19 +220,20 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
         moe_pairs = p.moe + 1 + 3*p.moe_max_tiles;
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][2], acc2[DUAL ? 2 : 1][DUAL ? 2 : 1];
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
         for (int j = 0; j < 2; j++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[i][j][r] = 0.0f;
+            for (int r = 0; r < 16; r++) { acc[i][j][r] = 0.0f; if (DUAL) acc2[DUAL ? i : 0][DUAL ? j : 0][r] = 0.0f; }
 
     // staging roles: thread -> (row = tid/2, half = tid&1): 32 of the 64 k of that row — every thread an activation row, the first 256
     // threads (waves 0-3) also a weight row
     const int srow = tid >> 1, shalf = tid & 1;
-    const bool w_role = BN == MQ_BM || tid < 2*MQ_BM;        // wave-uniform
-    const char * wrow_p = W + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*p.w_row_stride;
+    const bool w_role = DUAL || BN == MQ_BM || tid < 2*MQ_BM;        // wave-uniform
+    const int wt = DUAL ? tid >> 8 : 0;                              // DUAL: which weight tile this thread dequantizes
+    const char * wrow_p = (DUAL && wt ? p.W2 : W) + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*p.w_row_stride;
     const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*k;
     if (p.moe) {
         const int pair = moe_pairs[moe_first + min(srow, moe_cnt - 1)];
@@ -255,8 +261,8 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
     };
     auto commit = [&](int step, int buf) {       // decode the staged registers into LDS buffer `buf`
         const int kc = step*MQ_BK + 32*shalf;
-        char * wp = lds + buf*STAGE + (srow & (MQ_BM - 1))*MQ_LD + shalf*64;
-        char * xp = lds + buf*STAGE + WTILE + srow*MQ_LD + shalf*64;
+        char * wp = lds + buf*STAGE + wt*WTILE + (srow & (MQ_BM - 1))*MQ_LD + shalf*64;
+        char * xp = lds + buf*STAGE + WT*WTILE + srow*MQ_LD + shalf*64;
         if (kc >= k) {
 #pragma unroll
             for (int i = 0; i < 4; i++) xv[i] = int4v{ 0, 0, 0, 0 };
@@ -293,15 +299,16 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
     for (int step = 0; step < nsteps; step++) {
         const int buf = step & 1;
         if (step + 1 < nsteps) fetch(step0 + step + 1);  // global loads in flight during the MFMAs below
-        const char * lw = lds + buf*STAGE, * lx = lw + WTILE;
+        const char * lw = lds + buf*STAGE, * lx = lw + WT*WTILE;
         // ---- MFMA: A = activations (rows = tokens), B = weights (cols = weight rows) ----
 #pragma unroll
         for (int kk = 0; kk < MQ_BK/16; kk++) {
-            int4v a[2], b[2];
+            int4v a[2], b[2], b2[2];
 #pragma unroll
             for (int i = 0; i < 2; i++) {
                 a[i] = *(const int4v *) (lx + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
                 b[i] = *(const int4v *) (lw + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+                if (DUAL) b2[i] = *(const int4v *) (lw + WTILE + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
             }
 #pragma unroll
             for (int i = 0; i < 2; i++)
@@ -309,6 +316,7 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
                 for (int j = 0; j < 2; j++) {
                     if (TYPE == T_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
                     else               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
+                    if (DUAL) acc2[DUAL ? i : 0][DUAL ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b2[j]), acc2[DUAL ? i : 0][DUAL ? j : 0], 0, 0, 0);
                 }
         }
         if (step + 1 < nsteps) commit(step0 + step + 1, buf ^ 1);  // the other buffer was last read at step-1: every wave passed the barrier since
@@ -331,7 +339,8 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
                     }
                 } else if (col < m && row < n) {
                     float * o = (float *) (dst + (size_t) row*p.dst_nb1 + (size_t) col*4);
-                    if (p.ksplit > 1) atomicAdd(o, acc[i][j][r]);   // two addends on a zeroed element: the sum does not depend on their order
+                    if (DUAL) { const float g = acc[i][j][r]; *o = (g/(1.0f + expf(-g)))*acc2[DUAL ? i : 0][DUAL ? j : 0][r]; }   // silu(gate)*up, as elem.hip k_glu
+                    else if (p.ksplit > 1) atomicAdd(o, acc[i][j][r]);   // two addends on a zeroed element: the sum does not depend on their order
                     else              *o = acc[i][j][r];
                 }
             }
@@ -341,6 +350,7 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
 
 constexpr size_t MQ_LDS_BYTES = 4*(size_t) MQ_BM*MQ_LD;
 constexpr size_t MQ_LDS_BYTES_256 = 2*(size_t)(MQ_BM + 256)*MQ_LD;
+constexpr size_t MQ_LDS_BYTES_DUAL = 2*(size_t)(2*MQ_BM + 256)*MQ_LD;
 
 // 108 KB of dynamic LDS: more than the 64 KB a kernel gets without asking
 template <int T_>
@@ -372,7 +382,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
-    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, 0, 0 };
+    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
     const int mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     a.mtiles = mtiles;
     // 256-token tiles when they still fill the chip (m = 14336, n = 512: 224 workgroups); else 128-token tiles, and a grid that would
@@ -407,6 +417,39 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
     }
 #undef MI_MMQ
     if (wide4) hipLaunchKernelGGL(k_add_plane, dim3((unsigned)((m*n/4 + 255)/256)), dim3(256), 0, stream, dst, plane, m*n/4);
+}
+
+// gate / up + SwiGLU of build_ffn (src/llama-graph.cpp:632-774) for many tokens: dst[n][m] = silu(Wg.x) * (Wu.x)
+template <int T_>
+static void launch_mmq_dual(dim3 grid, const mmq_args & a, hipStream_t stream) {
+    static const bool once = [] {
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq<T_, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_DUAL));
+        return true;
+    }();
+    (void) once;
+    hipLaunchKernelGGL((k_mmq<T_, 256, true>), grid, dim3(512), MQ_LDS_BYTES_DUAL, stream, a);
+}
+bool mul_mat_q_glu_supported(int64_t m, int64_t n) { return n >= 256 && ((m + MQ_BM - 1)/MQ_BM)*((n + 255)/256) >= 160; }
+void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_stride, int64_t m, int64_t k,
+                   const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
+    if (m == 0 || n == 0) return;
+    uint16_t * xb = (uint16_t *) scratch;
+    if (!scratch_ready) {
+        act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
+        hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
+    }
+    mmq_args a = { (const char *) Wg, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, (const char *) Wu, nullptr, 0, 0, 0 };
+    a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
+    const dim3 grid((unsigned)((n + 255)/256), (unsigned) a.mtiles, 1);
+    switch (type_a) {
+        case T_Q4_0:  launch_mmq_dual<T_Q4_0>(grid, a, stream);  break;
+        case T_Q8_0:  launch_mmq_dual<T_Q8_0>(grid, a, stream);  break;
+        case T_Q4_K:  launch_mmq_dual<T_Q4_K>(grid, a, stream);  break;
+        case T_Q5_K:  launch_mmq_dual<T_Q5_K>(grid, a, stream);  break;
+        case T_Q6_K:  launch_mmq_dual<T_Q6_K>(grid, a, stream);  break;
+        case T_MXFP4: launch_mmq_dual<T_MXFP4>(grid, a, stream); break;
+        default: fprintf(stderr, "mmq_glu: unsupported type %d\n", type_a); abort();
+    }
 }
 
 // ---- MUL_MAT_ID for many tokens: pairs (token, slot) sorted by expert, then the tiled kernel above per (expert, 128 pairs) ----
@@ -459,7 +502,7 @@ void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expe
     hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
     moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, max_tiles, table };
     hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
-    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr,
+    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr,
                    table, max_tiles, (int) n_used, (int) n_b };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     const dim3 grid((unsigned) max_tiles, (unsigned) a.mtiles, 1);
@@ -490,7 +533,7 @@ void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t str
     act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
     hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((p.ne10 + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
-                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, 0, 0, 0 };
+                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
     hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
 }

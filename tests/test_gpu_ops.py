@@ -451,6 +451,41 @@ def test_ffn_at_model_size(t_ff, t_down):
     assert orc.nmse(res[0], res[1]) <= 1e-6
 
 
+@pytest.mark.parametrize("name,ff,k,n,gate_first", [("q4_K", 10240, 512, 512, True), ("q6_K", 10300, 256, 300, False), ("q8_0", 20500, 288, 257, True),
+                                                  ("mxfp4", 10240, 96, 300, True), ("q5_K", 5200, 512, 1000, False), ("q4_0", 10250, 64, 512, True)])
+def test_prefill_gate_up_glu_fused(name, ff, k, n, gate_first):
+    """build_ffn's gate / up / swiglu for many tokens (src/llama-graph.cpp:646-691): with fusion on, one matrix-core kernel computes both
+    products and the SwiGLU (mmq.hip DUAL) — checked against node-by-node execution (same bf16 operands: only expf's argument rounding
+    can differ) and against the oracle's exact product."""
+    rng = np.random.default_rng(ff + k + n)
+    x = rng.uniform(-1, 1, size=(1, 1, n, k)).astype(np.float32)
+    wg = orc.random_blocks(rng, QTYPES[name], (ff,), k, scale=2.0 / np.sqrt(k)); wu = orc.random_blocks(rng, QTYPES[name], (ff,), k, scale=2.0 / np.sqrt(k))
+    res = {}
+    for fusion in (1, 0):
+        be = backend(); be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            xt = ctx.new_tensor(gg.F32, (k, n)); g_ = ctx.new_tensor(QTYPES[name], (k, ff)); u_ = ctx.new_tensor(QTYPES[name], (k, ff))
+            if gate_first:
+                gate = L.ggml_mul_mat(ctx.ctx, g_, xt); up = L.ggml_mul_mat(ctx.ctx, u_, xt)
+            else:
+                up = L.ggml_mul_mat(ctx.ctx, u_, xt); gate = L.ggml_mul_mat(ctx.ctx, g_, xt)
+            act = L.ggml_swiglu_split(ctx.ctx, gate, up)
+            assert ctx.alloc(be)
+            gg.tensor_set(xt, x); gg.tensor_set(g_, wg); gg.tensor_set(u_, wu)
+            c0 = be.counters()
+            be.compute(gg.graph_of(ctx, act))
+            c1 = be.counters()
+            res[fusion] = gg.tensor_get(act)[0, 0].copy()
+        be.set_option("fusion", 1)
+        if fusion:
+            assert c1["mmq_launches"] - c0["mmq_launches"] == 1, "the gate / up / swiglu chain did not run as one kernel"
+    exact = ref.swiglu(orc.mul_mat_2d(wg, QTYPES[name], x[0, 0], "exact"), orc.mul_mat_2d(wu, QTYPES[name], x[0, 0], "exact")).astype(np.float32)
+    assert np.isfinite(res[1]).all()
+    assert orc.nmse(exact, res[1]) <= 5e-4
+    assert orc.nmse(exact, res[1]) <= 5e-5, orc.nmse(exact, res[1])
+    assert orc.nmse(res[0], res[1]) <= 1e-9, orc.nmse(res[0], res[1])
+
+
 @pytest.mark.parametrize("name", ["q8_0", "q4_0"])
 @pytest.mark.parametrize("ne0,rows,r,b", [(256, 5, 1, 1), (256, 11, 7, 3), (96, 3, 2, 7), (1024, 64, 5, 1)])
 def test_set_rows_quantized_dst(name, ne0, rows, r, b):
