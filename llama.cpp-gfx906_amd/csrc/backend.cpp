@@ -480,7 +480,7 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             }
             if (s > need) need = s;
         } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16 && n->src[1]->type == GGML_TYPE_F32 && n->src[1]->ne[1] > MMVQ_MAX_N) {
-            const size_t s = (size_t) ggml_nelements(n->src[1])*2 + 256;     // f16 copy of src1 for the matrix-core attention products
+            const size_t s = (size_t)((n->src[1]->ne[0] + 63) & ~(int64_t) 63)*(size_t) ggml_nrows(n->src[1])*2 + 1024;     // f16 copy of src1 (rows padded to 64) for the matrix-core attention products
             if (s > need) need = s;
         }
     }

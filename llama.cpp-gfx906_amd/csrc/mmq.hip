@@ -18,6 +18,8 @@
 #include "dev_common.h"
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace mi355x {
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -34,19 +36,22 @@ static __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{ a, b }, bf16x2_t));
 }
 
-// ---- f32 -> bf16 / f16 activation pre-pass: strided f32 rows -> dense [batch][n][k] 16-bit ----
+// ---- f32 -> bf16 / f16 activation pre-pass: strided f32 rows -> dense [batch][n][kp] 16-bit, kp = k rounded up to the 64-wide k-step
+//      and the tail filled with zeros (the mat-mul kernel then needs no k-tail handling for its activations) ----
+static __host__ __device__ __forceinline__ int64_t mmq_kp(int64_t k) { return (k + 63) & ~(int64_t) 63; }
 struct act16_args { const char * x; size_t nb1, nb2, nb3; int64_t k, n, ne2; uint16_t * y; };
 template <bool F16>
 __global__ void __launch_bounds__(256) k_act_to_16(const act16_args p) {
     const int64_t row = blockIdx.y, bz = blockIdx.z;
     const int64_t i2 = bz % p.ne2, i3 = bz / p.ne2;
     const int64_t i0 = ((int64_t) blockIdx.x*256 + threadIdx.x)*4;
-    if (i0 >= p.k) return;
-    const float4v v = __builtin_bit_cast(float4v, ld_b128(p.x + row*p.nb1 + i2*p.nb2 + i3*p.nb3 + i0*4));
+    const int64_t kp = mmq_kp(p.k);
+    if (i0 >= kp) return;
+    const float4v v = i0 < p.k ? __builtin_bit_cast(float4v, ld_b128(p.x + row*p.nb1 + i2*p.nb2 + i3*p.nb3 + i0*4)) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
     uint2 o;
     if (F16) { o.x = (uint32_t) f32_to_f16_bits(v.x) | ((uint32_t) f32_to_f16_bits(v.y) << 16); o.y = (uint32_t) f32_to_f16_bits(v.z) | ((uint32_t) f32_to_f16_bits(v.w) << 16); }
     else     { o.x = pack_bf16(v.x, v.y); o.y = pack_bf16(v.z, v.w); }
-    *(uint2 *) (p.y + (bz*p.n + row)*p.k + i0) = o;
+    *(uint2 *) (p.y + (bz*p.n + row)*kp + i0) = o;
 }
 
 // ---- 32 consecutive elements [c32*32, c32*32 + 32) of one weight row, in two steps so that the loads of the NEXT k-step can
@@ -54,54 +59,61 @@ __global__ void __launch_bounds__(256) k_act_to_16(const act16_args p) {
 struct raw32 { int4v v[5]; uint32_t s; };
 
 static __device__ __forceinline__ void k4_sc_m(const uint32_t (&hw)[4], int j, float & sc, float & m) {   // quants.py:479-501
-    // the 12 scale bytes are hw[1..3]; byte i = (hw[1 + i/4] >> 8*(i%4)) & 0xFF
-    auto byte = [&](int i) -> uint32_t { const uint32_t w = i < 4 ? hw[1] : (i < 8 ? hw[2] : hw[3]); return (w >> (8*(i & 3))) & 0xFF; };
-    if (j < 4) { sc = (float)(byte(j) & 63); m = (float)(byte(j + 4) & 63); }
-    else { sc = (float)((byte(j + 4) & 0xF) | ((byte(j - 4) >> 6) << 4)); m = (float)((byte(j + 4) >> 4) | ((byte(j) >> 6) << 4)); }
+    // the 12 scale bytes are hw[1..3]. Branch-free (a branch here would split the block the MFMAs and the decode are interleaved in):
+    // with a, b, c = byte (j & 3) of hw[1], hw[2], hw[3]: j < 4: sc = a & 63, m = b & 63; else sc = (c & 15) | (a >> 6) << 4, m = (c >> 4) | (b >> 6) << 4
+    const int sh = 8*(j & 3);
+    const uint32_t a = (hw[1] >> sh) & 0xFF, b = (hw[2] >> sh) & 0xFF, c = (hw[3] >> sh) & 0xFF;
+    const uint32_t hi = 0u - (uint32_t)((j >> 2) & 1);      // all ones for j >= 4; bit-select, not ?: (which the compiler turns back into a branch)
+    const uint32_t s6 = ((a & 63) & ~hi) | (((c & 0xF) | ((a >> 6) << 4)) & hi);
+    const uint32_t m6 = ((b & 63) & ~hi) | (((c >> 4)  | ((b >> 6) << 4)) & hi);
+    sc = (float) s6; m = (float) m6;
 }
 
+// dq_head = what is common to the 32 elements (scales), decode4 = elements [4*wi, 4*wi + 4) of the chunk, wi = 0..7 a compile-time
+// constant: the kernel spreads the eight pieces of a chunk between its MFMAs
+struct dq_head { float a, b; };
 template <int TYPE> static __device__ __forceinline__ raw32 load_raw32(const char * row, int c32);
-template <int TYPE> static __device__ __forceinline__ void decode32(const raw32 & r, int c32, float (&o)[32]);
+template <int TYPE> static __device__ __forceinline__ dq_head decode_head(const raw32 & r, int c32);
+template <int TYPE> static __device__ __forceinline__ void decode4(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]);
 
-// Q4_0 — quants.py:241-251
+static __device__ __forceinline__ uint32_t raw_word(const raw32 & r, int i) {      // 32-bit word i of the 16-byte vectors, i a constant
+    const int4v v = r.v[i >> 2];
+    return (uint32_t) ((i & 3) == 0 ? v.x : (i & 3) == 1 ? v.y : (i & 3) == 2 ? v.z : v.w);
+}
+
+// Q4_0 — quants.py:241-251: element j < 16 = low nibble of byte j, element 16 + j = high nibble
 template <> __device__ __forceinline__ raw32 load_raw32<T_Q4_0>(const char * row, int c32) {
     raw32 r; const char * b = row + (size_t) c32*18; r.s = ld_u16(b); r.v[0] = ld_b128(b + 2); return r;
 }
-template <> __device__ __forceinline__ void decode32<T_Q4_0>(const raw32 & r, int, float (&o)[32]) {
-    const float d = f16_bits_to_f32((uint16_t) r.s);
-    const uint32_t w[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
+template <> __device__ __forceinline__ dq_head decode_head<T_Q4_0>(const raw32 & r, int) { return { f16_bits_to_f32((uint16_t) r.s), 0.0f }; }
+template <> __device__ __forceinline__ void decode4<T_Q4_0>(const raw32 & r, const dq_head & h, int, int wi, float (&o)[4]) {
+    const uint32_t q4 = (raw_word(r, wi & 3) >> (4*(wi >> 2))) & 0x0F0F0F0Fu;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t byte = (w[j >> 2] >> (8*(j & 3))) & 0xFF;
-        o[j] = (float)((int)(byte & 0xF) - 8)*d;
-        o[j + 16] = (float)((int)(byte >> 4) - 8)*d;
-    }
+    for (int b = 0; b < 4; b++) o[b] = (float)((int)((q4 >> (8*b)) & 0xFF) - 8)*h.a;
 }
 // Q8_0 — quants.py:396-401
 template <> __device__ __forceinline__ raw32 load_raw32<T_Q8_0>(const char * row, int c32) {
     raw32 r; const char * b = row + (size_t) c32*34; r.s = ld_u16(b); r.v[0] = ld_b128(b + 2); r.v[1] = ld_b128(b + 18); return r;
 }
-template <> __device__ __forceinline__ void decode32<T_Q8_0>(const raw32 & r, int, float (&o)[32]) {
-    const float d = f16_bits_to_f32((uint16_t) r.s);
-    const uint32_t w[8] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w, (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w };
+template <> __device__ __forceinline__ dq_head decode_head<T_Q8_0>(const raw32 & r, int) { return { f16_bits_to_f32((uint16_t) r.s), 0.0f }; }
+template <> __device__ __forceinline__ void decode4<T_Q8_0>(const raw32 & r, const dq_head & h, int, int wi, float (&o)[4]) {
+    const uint32_t w = raw_word(r, wi);
 #pragma unroll
-    for (int j = 0; j < 32; j++) o[j] = (float)(int8_t)((w[j >> 2] >> (8*(j & 3))) & 0xFF)*d;
+    for (int b = 0; b < 4; b++) o[b] = (float)(int8_t)((w >> (8*b)) & 0xFF)*h.a;
 }
-// MXFP4 — quants.py:656-700
+// MXFP4 — quants.py:656-700: nibble order as Q4_0; kvalues (quants.py:659): magnitude by the low 3 bits, sign by bit 3
 template <> __device__ __forceinline__ raw32 load_raw32<T_MXFP4>(const char * row, int c32) {
     raw32 r; const char * b = row + (size_t) c32*17; r.s = *(const uint8_t *) b; r.v[0] = ld_b128(b + 1); return r;
 }
-template <> __device__ __forceinline__ void decode32<T_MXFP4>(const raw32 & r, int, float (&o)[32]) {
-    const float d = e8m0_to_f32_half(r.s);
-    const uint32_t w[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
-    const uint64_t mag = 0x0C08060403020100ull;   // kvalues (quants.py:659): magnitude by the low 3 bits, sign by bit 3
+template <> __device__ __forceinline__ dq_head decode_head<T_MXFP4>(const raw32 & r, int) { return { e8m0_to_f32_half(r.s), 0.0f }; }
+template <> __device__ __forceinline__ void decode4<T_MXFP4>(const raw32 & r, const dq_head & h, int, int wi, float (&o)[4]) {
+    const uint32_t q4 = (raw_word(r, wi & 3) >> (4*(wi >> 2))) & 0x0F0F0F0Fu;
+    const uint64_t mag = 0x0C08060403020100ull;
 #pragma unroll
-    for (int j = 0; j < 16; j++) {
-        const uint32_t byte = (w[j >> 2] >> (8*(j & 3))) & 0xFF;
-        const uint32_t lo = byte & 0xF, hi = byte >> 4;
-        const float vl = (float)((mag >> (8*(lo & 7))) & 0xFF), vh = (float)((mag >> (8*(hi & 7))) & 0xFF);
-        o[j] = ((lo & 8) ? -vl : vl)*d;
-        o[j + 16] = ((hi & 8) ? -vh : vh)*d;
+    for (int b = 0; b < 4; b++) {
+        const uint32_t q = (q4 >> (8*b)) & 0xFF;
+        const float v = (float)((mag >> (8*(q & 7))) & 0xFF)*h.a;
+        o[b] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ ((q & 8) << 28));      // -v for the upper half of the table
     }
 }
 // Q4_K — quants.py:504-522
@@ -109,21 +121,18 @@ template <> __device__ __forceinline__ raw32 load_raw32<T_Q4_K>(const char * row
     raw32 r; const int sb = c32 & 7; const char * b = row + (size_t)(c32 >> 3)*144;
     r.v[0] = *(const int4v *) b; r.v[1] = *(const int4v *) (b + 16 + 32*(sb >> 1)); r.v[2] = *(const int4v *) (b + 32 + 32*(sb >> 1)); r.s = 0; return r;
 }
-template <> __device__ __forceinline__ void decode32<T_Q4_K>(const raw32 & r, int c32, float (&o)[32]) {
-    const int sb = c32 & 7;
+static __device__ __forceinline__ dq_head k45_head(const raw32 & r, int c32) {
     const uint32_t hw[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
     const float d = f16_bits_to_f32((uint16_t)(hw[0] & 0xFFFF)), dmin = f16_bits_to_f32((uint16_t)(hw[0] >> 16));
-    float sc, m; k4_sc_m(hw, sb, sc, m);
-    const float d1 = d*sc, m1 = dmin*m;
-    const uint32_t w[8] = { (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w, (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w };
-    const int sh = (sb & 1)*4;
+    float sc, m; k4_sc_m(hw, c32 & 7, sc, m);
+    return { d*sc, dmin*m };
+}
+template <> __device__ __forceinline__ dq_head decode_head<T_Q4_K>(const raw32 & r, int c32) { return k45_head(r, c32); }
+template <> __device__ __forceinline__ void decode4<T_Q4_K>(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]) {
     // word-wise: one shift + mask per 4 nibbles, then v_cvt_f32_ubyte{0..3} straight from the masked word
+    const uint32_t q4 = (raw_word(r, 4 + wi) >> ((c32 & 1)*4)) & 0x0F0F0F0Fu;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-        const uint32_t q4 = (w[i] >> sh) & 0x0F0F0F0Fu;
-#pragma unroll
-        for (int b = 0; b < 4; b++) o[4*i + b] = d1*(float)((q4 >> (8*b)) & 0xFF) - m1;
-    }
+    for (int b = 0; b < 4; b++) o[b] = h.a*(float)((q4 >> (8*b)) & 0xFF) - h.b;
 }
 // Q5_K — quants.py:527-549
 template <> __device__ __forceinline__ raw32 load_raw32<T_Q5_K>(const char * row, int c32) {
@@ -131,21 +140,12 @@ template <> __device__ __forceinline__ raw32 load_raw32<T_Q5_K>(const char * row
     r.v[0] = *(const int4v *) b; r.v[1] = *(const int4v *) (b + 16); r.v[2] = *(const int4v *) (b + 32);
     r.v[3] = *(const int4v *) (b + 48 + 32*(sb >> 1)); r.v[4] = *(const int4v *) (b + 64 + 32*(sb >> 1)); r.s = 0; return r;
 }
-template <> __device__ __forceinline__ void decode32<T_Q5_K>(const raw32 & r, int c32, float (&o)[32]) {
-    const int sb = c32 & 7;
-    const uint32_t hw[4] = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w };
-    const float d = f16_bits_to_f32((uint16_t)(hw[0] & 0xFFFF)), dmin = f16_bits_to_f32((uint16_t)(hw[0] >> 16));
-    float sc, m; k4_sc_m(hw, sb, sc, m);
-    const float d1 = d*sc, m1 = dmin*m;
-    const uint32_t qh[8] = { (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w, (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w };
-    const uint32_t w[8]  = { (uint32_t) r.v[3].x, (uint32_t) r.v[3].y, (uint32_t) r.v[3].z, (uint32_t) r.v[3].w, (uint32_t) r.v[4].x, (uint32_t) r.v[4].y, (uint32_t) r.v[4].z, (uint32_t) r.v[4].w };
-    const int sh = (sb & 1)*4;
+template <> __device__ __forceinline__ dq_head decode_head<T_Q5_K>(const raw32 & r, int c32) { return k45_head(r, c32); }
+template <> __device__ __forceinline__ void decode4<T_Q5_K>(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]) {
+    const int sb = c32 & 7;      // word-wise: 4 quants per word = low nibbles | (bit sb of the qh bytes) << 4
+    const uint32_t q5 = ((raw_word(r, 12 + wi) >> ((sb & 1)*4)) & 0x0F0F0F0Fu) | (((raw_word(r, 4 + wi) >> sb) & 0x01010101u) << 4);
 #pragma unroll
-    for (int i = 0; i < 8; i++) {      // word-wise: 4 quants per word = low nibbles | (bit sb of the qh bytes) << 4
-        const uint32_t q5 = ((w[i] >> sh) & 0x0F0F0F0Fu) | (((qh[i] >> sb) & 0x01010101u) << 4);
-#pragma unroll
-        for (int b = 0; b < 4; b++) o[4*i + b] = d1*(float)((q5 >> (8*b)) & 0xFF) - m1;
-    }
+    for (int b = 0; b < 4; b++) o[b] = h.a*(float)((q5 >> (8*b)) & 0xFF) - h.b;
 }
 // Q6_K — quants.py:554-572. chunk c of a 256-superblock: half n = c>>2, quarter pq = c&3: elements 128n + 32pq + l
 template <> __device__ __forceinline__ raw32 load_raw32<T_Q6_K>(const char * row, int c32) {
@@ -155,20 +155,16 @@ template <> __device__ __forceinline__ raw32 load_raw32<T_Q6_K>(const char * row
     r.s = (uint32_t) ld_u16(b + 208) | ((uint32_t) ld_u16(b + 192 + 8*n + 2*pq) << 16);
     return r;
 }
-template <> __device__ __forceinline__ void decode32<T_Q6_K>(const raw32 & r, int c32, float (&o)[32]) {
-    const int pq = c32 & 3;
+template <> __device__ __forceinline__ dq_head decode_head<T_Q6_K>(const raw32 & r, int) {
     const float d = f16_bits_to_f32((uint16_t)(r.s & 0xFFFF));
-    const float s0 = d*(float)(int8_t)((r.s >> 16) & 0xFF), s1 = d*(float)(int8_t)(r.s >> 24);
-    const uint32_t w[8]  = { (uint32_t) r.v[0].x, (uint32_t) r.v[0].y, (uint32_t) r.v[0].z, (uint32_t) r.v[0].w, (uint32_t) r.v[1].x, (uint32_t) r.v[1].y, (uint32_t) r.v[1].z, (uint32_t) r.v[1].w };
-    const uint32_t qh[8] = { (uint32_t) r.v[2].x, (uint32_t) r.v[2].y, (uint32_t) r.v[2].z, (uint32_t) r.v[2].w, (uint32_t) r.v[3].x, (uint32_t) r.v[3].y, (uint32_t) r.v[3].z, (uint32_t) r.v[3].w };
-    const int sh = (pq >> 1)*4, hs = 2*pq;
+    return { d*(float)(int8_t)((r.s >> 16) & 0xFF), d*(float)(int8_t)(r.s >> 24) };
+}
+template <> __device__ __forceinline__ void decode4<T_Q6_K>(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]) {
+    const int pq = c32 & 3;      // word-wise: 4 quants per word = low nibbles | (2 bits of the qh bytes) << 4, each 0..63
+    const uint32_t q6 = ((raw_word(r, wi) >> ((pq >> 1)*4)) & 0x0F0F0F0Fu) | (((raw_word(r, 8 + wi) >> (2*pq)) & 0x03030303u) << 4);
+    const float sc = wi < 4 ? h.a : h.b;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {      // word-wise: 4 quants per word = low nibbles | (2 bits of the qh bytes) << 4, each 0..63
-        const uint32_t q6 = ((w[i] >> sh) & 0x0F0F0F0Fu) | (((qh[i] >> hs) & 0x03030303u) << 4);
-        const float sc = i < 4 ? s0 : s1;
-#pragma unroll
-        for (int b = 0; b < 4; b++) o[4*i + b] = sc*(float)((int)((q6 >> (8*b)) & 0xFF) - 32);
-    }
+    for (int b = 0; b < 4; b++) o[b] = sc*(float)((int)((q6 >> (8*b)) & 0xFF) - 32);
 }
 
 // ---- the tiled kernel ----
@@ -198,7 +194,8 @@ struct mmq_args {
 // gate tile, waves 4-7 the up tile (every wave has dequantization work now), every wave multiplies its 64 x 64 token / row tile with
 // both: 32 MFMAs per k-step and wave against one 64-element dequantization, one result tensor instead of two plus a GLU kernel
 template <int TYPE, int BN = MQ_BN, bool DUAL = false>
-__global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
+__global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mmq(const mmq_args p) {   // LDS allows 8 waves per CU anyway; without the
+    // occupancy pin the scheduler reverts the interleaved order below to keep a third wave's worth of registers free
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile [| W2 tile] | X tile)
     constexpr int WTILE = MQ_BM*MQ_LD, XTILE = BN*MQ_LD, WT = DUAL ? 2 : 1, STAGE = WT*WTILE + XTILE;     // bytes
     static_assert(!DUAL || BN == 256, "the dual kernel has 8 waves");
@@ -209,7 +206,8 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
     const int m = p.m, n = p.n, k = p.k;
     const int i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
     const char * W = p.W + (size_t)(i12/p.r2)*p.w_nb2 + (size_t)(i13/p.r3)*p.w_nb3;
-    const uint16_t * X = p.X + (size_t) blockIdx.z*n*k;
+    const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);               // row length of the activation copy (zero-padded)
+    const uint16_t * X = p.X + (size_t) blockIdx.z*n*kp;
     char * dst = (khalf >= 2 ? p.dst2 : p.dst) + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
     int moe_first = 0, moe_cnt = 0;
     const int * moe_pairs = nullptr;
@@ -234,94 +232,120 @@ __global__ void __launch_bounds__(BN*2) k_mmq(const mmq_args p) {
     const bool w_role = DUAL || BN == MQ_BM || tid < 2*MQ_BM;        // wave-uniform
     const int wt = DUAL ? tid >> 8 : 0;                              // DUAL: which weight tile this thread dequantizes
     const char * wrow_p = (DUAL && wt ? p.W2 : W) + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*p.w_row_stride;
-    const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*k;
+    const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*kp;
     if (p.moe) {
         const int pair = moe_pairs[moe_first + min(srow, moe_cnt - 1)];
-        xrow_p = p.X + (size_t)((pair/p.n_used)*p.n_b + (pair % p.n_used) % p.n_b)*k;
+        xrow_p = p.X + (size_t)((pair/p.n_used)*p.n_b + (pair % p.n_used) % p.n_b)*kp;
     }
     // split-K: each half walks k/2 (a multiple of 256, so block boundaries stay aligned); steps are counted from step0
     const int nsteps_all = (k + MQ_BK - 1)/MQ_BK;
     const int nsteps = p.ksplit > 1 ? nsteps_all/p.ksplit : nsteps_all;
     const int step0 = khalf*nsteps;
 
-    // register stage: raw weight bytes + 32 activations of the NEXT k-step (addresses clamped, results discarded past k)
-    raw32 rw; int4v xv[4]; int4v wf[4];
-    auto fetch = [&](int step) {
-        const int kc = min(step*MQ_BK + 32*shalf, k - 32);
-        if (w_role) {
-            if (TYPE == T_F16) {
-#pragma unroll
-                for (int i = 0; i < 4; i++) wf[i] = ld_b128(wrow_p + (size_t) kc*2 + 16*i);
-            } else {
-                rw = load_raw32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kc >> 5);
-            }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) xv[i] = ld_b128((const char *) (xrow_p + kc) + 16*i);
-    };
-    auto commit = [&](int step, int buf) {       // decode the staged registers into LDS buffer `buf`
-        const int kc = step*MQ_BK + 32*shalf;
-        char * wp = lds + buf*STAGE + wt*WTILE + (srow & (MQ_BM - 1))*MQ_LD + shalf*64;
-        char * xp = lds + buf*STAGE + WT*WTILE + srow*MQ_LD + shalf*64;
-        if (kc >= k) {
-#pragma unroll
-            for (int i = 0; i < 4; i++) xv[i] = int4v{ 0, 0, 0, 0 };
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) *(int4v *) (xp + 16*i) = xv[i];
-        if (w_role) {
-            int4v wpk[4];
-            if (kc < k) {
+    // Software pipeline, two register stages: iteration s issues the global loads of step s+2, runs the MFMAs of step s from one LDS
+    // buffer and — interleaved with them instruction by instruction (sched_group_barrier) — decodes step s+1 (loaded one iteration
+    // ago, so nothing waits on memory) into the other buffer. Lock-step phases (all waves decode, then all waves multiply) left the
+    // matrix cores idle during the decode and the VALU idle during the MFMAs: ~5400 clocks per k-step against 1024 of MFMA work.
+    // Every iteration is the same straight-line block: steps past the end are fetched from clamped addresses and committed to a
+    // buffer nobody reads; in a k tail (k % 64 == 32) the activation copy holds zeros, so the clamped (finite) weights drop out.
+    struct stage_regs { raw32 rw; int4v xv[4]; };
+    auto run = [&](auto w_role_tag) {
+        constexpr bool WR = decltype(w_role_tag)::value;
+        auto fetch = [&](stage_regs & r, int step) {
+            const int kc = step*MQ_BK + 32*shalf, kcl = min(kc, k - 32);
+            if (WR) {
                 if (TYPE == T_F16) {
 #pragma unroll
-                    for (int i = 0; i < 4; i++) wpk[i] = wf[i];
+                    for (int i = 0; i < 4; i++) r.rw.v[i] = ld_b128(wrow_p + (size_t) kcl*2 + 16*i);
                 } else {
-                    float wv[32];
-                    decode32<TYPE == T_F16 ? T_Q8_0 : TYPE>(rw, kc >> 5, wv);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        wpk[i].x = (int) pack_bf16(wv[8*i + 0], wv[8*i + 1]); wpk[i].y = (int) pack_bf16(wv[8*i + 2], wv[8*i + 3]);
-                        wpk[i].z = (int) pack_bf16(wv[8*i + 4], wv[8*i + 5]); wpk[i].w = (int) pack_bf16(wv[8*i + 6], wv[8*i + 7]);
-                    }
+                    r.rw = load_raw32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kcl >> 5);
                 }
-            } else {
-#pragma unroll
-                for (int i = 0; i < 4; i++) wpk[i] = int4v{ 0, 0, 0, 0 };
             }
 #pragma unroll
-            for (int i = 0; i < 4; i++) *(int4v *) (wp + 16*i) = wpk[i];
-        }
-    };
-
-    fetch(step0);
-    commit(step0, 0);
-    __syncthreads();
-    for (int step = 0; step < nsteps; step++) {
-        const int buf = step & 1;
-        if (step + 1 < nsteps) fetch(step0 + step + 1);  // global loads in flight during the MFMAs below
-        const char * lw = lds + buf*STAGE, * lx = lw + WT*WTILE;
-        // ---- MFMA: A = activations (rows = tokens), B = weights (cols = weight rows) ----
-#pragma unroll
-        for (int kk = 0; kk < MQ_BK/16; kk++) {
-            int4v a[2], b[2], b2[2];
+            for (int i = 0; i < 4; i++) r.xv[i] = ld_b128((const char *) (xrow_p + min(kc, kp - 32)) + 16*i);
+        };
+        // one eighth of a thread's staging work for step `step`: 16 bytes of activations into LDS, 8 weights decoded, packed and stored
+        auto commit_piece = [&](const stage_regs & r, const dq_head & h, int step, int buf, int g) {
+            const int kcl = min(step*MQ_BK + 32*shalf, k - 32);
+            char * wp = lds + buf*STAGE + wt*WTILE + (srow & (MQ_BM - 1))*MQ_LD + shalf*64;
+            char * xp = lds + buf*STAGE + WT*WTILE + srow*MQ_LD + shalf*64;
+            *(int4v *) (xp + 16*g) = r.xv[g];
+            if (WR) {
+                int4v wpk;
+                if (TYPE == T_F16) {
+                    wpk = r.rw.v[g];
+                } else {
+                    float lo[4], hi[4];
+                    decode4<TYPE == T_F16 ? T_Q8_0 : TYPE>(r.rw, h, kcl >> 5, 2*g, lo);
+                    decode4<TYPE == T_F16 ? T_Q8_0 : TYPE>(r.rw, h, kcl >> 5, 2*g + 1, hi);
+                    wpk.x = (int) pack_bf16(lo[0], lo[1]); wpk.y = (int) pack_bf16(lo[2], lo[3]);
+                    wpk.z = (int) pack_bf16(hi[0], hi[1]); wpk.w = (int) pack_bf16(hi[2], hi[3]);
+                }
+                *(int4v *) (wp + 16*g) = wpk;
+            }
+        };
+        auto head_of = [&](const stage_regs & r, int step) -> dq_head {
+            if (!WR || TYPE == T_F16) return { 0.0f, 0.0f };
+            return decode_head<TYPE == T_F16 ? T_Q8_0 : TYPE>(r.rw, min(step*MQ_BK + 32*shalf, k - 32) >> 5);
+        };
+        struct frags { int4v a[2], b[2], b2[DUAL ? 2 : 1]; };
+        // A = activations (rows = tokens), B = weights (cols = weight rows)
+        auto read_frags = [&](frags & f, int buf, int kk) {
+            const char * lw = lds + buf*STAGE, * lx = lw + WT*WTILE;
 #pragma unroll
             for (int i = 0; i < 2; i++) {
-                a[i] = *(const int4v *) (lx + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
-                b[i] = *(const int4v *) (lw + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
-                if (DUAL) b2[i] = *(const int4v *) (lw + WTILE + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+                f.a[i] = *(const int4v *) (lx + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+                f.b[i] = *(const int4v *) (lw + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+                if (DUAL) f.b2[DUAL ? i : 0] = *(const int4v *) (lw + WTILE + (wm*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
             }
+        };
+        auto mfma_row = [&](const frags & f, int i) {       // the MFMAs of token sub-tile i: 2 (4 with the second weight tile)
 #pragma unroll
-            for (int i = 0; i < 2; i++)
+            for (int j = 0; j < 2; j++) {
+                if (TYPE == T_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i]), __builtin_bit_cast(f16x8, f.b[j]), acc[i][j], 0, 0, 0);
+                else               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
+                if (DUAL) acc2[DUAL ? i : 0][DUAL ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b2[DUAL ? j : 0]), acc2[DUAL ? i : 0][DUAL ? j : 0], 0, 0, 0);
+            }
+        };
+        // The order is pinned by hand (sched_barrier(0): nothing crosses): the scheduler left to itself — and sched_group_barrier
+        // pipelines were not honoured here — puts all MFMAs first and the whole decode after them.
+        auto iteration = [&](stage_regs & cur, stage_regs & nxt, int s, int buf) {
+            fetch(nxt, step0 + s + 2);
+            const dq_head h = head_of(cur, step0 + s + 1);
+            frags f0, f1;       // operand fragments, read one k-slice ahead (the dual kernel has no registers left for that)
+            if (!DUAL) read_frags(f0, buf, 0);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int j = 0; j < 2; j++) {
-                    if (TYPE == T_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a[i]), __builtin_bit_cast(f16x8, b[j]), acc[i][j], 0, 0, 0);
-                    else               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b[j]), acc[i][j], 0, 0, 0);
-                    if (DUAL) acc2[DUAL ? i : 0][DUAL ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a[i]), __builtin_bit_cast(bf16x8, b2[j]), acc2[DUAL ? i : 0][DUAL ? j : 0], 0, 0, 0);
-                }
+            for (int kk = 0; kk < MQ_BK/16; kk++) {
+                frags & f = (!DUAL && (kk & 1)) ? f1 : f0; frags & fn = (kk & 1) ? f0 : f1;
+                if (DUAL) read_frags(f, buf, kk);
+                else if (kk + 1 < MQ_BK/16) read_frags(fn, buf, kk + 1);
+                mfma_row(f, 0);
+                if (!DUAL) { __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); }
+                else       { commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage_regs p0, p1;
+        fetch(p0, step0);
+        fetch(p1, step0 + 1);
+        {
+            const dq_head h = head_of(p0, step0);
+#pragma unroll
+            for (int g = 0; g < 4; g++) commit_piece(p0, h, step0, 0, g);
         }
-        if (step + 1 < nsteps) commit(step0 + step + 1, buf ^ 1);  // the other buffer was last read at step-1: every wave passed the barrier since
         __syncthreads();
-    }
+        __builtin_amdgcn_sched_barrier(0);
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            iteration(p1, p0, s, 0);
+            iteration(p0, p1, s + 1, 1);
+        }
+        if (s < nsteps) iteration(p1, p0, s, 0);
+    };
+    if (w_role) run(std::true_type{}); else run(std::false_type{});
     // ---- store: D[row = token][col = weight row]; col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) ----
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -363,7 +387,7 @@ static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
     hipLaunchKernelGGL((k_mmq<T_, 256>), grid, dim3(512), MQ_LDS_BYTES_256, stream, a);
 }
 
-static size_t mmq_x_bytes(int64_t k, int64_t n) { return ((size_t) n*k*2 + 255) & ~(size_t) 255; }
+static size_t mmq_x_bytes(int64_t k, int64_t n) { return ((size_t) n*mmq_kp(k)*2 + 255) & ~(size_t) 255; }
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m) { return mmq_x_bytes(k, n) + (size_t) m*n*4 + 512; }     // bf16 copy of x | second plane of a 4-way split-K
 
 __global__ void __launch_bounds__(256) k_add_plane(float * dst, const float * plane, int64_t n4) {
@@ -380,7 +404,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
     uint16_t * xb = (uint16_t *) scratch;
     if (!scratch_ready) {
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
-        hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
+        hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
     mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
     const int mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
@@ -436,7 +460,7 @@ void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_st
     uint16_t * xb = (uint16_t *) scratch;
     if (!scratch_ready) {
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
-        hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
+        hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
     mmq_args a = { (const char *) Wg, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, (const char *) Wu, nullptr, 0, 0, 0 };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
@@ -487,7 +511,7 @@ __global__ void __launch_bounds__(256) k_moe_sort(const moe_sort_args p) {
 static int moe_max_tiles(int64_t n_pairs, int64_t n_expert) { return (int)(n_pairs/MQ_BN + n_expert); }
 bool mul_mat_q_id_supported(int64_t n_expert, int64_t n_used, int64_t n_tokens) { return n_expert <= 256 && n_used*n_tokens < (1 << 24); }
 size_t mul_mat_q_id_scratch_bytes(int64_t k, int64_t n_b, int64_t n_tokens, int64_t n_used, int64_t n_expert) {
-    return (((size_t) k*n_b*n_tokens*2 + 255) & ~(size_t) 255) + (size_t)(1 + 3*moe_max_tiles(n_used*n_tokens, n_expert) + n_used*n_tokens)*4 + 256;
+    return mmq_x_bytes(k, n_b*n_tokens) + (size_t)(1 + 3*moe_max_tiles(n_used*n_tokens, n_expert) + n_used*n_tokens)*4 + 256;
 }
 
 void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
@@ -496,10 +520,10 @@ void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expe
                   void * scratch, float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream) {
     if (m == 0 || n_used*n_tokens == 0) return;
     uint16_t * xb = (uint16_t *) scratch;
-    int * table = (int *) ((char *) scratch + (((size_t) k*n_b*n_tokens*2 + 255) & ~(size_t) 255));
+    int * table = (int *) ((char *) scratch + mmq_x_bytes(k, n_b*n_tokens));
     const int max_tiles = moe_max_tiles(n_used*n_tokens, n_expert);
     act16_args pa = { (const char *) b, b_nb1, b_nb2, 0, k, n_b, n_tokens, xb };     // dense [token][n_b][k] bf16
-    hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((k + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
+    hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
     moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, max_tiles, table };
     hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
     mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr,
@@ -524,14 +548,14 @@ bool mul_mat_dense_mfma_supported(const mm_dense_args & p) {
     return p.type_a == T_F16 && p.type_b == T_F32 && p.nb00 == 2 && p.nb10 == 4 && p.ne11 > MMVQ_MAX_N && p.ne00 % 32 == 0 &&
            p.ne12*p.ne13 <= 65535 && p.ne01 < (1ll << 30) && p.ne11 < (1ll << 30);
 }
-size_t mul_mat_dense_mfma_scratch_bytes(const mm_dense_args & p) { return (size_t) p.ne10*p.ne11*p.ne12*p.ne13*2 + 256; }
+size_t mul_mat_dense_mfma_scratch_bytes(const mm_dense_args & p) { return mmq_x_bytes(p.ne10, p.ne11*p.ne12*p.ne13) + 256; }
 
 void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t stream) {
     if (p.ne01 == 0 || p.ne11 == 0 || p.ne12*p.ne13 == 0) return;
     uint16_t * xb = (uint16_t *) scratch;
     const int64_t nbatch = p.ne12*p.ne13;
     act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
-    hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((p.ne10 + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
+    hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((mmq_kp(p.ne10) + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
                    (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
