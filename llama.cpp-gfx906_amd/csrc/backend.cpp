@@ -504,7 +504,8 @@ static act_q8 get_act(mi_backend_ctx * c, const void * x, int64_t k, int64_t n_i
 
 static constexpr int ACT_KIND_BF16 = -16;   // aq.kind of the dense bf16 copy the MFMA prefill kernel reads
 
-static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
+// out/res: the prefill residual fusion (try_fused_prefill_add) writes W.x + res into `out` instead of W.x into dst
+static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml_tensor * out = nullptr, const struct ggml_tensor * res = nullptr) {
     const struct ggml_tensor * a = dst->src[0];
     const struct ggml_tensor * b = dst->src[1];
     if (ggml_is_quantized(a->type)) {
@@ -525,7 +526,9 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst) {
                     // the scratch holds the bf16 copy of the activations; wq/wk/wv and gate/up read the same ones: convert once
                     const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == bp && c->aq.k == K && c->aq.n_inner == N &&
                                        c->aq.s_inner == b->nb[1];
-                    mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, ready, d, dst->nb[1], c->stream);
+                    if (out) mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, ready, (float *) out->data, out->nb[1],
+                                       (const float *) res->data, res->nb[1], c->stream);
+                    else     mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, ready, d, dst->nb[1], nullptr, 0, c->stream);
                     if (ready) c->cnt.act_quant_reused++;
                     else c->aq = { bp, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
                     c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 0 : 1;
@@ -1054,6 +1057,22 @@ static int try_fused_prefill_glu(mi_backend_ctx * c, struct ggml_cgraph * g, int
     return j2 - i + 1;
 }
 
+// Prefill: MUL_MAT -> ADD(residual) (build_attn's wo, build_ffn's down: src/llama-model.cpp:6057,6096) — the residual is added in the
+// mat-mul's epilogue, or by the pass that combines its split-k planes
+static int try_fused_prefill_add(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * n = g->nodes[i];
+    const struct ggml_tensor * a = n->src[0]; const struct ggml_tensor * b = n->src[1];
+    if (!ggml_is_quantized(a->type) || b->type != GGML_TYPE_F32 || b->ne[1] <= MMVQ_MAX_N || b->ne[2] != 1 || b->ne[3] != 1 || a->ne[2] != 1 || a->ne[3] != 1 ||
+        b->nb[0] != 4 || !is_internal(c, n)) return 0;
+    const int j = next_real(g, i); if (j < 0) return 0;
+    struct ggml_tensor * nx = g->nodes[j];
+    if (nx->op != GGML_OP_ADD || (nx->src[0] != n && nx->src[1] != n) || nx->type != GGML_TYPE_F32 || !ggml_is_contiguous(nx) || !ggml_are_same_shape(nx, n)) return 0;
+    const struct ggml_tensor * other = nx->src[0] == n ? nx->src[1] : nx->src[0];
+    if (other == n || other->type != GGML_TYPE_F32 || !ggml_are_same_shape(other, n) || other->nb[0] != 4) return 0;
+    op_mul_mat(c, n, nx, other);
+    return j - i + 1;
+}
+
 // returns the number of graph nodes consumed (>= 1)
 static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * node = g->nodes[i];
@@ -1070,6 +1089,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
             if (!f) f = try_fused_moe_route(c, g, i);
             if (!f) f = try_fused_prefill_glu(c, g, i);
+            if (!f) f = try_fused_prefill_add(c, g, i);
         } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
         else if (node->op == GGML_OP_GET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_moe_combine(c, g, i); }
         else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);

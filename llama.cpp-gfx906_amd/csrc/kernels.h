@@ -52,11 +52,13 @@ void mul_mat_vec_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_
                       float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream);
 
 // ---- quantized mat-mat (prefill, n > MMVQ_MAX_N): dequantize-to-bf16 tiles in LDS + v_mfma_f32_32x32x16_bf16 ----
-// x: f32 rows of k floats at x + i*x_row_stride; scratch: mul_mat_q_scratch_bytes(k, n, m) bytes (the bf16 copy of x + a split-K plane)
+// x: f32 rows of k floats at x + i*x_row_stride; scratch: mul_mat_q_scratch_bytes(k, n, m) bytes (the bf16 copy of x + the split-K planes)
 // (scratch_ready: it already holds the copy of exactly this x — the caller's cache — so the conversion pass is skipped)
+// res != NULL: dst = W.x + res (f32 rows of m floats at res + i*res_row_stride; may be dst itself) — the residual ADD of build_attn / build_ffn
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m);
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
-               const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
+               const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes,
+               const float * res, size_t res_row_stride, hipStream_t stream);
 
 // gate / up + SwiGLU for many tokens in one kernel: dst[n][m] = silu(Wg.x) * (Wu.x) (both weight tensors of one type and shape);
 // supported when the 256-token tiles fill the chip

@@ -177,8 +177,9 @@ struct mmq_args {
     const uint16_t * X; int n;                 // dense [batch][n][k] 16-bit
     char * dst; size_t dst_nb1, dst_nb2, dst_nb3;
     int ne12, r2, r3;                          // batch = blockIdx.z = i13*ne12 + i12; weights broadcast: i02 = i12/r2, i03 = i13/r3
-    int ksplit, mtiles;                        // ksplit = 2 | 4: blockIdx.y = part*mtiles + m-tile; parts 0,1 atomically add into a zeroed dst,
-    char * dst2;                               //   parts 2,3 into the zeroed plane dst2 (same layout): never more than two addends per element
+    int ksplit, mtiles;                        // ksplit = 2 | 4: blockIdx.y = part*mtiles + m-tile; part i stores its partial product into plane i
+    char * dst2;                               //   of dst2 (dense [n][m] f32 each); k_combine adds the planes in a fixed order: deterministic, nothing to clear
+    const char * res; size_t res_nb1;          // ksplit == 1: f32 rows added to the product in the epilogue (the residual of build_attn / build_ffn), or NULL
     const char * W2;                           // DUAL kernel: the second weight tensor (dst = silu(W.x) * (W2.x), build_ffn's gate / up + swiglu)
     // MUL_MAT_ID (grouped by expert): blockIdx.x walks the tile table k_moe_sort wrote; a tile = up to 128 (token, slot) pairs of ONE expert
     const int * moe;                           // NULL, or [0] = n_tiles, then {expert, first, count}[max_tiles], then sorted pair ids
@@ -208,7 +209,8 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     const char * W = p.W + (size_t)(i12/p.r2)*p.w_nb2 + (size_t)(i13/p.r3)*p.w_nb3;
     const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);               // row length of the activation copy (zero-padded)
     const uint16_t * X = p.X + (size_t) blockIdx.z*n*kp;
-    char * dst = (khalf >= 2 ? p.dst2 : p.dst) + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
+    char * dst = p.ksplit > 1 ? p.dst2 + (size_t) khalf*p.m*p.n*4 : p.dst + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
+    const size_t dst_nb1 = p.ksplit > 1 ? (size_t) p.m*4 : p.dst_nb1;
     int moe_first = 0, moe_cnt = 0;
     const int * moe_pairs = nullptr;
     if (p.moe) {                               // workgroup-uniform
@@ -362,10 +364,10 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
                         *(float *) (p.dst + (size_t)(pair/p.n_used)*p.dst_nb2 + (size_t)(pair % p.n_used)*p.dst_nb1 + (size_t) col*4) = acc[i][j][r];
                     }
                 } else if (col < m && row < n) {
-                    float * o = (float *) (dst + (size_t) row*p.dst_nb1 + (size_t) col*4);
+                    float * o = (float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4);
                     if (DUAL) { const float g = acc[i][j][r]; *o = (g/(1.0f + expf(-g)))*acc2[DUAL ? i : 0][DUAL ? j : 0][r]; }   // silu(gate)*up, as elem.hip k_glu
-                    else if (p.ksplit > 1) atomicAdd(o, acc[i][j][r]);   // two addends on a zeroed element: the sum does not depend on their order
-                    else              *o = acc[i][j][r];
+                    else if (p.res && p.ksplit == 1) *o = acc[i][j][r] + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
+                    else *o = acc[i][j][r];
                 }
             }
         }
@@ -388,45 +390,46 @@ static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
 }
 
 static size_t mmq_x_bytes(int64_t k, int64_t n) { return ((size_t) n*mmq_kp(k)*2 + 255) & ~(size_t) 255; }
-size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m) { return mmq_x_bytes(k, n) + (size_t) m*n*4 + 512; }     // bf16 copy of x | second plane of a 4-way split-K
+size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m) { return mmq_x_bytes(k, n) + (size_t) 4*m*n*4 + 512; }     // bf16 copy of x | up to 4 split-k planes
 
-__global__ void __launch_bounds__(256) k_add_plane(float * dst, const float * plane, int64_t n4) {
+// dst = plane 0 + plane 1 [+ plane 2 + plane 3] [+ residual], always in this order; 4 consecutive weight rows of one token per thread
+template <int NP>
+__global__ void __launch_bounds__(256) k_combine(char * dst, size_t dst_nb1, const float * planes, const char * res, size_t res_nb1, int64_t m4, int64_t n) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
-    if (i >= n4) return;
-    float4v a = ((const float4v *) dst)[i]; const float4v b = ((const float4v *) plane)[i];
-    a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
-    ((float4v *) dst)[i] = a;
+    if (i >= m4*n) return;
+    const int64_t row = i / m4, c4 = i - row*m4;
+    float4v a = ((const float4v *) planes)[i];
+#pragma unroll
+    for (int pl = 1; pl < NP; pl++) { const float4v b = ((const float4v *) planes)[(int64_t) pl*m4*n + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (res) { const float4v b = *(const float4v *) (res + (size_t) row*res_nb1 + (size_t) c4*16); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    *(float4v *) (dst + (size_t) row*dst_nb1 + (size_t) c4*16) = a;
 }
 
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
-               const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
+               const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes,
+               const float * res, size_t res_row_stride, hipStream_t stream) {
     if (m == 0 || n == 0) return;
     uint16_t * xb = (uint16_t *) scratch;
     if (!scratch_ready) {
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
-    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
+    mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr,
+                   (const char *) res, res_row_stride, nullptr, nullptr, 0, 0, 0 };
     const int mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     a.mtiles = mtiles;
     // 256-token tiles when they still fill the chip (m = 14336, n = 512: 224 workgroups); else 128-token tiles, and a grid that would
-    // leave the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k; dst rows must be dense for the memset
+    // leave the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k
     const int64_t wtiles = (int64_t) mtiles*((n + 255)/256);
-    const bool dense_dst = dst_col_stride_bytes == (size_t) m*4;
-    // a long-k matrix with few rows (ffn_down: m = 4096, k = 14336): 256-token tiles and k in four parts — parts 0,1 add into dst, parts
-    // 2,3 into a second plane (two addends per element each: order-independent), one pass adds the planes
-    const bool wide4 = n >= 256 && wtiles < 160 && wtiles*4 >= 160 && k % 1024 == 0 && k >= 8192 && dense_dst && (m*n) % 4 == 0;
+    const bool vec_ok = m % 4 == 0 && dst_col_stride_bytes % 16 == 0 && ((uintptr_t) dst % 16) == 0 && (!res || (res_row_stride % 16 == 0 && ((uintptr_t) res % 16) == 0));
+    // a long-k matrix with few rows (ffn_down: m = 4096, k = 14336): 256-token tiles and k in four parts
+    const bool wide4 = n >= 256 && wtiles < 160 && wtiles*4 >= 160 && k % 1024 == 0 && k >= 8192 && vec_ok;
     const bool wide = (n >= 256 && wtiles >= 160) || wide4;
     const int ntiles = wide ? (int)((n + 255)/256) : (int)((n + MQ_BN - 1)/MQ_BN);
-    float * plane = (float *) ((char *) scratch + mmq_x_bytes(k, n));
-    if (wide4) {
-        a.ksplit = 4; a.dst2 = (char *) plane;
-        MI_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t) m*n*4, stream));
-        MI_HIP_CHECK(hipMemsetAsync(plane, 0, (size_t) m*n*4, stream));
-    } else if (!wide && (int64_t) ntiles*mtiles <= 160 && k % 512 == 0 && k >= 2048 && dense_dst) {
-        a.ksplit = 2;
-        MI_HIP_CHECK(hipMemsetAsync(dst, 0, (size_t) m*n*4, stream));
-    }
+    float * planes = (float *) ((char *) scratch + mmq_x_bytes(k, n));
+    if (wide4) a.ksplit = 4;
+    else if (!wide && (int64_t) ntiles*mtiles <= 160 && k % 512 == 0 && k >= 2048 && vec_ok) a.ksplit = 2;
+    if (a.ksplit > 1) a.dst2 = (char *) planes;
     const dim3 grid((unsigned) ntiles, (unsigned)(mtiles*a.ksplit), 1);
 #define MI_MMQ(T_) do { if (wide) launch_mmq_wide<T_>(grid, a, stream); \
                         else      hipLaunchKernelGGL((k_mmq<T_, 128>), grid, dim3(256), MQ_LDS_BYTES, stream, a); } while (0)
@@ -440,7 +443,9 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         default: fprintf(stderr, "mmq: unsupported type %d\n", type_a); abort();
     }
 #undef MI_MMQ
-    if (wide4) hipLaunchKernelGGL(k_add_plane, dim3((unsigned)((m*n/4 + 255)/256)), dim3(256), 0, stream, dst, plane, m*n/4);
+    const unsigned cgrid = (unsigned)((m/4*n + 255)/256);
+    if (a.ksplit == 4)      hipLaunchKernelGGL(k_combine<4>, dim3(cgrid), dim3(256), 0, stream, (char *) dst, dst_col_stride_bytes, planes, (const char *) res, res_row_stride, m/4, n);
+    else if (a.ksplit == 2) hipLaunchKernelGGL(k_combine<2>, dim3(cgrid), dim3(256), 0, stream, (char *) dst, dst_col_stride_bytes, planes, (const char *) res, res_row_stride, m/4, n);
 }
 
 // gate / up + SwiGLU of build_ffn (src/llama-graph.cpp:632-774) for many tokens: dst[n][m] = silu(Wg.x) * (Wu.x)
@@ -462,7 +467,7 @@ void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_st
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
-    mmq_args a = { (const char *) Wg, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, (const char *) Wu, nullptr, 0, 0, 0 };
+    mmq_args a = { (const char *) Wg, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, (const char *) Wu, nullptr, 0, 0, 0 };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     const dim3 grid((unsigned)((n + 255)/256), (unsigned) a.mtiles, 1);
     switch (type_a) {
@@ -526,7 +531,7 @@ void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expe
     hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
     moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, max_tiles, table };
     hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
-    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr,
+    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, nullptr,
                    table, max_tiles, (int) n_used, (int) n_b };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     const dim3 grid((unsigned) max_tiles, (unsigned) a.mtiles, 1);
@@ -557,7 +562,7 @@ void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t str
     act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
     hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((mmq_kp(p.ne10) + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
-                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
+                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0 };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
     hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
 }

@@ -486,6 +486,35 @@ def test_prefill_gate_up_glu_fused(name, ff, k, n, gate_first):
     assert orc.nmse(res[0], res[1]) <= 1e-9, orc.nmse(res[0], res[1])
 
 
+@pytest.mark.parametrize("name,m,k,n", [("q4_K", 1024, 2048, 512), ("q6_K", 300, 512, 100), ("q8_0", 10240, 288, 512), ("q4_K", 5120, 8192, 300),
+                                        ("mxfp4", 1026, 2880, 64), ("q5_K", 1028, 2048, 257)])
+def test_prefill_mul_mat_residual_fused(name, m, k, n):
+    """build_attn's wo / build_ffn's down followed by the residual ADD, many tokens (src/llama-model.cpp:6057,6096): with fusion on the
+    residual is added in the mat-mul's epilogue (or by the pass that combines the split-k planes). The shapes walk through the launch
+    variants: k split in two, no split with ragged tiles, 256-token tiles, k split in four; m not a multiple of 4 (no split)."""
+    rng = np.random.default_rng(m + k + n)
+    x = rng.uniform(-1, 1, size=(1, 1, n, k)).astype(np.float32)
+    r = rng.uniform(-3, 3, size=(1, 1, n, m)).astype(np.float32)
+    w = orc.random_blocks(rng, QTYPES[name], (m,), k)
+    res = {}
+    for fusion in (1, 0):
+        be = backend(); be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            xt = ctx.new_tensor(gg.F32, (k, n)); rt = ctx.new_tensor(gg.F32, (m, n)); wt = ctx.new_tensor(QTYPES[name], (k, m))
+            out = L.ggml_add(ctx.ctx, L.ggml_mul_mat(ctx.ctx, wt, xt), rt) if m % 2 == 0 else L.ggml_add(ctx.ctx, rt, L.ggml_mul_mat(ctx.ctx, wt, xt))
+            assert ctx.alloc(be)
+            gg.tensor_set(xt, x); gg.tensor_set(rt, r); gg.tensor_set(wt, w)
+            c0 = be.counters(); be.compute(gg.graph_of(ctx, out)); c1 = be.counters()
+            res[fusion] = gg.tensor_get(out)[0, 0].copy()
+        be.set_option("fusion", 1)
+        if fusion:
+            assert c1["nodes_computed"] - c0["nodes_computed"] == 2
+    exact = orc.mul_mat_2d(w, QTYPES[name], x[0, 0], "exact") + r[0, 0]
+    assert np.isfinite(res[1]).all()
+    assert orc.nmse(exact, res[1]) <= 2e-5, orc.nmse(exact, res[1])
+    assert np.array_equal(res[0], res[1]), "same kernels, same summation order: the fused result must be bit-identical"
+
+
 @pytest.mark.parametrize("name", ["q8_0", "q4_0"])
 @pytest.mark.parametrize("ne0,rows,r,b", [(256, 5, 1, 1), (256, 11, 7, 3), (96, 3, 2, 7), (1024, 64, 5, 1)])
 def test_set_rows_quantized_dst(name, ne0, rows, r, b):
