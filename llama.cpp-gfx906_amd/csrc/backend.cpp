@@ -1057,6 +1057,62 @@ static int try_fused_prefill_glu(mi_backend_ctx * c, struct ggml_cgraph * g, int
     return j2 - i + 1;
 }
 
+static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i);
+
+// Prefill: the mat-muls that directly follow each other on the same many-token activations — wq / wk / wv of build_attn
+// (src/llama-model.cpp:6017-6040), each optionally followed by its (RESHAPE ->) ROPE — as ONE launch of 256-token tiles: alone, wk / wv
+// (1024 rows) are 32 tiles on 256 CUs. The ROPEs run after the launch, i.e. later than in graph order relative to the following
+// mat-muls: allowed only if no output of one chain overlaps an output of another (the allocator may have recycled a dead buffer).
+static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    static const bool on = !getenv("GGML_MI355X_PREFILL_QKV") || atoi(getenv("GGML_MI355X_PREFILL_QKV")) != 0;
+    if (!on) return 0;
+    const struct ggml_tensor * b = g->nodes[i]->src[1];
+    struct chain { int mm, rope, end; } ch[3];
+    int nc = 0, at = i;
+    while (nc < 3 && at >= 0) {
+        struct ggml_tensor * n = g->nodes[at];
+        if (n->op != GGML_OP_MUL_MAT) break;
+        const struct ggml_tensor * a = n->src[0];
+        if (n->src[1] != b || !ggml_is_quantized(a->type) || b->type != GGML_TYPE_F32 || b->ne[1] <= MMVQ_MAX_N || b->ne[2] != 1 || b->ne[3] != 1 ||
+            a->ne[2] != 1 || a->ne[3] != 1 || b->nb[0] != 4 || a->ne[0] != g->nodes[i]->src[0]->ne[0] || n->nb[0] != 4) break;
+        ch[nc] = { at, -1, at };
+        const int j = next_real(g, at);
+        if (j > 0 && g->nodes[j]->op == GGML_OP_ROPE && base_of(g->nodes[j]->src[0]) == n) { ch[nc].rope = j; ch[nc].end = j; }
+        nc++;
+        at = next_real(g, ch[nc - 1].end);
+    }
+    if (nc < 2) return 0;
+    for (int q = 0; q < nc; q++) {
+        const struct ggml_tensor * oq[2] = { g->nodes[ch[q].mm], ch[q].rope >= 0 ? g->nodes[ch[q].rope] : nullptr };
+        for (int u = 0; u < 2; u++) {
+            if (!oq[u]) continue;
+            if (ranges_overlap(oq[u]->data, ggml_nbytes(oq[u]), b->data, ggml_nbytes(b))) return 0;
+            for (int r = q + 1; r < nc; r++) {
+                const struct ggml_tensor * orr[2] = { g->nodes[ch[r].mm], ch[r].rope >= 0 ? g->nodes[ch[r].rope] : nullptr };
+                for (int v = 0; v < 2; v++) if (orr[v] && ranges_overlap(oq[u]->data, ggml_nbytes(oq[u]), orr[v]->data, ggml_nbytes(orr[v]))) return 0;
+            }
+        }
+    }
+    int types[3]; const void * W[3]; size_t wrs[3]; int64_t m[3]; float * dst[3]; size_t dstride[3];
+    uint64_t wbytes = 0;
+    for (int q = 0; q < nc; q++) {
+        const struct ggml_tensor * n = g->nodes[ch[q].mm]; const struct ggml_tensor * a = n->src[0];
+        types[q] = (int) a->type; W[q] = a->data; wrs[q] = a->nb[1]; m[q] = a->ne[1]; dst[q] = (float *) n->data; dstride[q] = n->nb[1];
+        wbytes += (uint64_t) a->ne[1]*ggml_row_size(a->type, a->ne[0]);
+    }
+    const int64_t K = b->ne[0], N = b->ne[1];
+    const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1];
+    prof_begin(c, types[0], m[0] + m[1] + (nc > 2 ? m[2] : 0), K, N, wbytes);
+    const bool done = mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, c->stream);
+    prof_end(c);
+    if (!done) { if (c->profiling && !c->prof_suspend) c->prof.pop_back(); return 0; }
+    if (ready) c->cnt.act_quant_reused++;
+    else c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
+    c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 1 : 2; c->cnt.weight_bytes += wbytes;
+    for (int q = 0; q < nc; q++) if (ch[q].rope >= 0) compute_node(c, g, ch[q].rope);
+    return ch[nc - 1].end - i + 1;
+}
+
 // Prefill: MUL_MAT -> ADD(residual) (build_attn's wo, build_ffn's down: src/llama-model.cpp:6057,6096) — the residual is added in the
 // mat-mul's epilogue, or by the pass that combines its split-k planes
 static int try_fused_prefill_add(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
@@ -1089,6 +1145,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
             if (!f) f = try_fused_moe_route(c, g, i);
             if (!f) f = try_fused_prefill_glu(c, g, i);
+            if (!f) f = try_fused_prefill_qkv(c, g, i);
             if (!f) f = try_fused_prefill_add(c, g, i);
         } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
         else if (node->op == GGML_OP_GET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_moe_combine(c, g, i); }

@@ -172,6 +172,8 @@ constexpr int MQ_BM = 128, MQ_BN = 128, MQ_BK = 64, MQ_LD = MQ_BK*2 + 16;   // L
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+// several weight tensors against the same activations in one launch (wq / wk / wv): the m-tiles of the segments are laid end to end
+struct mmq_seg { const char * W; char * dst; size_t w_row_stride, dst_nb1; int m, tile0, col0, type2; };   // col0: first column in a split-k plane; type2: decode as TYPE2
 struct mmq_args {
     const char * W; size_t w_row_stride, w_nb2, w_nb3; int m, k;
     const uint16_t * X; int n;                 // dense [batch][n][k] 16-bit
@@ -184,6 +186,7 @@ struct mmq_args {
     // MUL_MAT_ID (grouped by expert): blockIdx.x walks the tile table k_moe_sort wrote; a tile = up to 128 (token, slot) pairs of ONE expert
     const int * moe;                           // NULL, or [0] = n_tiles, then {expert, first, count}[max_tiles], then sorted pair ids
     int moe_max_tiles, n_used, n_b;            // pair = token*n_used + slot; X row of a pair = token*n_b + slot % n_b
+    int nseg; mmq_seg seg[3];                  // nseg > 0: W / m / dst / strides per segment; p.m = the summed rows (the width of a split-k plane)
 };
 
 // TYPE = a block format (bf16 MFMA on dequantized weights) or T_F16 (f16 MFMA, weights copied as they are: the attention
@@ -194,7 +197,7 @@ struct mmq_args {
 // DUAL (BN = 256 only): two weight tensors against the same activations and their SwiGLU in the epilogue — waves 0-3 dequantize the
 // gate tile, waves 4-7 the up tile (every wave has dequantization work now), every wave multiplies its 64 x 64 token / row tile with
 // both: 32 MFMAs per k-step and wave against one 64-element dequantization, one result tensor instead of two plus a GLU kernel
-template <int TYPE, int BN = MQ_BN, bool DUAL = false>
+template <int TYPE, int BN = MQ_BN, bool DUAL = false, int TYPE2 = TYPE>
 __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mmq(const mmq_args p) {   // LDS allows 8 waves per CU anyway; without the
     // occupancy pin the scheduler reverts the interleaved order below to keep a third wave's worth of registers free
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile [| W2 tile] | X tile)
@@ -202,15 +205,24 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     static_assert(!DUAL || BN == 256, "the dual kernel has 8 waves");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;      // which part of k
-    const int m0 = ((int) blockIdx.y - khalf*p.mtiles)*MQ_BM, n0 = blockIdx.x*BN;   // the n-tiles of one weight tile are dispatched together
+    int mt = (int) blockIdx.y - khalf*p.mtiles;
+    const int n0 = blockIdx.x*BN;                        // the n-tiles of one weight tile are dispatched together
     const int wm = wave & 1, wn = wave >> 1;             // wave tile: weight rows wm*64.., tokens wn*64..
-    const int m = p.m, n = p.n, k = p.k;
+    const int n = p.n, k = p.k;
+    int m = p.m, col0 = 0; bool use2 = false;
     const int i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
     const char * W = p.W + (size_t)(i12/p.r2)*p.w_nb2 + (size_t)(i13/p.r3)*p.w_nb3;
+    size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst;
+    if (p.nseg) {                              // workgroup-uniform
+        const int si = (mt >= p.seg[1].tile0 ? 1 : 0) + (p.nseg > 2 && mt >= p.seg[2].tile0 ? 1 : 0);
+        W = p.seg[si].W; m = p.seg[si].m; w_row_stride = p.seg[si].w_row_stride; seg_dst = p.seg[si].dst; seg_dst_nb1 = p.seg[si].dst_nb1;
+        col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0;
+    }
+    const int m0 = mt*MQ_BM;
     const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);               // row length of the activation copy (zero-padded)
     const uint16_t * X = p.X + (size_t) blockIdx.z*n*kp;
-    char * dst = p.ksplit > 1 ? p.dst2 + (size_t) khalf*p.m*p.n*4 : p.dst + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
-    const size_t dst_nb1 = p.ksplit > 1 ? (size_t) p.m*4 : p.dst_nb1;
+    char * dst = p.ksplit > 1 ? p.dst2 + (size_t) khalf*p.m*p.n*4 + (size_t) col0*4 : seg_dst + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
+    const size_t dst_nb1 = p.ksplit > 1 ? (size_t) p.m*4 : seg_dst_nb1;
     int moe_first = 0, moe_cnt = 0;
     const int * moe_pairs = nullptr;
     if (p.moe) {                               // workgroup-uniform
@@ -233,7 +245,7 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int srow = tid >> 1, shalf = tid & 1;
     const bool w_role = DUAL || BN == MQ_BM || tid < 2*MQ_BM;        // wave-uniform
     const int wt = DUAL ? tid >> 8 : 0;                              // DUAL: which weight tile this thread dequantizes
-    const char * wrow_p = (DUAL && wt ? p.W2 : W) + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*p.w_row_stride;
+    const char * wrow_p = (DUAL && wt ? p.W2 : W) + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*w_row_stride;
     const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*kp;
     if (p.moe) {
         const int pair = moe_pairs[moe_first + min(srow, moe_cnt - 1)];
@@ -251,16 +263,17 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     // Every iteration is the same straight-line block: steps past the end are fetched from clamped addresses and committed to a
     // buffer nobody reads; in a k tail (k % 64 == 32) the activation copy holds zeros, so the clamped (finite) weights drop out.
     struct stage_regs { raw32 rw; int4v xv[4]; };
-    auto run = [&](auto w_role_tag) {
+    auto run = [&](auto w_role_tag, auto type_tag) {
         constexpr bool WR = decltype(w_role_tag)::value;
+        constexpr int TY = decltype(type_tag)::value;      // the block format this workgroup's segment is decoded as
         auto fetch = [&](stage_regs & r, int step) {
             const int kc = step*MQ_BK + 32*shalf, kcl = min(kc, k - 32);
             if (WR) {
-                if (TYPE == T_F16) {
+                if (TY == T_F16) {
 #pragma unroll
                     for (int i = 0; i < 4; i++) r.rw.v[i] = ld_b128(wrow_p + (size_t) kcl*2 + 16*i);
                 } else {
-                    r.rw = load_raw32<TYPE == T_F16 ? T_Q8_0 : TYPE>(wrow_p, kcl >> 5);
+                    r.rw = load_raw32<TY == T_F16 ? T_Q8_0 : TY>(wrow_p, kcl >> 5);
                 }
             }
 #pragma unroll
@@ -274,12 +287,12 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
             *(int4v *) (xp + 16*g) = r.xv[g];
             if (WR) {
                 int4v wpk;
-                if (TYPE == T_F16) {
+                if (TY == T_F16) {
                     wpk = r.rw.v[g];
                 } else {
                     float lo[4], hi[4];
-                    decode4<TYPE == T_F16 ? T_Q8_0 : TYPE>(r.rw, h, kcl >> 5, 2*g, lo);
-                    decode4<TYPE == T_F16 ? T_Q8_0 : TYPE>(r.rw, h, kcl >> 5, 2*g + 1, hi);
+                    decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g, lo);
+                    decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g + 1, hi);
                     wpk.x = (int) pack_bf16(lo[0], lo[1]); wpk.y = (int) pack_bf16(lo[2], lo[3]);
                     wpk.z = (int) pack_bf16(hi[0], hi[1]); wpk.w = (int) pack_bf16(hi[2], hi[3]);
                 }
@@ -287,8 +300,8 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
             }
         };
         auto head_of = [&](const stage_regs & r, int step) -> dq_head {
-            if (!WR || TYPE == T_F16) return { 0.0f, 0.0f };
-            return decode_head<TYPE == T_F16 ? T_Q8_0 : TYPE>(r.rw, min(step*MQ_BK + 32*shalf, k - 32) >> 5);
+            if (!WR || TY == T_F16) return { 0.0f, 0.0f };
+            return decode_head<TY == T_F16 ? T_Q8_0 : TY>(r.rw, min(step*MQ_BK + 32*shalf, k - 32) >> 5);
         };
         struct frags { int4v a[2], b[2], b2[DUAL ? 2 : 1]; };
         // A = activations (rows = tokens), B = weights (cols = weight rows)
@@ -304,7 +317,7 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
         auto mfma_row = [&](const frags & f, int i) {       // the MFMAs of token sub-tile i: 2 (4 with the second weight tile)
 #pragma unroll
             for (int j = 0; j < 2; j++) {
-                if (TYPE == T_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i]), __builtin_bit_cast(f16x8, f.b[j]), acc[i][j], 0, 0, 0);
+                if (TY == T_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i]), __builtin_bit_cast(f16x8, f.b[j]), acc[i][j], 0, 0, 0);
                 else               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b[j]), acc[i][j], 0, 0, 0);
                 if (DUAL) acc2[DUAL ? i : 0][DUAL ? j : 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b2[DUAL ? j : 0]), acc2[DUAL ? i : 0][DUAL ? j : 0], 0, 0, 0);
             }
@@ -347,7 +360,12 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
         }
         if (s < nsteps) iteration(p1, p0, s, 0);
     };
-    if (w_role) run(std::true_type{}); else run(std::false_type{});
+    if constexpr (TYPE2 != TYPE) {
+        if (use2) { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE2>{}); else run(std::false_type{}, std::integral_constant<int, TYPE2>{}); }
+        else      { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{});  else run(std::false_type{}, std::integral_constant<int, TYPE>{}); }
+    } else {
+        if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{}); else run(std::false_type{}, std::integral_constant<int, TYPE>{});
+    }
     // ---- store: D[row = token][col = weight row]; col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) ----
 #pragma unroll
     for (int i = 0; i < 2; i++) {
@@ -446,6 +464,86 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
     const unsigned cgrid = (unsigned)((m/4*n + 255)/256);
     if (a.ksplit == 4)      hipLaunchKernelGGL(k_combine<4>, dim3(cgrid), dim3(256), 0, stream, (char *) dst, dst_col_stride_bytes, planes, (const char *) res, res_row_stride, m/4, n);
     else if (a.ksplit == 2) hipLaunchKernelGGL(k_combine<2>, dim3(cgrid), dim3(256), 0, stream, (char *) dst, dst_col_stride_bytes, planes, (const char *) res, res_row_stride, m/4, n);
+}
+
+// ---- several mat-muls on the same activations as one launch (wq / wk / wv of build_attn, src/llama-model.cpp:6017-6040) ----
+struct combine_seg_args { const float * planes; int64_t m4_tot, n; int nseg; char * dst[3]; size_t dst_nb1[3]; int col4[3]; };
+template <int NP>
+__global__ void __launch_bounds__(256) k_combine_seg(const combine_seg_args p) {
+    const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
+    if (i >= p.m4_tot*p.n) return;
+    const int64_t row = i / p.m4_tot; const int c4 = (int)(i - row*p.m4_tot);
+    float4v a = ((const float4v *) p.planes)[i];
+#pragma unroll
+    for (int pl = 1; pl < NP; pl++) { const float4v b = ((const float4v *) p.planes)[(int64_t) pl*p.m4_tot*p.n + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    const int si = (c4 >= p.col4[1] ? 1 : 0) + (p.nseg > 2 && c4 >= p.col4[2] ? 1 : 0);
+    *(float4v *) (p.dst[si] + (size_t) row*p.dst_nb1[si] + (size_t)(c4 - p.col4[si])*16) = a;
+}
+
+template <int T_, int T2_>
+static void launch_mmq_multi(dim3 grid, const mmq_args & a, hipStream_t stream) {
+    static const bool once = [] {
+        MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq<T_, 256, false, T2_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
+        return true;
+    }();
+    (void) once;
+    hipLaunchKernelGGL((k_mmq<T_, 256, false, T2_>), grid, dim3(512), MQ_LDS_BYTES_256, stream, a);
+}
+
+// false: not done (too few tiles for 256-token tiles, an unsupported mix of types, scratch too small) — the caller runs them one by one
+bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const size_t * w_row_stride, const int64_t * m, float * const * dst, const size_t * dst_stride,
+                     int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready, hipStream_t stream) {
+    if (nseg < 2 || nseg > 3 || n < 256) return false;
+    int t1 = types[0], t2 = types[0];
+    for (int s = 1; s < nseg; s++) if (types[s] != t1) { if (t2 != t1 && types[s] != t2) return false; t2 = types[s]; }
+    if (t1 != t2) {
+        if (t1 == T_Q6_K) { const int t = t1; t1 = t2; t2 = t; }
+        if (!(t2 == T_Q6_K && (t1 == T_Q4_K || t1 == T_Q5_K))) return false;       // the mixed pairs of the K-quant mixes (attn_v one step up)
+    }
+    mmq_args a = { nullptr, 0, 0, 0, 0, (int) k, (const uint16_t *) scratch, (int) n, nullptr, 0, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0 };
+    a.nseg = nseg;
+    int64_t m_tot = 0; int tiles = 0; bool vec_ok = true;
+    for (int s = 0; s < nseg; s++) {
+        a.seg[s] = { (const char *) W[s], (char *) dst[s], w_row_stride[s], dst_stride[s], (int) m[s], tiles, (int) m_tot, types[s] != t1 ? 1 : 0 };
+        vec_ok = vec_ok && m[s] % 4 == 0 && dst_stride[s] % 16 == 0 && ((uintptr_t) dst[s] % 16) == 0;
+        m_tot += m[s]; tiles += (int)((m[s] + MQ_BM - 1)/MQ_BM);
+    }
+    if (nseg < 3) a.seg[2] = a.seg[1];
+    if (m_tot >= (1ll << 30)) return false;
+    a.m = (int) m_tot; a.mtiles = tiles;
+    const int ntiles = (int)((n + 255)/256);
+    const int64_t wt = (int64_t) tiles*ntiles;
+    if (wt >= 160) a.ksplit = 1;
+    else if (wt*2 >= 160 && k % 512 == 0 && k >= 2048 && vec_ok) a.ksplit = 2;
+    else if (wt*4 >= 160 && k % 1024 == 0 && k >= 4096 && vec_ok) a.ksplit = 4;
+    else return false;
+    if (mmq_x_bytes(k, n) + (a.ksplit > 1 ? (size_t) a.ksplit*m_tot*n*4 : 0) + 512 > scratch_size) return false;
+    if (!scratch_ready) {
+        act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, (uint16_t *) scratch };
+        hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
+    }
+    float * planes = (float *) ((char *) scratch + mmq_x_bytes(k, n));
+    if (a.ksplit > 1) a.dst2 = (char *) planes;
+    const dim3 grid((unsigned) ntiles, (unsigned)(tiles*a.ksplit), 1);
+    if (t1 != t2) {
+        if (t1 == T_Q4_K) launch_mmq_multi<T_Q4_K, T_Q6_K>(grid, a, stream); else launch_mmq_multi<T_Q5_K, T_Q6_K>(grid, a, stream);
+    } else switch (t1) {
+        case T_Q4_0:  launch_mmq_wide<T_Q4_0>(grid, a, stream);  break;
+        case T_Q8_0:  launch_mmq_wide<T_Q8_0>(grid, a, stream);  break;
+        case T_Q4_K:  launch_mmq_wide<T_Q4_K>(grid, a, stream);  break;
+        case T_Q5_K:  launch_mmq_wide<T_Q5_K>(grid, a, stream);  break;
+        case T_Q6_K:  launch_mmq_wide<T_Q6_K>(grid, a, stream);  break;
+        case T_MXFP4: launch_mmq_wide<T_MXFP4>(grid, a, stream); break;
+        default: fprintf(stderr, "mmq_multi: unsupported type %d\n", t1); abort();
+    }
+    if (a.ksplit > 1) {
+        combine_seg_args ca = { planes, m_tot/4, n, nseg, { nullptr, nullptr, nullptr }, { 0, 0, 0 }, { 0, 0, 0 } };
+        for (int s = 0; s < 3; s++) { const int q = s < nseg ? s : nseg - 1; ca.dst[s] = a.seg[q].dst; ca.dst_nb1[s] = a.seg[q].dst_nb1; ca.col4[s] = a.seg[q].col0/4; }
+        const unsigned cgrid = (unsigned)((m_tot/4*n + 255)/256);
+        if (a.ksplit == 4) hipLaunchKernelGGL(k_combine_seg<4>, dim3(cgrid), dim3(256), 0, stream, ca);
+        else               hipLaunchKernelGGL(k_combine_seg<2>, dim3(cgrid), dim3(256), 0, stream, ca);
+    }
+    return true;
 }
 
 // gate / up + SwiGLU of build_ffn (src/llama-graph.cpp:632-774) for many tokens: dst[n][m] = silu(Wg.x) * (Wu.x)

@@ -486,6 +486,50 @@ def test_prefill_gate_up_glu_fused(name, ff, k, n, gate_first):
     assert orc.nmse(res[0], res[1]) <= 1e-9, orc.nmse(res[0], res[1])
 
 
+@pytest.mark.parametrize("types,ms,k,n,hd", [(("q4_K", "q4_K", "q6_K"), (4096, 1024, 1024), 4096, 512, 128), (("q4_K", "q4_K", "q4_K"), (2048, 512, 512), 4096, 300, 64),
+                                            (("q6_K", "q5_K", "q5_K"), (7000, 7000, 7200), 256, 257, 8), (("q8_0", "q8_0"), (2048, 2048), 2048, 1000, 64),
+                                            (("mxfp4", "mxfp4", "mxfp4"), (14336, 4096, 4096), 2880, 256, 64), (("q4_0", "q4_K", "q4_0"), (4096, 1024, 1024), 1024, 512, 64)])
+def test_prefill_qkv_group(types, ms, k, n, hd):
+    """wq / wk / wv of build_attn on many tokens (src/llama-model.cpp:6017-6040): mat-muls on the same activations, the first two followed by
+    RESHAPE -> ROPE. With fusion on they run as one launch of 256-token tiles (two block formats at most), the ROPEs after it. Shapes:
+    k split in two / in four / not at all, ragged tiles, a type mix without a kernel (falls back to one launch per mat-mul)."""
+    rng = np.random.default_rng(sum(ms) + k + n)
+    x = rng.uniform(-1, 1, size=(1, 1, n, k)).astype(np.float32)
+    ws = [orc.random_blocks(rng, QTYPES[t], (m,), k) for t, m in zip(types, ms)]
+    pos = np.arange(n, dtype=np.int32)
+    res = {}
+    for fusion in (1, 0):
+        be = backend(); be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            xt = ctx.new_tensor(gg.F32, (k, n)); pt = ctx.new_tensor(gg.I32, (n,))
+            wt = [ctx.new_tensor(QTYPES[t], (k, m)) for t, m in zip(types, ms)]
+            outs = []
+            for q, w_ in enumerate(wt):
+                o = L.ggml_mul_mat(ctx.ctx, w_, xt)
+                if q < 2 and ms[q] % hd == 0:
+                    o = L.ggml_rope_ext(ctx.ctx, L.ggml_reshape_3d(ctx.ctx, o, hd, ms[q] // hd, n), pt, None, hd, 0, 8192, 10000.0, 1.0, 0.0, 1.0, 32.0, 1.0)
+                outs.append(o)
+            assert ctx.alloc(be)
+            g_ = gg.graph_of(ctx, *outs)
+            gg.tensor_set(xt, x); gg.tensor_set(pt, pos)
+            for t_, w_ in zip(wt, ws):
+                gg.tensor_set(t_, w_)
+            c0 = be.counters(); be.compute(g_); c1 = be.counters()
+            res[fusion] = [gg.tensor_get(o).reshape(n, -1).copy() for o in outs]
+        be.set_option("fusion", 1)
+        tiles = sum((m + 127) // 128 for m in ms) * ((n + 255) // 256)       # the launcher's rule (mmq.hip mul_mat_q_multi)
+        fills = tiles >= 160 or (tiles * 2 >= 160 and k % 512 == 0 and k >= 2048) or (tiles * 4 >= 160 and k % 1024 == 0 and k >= 4096)
+        if fusion and fills and n >= 256 and len(set(types)) <= 2 and not ("q4_0" in types and "q4_K" in types):
+            assert c1["mmq_launches"] - c0["mmq_launches"] == 1, "the mat-muls did not run as one launch"
+    for q in range(len(types)):
+        exact = orc.mul_mat_2d(ws[q], QTYPES[types[q]], x[0, 0], "exact")
+        if q < 2 and ms[q] % hd == 0:
+            exact = ref.rope(exact.reshape(1, n, ms[q] // hd, hd).astype(np.float32), pos, hd, 0, 8192, 10000.0, 1.0, 0.0, 1.0, 32.0, 1.0, None).reshape(n, -1)
+        assert np.isfinite(res[1][q]).all()
+        assert orc.nmse(exact, res[1][q]) <= 2e-5, (q, orc.nmse(exact, res[1][q]))
+        assert orc.nmse(res[0][q], res[1][q]) <= 1e-10, (q, orc.nmse(res[0][q], res[1][q]))
+
+
 @pytest.mark.parametrize("name,m,k,n", [("q4_K", 1024, 2048, 512), ("q6_K", 300, 512, 100), ("q8_0", 10240, 288, 512), ("q4_K", 5120, 8192, 300),
                                         ("mxfp4", 1026, 2880, 64), ("q5_K", 1028, 2048, 257)])
 def test_prefill_mul_mat_residual_fused(name, m, k, n):
