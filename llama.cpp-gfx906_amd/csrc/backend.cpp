@@ -1213,7 +1213,18 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                             fresh_aq = true;
                             break;
                         }
-                        rms_norm_mul(desc(s0), desc(w), nullptr, desc(mul), op_f32(node, 0), c->stream);
+                        // prefill: a quantized mat-mul on many tokens reads the product next — its bf16 copy comes out of this kernel too
+                        uint16_t * y16 = nullptr;
+                        if (mm && mm->op == GGML_OP_MUL_MAT && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) && mul->ne[1] > MMVQ_MAX_N &&
+                            mul->ne[2] == 1 && mul->ne[3] == 1 && rms_norm_mul_bf16_supported(desc(s0), desc(w), desc(mul)) &&
+                            mul_mat_q_scratch_bytes(mul->ne[0], mul->ne[1], 0) <= c->scratch_size) {
+                            y16 = (uint16_t *) c->scratch;
+                        }
+                        rms_norm_mul(desc(s0), desc(w), nullptr, desc(mul), op_f32(node, 0), c->stream, y16);
+                        if (y16) {
+                            c->aq = { mul->data, mul->ne[0], mul->ne[1], 1, mul->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(mul->ne[1] - 1)*mul->nb[1] + (size_t) mul->ne[0]*4 };
+                            fresh_aq = true;
+                        }
                         c->cnt.kernels_launched++;
                         consumed = 2;
                         break;

@@ -121,4 +121,11 @@ static __device__ __forceinline__ int4v ld_b128_nt(const void * p) {
 #endif
 }
 
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float  f32x2_t  __attribute__((ext_vector_type(2)));
+// two floats -> two bf16 in one word: one v_cvt_pk_bf16_f32 (round to nearest even), not the ~8 integer operations of the bit formula
+static __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{ a, b }, bf16x2_t));
+}
+
 } // namespace mi355x

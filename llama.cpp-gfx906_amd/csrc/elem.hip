@@ -84,7 +84,9 @@ static __device__ __forceinline__ float block_max(float v, float * sh) {
 // ---- RMS_NORM (+MUL (+ADD)) — src/llama-graph.cpp:597-630; tests/test-backend-ops.cpp:2773,2856 ------
 // y = x / sqrt(mean(x^2) + eps) [* w] [+ add]; one workgroup per row.
 template <bool HAS_W, bool HAS_ADD>
-__global__ void __launch_bounds__(256) k_rms_norm(const td src, const td w, const td add, const td dst, float eps) {
+__global__ void __launch_bounds__(256) k_rms_norm(const td src, const td w, const td add, const td dst, float eps, uint16_t * y16, int kp16) {
+    // y16 != NULL (the host has checked the conditions of the 16-byte path below): also the bf16 copy of the result the prefill mat-mul reads,
+    // rows of kp16 elements with a zero tail (mmq.hip k_act_to_16's layout) — saves that pass
     __shared__ float sh[4];
     const int64_t row = blockIdx.x;
     const idx4 rx = unravel(row, src.ne1, src.ne2, 1ll << 30); const int64_t i1 = rx.i0, i2 = rx.i1, i3 = rx.i2;
@@ -116,7 +118,9 @@ __global__ void __launch_bounds__(256) k_rms_norm(const td src, const td w, cons
             if (HAS_W)   { const float4v t = *(const float4v *) (wp + (size_t) i*4); v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w; }
             if (HAS_ADD) { const float4v t = *(const float4v *) (ap + (size_t) i*4); v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w; }
             *(float4v *) (y + (size_t) i*4) = v;
+            if (y16) *(uint2 *) (y16 + (size_t) row*kp16 + i) = uint2{ pack_bf16(v.x, v.y), pack_bf16(v.z, v.w) };
         }
+        if (y16) for (int i = n0 + threadIdx.x*4; i < kp16; i += blockDim.x*4) *(uint2 *) (y16 + (size_t) row*kp16 + i) = uint2{ 0u, 0u };
         return;
     }
     for (int64_t i = threadIdx.x; i < src.ne0; i += blockDim.x) {
@@ -132,14 +136,20 @@ static int rows_block(int64_t ne0) { return ne0 >= 1024 ? 256 : (ne0 >= 256 ? 12
 void rms_norm(const tensor_desc & src, const tensor_desc & dst, float eps, hipStream_t stream) {
     const int64_t nrows = src.ne[1]*src.ne[2]*src.ne[3];
     if (nrows == 0) return;
-    hipLaunchKernelGGL((k_rms_norm<false, false>), dim3((unsigned) nrows), dim3(rows_block(src.ne[0])), 0, stream, mk(src), td{}, td{}, mk(dst), eps);
+    hipLaunchKernelGGL((k_rms_norm<false, false>), dim3((unsigned) nrows), dim3(rows_block(src.ne[0])), 0, stream, mk(src), td{}, td{}, mk(dst), eps, (uint16_t *) nullptr, 0);
 }
-void rms_norm_mul(const tensor_desc & src, const tensor_desc & w, const tensor_desc * add, const tensor_desc & dst, float eps, hipStream_t stream) {
+bool rms_norm_mul_bf16_supported(const tensor_desc & src, const tensor_desc & w, const tensor_desc & dst) {   // the kernel's 16-byte path, 2-d rows
+    return src.ne[0] % 4 == 0 && src.ne[0] < (1ll << 30) && src.ne[2] == 1 && src.ne[3] == 1 && w.ne[0] == src.ne[0] && w.ne[1] == 1 && w.ne[2] == 1 && w.ne[3] == 1 &&
+           ((uintptr_t) src.data % 16) == 0 && src.nb[1] % 16 == 0 && ((uintptr_t) dst.data % 16) == 0 && dst.nb[1] % 16 == 0 && ((uintptr_t) w.data % 16) == 0 &&
+           src.nb[0] == 4 && dst.nb[0] == 4 && w.nb[0] == 4;
+}
+void rms_norm_mul(const tensor_desc & src, const tensor_desc & w, const tensor_desc * add, const tensor_desc & dst, float eps, hipStream_t stream, uint16_t * y16) {
     const int64_t nrows = src.ne[1]*src.ne[2]*src.ne[3];
     if (nrows == 0) return;
     const dim3 g((unsigned) nrows), b(rows_block(src.ne[0]));
-    if (add) hipLaunchKernelGGL((k_rms_norm<true, true>),  g, b, 0, stream, mk(src), mk(w), mk(*add), mk(dst), eps);
-    else     hipLaunchKernelGGL((k_rms_norm<true, false>), g, b, 0, stream, mk(src), mk(w), td{},     mk(dst), eps);
+    const int kp16 = (int)((src.ne[0] + 63) & ~(int64_t) 63);
+    if (add) hipLaunchKernelGGL((k_rms_norm<true, true>),  g, b, 0, stream, mk(src), mk(w), mk(*add), mk(dst), eps, (uint16_t *) nullptr, 0);
+    else     hipLaunchKernelGGL((k_rms_norm<true, false>), g, b, 0, stream, mk(src), mk(w), td{},     mk(dst), eps, y16, kp16);
 }
 
 // ---- ADD / MUL / DIV / SUB with ggml repeat-broadcast — tests/test-backend-ops.cpp:2469 ----------------

@@ -99,7 +99,10 @@ struct tensor_desc {           // a strided 4-D view, ggml convention (ne = elem
 
 void rms_norm(const tensor_desc & src, const tensor_desc & dst, float eps, hipStream_t stream);
 // fused RMS_NORM * w (+ add) — tests/test-backend-ops.cpp:2856
-void rms_norm_mul(const tensor_desc & src, const tensor_desc & w, const tensor_desc * add, const tensor_desc & dst, float eps, hipStream_t stream);
+// y16 != NULL (no add; rms_norm_mul_bf16_supported): also writes the bf16 copy of the result in the layout the prefill mat-mul reads
+// (rows of ne0 rounded up to 64 elements, zero tail), so that its activation pre-pass is skipped
+bool rms_norm_mul_bf16_supported(const tensor_desc & src, const tensor_desc & w, const tensor_desc & dst);
+void rms_norm_mul(const tensor_desc & src, const tensor_desc & w, const tensor_desc * add, const tensor_desc & dst, float eps, hipStream_t stream, uint16_t * y16 = nullptr);
 enum bin_op { BIN_ADD = 0, BIN_MUL = 1, BIN_DIV = 2, BIN_SUB = 3 };
 void bin_bcast(int op, const tensor_desc & a, const tensor_desc & b, const tensor_desc & dst, hipStream_t stream);
 void add_id(const tensor_desc & a, const tensor_desc & bias, const tensor_desc & ids, const tensor_desc & dst, hipStream_t stream);

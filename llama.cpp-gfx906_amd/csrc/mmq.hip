@@ -29,12 +29,6 @@ static __device__ __forceinline__ uint32_t bf16_rne(float f) {   // finite input
     uint32_t u = __builtin_bit_cast(uint32_t, f);
     return (u + 0x7FFFu + ((u >> 16) & 1u)) >> 16;
 }
-typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-typedef float  f32x2_t  __attribute__((ext_vector_type(2)));
-// one v_cvt_pk_bf16_f32 (round to nearest even), not the ~8 integer operations of the bit formula
-static __device__ __forceinline__ uint32_t pack_bf16(float a, float b) {
-    return __builtin_bit_cast(uint32_t, __builtin_convertvector(f32x2_t{ a, b }, bf16x2_t));
-}
 
 // ---- f32 -> bf16 / f16 activation pre-pass: strided f32 rows -> dense [batch][n][kp] 16-bit, kp = k rounded up to the 64-wide k-step
 //      and the tail filled with zeros (the mat-mul kernel then needs no k-tail handling for its activations) ----

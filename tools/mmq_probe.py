@@ -1,10 +1,13 @@
 """mmq_probe.py — prefill mat-mul rate (MUL_MAT, n = 512 tokens) per weight type and Llama-3-8B shape; wall clock over repeated graphs."""
+import os
 import sys
 import time
 
 import numpy as np
 
-sys.path.insert(0, "tests"); sys.path.insert(0, "oracle"); sys.path.insert(0, ".")
+_root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for _d in ("tests", "oracle", ""):
+    sys.path.insert(0, os.path.join(_root, _d))
 import oracle as orc
 from gpu_util import QTYPES, backend, gg
 
