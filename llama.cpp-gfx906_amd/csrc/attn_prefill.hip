@@ -7,7 +7,9 @@
 // row of cells per head dimension). Arithmetic as the node-by-node path: q and the probabilities rounded to f16 (the vec_dot type
 // of an F16 matrix), f32 accumulation, soft_max in f32.
 //
-// One wave per (head, 32 queries). Everything is computed TRANSPOSED so that a lane owns ONE query column:
+// One workgroup of 4 waves per (head, 32 queries); wave w takes the cell blocks w, w + 4, ... (a block whose mask is -inf for all of the
+// 32 x 32 pairs — the causal future — is skipped before any arithmetic) and the four partial (max, sum, O) states are merged through
+// LDS at the end. Everything is computed TRANSPOSED so that a lane owns ONE query column:
 //   S^T[32 cells x 32 queries] = K[32 x hd] . Q^T      (v_mfma_f32_32x32x16_f16, A = K rows straight from the cache, B = Q^T)
 //   per-lane online softmax over the 16 cells a lane holds (+ one exchange with lane ^ 32: the other 16 cells of the same query)
 //   O^T[hd x 32 queries] += V^T[hd x 32 cells] . P^T   (A = rows of the transposed V cache, B = P^T straight from the registers of S^T)
@@ -39,10 +41,12 @@ static __device__ __forceinline__ float xhalf(float v, int lane) {      // the v
 
 // VT: transposed V cache (rows over cells). !VT: V rows are cells (FLASH_ATTN_EXT): the 8 cells of a k-slot group are then 8 two-byte
 // gathers per operand — correct, not fast; a transposing LDS read is the next step for that layout.
+constexpr int APF_NW = 4;
 template <int HD, bool VT = true>
-__global__ void __launch_bounds__(64) k_attn_prefill(const attn_pf_args p) {
+__global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p) {
     constexpr int NC = HD/16, NDT = HD/32;
-    const int lane = threadIdx.x, ql = lane & 31, hf = lane >> 5;
+    __shared__ float part[(APF_NW - 1)*(16*NDT + 2)*64];      // waves 1..3: o[NDT][16], m, l per lane
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 31, hf = lane >> 5;
     const int h = blockIdx.y, hk = h/(p.n_head/p.n_head_kv);
     const int q0 = blockIdx.x*32;
     const int t = min(q0 + ql, p.T - 1);
@@ -69,7 +73,30 @@ __global__ void __launch_bounds__(64) k_attn_prefill(const attn_pf_args p) {
                             : p.v + (size_t) hk*p.v_nb2 + (size_t) ql*2 + (size_t)(4*hf)*p.v_nb1;
     const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 : nullptr;
 
-    for (int kv0 = 0; kv0 < p.n_kv; kv0 += 32) {
+    for (int kv0 = 32*wave; kv0 < p.n_kv; kv0 += 32*APF_NW) {
+        // ---- the mask of this lane's 16 cells; a block nobody may look at is skipped ----
+        float mk[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            mk[4*j] = mk[4*j + 1] = mk[4*j + 2] = mk[4*j + 3] = 0.0f;
+            if (mrow) {
+                const int cell = kv0 + 8*j + 4*hf;
+                if (p.mask_f16) {
+                    const int2v raw = ld_b64(mrow + (size_t) cell*2);
+                    const f16x4 hv = __builtin_bit_cast(f16x4, raw);
+                    mk[4*j] = (float) hv[0]; mk[4*j + 1] = (float) hv[1]; mk[4*j + 2] = (float) hv[2]; mk[4*j + 3] = (float) hv[3];
+                } else {
+                    const float4v fv = __builtin_bit_cast(float4v, ld_b128(mrow + (size_t) cell*4));
+                    mk[4*j] = fv.x; mk[4*j + 1] = fv.y; mk[4*j + 2] = fv.z; mk[4*j + 3] = fv.w;
+                }
+            }
+        }
+        if (mrow) {
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; r++) mx = fmaxf(mx, mk[r]);
+            if (__builtin_amdgcn_ballot_w64(mx != -INFINITY) == 0) continue;       // wave-uniform
+        }
         // ---- S^T = K . Q^T ----
         f32x16 s;
 #pragma unroll
@@ -83,22 +110,7 @@ __global__ void __launch_bounds__(64) k_attn_prefill(const attn_pf_args p) {
         // ---- scale + mask; s[r] belongs to cell kv0 + (r & 3) + 8 (r >> 2) + 4 hf of query t ----
         float bm = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            float mk[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
-            if (mrow) {
-                const int cell = kv0 + 8*j + 4*hf;
-                if (p.mask_f16) {
-                    const int2v raw = ld_b64(mrow + (size_t) cell*2);
-                    const f16x4 hv = __builtin_bit_cast(f16x4, raw);
-                    mk[0] = (float) hv[0]; mk[1] = (float) hv[1]; mk[2] = (float) hv[2]; mk[3] = (float) hv[3];
-                } else {
-                    const float4v fv = __builtin_bit_cast(float4v, ld_b128(mrow + (size_t) cell*4));
-                    mk[0] = fv.x; mk[1] = fv.y; mk[2] = fv.z; mk[3] = fv.w;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) { s[4*j + i] = s[4*j + i]*p.scale + mk[i]; bm = fmaxf(bm, s[4*j + i]); }
-        }
+        for (int r = 0; r < 16; r++) { s[r] = s[r]*p.scale + mk[r]; bm = fmaxf(bm, s[r]); }
         bm = fmaxf(bm, xhalf(bm, lane));
         const float m_new = fmaxf(m, bm);
         const float alpha = m == -INFINITY ? 0.0f : expf(m - m_new);     // m_new == -inf only while every cell so far was masked: p = 0
@@ -135,6 +147,30 @@ __global__ void __launch_bounds__(64) k_attn_prefill(const attn_pf_args p) {
             }
         }
     }
+    // ---- merge the four waves' states (same lane = same query and the same cells-within-block pattern) ----
+    constexpr int PS = 16*NDT + 2;
+    if (wave > 0) {
+        float * pp = part + (size_t)(wave - 1)*PS*64 + lane;
+#pragma unroll
+        for (int d = 0; d < NDT; d++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) pp[(16*d + r)*64] = o[d][r];
+        pp[(16*NDT)*64] = m; pp[(16*NDT + 1)*64] = l;
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int w = 1; w < APF_NW; w++) {
+        const float * pp = part + (size_t)(w - 1)*PS*64 + lane;
+        const float mw = pp[(16*NDT)*64], lw = pp[(16*NDT + 1)*64];
+        const float m_new = fmaxf(m, mw);
+        const float a = m == -INFINITY ? 0.0f : expf(m - m_new), b = mw == -INFINITY ? 0.0f : expf(mw - m_new);
+        l = l*a + lw*b; m = m_new;
+#pragma unroll
+        for (int d = 0; d < NDT; d++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[d][r] = o[d][r]*a + pp[(16*d + r)*64]*b;
+    }
     // ---- finish: both halves' denominators, the sink logit (src/llama-graph.cpp:1313), normalise, store ----
     float lt = l + xhalf(l, lane);
     float fin = 1.0f;
@@ -166,12 +202,12 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
                        (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
     const dim3 grid((unsigned)((T + 31)/32), (unsigned) n_head);
     if (!v_trans) {
-        if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128, false>), grid, dim3(64), 0, stream, a);
-        else                 hipLaunchKernelGGL((k_attn_prefill<64, false>),  grid, dim3(64), 0, stream, a);
+        if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128, false>), grid, dim3(64*APF_NW), 0, stream, a);
+        else                 hipLaunchKernelGGL((k_attn_prefill<64, false>),  grid, dim3(64*APF_NW), 0, stream, a);
         return;
     }
-    if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128>), grid, dim3(64), 0, stream, a);
-    else                 hipLaunchKernelGGL((k_attn_prefill<64>),  grid, dim3(64), 0, stream, a);
+    if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128>), grid, dim3(64*APF_NW), 0, stream, a);
+    else                 hipLaunchKernelGGL((k_attn_prefill<64>),  grid, dim3(64*APF_NW), 0, stream, a);
 }
 
 } // namespace mi355x
