@@ -7,8 +7,8 @@
 // row of cells per head dimension). Arithmetic as the node-by-node path: q and the probabilities rounded to f16 (the vec_dot type
 // of an F16 matrix), f32 accumulation, soft_max in f32.
 //
-// One workgroup of 4 waves per (head, 32 queries); wave w takes the cell blocks w, w + 4, ... (a block whose mask is -inf for all of the
-// 32 x 32 pairs — the causal future — is skipped before any arithmetic) and the four partial (max, sum, O) states are merged through
+// One workgroup of 8 waves per (head, 32 queries); wave w takes the cell blocks w, w + 8, ... (a block whose mask is -inf for all of the
+// 32 x 32 pairs — the causal future — is skipped before any arithmetic) and the partial (max, sum, O) states are merged through
 // LDS at the end. Everything is computed TRANSPOSED so that a lane owns ONE query column:
 //   S^T[32 cells x 32 queries] = K[32 x hd] . Q^T      (v_mfma_f32_32x32x16_f16, A = K rows straight from the cache, B = Q^T)
 //   per-lane online softmax over the 16 cells a lane holds (+ one exchange with lane ^ 32: the other 16 cells of the same query)
@@ -41,11 +41,13 @@ static __device__ __forceinline__ float xhalf(float v, int lane) {      // the v
 
 // VT: transposed V cache (rows over cells). !VT: V rows are cells (FLASH_ATTN_EXT): the 8 cells of a k-slot group are then 8 two-byte
 // gathers per operand — correct, not fast; a transposing LDS read is the next step for that layout.
-constexpr int APF_NW = 4;
-template <int HD, bool VT = true>
+constexpr int APF_NW = 8;       // 2 waves per SIMD at 256 registers each: one workgroup per CU
+// MASK: 0 = none, 1 = f32, 2 = f16 — a template parameter, not a branch: every load of a block (mask, K, V) is issued before the first
+// use, so a block costs one memory round trip (as run-time branches the loads sat in blocks of their own, each waiting for its data)
+template <int HD, bool VT, int MASK>
 __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p) {
     constexpr int NC = HD/16, NDT = HD/32;
-    __shared__ float part[(APF_NW - 1)*(16*NDT + 2)*64];      // waves 1..3: o[NDT][16], m, l per lane
+    extern __shared__ float part[];                           // [(APF_NW - 1)*(16*NDT + 2)*64]: the other waves' o[NDT][16], m, l per lane
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 31, hf = lane >> 5;
     const int h = blockIdx.y, hk = h/(p.n_head/p.n_head_kv);
     const int q0 = blockIdx.x*32;
@@ -76,22 +78,48 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
     for (int kv0 = 32*wave; kv0 < p.n_kv; kv0 += 32*APF_NW) {
         // ---- the mask of this lane's 16 cells; a block nobody may look at is skipped ----
         float mk[16];
+        if (MASK == 2) {
+            int2v raw[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
-            mk[4*j] = mk[4*j + 1] = mk[4*j + 2] = mk[4*j + 3] = 0.0f;
-            if (mrow) {
-                const int cell = kv0 + 8*j + 4*hf;
-                if (p.mask_f16) {
-                    const int2v raw = ld_b64(mrow + (size_t) cell*2);
-                    const f16x4 hv = __builtin_bit_cast(f16x4, raw);
-                    mk[4*j] = (float) hv[0]; mk[4*j + 1] = (float) hv[1]; mk[4*j + 2] = (float) hv[2]; mk[4*j + 3] = (float) hv[3];
+            for (int j = 0; j < 4; j++) raw[j] = ld_b64(mrow + (size_t)(kv0 + 8*j + 4*hf)*2);
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const f16x4 hv = __builtin_bit_cast(f16x4, raw[j]);
+                mk[4*j] = (float) hv[0]; mk[4*j + 1] = (float) hv[1]; mk[4*j + 2] = (float) hv[2]; mk[4*j + 3] = (float) hv[3];
+            }
+        } else if (MASK == 1) {
+            float4v fv[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) fv[j] = __builtin_bit_cast(float4v, ld_b128(mrow + (size_t)(kv0 + 8*j + 4*hf)*4));
+#pragma unroll
+            for (int j = 0; j < 4; j++) { mk[4*j] = fv[j].x; mk[4*j + 1] = fv[j].y; mk[4*j + 2] = fv[j].z; mk[4*j + 3] = fv[j].w; }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; r++) mk[r] = 0.0f;
+        }
+        // K rows and the V operands of the whole block: in flight together with the mask
+        const char * krow = kbase + (size_t)(kv0 + ql)*p.k_nb1;
+        int4v kraw[NC];
+#pragma unroll
+        for (int c = 0; c < NC; c++) kraw[c] = *(const int4v *) (krow + (size_t) c*32);
+        int4v va[2][NDT];
+#pragma unroll
+        for (int c2 = 0; c2 < 2; c2++)
+#pragma unroll
+            for (int d = 0; d < NDT; d++) {
+                if (VT) {
+                    const char * vp = vbase + (size_t)(32*d)*p.v_nb1 + (size_t)(kv0 + 16*c2)*2;
+                    const int2v lo = ld_b64(vp), hi = ld_b64(vp + 16);
+                    va[c2][d] = int4v{ lo.x, lo.y, hi.x, hi.y };
                 } else {
-                    const float4v fv = __builtin_bit_cast(float4v, ld_b128(mrow + (size_t) cell*4));
-                    mk[4*j] = fv.x; mk[4*j + 1] = fv.y; mk[4*j + 2] = fv.z; mk[4*j + 3] = fv.w;
+                    const char * vp = vbase + (size_t)(32*d)*2 + (size_t)(kv0 + 16*c2)*p.v_nb1;      // cell kv0 + 16 c2 + 4 hf, dim 32 d + ql
+                    uint32_t hv[8];
+#pragma unroll
+                    for (int sl = 0; sl < 8; sl++) hv[sl] = ld_u16(vp + (size_t)(8*(sl >> 2) + (sl & 3))*p.v_nb1);
+                    va[c2][d] = int4v{ (int)(hv[0] | (hv[1] << 16)), (int)(hv[2] | (hv[3] << 16)), (int)(hv[4] | (hv[5] << 16)), (int)(hv[6] | (hv[7] << 16)) };
                 }
             }
-        }
-        if (mrow) {
+        if (MASK) {
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; r++) mx = fmaxf(mx, mk[r]);
@@ -101,12 +129,8 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
         f32x16 s;
 #pragma unroll
         for (int r = 0; r < 16; r++) s[r] = 0.0f;
-        const char * krow = kbase + (size_t)(kv0 + ql)*p.k_nb1;
 #pragma unroll
-        for (int c = 0; c < NC; c++) {
-            const int4v kraw = *(const int4v *) (krow + (size_t) c*32);
-            s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kraw), qb[c], s, 0, 0, 0);
-        }
+        for (int c = 0; c < NC; c++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kraw[c]), qb[c], s, 0, 0, 0);
         // ---- scale + mask; s[r] belongs to cell kv0 + (r & 3) + 8 (r >> 2) + 4 hf of query t ----
         float bm = -INFINITY;
 #pragma unroll
@@ -131,19 +155,7 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
                                (_Float16) pr[8*c2 + 4], (_Float16) pr[8*c2 + 5], (_Float16) pr[8*c2 + 6], (_Float16) pr[8*c2 + 7] };
 #pragma unroll
             for (int d = 0; d < NDT; d++) {
-                int4v va;
-                if (VT) {
-                    const char * vp = vbase + (size_t)(32*d)*p.v_nb1 + (size_t)(kv0 + 16*c2)*2;
-                    const int2v lo = ld_b64(vp), hi = ld_b64(vp + 16);
-                    va = int4v{ lo.x, lo.y, hi.x, hi.y };
-                } else {
-                    const char * vp = vbase + (size_t)(32*d)*2 + (size_t)(kv0 + 16*c2)*p.v_nb1;      // cell kv0 + 16 c2 + 4 hf, dim 32 d + ql
-                    uint32_t hv[8];
-#pragma unroll
-                    for (int sl = 0; sl < 8; sl++) hv[sl] = ld_u16(vp + (size_t)(8*(sl >> 2) + (sl & 3))*p.v_nb1);
-                    va = int4v{ (int)(hv[0] | (hv[1] << 16)), (int)(hv[2] | (hv[3] << 16)), (int)(hv[4] | (hv[5] << 16)), (int)(hv[6] | (hv[7] << 16)) };
-                }
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, va), pb, o[d], 0, 0, 0);
+                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, va[c2][d]), pb, o[d], 0, 0, 0);
             }
         }
     }
@@ -159,7 +171,7 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
     }
     __syncthreads();
     if (wave > 0) return;
-#pragma unroll
+#pragma unroll 1
     for (int w = 1; w < APF_NW; w++) {
         const float * pp = part + (size_t)(w - 1)*PS*64 + lane;
         const float mw = pp[(16*NDT)*64], lw = pp[(16*NDT + 1)*64];
@@ -201,13 +213,17 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
     attn_pf_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
                        (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
     const dim3 grid((unsigned)((T + 31)/32), (unsigned) n_head);
-    if (!v_trans) {
-        if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128, false>), grid, dim3(64*APF_NW), 0, stream, a);
-        else                 hipLaunchKernelGGL((k_attn_prefill<64, false>),  grid, dim3(64*APF_NW), 0, stream, a);
-        return;
-    }
-    if (head_dim == 128) hipLaunchKernelGGL((k_attn_prefill<128>), grid, dim3(64*APF_NW), 0, stream, a);
-    else                 hipLaunchKernelGGL((k_attn_prefill<64>),  grid, dim3(64*APF_NW), 0, stream, a);
+    const int mk = !mask ? 0 : (mask_f16 ? 2 : 1);
+#define MI_APF1(HD_, VT_, MK_) do { \
+        constexpr size_t lds_ = (size_t)(APF_NW - 1)*(16*(HD_/32) + 2)*64*4; \
+        static const bool once_ = [] { MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_prefill<HD_, VT_, MK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_)); return true; }(); \
+        (void) once_; \
+        hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, MK_>), grid, dim3(64*APF_NW), lds_, stream, a); } while (0)
+#define MI_APF(HD_, VT_) do { if (mk == 0) MI_APF1(HD_, VT_, 0); else if (mk == 1) MI_APF1(HD_, VT_, 1); else MI_APF1(HD_, VT_, 2); } while (0)
+    if (!v_trans) { if (head_dim == 128) MI_APF(128, false); else MI_APF(64, false); }
+    else          { if (head_dim == 128) MI_APF(128, true);  else MI_APF(64, true); }
+#undef MI_APF
+#undef MI_APF1
 }
 
 } // namespace mi355x
