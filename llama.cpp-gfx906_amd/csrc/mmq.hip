@@ -68,7 +68,9 @@ static __device__ __forceinline__ void k4_sc_m(const uint32_t (&hw)[4], int j, f
 struct dq_head { float a, b; };
 template <int TYPE> static __device__ __forceinline__ raw32 load_raw32(const char * row, int c32);
 template <int TYPE> static __device__ __forceinline__ dq_head decode_head(const raw32 & r, int c32);
-template <int TYPE> static __device__ __forceinline__ void decode4(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]);
+// ws = the word slot piece wi's words sit in (a constant: it indexes registers); wi itself may be a run-time value (arithmetic only).
+// k_mmq loads whole chunks: ws = wi; k_mmq16 loads a quarter chunk into slots 0, 1
+template <int TYPE> static __device__ __forceinline__ void decode4(const raw32 & r, const dq_head & h, int c32, int ws, int wi, float (&o)[4]);
 
 static __device__ __forceinline__ uint32_t raw_word(const raw32 & r, int i) {      // 32-bit word i of the 16-byte vectors, i a constant
     const int4v v = r.v[i >> 2];
@@ -80,8 +82,8 @@ template <> __device__ __forceinline__ raw32 load_raw32<T_Q4_0>(const char * row
     raw32 r; const char * b = row + (size_t) c32*18; r.s = ld_u16(b); r.v[0] = ld_b128(b + 2); return r;
 }
 template <> __device__ __forceinline__ dq_head decode_head<T_Q4_0>(const raw32 & r, int) { return { f16_bits_to_f32((uint16_t) r.s), 0.0f }; }
-template <> __device__ __forceinline__ void decode4<T_Q4_0>(const raw32 & r, const dq_head & h, int, int wi, float (&o)[4]) {
-    const uint32_t q4 = (raw_word(r, wi & 3) >> (4*(wi >> 2))) & 0x0F0F0F0Fu;
+template <> __device__ __forceinline__ void decode4<T_Q4_0>(const raw32 & r, const dq_head & h, int, int ws, int wi, float (&o)[4]) {
+    const uint32_t q4 = (raw_word(r, ws & 3) >> (4*(wi >> 2))) & 0x0F0F0F0Fu;
 #pragma unroll
     for (int b = 0; b < 4; b++) o[b] = (float)((int)((q4 >> (8*b)) & 0xFF) - 8)*h.a;
 }
@@ -90,8 +92,8 @@ template <> __device__ __forceinline__ raw32 load_raw32<T_Q8_0>(const char * row
     raw32 r; const char * b = row + (size_t) c32*34; r.s = ld_u16(b); r.v[0] = ld_b128(b + 2); r.v[1] = ld_b128(b + 18); return r;
 }
 template <> __device__ __forceinline__ dq_head decode_head<T_Q8_0>(const raw32 & r, int) { return { f16_bits_to_f32((uint16_t) r.s), 0.0f }; }
-template <> __device__ __forceinline__ void decode4<T_Q8_0>(const raw32 & r, const dq_head & h, int, int wi, float (&o)[4]) {
-    const uint32_t w = raw_word(r, wi);
+template <> __device__ __forceinline__ void decode4<T_Q8_0>(const raw32 & r, const dq_head & h, int, int ws, int, float (&o)[4]) {
+    const uint32_t w = raw_word(r, ws);
 #pragma unroll
     for (int b = 0; b < 4; b++) o[b] = (float)(int8_t)((w >> (8*b)) & 0xFF)*h.a;
 }
@@ -100,8 +102,8 @@ template <> __device__ __forceinline__ raw32 load_raw32<T_MXFP4>(const char * ro
     raw32 r; const char * b = row + (size_t) c32*17; r.s = *(const uint8_t *) b; r.v[0] = ld_b128(b + 1); return r;
 }
 template <> __device__ __forceinline__ dq_head decode_head<T_MXFP4>(const raw32 & r, int) { return { e8m0_to_f32_half(r.s), 0.0f }; }
-template <> __device__ __forceinline__ void decode4<T_MXFP4>(const raw32 & r, const dq_head & h, int, int wi, float (&o)[4]) {
-    const uint32_t q4 = (raw_word(r, wi & 3) >> (4*(wi >> 2))) & 0x0F0F0F0Fu;
+template <> __device__ __forceinline__ void decode4<T_MXFP4>(const raw32 & r, const dq_head & h, int, int ws, int wi, float (&o)[4]) {
+    const uint32_t q4 = (raw_word(r, ws & 3) >> (4*(wi >> 2))) & 0x0F0F0F0Fu;
     const uint64_t mag = 0x0C08060403020100ull;
 #pragma unroll
     for (int b = 0; b < 4; b++) {
@@ -122,9 +124,9 @@ static __device__ __forceinline__ dq_head k45_head(const raw32 & r, int c32) {
     return { d*sc, dmin*m };
 }
 template <> __device__ __forceinline__ dq_head decode_head<T_Q4_K>(const raw32 & r, int c32) { return k45_head(r, c32); }
-template <> __device__ __forceinline__ void decode4<T_Q4_K>(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]) {
+template <> __device__ __forceinline__ void decode4<T_Q4_K>(const raw32 & r, const dq_head & h, int c32, int ws, int, float (&o)[4]) {
     // word-wise: one shift + mask per 4 nibbles, then v_cvt_f32_ubyte{0..3} straight from the masked word
-    const uint32_t q4 = (raw_word(r, 4 + wi) >> ((c32 & 1)*4)) & 0x0F0F0F0Fu;
+    const uint32_t q4 = (raw_word(r, 4 + ws) >> ((c32 & 1)*4)) & 0x0F0F0F0Fu;
 #pragma unroll
     for (int b = 0; b < 4; b++) o[b] = h.a*(float)((q4 >> (8*b)) & 0xFF) - h.b;
 }
@@ -135,9 +137,9 @@ template <> __device__ __forceinline__ raw32 load_raw32<T_Q5_K>(const char * row
     r.v[3] = *(const int4v *) (b + 48 + 32*(sb >> 1)); r.v[4] = *(const int4v *) (b + 64 + 32*(sb >> 1)); r.s = 0; return r;
 }
 template <> __device__ __forceinline__ dq_head decode_head<T_Q5_K>(const raw32 & r, int c32) { return k45_head(r, c32); }
-template <> __device__ __forceinline__ void decode4<T_Q5_K>(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]) {
+template <> __device__ __forceinline__ void decode4<T_Q5_K>(const raw32 & r, const dq_head & h, int c32, int ws, int, float (&o)[4]) {
     const int sb = c32 & 7;      // word-wise: 4 quants per word = low nibbles | (bit sb of the qh bytes) << 4
-    const uint32_t q5 = ((raw_word(r, 12 + wi) >> ((sb & 1)*4)) & 0x0F0F0F0Fu) | (((raw_word(r, 4 + wi) >> sb) & 0x01010101u) << 4);
+    const uint32_t q5 = ((raw_word(r, 12 + ws) >> ((sb & 1)*4)) & 0x0F0F0F0Fu) | (((raw_word(r, 4 + ws) >> sb) & 0x01010101u) << 4);
 #pragma unroll
     for (int b = 0; b < 4; b++) o[b] = h.a*(float)((q5 >> (8*b)) & 0xFF) - h.b;
 }
@@ -153,9 +155,9 @@ template <> __device__ __forceinline__ dq_head decode_head<T_Q6_K>(const raw32 &
     const float d = f16_bits_to_f32((uint16_t)(r.s & 0xFFFF));
     return { d*(float)(int8_t)((r.s >> 16) & 0xFF), d*(float)(int8_t)(r.s >> 24) };
 }
-template <> __device__ __forceinline__ void decode4<T_Q6_K>(const raw32 & r, const dq_head & h, int c32, int wi, float (&o)[4]) {
+template <> __device__ __forceinline__ void decode4<T_Q6_K>(const raw32 & r, const dq_head & h, int c32, int ws, int wi, float (&o)[4]) {
     const int pq = c32 & 3;      // word-wise: 4 quants per word = low nibbles | (2 bits of the qh bytes) << 4, each 0..63
-    const uint32_t q6 = ((raw_word(r, wi) >> ((pq >> 1)*4)) & 0x0F0F0F0Fu) | (((raw_word(r, 8 + wi) >> (2*pq)) & 0x03030303u) << 4);
+    const uint32_t q6 = ((raw_word(r, ws) >> ((pq >> 1)*4)) & 0x0F0F0F0Fu) | (((raw_word(r, 8 + ws) >> (2*pq)) & 0x03030303u) << 4);
     const float sc = wi < 4 ? h.a : h.b;
 #pragma unroll
     for (int b = 0; b < 4; b++) o[b] = sc*(float)((int)((q6 >> (8*b)) & 0xFF) - 32);
@@ -285,8 +287,8 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
                     wpk = r.rw.v[g];
                 } else {
                     float lo[4], hi[4];
-                    decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g, lo);
-                    decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g + 1, hi);
+                    decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g, 2*g, lo);
+                    decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g + 1, 2*g + 1, hi);
                     wpk.x = (int) pack_bf16(lo[0], lo[1]); wpk.y = (int) pack_bf16(lo[2], lo[3]);
                     wpk.z = (int) pack_bf16(hi[0], hi[1]); wpk.w = (int) pack_bf16(hi[2], hi[3]);
                 }
@@ -386,6 +388,186 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     }
 }
 
+// ---- the same tile (128 weight rows x 256 tokens x 64 k) on 16 waves -------------------------------------------------------------
+// k_mmq's 8 waves run at ~170 clocks per MFMA and wave whatever the tile shape — a wave's own chain of MFMA, decode VALU, LDS store
+// and waits — so 2 waves per SIMD keep the matrix cores 36 % busy. Here a wave owns 64 tokens x 32 rows (32 accumulator registers,
+// 8 MFMAs per k-step), decodes 8 weights and stages 16 activations per k-step: 4 waves per SIMD at <= 128 VGPRs.
+// Quarter-chunk loads: thread -> (row, 32-chunk, quarter q): pieces 2q, 2q + 1; their words land in word slots 0, 1 of each vector.
+template <int TYPE> static __device__ __forceinline__ raw32 load_raw8(const char * row, int c32, int q);
+template <> __device__ __forceinline__ raw32 load_raw8<T_Q4_0>(const char * row, int c32, int q) {
+    raw32 r; const char * b = row + (size_t) c32*18; r.s = ld_u16(b); const int2v t = ld_b64(b + 2 + 8*(q & 1)); r.v[0].x = t.x; r.v[0].y = t.y; return r;
+}
+template <> __device__ __forceinline__ raw32 load_raw8<T_MXFP4>(const char * row, int c32, int q) {
+    raw32 r; const char * b = row + (size_t) c32*17; r.s = *(const uint8_t *) b; const int2v t = ld_b64(b + 1 + 8*(q & 1)); r.v[0].x = t.x; r.v[0].y = t.y; return r;
+}
+template <> __device__ __forceinline__ raw32 load_raw8<T_Q8_0>(const char * row, int c32, int q) {
+    raw32 r; const char * b = row + (size_t) c32*34; r.s = ld_u16(b); const int2v t = ld_b64(b + 2 + 8*q); r.v[0].x = t.x; r.v[0].y = t.y; return r;
+}
+template <> __device__ __forceinline__ raw32 load_raw8<T_Q4_K>(const char * row, int c32, int q) {
+    raw32 r; const int sb = c32 & 7; const char * b = row + (size_t)(c32 >> 3)*144;
+    r.v[0] = *(const int4v *) b; r.s = 0;
+    const int2v t = *(const int2v *) (b + 16 + 32*(sb >> 1) + 8*q); r.v[1].x = t.x; r.v[1].y = t.y; return r;
+}
+template <> __device__ __forceinline__ raw32 load_raw8<T_Q5_K>(const char * row, int c32, int q) {
+    raw32 r; const int sb = c32 & 7; const char * b = row + (size_t)(c32 >> 3)*176;
+    r.v[0] = *(const int4v *) b; r.s = 0;
+    const int2v h = *(const int2v *) (b + 16 + 8*q), t = *(const int2v *) (b + 48 + 32*(sb >> 1) + 8*q);
+    r.v[1].x = h.x; r.v[1].y = h.y; r.v[3].x = t.x; r.v[3].y = t.y; return r;
+}
+template <> __device__ __forceinline__ raw32 load_raw8<T_Q6_K>(const char * row, int c32, int q) {
+    raw32 r; const int c = c32 & 7, n = c >> 2, pq = c & 3; const char * b = row + (size_t)(c32 >> 3)*210;   // 2-byte aligned only
+    const int2v l = ld_b64(b + 64*n + 32*(pq & 1) + 8*q), h = ld_b64(b + 128 + 32*n + 8*q);
+    r.v[0].x = l.x; r.v[0].y = l.y; r.v[2].x = h.x; r.v[2].y = h.y;
+    r.s = (uint32_t) ld_u16(b + 208) | ((uint32_t) ld_u16(b + 192 + 8*n + 2*pq) << 16);
+    return r;
+}
+
+template <int TYPE, int TYPE2 = TYPE>
+__global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
+    constexpr int BN = 256, WTILE = MQ_BM*MQ_LD, XTILE = BN*MQ_LD, STAGE = WTILE + XTILE;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;
+    int mt = (int) blockIdx.y - khalf*p.mtiles;
+    const int n0 = blockIdx.x*BN;
+    const int wm = wave & 3, wn = wave >> 2;             // wave tile: weight rows wm*32.., tokens wn*64..
+    const int n = p.n, k = p.k;
+    int m = p.m, col0 = 0; bool use2 = false;
+    const char * W = p.W;
+    size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst;
+    if (p.nseg) {                              // workgroup-uniform
+        const int si = (mt >= p.seg[1].tile0 ? 1 : 0) + (p.nseg > 2 && mt >= p.seg[2].tile0 ? 1 : 0);
+        W = p.seg[si].W; m = p.seg[si].m; w_row_stride = p.seg[si].w_row_stride; seg_dst = p.seg[si].dst; seg_dst_nb1 = p.seg[si].dst_nb1;
+        col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0;
+    }
+    const int m0 = mt*MQ_BM;
+    const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);
+    char * dst = p.ksplit > 1 ? p.dst2 + (size_t) khalf*p.m*p.n*4 + (size_t) col0*4 : seg_dst;
+    const size_t dst_nb1 = p.ksplit > 1 ? (size_t) p.m*4 : seg_dst_nb1;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[i][r] = 0.0f;
+
+    // staging roles: weights: row = tid/8, 32-chunk = (tid/4)&1, quarter = tid&3 (8 weights); activations: row = tid/4, 16 of the 64 k
+    const int wrow = tid >> 3, wchunk = (tid >> 2) & 1, wq = tid & 3;
+    const int xrow = tid >> 2, xq = tid & 3;
+    const char * wrow_p = W + (size_t) min(m0 + wrow, m - 1)*w_row_stride;
+    const uint16_t * xrow_p = p.X + (size_t) min(n0 + xrow, n - 1)*kp + 16*xq;
+    const int nsteps_all = (k + MQ_BK - 1)/MQ_BK;
+    const int nsteps = p.ksplit > 1 ? nsteps_all/p.ksplit : nsteps_all;
+    const int step0 = khalf*nsteps;
+
+    struct stage_regs { raw32 rw; int4v xv[2]; };
+    auto run = [&](auto type_tag) {
+        constexpr int TY = decltype(type_tag)::value;
+        auto fetch = [&](stage_regs & r, int step) {
+            const int kcl = min(step*MQ_BK + 32*wchunk, k - 32);
+            r.rw = load_raw8<TY>(wrow_p, kcl >> 5, wq);
+            const char * xs = (const char *) (xrow_p + min(step*MQ_BK, kp - MQ_BK));
+            r.xv[0] = ld_b128(xs); r.xv[1] = ld_b128(xs + 16);
+        };
+        auto wpos = [&](int buf) -> char * { return lds + buf*STAGE + wrow*MQ_LD + wchunk*64 + wq*16; };
+        auto xpos = [&](int buf) -> char * { return lds + buf*STAGE + WTILE + xrow*MQ_LD + xq*32; };
+        auto c32_of = [&](int step) -> int { return min(step*MQ_BK + 32*wchunk, k - 32) >> 5; };
+        struct frags { int4v a[2], b; };
+        auto read_frags = [&](frags & f, int buf, int kk) {
+            const char * lw = lds + buf*STAGE, * lx = lw + WTILE;
+#pragma unroll
+            for (int i = 0; i < 2; i++) f.a[i] = *(const int4v *) (lx + (wn*64 + i*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+            f.b = *(const int4v *) (lw + (wm*32 + (lane & 31))*MQ_LD + kk*32 + (lane >> 5)*16);
+        };
+        auto mfma = [&](const frags & f, int i) {
+            acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, f.a[i]), __builtin_bit_cast(bf16x8, f.b), acc[i], 0, 0, 0);
+        };
+        auto iteration = [&](stage_regs & cur, stage_regs & nxt, int s, int buf) {
+            fetch(nxt, step0 + s + 2);
+            const int c32 = c32_of(step0 + s + 1);
+            const dq_head h = decode_head<TY>(cur.rw, c32);
+            frags f0, f1;
+            read_frags(f0, buf, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            float lo[4], hi[4];
+            // kk = 0: activations, first half
+            read_frags(f1, buf, 1);
+            mfma(f0, 0);
+            *(int4v *) (xpos(buf ^ 1)) = cur.xv[0];
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(f0, 1);
+            decode4<TY>(cur.rw, h, c32, 0, 2*wq, lo);
+            __builtin_amdgcn_sched_barrier(0);
+            // kk = 1
+            read_frags(f0, buf, 2);
+            mfma(f1, 0);
+            decode4<TY>(cur.rw, h, c32, 1, 2*wq + 1, hi);
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(f1, 1);
+            {
+                int4v wpk;
+                wpk.x = (int) pack_bf16(lo[0], lo[1]); wpk.y = (int) pack_bf16(lo[2], lo[3]);
+                wpk.z = (int) pack_bf16(hi[0], hi[1]); wpk.w = (int) pack_bf16(hi[2], hi[3]);
+                *(int4v *) (wpos(buf ^ 1)) = wpk;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            // kk = 2
+            read_frags(f1, buf, 3);
+            mfma(f0, 0);
+            *(int4v *) (xpos(buf ^ 1) + 16) = cur.xv[1];
+            __builtin_amdgcn_sched_barrier(0);
+            mfma(f0, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // kk = 3
+            mfma(f1, 0);
+            mfma(f1, 1);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        stage_regs p0, p1;
+        fetch(p0, step0);
+        fetch(p1, step0 + 1);
+        {
+            const int c32 = c32_of(step0);
+            const dq_head h = decode_head<TY>(p0.rw, c32);
+            float lo[4], hi[4];
+            decode4<TY>(p0.rw, h, c32, 0, 2*wq, lo); decode4<TY>(p0.rw, h, c32, 1, 2*wq + 1, hi);
+            int4v wpk;
+            wpk.x = (int) pack_bf16(lo[0], lo[1]); wpk.y = (int) pack_bf16(lo[2], lo[3]);
+            wpk.z = (int) pack_bf16(hi[0], hi[1]); wpk.w = (int) pack_bf16(hi[2], hi[3]);
+            *(int4v *) (wpos(0)) = wpk;
+            *(int4v *) (xpos(0)) = p0.xv[0]; *(int4v *) (xpos(0) + 16) = p0.xv[1];
+        }
+        __syncthreads();
+        __builtin_amdgcn_sched_barrier(0);
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            iteration(p1, p0, s, 0);
+            iteration(p0, p1, s + 1, 1);
+        }
+        if (s < nsteps) iteration(p1, p0, s, 0);
+    };
+    if constexpr (TYPE2 != TYPE) {
+        if (use2) run(std::integral_constant<int, TYPE2>{}); else run(std::integral_constant<int, TYPE>{});
+    } else {
+        run(std::integral_constant<int, TYPE>{});
+    }
+    // ---- store: D[row = token][col = weight row] ----
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int col = m0 + wm*32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = n0 + wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
+            if (col < m && row < n) {
+                float * o = (float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4);
+                if (p.res && p.ksplit == 1) *o = acc[i][r] + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
+                else *o = acc[i][r];
+            }
+        }
+    }
+}
+
 constexpr size_t MQ_LDS_BYTES = 4*(size_t) MQ_BM*MQ_LD;
 constexpr size_t MQ_LDS_BYTES_256 = 2*(size_t)(MQ_BM + 256)*MQ_LD;
 constexpr size_t MQ_LDS_BYTES_DUAL = 2*(size_t)(2*MQ_BM + 256)*MQ_LD;
@@ -398,6 +580,16 @@ static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
         return true;
     }();
     (void) once;
+    static const bool w16 = !getenv("GGML_MI355X_MMQ16") || atoi(getenv("GGML_MI355X_MMQ16")) != 0;
+    if (w16 && !a.moe && a.ne12 == 1 && a.r2 == 1 && a.r3 == 1) {
+        static const bool once16 = [] {
+            MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq16<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
+            return true;
+        }();
+        (void) once16;
+        hipLaunchKernelGGL((k_mmq16<T_>), grid, dim3(1024), MQ_LDS_BYTES_256, stream, a);
+        return;
+    }
     hipLaunchKernelGGL((k_mmq<T_, 256>), grid, dim3(512), MQ_LDS_BYTES_256, stream, a);
 }
 
@@ -481,6 +673,16 @@ static void launch_mmq_multi(dim3 grid, const mmq_args & a, hipStream_t stream) 
         return true;
     }();
     (void) once;
+    static const bool w16 = !getenv("GGML_MI355X_MMQ16") || atoi(getenv("GGML_MI355X_MMQ16")) != 0;
+    if (w16) {
+        static const bool once16 = [] {
+            MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq16<T_, T2_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
+            return true;
+        }();
+        (void) once16;
+        hipLaunchKernelGGL((k_mmq16<T_, T2_>), grid, dim3(1024), MQ_LDS_BYTES_256, stream, a);
+        return;
+    }
     hipLaunchKernelGGL((k_mmq<T_, 256, false, T2_>), grid, dim3(512), MQ_LDS_BYTES_256, stream, a);
 }
 
