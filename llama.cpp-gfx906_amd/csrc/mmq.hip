@@ -626,8 +626,10 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
     // leave the chip half empty (m = 4096, n = 512: 128 tiles on 256 CUs) is split in two along k
     const int64_t wtiles = (int64_t) mtiles*((n + 255)/256);
     const bool vec_ok = m % 4 == 0 && dst_col_stride_bytes % 16 == 0 && ((uintptr_t) dst % 16) == 0 && (!res || (res_row_stride % 16 == 0 && ((uintptr_t) res % 16) == 0));
-    // a long-k matrix with few rows (ffn_down: m = 4096, k = 14336): 256-token tiles and k in four parts
-    const bool wide4 = n >= 256 && wtiles < 160 && wtiles*4 >= 160 && k % 1024 == 0 && k >= 8192 && vec_ok;
+    // few rows (wo: m = 4096, k = 4096; ffn_down: k = 14336): 256-token tiles and k in four parts (with the 16-wave kernel this beats
+    // 128-token tiles split in two also at k = 4096: wo 49 -> 42 us)
+    static const int64_t wide4_min_k = getenv("GGML_MI355X_WIDE4_MINK") ? atoll(getenv("GGML_MI355X_WIDE4_MINK")) : 4096;
+    const bool wide4 = n >= 256 && wtiles < 160 && wtiles*4 >= 160 && k % 1024 == 0 && k >= wide4_min_k && vec_ok;
     const bool wide = (n >= 256 && wtiles >= 160) || wide4;
     const int ntiles = wide ? (int)((n + 255)/256) : (int)((n + MQ_BN - 1)/MQ_BN);
     float * planes = (float *) ((char *) scratch + mmq_x_bytes(k, n));
