@@ -7,9 +7,8 @@
 // row of cells per head dimension). Arithmetic as the node-by-node path: q and the probabilities rounded to f16 (the vec_dot type
 // of an F16 matrix), f32 accumulation, soft_max in f32.
 //
-// One workgroup of 8 waves per (head, 32 queries); wave w takes the cell blocks w, w + 8, ... (a block whose mask is -inf for all of the
-// 32 x 32 pairs — the causal future — is skipped before any arithmetic) and the partial (max, sum, O) states are merged through
-// LDS at the end. Everything is computed TRANSPOSED so that a lane owns ONE query column:
+// One wave per (head, 32 queries); 8 waves (a GQA group x query tiles) share the K / V^T blocks through LDS (see the kernel). Everything is
+// computed TRANSPOSED so that a lane owns ONE query column:
 //   S^T[32 cells x 32 queries] = K[32 x hd] . Q^T      (v_mfma_f32_32x32x16_f16, A = K rows straight from the cache, B = Q^T)
 //   per-lane online softmax over the 16 cells a lane holds (+ one exchange with lane ^ 32: the other 16 cells of the same query)
 //   O^T[hd x 32 queries] += V^T[hd x 32 cells] . P^T   (A = rows of the transposed V cache, B = P^T straight from the registers of S^T)
@@ -41,16 +40,25 @@ static __device__ __forceinline__ float xhalf(float v, int lane) {      // the v
 
 // VT: transposed V cache (rows over cells). !VT: V rows are cells (FLASH_ATTN_EXT): the 8 cells of a k-slot group are then 8 two-byte
 // gathers per operand — correct, not fast; a transposing LDS read is the next step for that layout.
-constexpr int APF_NW = 8;       // 2 waves per SIMD at 256 registers each: one workgroup per CU
-// MASK: 0 = none, 1 = f32, 2 = f16 — a template parameter, not a branch: every load of a block (mask, K, V) is issued before the first
-// use, so a block costs one memory round trip (as run-time branches the loads sat in blocks of their own, each waiting for its data)
+constexpr int APF_NW = 8;
+constexpr int APF_KLD = 16;     // LDS row padding (bytes): K rows HD*2 + 16 (ds_read_b128 conflict-free), V^T rows 64 + 8 (ds_read_b64 conflict-free)
+// One workgroup of 8 waves = hpw heads of ONE kv head (the GQA group, or a power-of-two part of it) x 8/hpw tiles of 32 queries. The waves
+// walk the cell blocks together: a block's K rows and V^T rows are staged ONCE into LDS with coalesced loads (double-buffered, the next
+// block's loads in flight during the arithmetic) and every wave takes its MFMA operands from there. Before this, every wave gathered its
+// own K rows (2 KB apart) and V^T rows (n_ctx*2 bytes apart) 8-16 bytes at a time: 768 sector requests per block and wave, 42 us per
+// layer at 512 tokens and 399 us at 2048 however the blocks were spread over waves.
+// MASK: 0 = none, 1 = f32, 2 = f16 (a template parameter: the loads stay in one basic block). A wave skips the arithmetic of a block
+// whose mask is -inf for all its 32 x 32 pairs (the causal future); staging and barriers go on.
 template <int HD, bool VT, int MASK>
-__global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p) {
-    constexpr int NC = HD/16, NDT = HD/32;
-    extern __shared__ float part[];                           // [(APF_NW - 1)*(16*NDT + 2)*64]: the other waves' o[NDT][16], m, l per lane
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, ql = lane & 31, hf = lane >> 5;
-    const int h = blockIdx.y, hk = h/(p.n_head/p.n_head_kv);
-    const int q0 = blockIdx.x*32;
+__global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p, int hpw) {
+    constexpr int NC = HD/16, NDT = HD/32, CPR = HD/8;                 // CPR: 16-byte chunks per K row
+    constexpr int KROW = HD*2 + APF_KLD, VROW = 64 + 8;
+    __shared__ __attribute__((aligned(16))) char ldsk[2][32*KROW];
+    __shared__ __attribute__((aligned(16))) char ldsv[2][HD*VROW];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hf = lane >> 5;
+    const int h = blockIdx.y*hpw + wave % hpw, hk = h/(p.n_head/p.n_head_kv);
+    const int q0 = (blockIdx.x*(APF_NW/hpw) + wave/hpw)*32;
+    const bool active = q0 < p.T;                        // wave-uniform; an idle wave still stages and meets the barriers
     const int t = min(q0 + ql, p.T - 1);
 
     // Q^T as B operand: chunk c holds head dims 16c + 8 hf .. + 7 of query t, rounded to f16
@@ -68,129 +76,130 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
     for (int d = 0; d < NDT; d++)
 #pragma unroll
         for (int r = 0; r < 16; r++) o[d][r] = 0.0f;
-    float m = -INFINITY, l = 0.0f;     // running maximum (common to both halves) and this half's share of the denominator
+    float m = -INFINITY, l = 0.0f;     // running maximum (common to both halves; base-2 domain) and this half's share of the denominator
+    constexpr float LOG2E = 1.4426950408889634f;
+    const float scale2 = p.scale*LOG2E;
 
-    const char * kbase = p.k + (size_t) hk*p.k_nb2 + (size_t)(8*hf)*2;
-    const char * vbase = VT ? p.v + (size_t) hk*p.v_nb2 + (size_t) ql*p.v_nb1 + (size_t)(4*hf)*2
-                            : p.v + (size_t) hk*p.v_nb2 + (size_t) ql*2 + (size_t)(4*hf)*p.v_nb1;
-    const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 : nullptr;
+    // staging roles. K (and a row-major V): thread -> (cell = tid / CPR, 16-byte chunk); transposed V: thread -> (dim row = tid / 4, 8 cells)
+    const bool k_role = tid < 32*CPR, v_role = VT ? tid < HD*4 : k_role;
+    const int kcell = tid / CPR, kch = tid % CPR, vrow = tid >> 2, vch = tid & 3;
+    const char * kg = p.k + (size_t) hk*p.k_nb2 + (size_t) kch*16;
+    const char * vg = VT ? p.v + (size_t) hk*p.v_nb2 + (size_t) min(vrow, HD - 1)*p.v_nb1 + (size_t) vch*16
+                         : p.v + (size_t) hk*p.v_nb2 + (size_t) kch*16;
+    const char * mrow = MASK ? p.mask + (size_t) t*p.m_nb1 : nullptr;
 
-    for (int kv0 = 32*wave; kv0 < p.n_kv; kv0 += 32*APF_NW) {
-        // ---- the mask of this lane's 16 cells; a block nobody may look at is skipped ----
-        float mk[16];
+    int4v kst, vst;                    // the next block's K / V pieces
+    int4v mst[4];                      // the next block's mask values of this lane (f16: .xy used)
+    auto fetch = [&](int kv0) {
+        const int kvc = min(kv0, p.n_kv - 32);
+        if (k_role) kst = *(const int4v *) (kg + (size_t)(kvc + min(kcell, 31))*p.k_nb1);
+        if (v_role) vst = VT ? *(const int4v *) (vg + (size_t) kvc*2) : *(const int4v *) (vg + (size_t)(kvc + min(kcell, 31))*p.v_nb1);
         if (MASK == 2) {
-            int2v raw[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) raw[j] = ld_b64(mrow + (size_t)(kv0 + 8*j + 4*hf)*2);
+            for (int j = 0; j < 4; j++) { const int2v raw = ld_b64(mrow + (size_t)(kvc + 8*j + 4*hf)*2); mst[j].x = raw.x; mst[j].y = raw.y; }
+        } else if (MASK == 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) mst[j] = ld_b128(mrow + (size_t)(kvc + 8*j + 4*hf)*4);
+        }
+    };
+    auto stage = [&](int buf) {
+        if (k_role) *(int4v *) (ldsk[buf] + kcell*KROW + kch*16) = kst;
+        if (v_role) {
+            if (VT) {
+                *(int2v *) (ldsv[buf] + vrow*VROW + vch*16)     = int2v{ vst.x, vst.y };
+                *(int2v *) (ldsv[buf] + vrow*VROW + vch*16 + 8) = int2v{ vst.z, vst.w };
+            } else {        // transpose on the way in: 8 dims of one cell -> 8 rows of V^T
+                const uint32_t w[4] = { (uint32_t) vst.x, (uint32_t) vst.y, (uint32_t) vst.z, (uint32_t) vst.w };
+#pragma unroll
+                for (int e = 0; e < 8; e++) *(uint16_t *) (ldsv[buf] + (kch*8 + e)*VROW + kcell*2) = (uint16_t)(w[e >> 1] >> (16*(e & 1)));
+            }
+        }
+    };
+
+    fetch(0);
+    stage(0);
+    float mk[16];
+    auto take_mask = [&]() {
+        if (MASK == 2) {
 #pragma unroll
             for (int j = 0; j < 4; j++) {
-                const f16x4 hv = __builtin_bit_cast(f16x4, raw[j]);
+                const f16x4 hv = __builtin_bit_cast(f16x4, int2v{ mst[j].x, mst[j].y });
                 mk[4*j] = (float) hv[0]; mk[4*j + 1] = (float) hv[1]; mk[4*j + 2] = (float) hv[2]; mk[4*j + 3] = (float) hv[3];
             }
         } else if (MASK == 1) {
-            float4v fv[4];
 #pragma unroll
-            for (int j = 0; j < 4; j++) fv[j] = __builtin_bit_cast(float4v, ld_b128(mrow + (size_t)(kv0 + 8*j + 4*hf)*4));
-#pragma unroll
-            for (int j = 0; j < 4; j++) { mk[4*j] = fv[j].x; mk[4*j + 1] = fv[j].y; mk[4*j + 2] = fv[j].z; mk[4*j + 3] = fv[j].w; }
+            for (int j = 0; j < 4; j++) { const float4v fv = __builtin_bit_cast(float4v, mst[j]); mk[4*j] = fv.x; mk[4*j + 1] = fv.y; mk[4*j + 2] = fv.z; mk[4*j + 3] = fv.w; }
         } else {
 #pragma unroll
             for (int r = 0; r < 16; r++) mk[r] = 0.0f;
         }
-        // K rows and the V operands of the whole block: in flight together with the mask
-        const char * krow = kbase + (size_t)(kv0 + ql)*p.k_nb1;
-        int4v kraw[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++) kraw[c] = *(const int4v *) (krow + (size_t) c*32);
-        int4v va[2][NDT];
-#pragma unroll
-        for (int c2 = 0; c2 < 2; c2++)
-#pragma unroll
-            for (int d = 0; d < NDT; d++) {
-                if (VT) {
-                    const char * vp = vbase + (size_t)(32*d)*p.v_nb1 + (size_t)(kv0 + 16*c2)*2;
-                    const int2v lo = ld_b64(vp), hi = ld_b64(vp + 16);
-                    va[c2][d] = int4v{ lo.x, lo.y, hi.x, hi.y };
-                } else {
-                    const char * vp = vbase + (size_t)(32*d)*2 + (size_t)(kv0 + 16*c2)*p.v_nb1;      // cell kv0 + 16 c2 + 4 hf, dim 32 d + ql
-                    uint32_t hv[8];
-#pragma unroll
-                    for (int sl = 0; sl < 8; sl++) hv[sl] = ld_u16(vp + (size_t)(8*(sl >> 2) + (sl & 3))*p.v_nb1);
-                    va[c2][d] = int4v{ (int)(hv[0] | (hv[1] << 16)), (int)(hv[2] | (hv[3] << 16)), (int)(hv[4] | (hv[5] << 16)), (int)(hv[6] | (hv[7] << 16)) };
-                }
-            }
-        if (MASK) {
+    };
+    take_mask();
+    __syncthreads();
+
+    for (int kv0 = 0, buf = 0; kv0 < p.n_kv; kv0 += 32, buf ^= 1) {
+        fetch(kv0 + 32);               // clamped past the end: staged into a buffer nobody reads
+        bool need = active;
+        if (MASK && need) {
             float mx = -INFINITY;
 #pragma unroll
             for (int r = 0; r < 16; r++) mx = fmaxf(mx, mk[r]);
-            if (__builtin_amdgcn_ballot_w64(mx != -INFINITY) == 0) continue;       // wave-uniform
+            need = __builtin_amdgcn_ballot_w64(mx != -INFINITY) != 0;       // wave-uniform
         }
-        // ---- S^T = K . Q^T ----
-        f32x16 s;
+        if (need) {
+            // ---- S^T = K . Q^T ----
+            f32x16 s;
 #pragma unroll
-        for (int r = 0; r < 16; r++) s[r] = 0.0f;
+            for (int r = 0; r < 16; r++) s[r] = 0.0f;
+            const char * kl = ldsk[buf] + ql*KROW + hf*16;
 #pragma unroll
-        for (int c = 0; c < NC; c++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, kraw[c]), qb[c], s, 0, 0, 0);
-        // ---- scale + mask; s[r] belongs to cell kv0 + (r & 3) + 8 (r >> 2) + 4 hf of query t ----
-        float bm = -INFINITY;
+            for (int c = 0; c < NC; c++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, *(const int4v *) (kl + c*32)), qb[c], s, 0, 0, 0);
+            // ---- scale + mask; s[r] belongs to cell kv0 + (r & 3) + 8 (r >> 2) + 4 hf of query t. The softmax runs in the base-2 domain
+            //      (scores times log2 e, v_exp_f32 is 2^x): one instruction per exponential instead of expf's six ----
+            float bm = -INFINITY;
 #pragma unroll
-        for (int r = 0; r < 16; r++) { s[r] = s[r]*p.scale + mk[r]; bm = fmaxf(bm, s[r]); }
-        bm = fmaxf(bm, xhalf(bm, lane));
-        const float m_new = fmaxf(m, bm);
-        const float alpha = m == -INFINITY ? 0.0f : expf(m - m_new);     // m_new == -inf only while every cell so far was masked: p = 0
-        float psum = 0.0f;
-        float pr[16];
+            for (int r = 0; r < 16; r++) { s[r] = s[r]*scale2 + mk[r]*LOG2E; bm = fmaxf(bm, s[r]); }
+            bm = fmaxf(bm, xhalf(bm, lane));
+            const float m_new = fmaxf(m, bm);
+            const float alpha = m == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m - m_new);     // m_new == -inf only while every cell so far was masked: p = 0
+            float psum = 0.0f;
+            float pr[16];
 #pragma unroll
-        for (int r = 0; r < 16; r++) { pr[r] = s[r] == -INFINITY ? 0.0f : expf(s[r] - m_new); psum += pr[r]; }
-        l = l*alpha + psum;
-        m = m_new;
+            for (int r = 0; r < 16; r++) { pr[r] = s[r] == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(s[r] - m_new); psum += pr[r]; }
+            l = l*alpha + psum;
+            m = m_new;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {      // the running maximum settles early: most blocks rescale nothing
 #pragma unroll
-        for (int d = 0; d < NDT; d++)
+                for (int d = 0; d < NDT; d++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) o[d][r] *= alpha;
-        // ---- O^T += V^T . P^T: the k-slots of chunk c2 are the cells kv0 + 16 c2 + 8 (s >> 2) + 4 hf + (s & 3), s = 0..7 ----
+                    for (int r = 0; r < 16; r++) o[d][r] *= alpha;
+            }
+            // ---- O^T += V^T . P^T: the k-slots of chunk c2 are the cells kv0 + 16 c2 + 8 (s >> 2) + 4 hf + (s & 3), s = 0..7 ----
 #pragma unroll
-        for (int c2 = 0; c2 < 2; c2++) {
-            const f16x8 pb = { (_Float16) pr[8*c2 + 0], (_Float16) pr[8*c2 + 1], (_Float16) pr[8*c2 + 2], (_Float16) pr[8*c2 + 3],
-                               (_Float16) pr[8*c2 + 4], (_Float16) pr[8*c2 + 5], (_Float16) pr[8*c2 + 6], (_Float16) pr[8*c2 + 7] };
+            for (int c2 = 0; c2 < 2; c2++) {
+                const f16x8 pb = { (_Float16) pr[8*c2 + 0], (_Float16) pr[8*c2 + 1], (_Float16) pr[8*c2 + 2], (_Float16) pr[8*c2 + 3],
+                                   (_Float16) pr[8*c2 + 4], (_Float16) pr[8*c2 + 5], (_Float16) pr[8*c2 + 6], (_Float16) pr[8*c2 + 7] };
 #pragma unroll
-            for (int d = 0; d < NDT; d++) {
-                o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, va[c2][d]), pb, o[d], 0, 0, 0);
+                for (int d = 0; d < NDT; d++) {
+                    const char * vp = ldsv[buf] + (32*d + ql)*VROW + (16*c2 + 4*hf)*2;
+                    const int2v lo = *(const int2v *) vp, hi = *(const int2v *) (vp + 16);
+                    o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, int4v{ lo.x, lo.y, hi.x, hi.y }), pb, o[d], 0, 0, 0);
+                }
             }
         }
+        stage(buf ^ 1);                // last read before the previous barrier
+        take_mask();
+        __syncthreads();
     }
-    // ---- merge the four waves' states (same lane = same query and the same cells-within-block pattern) ----
-    constexpr int PS = 16*NDT + 2;
-    if (wave > 0) {
-        float * pp = part + (size_t)(wave - 1)*PS*64 + lane;
-#pragma unroll
-        for (int d = 0; d < NDT; d++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) pp[(16*d + r)*64] = o[d][r];
-        pp[(16*NDT)*64] = m; pp[(16*NDT + 1)*64] = l;
-    }
-    __syncthreads();
-    if (wave > 0) return;
-#pragma unroll 1
-    for (int w = 1; w < APF_NW; w++) {
-        const float * pp = part + (size_t)(w - 1)*PS*64 + lane;
-        const float mw = pp[(16*NDT)*64], lw = pp[(16*NDT + 1)*64];
-        const float m_new = fmaxf(m, mw);
-        const float a = m == -INFINITY ? 0.0f : expf(m - m_new), b = mw == -INFINITY ? 0.0f : expf(mw - m_new);
-        l = l*a + lw*b; m = m_new;
-#pragma unroll
-        for (int d = 0; d < NDT; d++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) o[d][r] = o[d][r]*a + pp[(16*d + r)*64]*b;
-    }
+    if (!active) return;
     // ---- finish: both halves' denominators, the sink logit (src/llama-graph.cpp:1313), normalise, store ----
     float lt = l + xhalf(l, lane);
     float fin = 1.0f;
     if (p.sinks) {
-        const float sk = p.sinks[h];
+        const float sk = p.sinks[h]*LOG2E;
         const float mf = fmaxf(m, sk);
-        fin = m == -INFINITY ? 0.0f : expf(m - mf);
-        lt = lt*fin + expf(sk - mf);
+        fin = m == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m - mf);
+        lt = lt*fin + __builtin_amdgcn_exp2f(sk - mf);
     }
     const float inv = fin/lt;
     if (q0 + ql < p.T) {
@@ -212,18 +221,18 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
                   int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans) {
     attn_pf_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
                        (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
-    const dim3 grid((unsigned)((T + 31)/32), (unsigned) n_head);
+    const int64_t R = n_head/n_head_kv;
+    const int hpw = R % 8 == 0 ? 8 : R % 4 == 0 ? 4 : R % 2 == 0 ? 2 : 1;          // heads of one kv head per workgroup
+    const int qpw = APF_NW/hpw;                                                      // query tiles per workgroup
+    const dim3 grid((unsigned)((T + 32*qpw - 1)/(32*qpw)), (unsigned)(n_head/hpw));
     const int mk = !mask ? 0 : (mask_f16 ? 2 : 1);
-#define MI_APF1(HD_, VT_, MK_) do { \
-        constexpr size_t lds_ = (size_t)(APF_NW - 1)*(16*(HD_/32) + 2)*64*4; \
-        static const bool once_ = [] { MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_prefill<HD_, VT_, MK_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_)); return true; }(); \
-        (void) once_; \
-        hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, MK_>), grid, dim3(64*APF_NW), lds_, stream, a); } while (0)
-#define MI_APF(HD_, VT_) do { if (mk == 0) MI_APF1(HD_, VT_, 0); else if (mk == 1) MI_APF1(HD_, VT_, 1); else MI_APF1(HD_, VT_, 2); } while (0)
+#define MI_APF(HD_, VT_) do { \
+        if (mk == 0)      hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, 0>), grid, dim3(64*APF_NW), 0, stream, a, hpw); \
+        else if (mk == 1) hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, 1>), grid, dim3(64*APF_NW), 0, stream, a, hpw); \
+        else              hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, 2>), grid, dim3(64*APF_NW), 0, stream, a, hpw); } while (0)
     if (!v_trans) { if (head_dim == 128) MI_APF(128, false); else MI_APF(64, false); }
     else          { if (head_dim == 128) MI_APF(128, true);  else MI_APF(64, true); }
 #undef MI_APF
-#undef MI_APF1
 }
 
 } // namespace mi355x
