@@ -338,7 +338,12 @@ def test_mul_mat_f32_f16_generic_strided():
 
 
 @pytest.mark.parametrize("hd,n_head,n_head_kv,n_kv,T,sinks", [(128, 8, 2, 256, 1, False), (128, 8, 2, 512, 3, True), (64, 4, 4, 256, 8, False),
-                                                            (128, 8, 2, 256, 33, False), (64, 8, 2, 512, 64, True), (128, 4, 1, 256, 40, False)])
+                                                            (128, 8, 2, 256, 33, False), (64, 8, 2, 512, 64, True), (128, 4, 1, 256, 40, False),
+                                                            # the prefill kernel's workgroup shapes: 1 / 2 / 8 heads of a kv head per workgroup, a GQA
+                                                            # ratio that is no power of two (3), idle waves in the last workgroup, a sliding window
+                                                            # (T = 130: cells more than 100 back are masked, so whole blocks at the START are skipped)
+                                                            (64, 4, 4, 256, 70, False), (128, 8, 4, 256, 100, True), (128, 16, 2, 512, 130, False),
+                                                            (64, 6, 2, 256, 45, True), (128, 32, 8, 1024, 300, False)])
 def test_flash_attn_ext(hd, n_head, n_head_kv, n_kv, T, sinks):
     """FLASH_ATTN_EXT as build_attn_mha emits it with -fa (src/llama-graph.cpp:1245-1265; tests/test-backend-ops.cpp:4559, NMSE 5e-4):
     q F32 permuted view, K and V F16 views of the cache with rows = cells (V NOT transposed), F16 mask padded in the token dimension,
@@ -352,6 +357,8 @@ def test_flash_attn_ext(hd, n_head, n_head_kv, n_kv, T, sinks):
     mask = np.full((1, 1, Tp, n_kv), -np.inf, np.float32)
     for t in range(T):
         mask[0, 0, t, : n_kv - T + t + 1] = 0.0          # causal: the T tokens are the last T cells
+        if T == 130:
+            mask[0, 0, t, : max(0, n_kv - T + t + 1 - 100)] = -np.inf
     sk = rng.uniform(-1, 1, size=(n_head,)).astype(np.float32)
     scale = 1.0 / np.sqrt(hd)
     with gg.Context() as ctx:
