@@ -1095,21 +1095,46 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
     }
     int types[3]; const void * W[3]; size_t wrs[3]; int64_t m[3]; float * dst[3]; size_t dstride[3];
     uint64_t wbytes = 0;
+    // the ROPEs go into the launch (epilogue, or the pass that combines split-k planes) when they are NORM-mode, share one descriptor and
+    // are the only readers of their mat-muls: the mat-mul then writes the ROPE node's tensor directly
+    mmvq_rope rd = {}; bool have_rd = false, rope_ok = true; int seg_rope[3] = { 0, 0, 0 };
+    for (int q = 0; q < nc && rope_ok; q++) {
+        if (ch[q].rope < 0) continue;
+        const struct ggml_tensor * mm = g->nodes[ch[q].mm]; const struct ggml_tensor * rp = g->nodes[ch[q].rope];
+        mmvq_rope r1 = {};
+        r1.pos = (const int32_t *) rp->src[1]->data; r1.freq_factors = rp->src[2] ? (const float *) rp->src[2]->data : nullptr; r1.head_dim = (int) rp->ne[0];
+        r1.p.n_dims = rp->op_params[1]; r1.p.mode = rp->op_params[2]; r1.p.n_ctx_orig = rp->op_params[4];
+        r1.p.freq_base = op_f32(rp, 5); r1.p.freq_scale = op_f32(rp, 6); r1.p.ext_factor = op_f32(rp, 7);
+        r1.p.attn_factor = op_f32(rp, 8); r1.p.beta_fast = op_f32(rp, 9); r1.p.beta_slow = op_f32(rp, 10);
+        rope_ok = rp->op_params[2] == 0 && rp->type == GGML_TYPE_F32 && ggml_is_contiguous(rp) && rp->src[1]->type == GGML_TYPE_I32 && rp->ne[3] == 1 &&
+                  rp->ne[2] == b->ne[1] && rp->ne[0]*rp->ne[1] == mm->ne[0] && rp->op_params[1] % 2 == 0 && rp->op_params[1] <= rp->ne[0] && rp->ne[0] % 4 == 0 &&
+                  ggml_nelements(rp->src[1]) == b->ne[1] && is_internal(c, mm) && (rp->src[0] == mm || is_internal(c, rp->src[0])) &&
+                  (!have_rd || memcmp(&rd, &r1, sizeof(rd)) == 0);
+        rd = r1; have_rd = true; seg_rope[q] = 1;
+    }
+    const bool fuse_rope = have_rd && rope_ok;
     for (int q = 0; q < nc; q++) {
         const struct ggml_tensor * n = g->nodes[ch[q].mm]; const struct ggml_tensor * a = n->src[0];
         types[q] = (int) a->type; W[q] = a->data; wrs[q] = a->nb[1]; m[q] = a->ne[1]; dst[q] = (float *) n->data; dstride[q] = n->nb[1];
+        if (fuse_rope && seg_rope[q]) { dst[q] = (float *) g->nodes[ch[q].rope]->data; dstride[q] = g->nodes[ch[q].rope]->nb[2]; }
         wbytes += (uint64_t) a->ne[1]*ggml_row_size(a->type, a->ne[0]);
     }
     const int64_t K = b->ne[0], N = b->ne[1];
     const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1];
     prof_begin(c, types[0], m[0] + m[1] + (nc > 2 ? m[2] : 0), K, N, wbytes);
-    const bool done = mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, c->stream);
+    bool roped = fuse_rope;
+    bool done = fuse_rope && mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, &rd, seg_rope, c->stream);
+    if (!done) {
+        roped = false;
+        for (int q = 0; q < nc; q++) { dst[q] = (float *) g->nodes[ch[q].mm]->data; dstride[q] = g->nodes[ch[q].mm]->nb[1]; }
+        done = mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, nullptr, nullptr, c->stream);
+    }
     prof_end(c);
     if (!done) { if (c->profiling && !c->prof_suspend) c->prof.pop_back(); return 0; }
     if (ready) c->cnt.act_quant_reused++;
     else c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
     c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 1 : 2; c->cnt.weight_bytes += wbytes;
-    for (int q = 0; q < nc; q++) if (ch[q].rope >= 0) compute_node(c, g, ch[q].rope);
+    if (!roped) for (int q = 0; q < nc; q++) if (ch[q].rope >= 0) compute_node(c, g, ch[q].rope);
     return ch[nc - 1].end - i + 1;
 }
 

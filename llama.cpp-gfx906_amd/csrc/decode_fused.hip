@@ -20,6 +20,7 @@
 #include <mutex>
 #include "mmvq_core.h"
 #include "quant_core.h"
+#include "rope_dev.h"
 
 #include <math.h>
 
@@ -308,10 +309,6 @@ void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, siz
 // ---------------------------------------------------------------------------------------------------------------
 // grouped mat-vec with epilogues (n = 1)
 // ---------------------------------------------------------------------------------------------------------------
-struct fused_rope {
-    const int32_t * pos; const float * ff; int n_dims, head_dim, n_ctx_orig;
-    float freq_scale, ext_factor, attn_factor, theta_scale, corr_lo, corr_hi;
-};
 
 struct fused_mmvq_args {
     mmvq_group g[MMVQ_MAX_GROUPS];
@@ -336,24 +333,6 @@ struct fused_mmvq_args {
 #define MI_STAMP(i_) do { } while (0)
 #endif
 
-static __device__ __forceinline__ void rope_pair(const fused_rope & r, int pos, int row_in_head, float & x0, float & x1) {
-    // NORM rope on the pair (2i, 2i+1) — same formulas as elem.hip k_rope<false>
-    if (row_in_head >= r.n_dims) return;
-    const int ip = row_in_head >> 1;
-    const float theta_base = (float) pos*powf(r.theta_scale, (float) ip);
-    const float theta_extrap = theta_base/(r.ff ? r.ff[ip] : 1.0f);
-    float theta_interp = r.freq_scale*theta_extrap, theta = theta_interp, mscale = r.attn_factor;
-    if (r.ext_factor != 0.0f) {
-        const float y = ((float) ip - r.corr_lo)/fmaxf(0.001f, r.corr_hi - r.corr_lo);
-        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y)))*r.ext_factor;
-        theta = theta_interp*(1.0f - ramp_mix) + theta_extrap*ramp_mix;
-        mscale *= 1.0f + 0.1f*logf(1.0f/r.freq_scale);
-    }
-    const float c = cosf(theta)*mscale, s = sinf(theta)*mscale;
-    const float a = x0, b = x1;
-    x0 = a*c - b*s;
-    x1 = a*s + b*c;
-}
 
 // PERSISTENT grouped mat-vec. A launch has ONE workgroup of 8 (or 16) waves per CU; each workgroup belongs to one group (weight
 // tensor) and its waves walk that tensor's row pairs (single rows for the dual GLU stream) with a grid stride, so that
@@ -719,9 +698,6 @@ extern "C" int mi355x_stamps_read(int slot, unsigned long long * out, int * meta
 }
 #endif
 
-static float rope_corr_dim_h(int n_dims, int n_ctx_orig, float n_rot, float base) {
-    return n_dims*logf(n_ctx_orig/(n_rot*2*(float) M_PI))/(2*logf(base));
-}
 
 static size_t pad256h(size_t x) { return (x + 255) & ~(size_t) 255; }
 
@@ -791,13 +767,7 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         a.x = in.x; a.norm_w = in.norm_w; a.eps = in.eps;
     }
     if (rope) {
-        a.rope.pos = rope->pos; a.rope.ff = rope->freq_factors; a.rope.n_dims = rope->p.n_dims; a.rope.head_dim = rope->head_dim;
-        a.rope.n_ctx_orig = rope->p.n_ctx_orig; a.rope.freq_scale = rope->p.freq_scale; a.rope.ext_factor = rope->p.ext_factor;
-        a.rope.attn_factor = rope->p.attn_factor;
-        a.rope.theta_scale = powf(rope->p.freq_base, -2.0f/rope->p.n_dims);
-        const float start = floorf(rope_corr_dim_h(rope->p.n_dims, rope->p.n_ctx_orig, rope->p.beta_fast, rope->p.freq_base));
-        const float end   = ceilf (rope_corr_dim_h(rope->p.n_dims, rope->p.n_ctx_orig, rope->p.beta_slow, rope->p.freq_base));
-        a.rope.corr_lo = fmaxf(0.0f, start); a.rope.corr_hi = fminf((float)(rope->p.n_dims - 1), end);
+        a.rope = make_fused_rope(*rope);
     }
     const size_t lds = bytes + 64;     // + FW floats for the RMS reduction
     int ta = groups[0].type, tb = groups[0].type;

@@ -60,9 +60,11 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes,
                const float * res, size_t res_row_stride, hipStream_t stream);
 
+struct mmvq_rope;
 // 2 or 3 mat-muls on the same activations (wq / wk / wv) as one launch of 256-token tiles; false = not done, run them one by one
 bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const size_t * w_row_stride, const int64_t * m, float * const * dst, const size_t * dst_stride,
-                     int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready, hipStream_t stream);
+                     int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready,
+                     const struct mmvq_rope * rope, const int * seg_rope, hipStream_t stream);     // rope != NULL: NORM rotary embedding on the segments flagged in seg_rope
 
 // gate / up + SwiGLU for many tokens in one kernel: dst[n][m] = silu(Wg.x) * (Wu.x) (both weight tensors of one type and shape);
 // supported when the 256-token tiles fill the chip

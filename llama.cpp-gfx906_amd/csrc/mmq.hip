@@ -17,6 +17,7 @@
 #include "blocks.h"
 #include "dev_common.h"
 #include "kernels.h"
+#include "rope_dev.h"
 
 #include <type_traits>
 
@@ -169,7 +170,8 @@ constexpr int MQ_BM = 128, MQ_BN = 128, MQ_BK = 64, MQ_LD = MQ_BK*2 + 16;   // L
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // several weight tensors against the same activations in one launch (wq / wk / wv): the m-tiles of the segments are laid end to end
-struct mmq_seg { const char * W; char * dst; size_t w_row_stride, dst_nb1; int m, tile0, col0, type2; };   // col0: first column in a split-k plane; type2: decode as TYPE2
+struct mmq_seg { const char * W; char * dst; size_t w_row_stride, dst_nb1; int m, tile0, col0, type2, rope; };   // col0: first column in a split-k plane; type2: decode
+                                               // as TYPE2; rope: the NORM rotary embedding (mmq_args::rope) is applied to this segment's rows of heads
 struct mmq_args {
     const char * W; size_t w_row_stride, w_nb2, w_nb3; int m, k;
     const uint16_t * X; int n;                 // dense [batch][n][k] 16-bit
@@ -182,6 +184,7 @@ struct mmq_args {
     // MUL_MAT_ID (grouped by expert): blockIdx.x walks the tile table k_moe_sort wrote; a tile = up to 128 (token, slot) pairs of ONE expert
     const int * moe;                           // NULL, or [0] = n_tiles, then {expert, first, count}[max_tiles], then sorted pair ids
     int moe_max_tiles, n_used, n_b;            // pair = token*n_used + slot; X row of a pair = token*n_b + slot % n_b
+    fused_rope rope;                           // for segments with .rope (wq, wk): RESHAPE -> ROPE of build_attn folded into the epilogue / the combine pass
     int nseg; mmq_seg seg[3];                  // nseg > 0: W / m / dst / strides per segment; p.m = the summed rows (the width of a split-k plane)
 };
 
@@ -432,13 +435,14 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
     const int n0 = blockIdx.x*BN;
     const int wm = wave & 3, wn = wave >> 2;             // wave tile: weight rows wm*32.., tokens wn*64..
     const int n = p.n, k = p.k;
-    int m = p.m, col0 = 0; bool use2 = false;
+    int m = p.m, col0 = 0; bool use2 = false, do_rope = false;
     const char * W = p.W;
     size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst;
     if (p.nseg) {                              // workgroup-uniform
         const int si = (mt >= p.seg[1].tile0 ? 1 : 0) + (p.nseg > 2 && mt >= p.seg[2].tile0 ? 1 : 0);
         W = p.seg[si].W; m = p.seg[si].m; w_row_stride = p.seg[si].w_row_stride; seg_dst = p.seg[si].dst; seg_dst_nb1 = p.seg[si].dst_nb1;
         col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0;
+        do_rope = p.seg[si].rope != 0 && p.ksplit == 1;           // with a k split the combine pass rotates
     }
     const int m0 = mt*MQ_BM;
     const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);
@@ -559,10 +563,17 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = n0 + wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
+            float v = acc[i][r];
+            if (do_rope) {                     // workgroup-uniform: the pair (2i, 2i + 1) of a head sits in two neighbouring lanes (m is even, heads start at even columns)
+                const float other = __shfl_xor(v, 1);
+                float x0 = (col & 1) ? other : v, x1 = (col & 1) ? v : other;
+                rope_pair(p.rope, p.rope.pos[min(row, n - 1)], (col % p.rope.head_dim) & ~1, x0, x1);
+                v = (col & 1) ? x1 : x0;
+            }
             if (col < m && row < n) {
                 float * o = (float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4);
-                if (p.res && p.ksplit == 1) *o = acc[i][r] + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
-                else *o = acc[i][r];
+                if (p.res && p.ksplit == 1) *o = v + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
+                else *o = v;
             }
         }
     }
@@ -655,7 +666,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
 }
 
 // ---- several mat-muls on the same activations as one launch (wq / wk / wv of build_attn, src/llama-model.cpp:6017-6040) ----
-struct combine_seg_args { const float * planes; int64_t m4_tot, n; int nseg; char * dst[3]; size_t dst_nb1[3]; int col4[3]; };
+struct combine_seg_args { const float * planes; int64_t m4_tot, n; int nseg; char * dst[3]; size_t dst_nb1[3]; int col4[3]; int rope_seg[3]; fused_rope rope; };
 template <int NP>
 __global__ void __launch_bounds__(256) k_combine_seg(const combine_seg_args p) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
@@ -665,6 +676,13 @@ __global__ void __launch_bounds__(256) k_combine_seg(const combine_seg_args p) {
 #pragma unroll
     for (int pl = 1; pl < NP; pl++) { const float4v b = ((const float4v *) p.planes)[(int64_t) pl*p.m4_tot*p.n + i]; a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
     const int si = (c4 >= p.col4[1] ? 1 : 0) + (p.nseg > 2 && c4 >= p.col4[2] ? 1 : 0);
+    if (p.rope_seg[si]) {                      // 4 consecutive columns = 2 pairs of one head
+        const int cih = ((c4 - p.col4[si])*4) % p.rope.head_dim, pos = p.rope.pos[row];
+        float x0 = a.x, x1 = a.y, x2 = a.z, x3 = a.w;
+        rope_pair(p.rope, pos, cih, x0, x1);
+        rope_pair(p.rope, pos, cih + 2, x2, x3);
+        a = float4v{ x0, x1, x2, x3 };
+    }
     *(float4v *) (p.dst[si] + (size_t) row*p.dst_nb1[si] + (size_t)(c4 - p.col4[si])*16) = a;
 }
 
@@ -690,8 +708,14 @@ static void launch_mmq_multi(dim3 grid, const mmq_args & a, hipStream_t stream) 
 
 // false: not done (too few tiles for 256-token tiles, an unsupported mix of types, scratch too small) — the caller runs them one by one
 bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const size_t * w_row_stride, const int64_t * m, float * const * dst, const size_t * dst_stride,
-                     int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready, hipStream_t stream) {
+                     int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready,
+                     const mmvq_rope * rope, const int * seg_rope, hipStream_t stream) {
     if (nseg < 2 || nseg > 3 || n < 256) return false;
+    static const bool w16 = !getenv("GGML_MI355X_MMQ16") || atoi(getenv("GGML_MI355X_MMQ16")) != 0;
+    if (rope) {        // epilogue / combine-pass ROPE: 16-wave kernel only, heads of an even size that start at column multiples of 4
+        if (!w16 || rope->head_dim % 4 != 0 || rope->p.n_dims % 2 != 0) return false;
+        for (int s = 0; s < nseg; s++) if (seg_rope[s] && m[s] % rope->head_dim != 0) return false;
+    }
     int t1 = types[0], t2 = types[0];
     for (int s = 1; s < nseg; s++) if (types[s] != t1) { if (t2 != t1 && types[s] != t2) return false; t2 = types[s]; }
     if (t1 != t2) {
@@ -702,11 +726,12 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
     a.nseg = nseg;
     int64_t m_tot = 0; int tiles = 0; bool vec_ok = true;
     for (int s = 0; s < nseg; s++) {
-        a.seg[s] = { (const char *) W[s], (char *) dst[s], w_row_stride[s], dst_stride[s], (int) m[s], tiles, (int) m_tot, types[s] != t1 ? 1 : 0 };
+        a.seg[s] = { (const char *) W[s], (char *) dst[s], w_row_stride[s], dst_stride[s], (int) m[s], tiles, (int) m_tot, types[s] != t1 ? 1 : 0, rope && seg_rope[s] ? 1 : 0 };
         vec_ok = vec_ok && m[s] % 4 == 0 && dst_stride[s] % 16 == 0 && ((uintptr_t) dst[s] % 16) == 0;
         m_tot += m[s]; tiles += (int)((m[s] + MQ_BM - 1)/MQ_BM);
     }
     if (nseg < 3) a.seg[2] = a.seg[1];
+    if (rope) a.rope = make_fused_rope(*rope);
     if (m_tot >= (1ll << 30)) return false;
     a.m = (int) m_tot; a.mtiles = tiles;
     const int ntiles = (int)((n + 255)/256);
@@ -715,6 +740,9 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
     else if (wt*2 >= 160 && k % 512 == 0 && k >= 2048 && vec_ok) a.ksplit = 2;
     else if (wt*4 >= 160 && k % 1024 == 0 && k >= 4096 && vec_ok) a.ksplit = 4;
     else return false;
+    // the rotation rides on the combine pass (one sincos per pair, no lane exchange); in the mat-mul epilogue both lanes of a pair would
+    // evaluate it (measured: pp2048 -2.6 % against separate ROPE kernels), so without a k split the caller keeps its ROPE launches
+    if (rope && a.ksplit == 1) return false;
     if (mmq_x_bytes(k, n) + (a.ksplit > 1 ? (size_t) a.ksplit*m_tot*n*4 : 0) + 512 > scratch_size) return false;
     if (!scratch_ready) {
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, (uint16_t *) scratch };
@@ -735,8 +763,8 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
         default: fprintf(stderr, "mmq_multi: unsupported type %d\n", t1); abort();
     }
     if (a.ksplit > 1) {
-        combine_seg_args ca = { planes, m_tot/4, n, nseg, { nullptr, nullptr, nullptr }, { 0, 0, 0 }, { 0, 0, 0 } };
-        for (int s = 0; s < 3; s++) { const int q = s < nseg ? s : nseg - 1; ca.dst[s] = a.seg[q].dst; ca.dst_nb1[s] = a.seg[q].dst_nb1; ca.col4[s] = a.seg[q].col0/4; }
+        combine_seg_args ca = { planes, m_tot/4, n, nseg, { nullptr, nullptr, nullptr }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, a.rope };
+        for (int s = 0; s < 3; s++) { const int q = s < nseg ? s : nseg - 1; ca.dst[s] = a.seg[q].dst; ca.dst_nb1[s] = a.seg[q].dst_nb1; ca.col4[s] = a.seg[q].col0/4; ca.rope_seg[s] = a.seg[q].rope; }
         const unsigned cgrid = (unsigned)((m_tot/4*n + 255)/256);
         if (a.ksplit == 4) hipLaunchKernelGGL(k_combine_seg<4>, dim3(cgrid), dim3(256), 0, stream, ca);
         else               hipLaunchKernelGGL(k_combine_seg<2>, dim3(cgrid), dim3(256), 0, stream, ca);
