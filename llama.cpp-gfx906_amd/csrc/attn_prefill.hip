@@ -49,15 +49,18 @@ constexpr int APF_KLD = 16;     // LDS row padding (bytes): K rows HD*2 + 16 (ds
 // layer at 512 tokens and 399 us at 2048 however the blocks were spread over waves.
 // MASK: 0 = none, 1 = f32, 2 = f16 (a template parameter: the loads stay in one basic block). A wave skips the arithmetic of a block
 // whose mask is -inf for all its 32 x 32 pairs (the causal future); staging and barriers go on.
-template <int HD, bool VT, int MASK>
+// KS = 2 (few workgroups, i.e. short prompts: the cell loop is the critical path): an iteration stages TWO cell blocks, the waves of a
+// (head, query tile) come in pairs — one per block — and the pair's states are merged through LDS at the end: half the iterations.
+template <int HD, bool VT, int MASK, int KS>
 __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p, int hpw) {
     constexpr int NC = HD/16, NDT = HD/32, CPR = HD/8;                 // CPR: 16-byte chunks per K row
-    constexpr int KROW = HD*2 + APF_KLD, VROW = 64 + 8;
-    __shared__ __attribute__((aligned(16))) char ldsk[2][32*KROW];
-    __shared__ __attribute__((aligned(16))) char ldsv[2][HD*VROW];
+    constexpr int KROW = HD*2 + APF_KLD, VROW = 64 + 8, KBLK = 32*KROW, VBLK = HD*VROW;
+    extern __shared__ __attribute__((aligned(16))) char lds_all[];     // K: [2][KS][KBLK] | V^T: [2][KS][VBLK]
+    char * const ldsk_base = lds_all, * const ldsv_base = lds_all + 2*KS*KBLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hf = lane >> 5;
     const int h = blockIdx.y*hpw + wave % hpw, hk = h/(p.n_head/p.n_head_kv);
-    const int q0 = (blockIdx.x*(APF_NW/hpw) + wave/hpw)*32;
+    const int ks = KS == 2 ? (wave/hpw) & 1 : 0;                        // which of the iteration's blocks this wave multiplies
+    const int q0 = (blockIdx.x*(APF_NW/(hpw*KS)) + wave/(hpw*KS))*32;
     const bool active = q0 < p.T;                        // wave-uniform; an idle wave still stages and meets the barriers
     const int t = min(q0 + ql, p.T - 1);
 
@@ -88,12 +91,16 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
                          : p.v + (size_t) hk*p.v_nb2 + (size_t) kch*16;
     const char * mrow = MASK ? p.mask + (size_t) t*p.m_nb1 : nullptr;
 
-    int4v kst, vst;                    // the next block's K / V pieces
+    int4v kst[KS], vst[KS];            // the next iteration's K / V pieces
     int4v mst[4];                      // the next block's mask values of this lane (f16: .xy used)
-    auto fetch = [&](int kv0) {
-        const int kvc = min(kv0, p.n_kv - 32);
-        if (k_role) kst = *(const int4v *) (kg + (size_t)(kvc + min(kcell, 31))*p.k_nb1);
-        if (v_role) vst = VT ? *(const int4v *) (vg + (size_t) kvc*2) : *(const int4v *) (vg + (size_t)(kvc + min(kcell, 31))*p.v_nb1);
+    auto fetch = [&](int kv0) {        // kv0 = first cell of the iteration (KS blocks)
+#pragma unroll
+        for (int b = 0; b < KS; b++) {
+            const int kvb = min(kv0 + 32*b, p.n_kv - 32);
+            if (k_role) kst[b] = *(const int4v *) (kg + (size_t)(kvb + min(kcell, 31))*p.k_nb1);
+            if (v_role) vst[b] = VT ? *(const int4v *) (vg + (size_t) kvb*2) : *(const int4v *) (vg + (size_t)(kvb + min(kcell, 31))*p.v_nb1);
+        }
+        const int kvc = min(kv0 + 32*ks, p.n_kv - 32);
         if (MASK == 2) {
 #pragma unroll
             for (int j = 0; j < 4; j++) { const int2v raw = ld_b64(mrow + (size_t)(kvc + 8*j + 4*hf)*2); mst[j].x = raw.x; mst[j].y = raw.y; }
@@ -103,15 +110,19 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
         }
     };
     auto stage = [&](int buf) {
-        if (k_role) *(int4v *) (ldsk[buf] + kcell*KROW + kch*16) = kst;
-        if (v_role) {
-            if (VT) {
-                *(int2v *) (ldsv[buf] + vrow*VROW + vch*16)     = int2v{ vst.x, vst.y };
-                *(int2v *) (ldsv[buf] + vrow*VROW + vch*16 + 8) = int2v{ vst.z, vst.w };
-            } else {        // transpose on the way in: 8 dims of one cell -> 8 rows of V^T
-                const uint32_t w[4] = { (uint32_t) vst.x, (uint32_t) vst.y, (uint32_t) vst.z, (uint32_t) vst.w };
 #pragma unroll
-                for (int e = 0; e < 8; e++) *(uint16_t *) (ldsv[buf] + (kch*8 + e)*VROW + kcell*2) = (uint16_t)(w[e >> 1] >> (16*(e & 1)));
+        for (int b = 0; b < KS; b++) {
+            char * lk = ldsk_base + (buf*KS + b)*KBLK, * lv = ldsv_base + (buf*KS + b)*VBLK;
+            if (k_role) *(int4v *) (lk + kcell*KROW + kch*16) = kst[b];
+            if (v_role) {
+                if (VT) {
+                    *(int2v *) (lv + vrow*VROW + vch*16)     = int2v{ vst[b].x, vst[b].y };
+                    *(int2v *) (lv + vrow*VROW + vch*16 + 8) = int2v{ vst[b].z, vst[b].w };
+                } else {        // transpose on the way in: 8 dims of one cell -> 8 rows of V^T
+                    const uint32_t w[4] = { (uint32_t) vst[b].x, (uint32_t) vst[b].y, (uint32_t) vst[b].z, (uint32_t) vst[b].w };
+#pragma unroll
+                    for (int e = 0; e < 8; e++) *(uint16_t *) (lv + (kch*8 + e)*VROW + kcell*2) = (uint16_t)(w[e >> 1] >> (16*(e & 1)));
+                }
             }
         }
     };
@@ -137,9 +148,9 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
     take_mask();
     __syncthreads();
 
-    for (int kv0 = 0, buf = 0; kv0 < p.n_kv; kv0 += 32, buf ^= 1) {
-        fetch(kv0 + 32);               // clamped past the end: staged into a buffer nobody reads
-        bool need = active;
+    for (int kv0 = 0, buf = 0; kv0 < p.n_kv; kv0 += 32*KS, buf ^= 1) {
+        fetch(kv0 + 32*KS);            // clamped past the end: staged into a buffer nobody reads
+        bool need = active && kv0 + 32*ks < p.n_kv;
         if (MASK && need) {
             float mx = -INFINITY;
 #pragma unroll
@@ -151,7 +162,7 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
             f32x16 s;
 #pragma unroll
             for (int r = 0; r < 16; r++) s[r] = 0.0f;
-            const char * kl = ldsk[buf] + ql*KROW + hf*16;
+            const char * kl = ldsk_base + (buf*KS + ks)*KBLK + ql*KROW + hf*16;
 #pragma unroll
             for (int c = 0; c < NC; c++) s = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, *(const int4v *) (kl + c*32)), qb[c], s, 0, 0, 0);
             // ---- scale + mask; s[r] belongs to cell kv0 + (r & 3) + 8 (r >> 2) + 4 hf of query t. The softmax runs in the base-2 domain
@@ -181,7 +192,7 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
                                    (_Float16) pr[8*c2 + 4], (_Float16) pr[8*c2 + 5], (_Float16) pr[8*c2 + 6], (_Float16) pr[8*c2 + 7] };
 #pragma unroll
                 for (int d = 0; d < NDT; d++) {
-                    const char * vp = ldsv[buf] + (32*d + ql)*VROW + (16*c2 + 4*hf)*2;
+                    const char * vp = ldsv_base + (buf*KS + ks)*VBLK + (32*d + ql)*VROW + (16*c2 + 4*hf)*2;
                     const int2v lo = *(const int2v *) vp, hi = *(const int2v *) (vp + 16);
                     o[d] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, int4v{ lo.x, lo.y, hi.x, hi.y }), pb, o[d], 0, 0, 0);
                 }
@@ -190,6 +201,27 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
         stage(buf ^ 1);                // last read before the previous barrier
         take_mask();
         __syncthreads();
+    }
+    if (KS == 2) {       // the odd wave of a pair hands its state over (the staging buffers are free: the loop's last barrier is behind us)
+        constexpr int PS = 16*NDT + 2;
+        float * part = (float *) lds_all + (size_t)(wave/(2*hpw)*hpw + wave % hpw)*PS*64 + lane;
+        if (ks == 1) {
+#pragma unroll
+            for (int d = 0; d < NDT; d++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) part[(16*d + r)*64] = o[d][r];
+            part[(16*NDT)*64] = m; part[(16*NDT + 1)*64] = l;
+        }
+        __syncthreads();
+        if (ks == 1) return;
+        const float mw = part[(16*NDT)*64], lw = part[(16*NDT + 1)*64];
+        const float m_new = fmaxf(m, mw);
+        const float a = m == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m - m_new), b = mw == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mw - m_new);
+        l = l*a + lw*b; m = m_new;
+#pragma unroll
+        for (int d = 0; d < NDT; d++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[d][r] = o[d][r]*a + part[(16*d + r)*64]*b;
     }
     if (!active) return;
     // ---- finish: both halves' denominators, the sink logit (src/llama-graph.cpp:1313), normalise, store ----
@@ -223,16 +255,24 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
                        (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
     const int64_t R = n_head/n_head_kv;
     const int hpw = R % 8 == 0 ? 8 : R % 4 == 0 ? 4 : R % 2 == 0 ? 2 : 1;          // heads of one kv head per workgroup
-    const int qpw = APF_NW/hpw;                                                      // query tiles per workgroup
+    // few workgroups (short prompts): pairs of waves split the cell blocks of an iteration, halving the loop that is the critical path
+    const int64_t wgs1 = ((T + 32*(APF_NW/hpw) - 1)/(32*(APF_NW/hpw)))*(n_head/hpw);
+    const int ksp = (hpw <= 4 && wgs1 < 160 && n_kv >= 128) ? 2 : 1;
+    const int qpw = APF_NW/(hpw*ksp);                                                // query tiles per workgroup
     const dim3 grid((unsigned)((T + 32*qpw - 1)/(32*qpw)), (unsigned)(n_head/hpw));
     const int mk = !mask ? 0 : (mask_f16 ? 2 : 1);
-#define MI_APF(HD_, VT_) do { \
-        if (mk == 0)      hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, 0>), grid, dim3(64*APF_NW), 0, stream, a, hpw); \
-        else if (mk == 1) hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, 1>), grid, dim3(64*APF_NW), 0, stream, a, hpw); \
-        else              hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, 2>), grid, dim3(64*APF_NW), 0, stream, a, hpw); } while (0)
+#define MI_APF2(HD_, VT_, MK_, KS_) do { \
+        constexpr size_t lds_ = (size_t) 2*KS_*(32*(HD_*2 + APF_KLD) + HD_*(64 + 8)); \
+        static const bool once_ = [] { MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_prefill<HD_, VT_, MK_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_)); return true; }(); \
+        (void) once_; \
+        hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, MK_, KS_>), grid, dim3(64*APF_NW), lds_, stream, a, hpw); } while (0)
+#define MI_APF1(HD_, VT_, MK_) do { if (ksp == 2) MI_APF2(HD_, VT_, MK_, 2); else MI_APF2(HD_, VT_, MK_, 1); } while (0)
+#define MI_APF(HD_, VT_) do { if (mk == 0) MI_APF1(HD_, VT_, 0); else if (mk == 1) MI_APF1(HD_, VT_, 1); else MI_APF1(HD_, VT_, 2); } while (0)
     if (!v_trans) { if (head_dim == 128) MI_APF(128, false); else MI_APF(64, false); }
     else          { if (head_dim == 128) MI_APF(128, true);  else MI_APF(64, true); }
 #undef MI_APF
+#undef MI_APF1
+#undef MI_APF2
 }
 
 } // namespace mi355x
