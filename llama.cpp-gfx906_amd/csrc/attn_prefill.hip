@@ -29,7 +29,8 @@ struct attn_pf_args {
     const char * v; size_t v_nb1, v_nb2;                // v [n_kv, hd, n_head_kv] f16 (transposed): nb1 = dim stride, nb2 = head stride
     const char * mask; size_t m_nb1; int mask_f16;      // mask [n_kv, T_pad]
     const float * sinks;
-    float * dst; size_t dst_nb1;                        // [hd*n_head, T]
+    float * dst; size_t dst_nb1;                        // [hd*n_head, T] (NULL: only the bf16 copy is wanted)
+    uint16_t * y16; int kp16;                           // != NULL: the result also as bf16 rows of kp16 elements — the activation copy the wo mat-mul reads (mmq.hip)
     int n_kv, n_head, n_head_kv, T;
     float scale;
 };
@@ -235,13 +236,15 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
     }
     const float inv = fin/lt;
     if (q0 + ql < p.T) {
-        float * orow = (float *) ((char *) p.dst + (size_t) t*p.dst_nb1) + (size_t) h*HD;
+        float * orow = p.dst ? (float *) ((char *) p.dst + (size_t) t*p.dst_nb1) + (size_t) h*HD : nullptr;
+        uint16_t * yrow = p.y16 ? p.y16 + (size_t) t*p.kp16 + (size_t) h*HD : nullptr;
 #pragma unroll
         for (int d = 0; d < NDT; d++)
 #pragma unroll
             for (int j = 0; j < 4; j++) {
                 const float4v ov = { o[d][4*j]*inv, o[d][4*j + 1]*inv, o[d][4*j + 2]*inv, o[d][4*j + 3]*inv };
-                *(float4v *) (orow + 32*d + 8*j + 4*hf) = ov;
+                if (orow) *(float4v *) (orow + 32*d + 8*j + 4*hf) = ov;
+                if (yrow) *(uint2 *) (yrow + 32*d + 8*j + 4*hf) = uint2{ pack_bf16(ov.x, ov.y), pack_bf16(ov.z, ov.w) };
             }
     }
 }
@@ -250,9 +253,9 @@ bool attn_prefill_supported(int64_t head_dim, int64_t n_kv) { return (head_dim =
 
 void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                   const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
-                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans) {
+                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans, uint16_t * y16) {
     attn_pf_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
-                       (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
+                       (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, y16, (int)((head_dim*n_head + 63) & ~(int64_t) 63), (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
     const int64_t R = n_head/n_head_kv;
     const int hpw = R % 8 == 0 ? 8 : R % 4 == 0 ? 4 : R % 2 == 0 ? 2 : 1;          // heads of one kv head per workgroup
     // few workgroups (short prompts): pairs of waves split the cell blocks of an iteration, halving the loop that is the critical path

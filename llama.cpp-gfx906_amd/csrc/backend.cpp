@@ -253,7 +253,9 @@ struct mi_backend_ctx {
     size_t scratch_size = 0;
 
     // activation-quantisation reuse inside one graph_compute
-    struct { const void * data; int64_t k, n_inner, n_outer; size_t s_inner, s_outer; int kind; act_q8 q; bool valid; size_t span; } aq = {};
+    struct { const void * data; int64_t k, n_inner, n_outer; size_t s_inner, s_outer; int kind; act_q8 q; bool valid; size_t span;
+             size_t off; } aq = {};   // off: where in the scratch the bf16 copy sits (a producer kernel that still reads offset 0 writes its result's copy higher up)
+    bool aq_fresh = false;             // set by a fusion matcher whose own kernel produced the cached copy (its node's write must not invalidate it)
 
     // hipGraph cache (one entry: llama.cpp re-submits the same decode graph, src/llama-context.cpp:728)
     bool use_graphs = true;
@@ -472,7 +474,7 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             const struct ggml_tensor * b = n->src[1];
             const int64_t rows = n->op == GGML_OP_MUL_MAT ? b->ne[1] : b->ne[1]*b->ne[2];
             size_t s = act_q8_bytes(kind, b->ne[0], rows);
-            if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows, n->src[0]->ne[1]);
+            if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows, n->src[0]->ne[1]) + mul_mat_q_x_bytes(b->ne[0], rows);   // + room for a producer's copy above its own
             if (n->op == GGML_OP_MUL_MAT_ID) {
                 const struct ggml_tensor * ids = n->src[2];
                 const size_t sg = mul_mat_q_id_scratch_bytes(b->ne[0], b->ne[1], ids->ne[1], ids->ne[0], n->src[0]->ne[2]);
@@ -526,9 +528,10 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml
                     // the scratch holds the bf16 copy of the activations; wq/wk/wv and gate/up read the same ones: convert once
                     const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == bp && c->aq.k == K && c->aq.n_inner == N &&
                                        c->aq.s_inner == b->nb[1];
-                    if (out) mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, ready, (float *) out->data, out->nb[1],
+                    void * scr = (char *) c->scratch + (ready ? c->aq.off : 0);
+                    if (out) mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, scr, ready, (float *) out->data, out->nb[1],
                                        (const float *) res->data, res->nb[1], c->stream);
-                    else     mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, c->scratch, ready, d, dst->nb[1], nullptr, 0, c->stream);
+                    else     mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, scr, ready, d, dst->nb[1], nullptr, 0, c->stream);
                     if (ready) c->cnt.act_quant_reused++;
                     else c->aq = { bp, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
                     c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 0 : 1;
@@ -781,6 +784,18 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     return last;
 }
 
+// the quantized many-token mat-mul that is the ONLY reader of t and directly follows node `last`, or NULL: its producer may then emit the
+// bf16 activation copy itself (and skip the f32 tensor)
+static const struct ggml_tensor * prefill_mm_consumer(mi_backend_ctx * c, const struct ggml_cgraph * g, int last, const struct ggml_tensor * t) {
+    static const bool on = !getenv("GGML_MI355X_PREFILL_BF16_OUT") || atoi(getenv("GGML_MI355X_PREFILL_BF16_OUT")) != 0;
+    const int j = next_real(g, last);
+    if (!on || j < 0) return nullptr;
+    const struct ggml_tensor * n = g->nodes[j];
+    if (n->op != GGML_OP_MUL_MAT || n->src[1] != t || !ggml_is_quantized(n->src[0]->type) || t->type != GGML_TYPE_F32 || t->ne[1] <= MMVQ_MAX_N || t->ne[2] != 1 || t->ne[3] != 1 ||
+        n->src[0]->ne[2] != 1 || n->src[0]->ne[3] != 1 || t->nb[0] != 4 || t->ne[0] % 64 != 0 || !is_internal(c, t)) return nullptr;
+    return n;
+}
+
 // SET_ROWS(k) immediately followed by SET_ROWS(v as [1, N] element scatter), f32 -> f16 (src/llama-kv-cache-unified.cpp:1123,1157-1167)
 static int try_fused_kv_store(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * sk = g->nodes[i];
@@ -831,10 +846,17 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     if (prefill) {
         if (mask && (mask->ne[1] < T || ((uintptr_t) mask->data % 16) || mask->nb[1] % 16)) return 0;
         if (v->nb[1] % 8 || v->nb[2] % 8 || ((uintptr_t) v->data % 8)) return 0;
+        // wo reads the result next: hand it the bf16 copy directly (nothing reads the scratch's offset 0 during this kernel)
+        const struct ggml_tensor * wo = prefill_mm_consumer(c, g, j3, ct);
+        const bool y16 = wo && mul_mat_q_scratch_bytes(hd*n_head, T, wo->src[0]->ne[1]) <= c->scratch_size;
         attn_prefill(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2],
                      mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, mask && mask->type == GGML_TYPE_F16,
-                     sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
-                     hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream);
+                     sm->src[2] ? (const float *) sm->src[2]->data : nullptr, y16 ? nullptr : (float *) ct->data, (size_t) hd*n_head*4,
+                     hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream, true, y16 ? (uint16_t *) c->scratch : nullptr);
+        if (y16) {
+            c->aq = { ct->data, hd*n_head, T, 1, ct->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(T - 1)*ct->nb[1] + (size_t) hd*n_head*4, 0 };
+            c->aq_fresh = true;
+        }
         c->cnt.kernels_launched++;
         return j3 - i + 1;
     }
@@ -1045,13 +1067,20 @@ static int try_fused_prefill_glu(mi_backend_ctx * c, struct ggml_cgraph * g, int
         !ggml_is_contiguous(gl) || !((gl->src[0] == nx && gl->src[1] == n) || (gl->src[0] == n && gl->src[1] == nx))) return 0;
     const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
     if (mul_mat_q_scratch_bytes(K, N, M) > c->scratch_size) return 0;
-    const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1];
+    const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1] && c->aq.off == 0;
+    // ffn_down reads the result next: the kernel writes its bf16 copy (above this kernel's own activation copy) instead of the f32 tensor
+    const struct ggml_tensor * down = prefill_mm_consumer(c, g, j2, gl);
+    const size_t off2 = mul_mat_q_x_bytes(K, N);
+    const bool y16 = down && off2 + mul_mat_q_scratch_bytes(M, N, down->src[0]->ne[1]) <= c->scratch_size;
     prof_begin(c, (int) a->type, 2*M, K, N, (uint64_t) 2*M*ggml_row_size(a->type, K));
     mul_mat_q_glu((int) a->type, gl->src[0]->src[0]->data, gl->src[1]->src[0]->data, a->nb[1], M, K, (const float *) b->data, b->nb[1], N,
-                  c->scratch, ready, (float *) gl->data, gl->nb[1], c->stream);
+                  c->scratch, ready, y16 ? nullptr : (float *) gl->data, gl->nb[1], c->stream, y16 ? (uint16_t *) ((char *) c->scratch + off2) : nullptr);
     prof_end(c);
     if (ready) c->cnt.act_quant_reused++;
-    else c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
+    if (y16) {
+        c->aq = { gl->data, M, N, 1, gl->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*gl->nb[1] + (size_t) M*4, off2 };
+        c->aq_fresh = true;
+    } else if (!ready) c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
     c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 1 : 2;
     c->cnt.weight_bytes += (uint64_t) 2*M*ggml_row_size(a->type, K);
     return j2 - i + 1;
@@ -1120,7 +1149,7 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
         wbytes += (uint64_t) a->ne[1]*ggml_row_size(a->type, a->ne[0]);
     }
     const int64_t K = b->ne[0], N = b->ne[1];
-    const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1];
+    const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1] && c->aq.off == 0;
     prof_begin(c, types[0], m[0] + m[1] + (nc > 2 ? m[2] : 0), K, N, wbytes);
     bool roped = fuse_rope;
     bool done = fuse_rope && mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, &rd, seg_rope, c->stream);
@@ -1177,6 +1206,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);
         if (f) {
             consumed = f;
+            fresh_aq = c->aq_fresh; c->aq_fresh = false;
             goto done;
         }
     }

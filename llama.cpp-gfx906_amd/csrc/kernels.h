@@ -69,8 +69,11 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
 // gate / up + SwiGLU for many tokens in one kernel: dst[n][m] = silu(Wg.x) * (Wu.x) (both weight tensors of one type and shape);
 // supported when the 256-token tiles fill the chip
 bool mul_mat_q_glu_supported(int64_t m, int64_t n);
+// y16 != NULL (m % 64 == 0): the result also (dst == NULL: only) as the bf16 activation copy of the mat-mul that follows (ffn_down), rows of m elements
 void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_stride, int64_t m, int64_t k,
-                   const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
+                   const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream,
+                   uint16_t * y16 = nullptr);
+size_t mul_mat_q_x_bytes(int64_t k, int64_t n);      // size of the bf16 activation copy at the start of the scratch
 
 // ---- MUL_MAT_ID for many tokens (src/llama-graph.cpp:569-595): (token, slot) pairs sorted by expert on the device, then the tiled
 // MFMA kernel per (expert, 128 pairs). b: f32 [k, n_b, n_tokens] (n_b = 1 or n_used); ids: i32 [n_used, n_tokens] (strided);
@@ -155,7 +158,8 @@ void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, siz
 bool attn_prefill_supported(int64_t head_dim, int64_t n_kv);
 void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                   const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
-                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans = true);
+                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans = true,
+                  uint16_t * y16 = nullptr);     // y16 != NULL: also (dst == NULL: only) the bf16 copy the following mat-mul reads, rows of hd*n_head (a multiple of 64)
 
 // grouped mat-vec (n = 1): up to MMVQ_MAX_GROUPS weight tensors that share one activation vector, each with an epilogue
 constexpr int MMVQ_MAX_GROUPS = 4;

@@ -180,6 +180,7 @@ struct mmq_args {
     int ksplit, mtiles;                        // ksplit = 2 | 4: blockIdx.y = part*mtiles + m-tile; part i stores its partial product into plane i
     char * dst2;                               //   of dst2 (dense [n][m] f32 each); k_combine adds the planes in a fixed order: deterministic, nothing to clear
     const char * res; size_t res_nb1;          // ksplit == 1: f32 rows added to the product in the epilogue (the residual of build_attn / build_ffn), or NULL
+    uint16_t * y16;                            // DUAL kernel: != NULL: the SwiGLU result as bf16 rows of m elements (dst may then be NULL)
     const char * W2;                           // DUAL kernel: the second weight tensor (dst = silu(W.x) * (W2.x), build_ffn's gate / up + swiglu)
     // MUL_MAT_ID (grouped by expert): blockIdx.x walks the tile table k_moe_sort wrote; a tile = up to 128 (token, slot) pairs of ONE expert
     const int * moe;                           // NULL, or [0] = n_tiles, then {expert, first, count}[max_tiles], then sorted pair ids
@@ -382,7 +383,11 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
                     }
                 } else if (col < m && row < n) {
                     float * o = (float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4);
-                    if (DUAL) { const float g = acc[i][j][r]; *o = (g/(1.0f + expf(-g)))*acc2[DUAL ? i : 0][DUAL ? j : 0][r]; }   // silu(gate)*up, as elem.hip k_glu
+                    if (DUAL) {         // silu(gate)*up, as elem.hip k_glu
+                        const float g = acc[i][j][r], y = (g/(1.0f + expf(-g)))*acc2[DUAL ? i : 0][DUAL ? j : 0][r];
+                        if (p.dst) *o = y;
+                        if (p.y16) { const uint32_t pk = pack_bf16(y, y); p.y16[(size_t) row*m + col] = (uint16_t) pk; }
+                    }
                     else if (p.res && p.ksplit == 1) *o = acc[i][j][r] + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
                     else *o = acc[i][j][r];
                 }
@@ -605,6 +610,7 @@ static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
 }
 
 static size_t mmq_x_bytes(int64_t k, int64_t n) { return ((size_t) n*mmq_kp(k)*2 + 255) & ~(size_t) 255; }
+size_t mul_mat_q_x_bytes(int64_t k, int64_t n) { return mmq_x_bytes(k, n); }
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m) { return mmq_x_bytes(k, n) + (size_t) 4*m*n*4 + 512; }     // bf16 copy of x | up to 4 split-k planes
 
 // dst = plane 0 + plane 1 [+ plane 2 + plane 3] [+ residual], always in this order; 4 consecutive weight rows of one token per thread
@@ -630,7 +636,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
     mmq_args a = { (const char *) W, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr,
-                   (const char *) res, res_row_stride, nullptr, nullptr, 0, 0, 0 };
+                   (const char *) res, res_row_stride, nullptr, nullptr, nullptr, 0, 0, 0 };
     const int mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     a.mtiles = mtiles;
     // 256-token tiles when they still fill the chip (m = 14336, n = 512: 224 workgroups); else 128-token tiles, and a grid that would
@@ -722,7 +728,7 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
         if (t1 == T_Q6_K) { const int t = t1; t1 = t2; t2 = t; }
         if (!(t2 == T_Q6_K && (t1 == T_Q4_K || t1 == T_Q5_K))) return false;       // the mixed pairs of the K-quant mixes (attn_v one step up)
     }
-    mmq_args a = { nullptr, 0, 0, 0, 0, (int) k, (const uint16_t *) scratch, (int) n, nullptr, 0, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0 };
+    mmq_args a = { nullptr, 0, 0, 0, 0, (int) k, (const uint16_t *) scratch, (int) n, nullptr, 0, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
     a.nseg = nseg;
     int64_t m_tot = 0; int tiles = 0; bool vec_ok = true;
     for (int s = 0; s < nseg; s++) {
@@ -784,14 +790,15 @@ static void launch_mmq_dual(dim3 grid, const mmq_args & a, hipStream_t stream) {
 }
 bool mul_mat_q_glu_supported(int64_t m, int64_t n) { return n >= 256 && ((m + MQ_BM - 1)/MQ_BM)*((n + 255)/256) >= 160; }
 void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_stride, int64_t m, int64_t k,
-                   const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
+                   const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes, hipStream_t stream,
+                   uint16_t * y16) {
     if (m == 0 || n == 0) return;
     uint16_t * xb = (uint16_t *) scratch;
     if (!scratch_ready) {
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, xb };
         hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n, 1), dim3(256), 0, stream, pa);
     }
-    mmq_args a = { (const char *) Wg, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, (const char *) Wu, nullptr, 0, 0, 0 };
+    mmq_args a = { (const char *) Wg, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, y16, (const char *) Wu, nullptr, 0, 0, 0 };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     const dim3 grid((unsigned)((n + 255)/256), (unsigned) a.mtiles, 1);
     switch (type_a) {
@@ -855,7 +862,7 @@ void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expe
     hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
     moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, max_tiles, table };
     hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
-    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, nullptr,
+    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, nullptr, nullptr,
                    table, max_tiles, (int) n_used, (int) n_b };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
     const dim3 grid((unsigned) max_tiles, (unsigned) a.mtiles, 1);
@@ -886,7 +893,7 @@ void mul_mat_dense_mfma(const mm_dense_args & p, void * scratch, hipStream_t str
     act16_args pa = { (const char *) p.b, p.nb11, p.nb12, p.nb13, p.ne10, p.ne11, p.ne12, xb };
     hipLaunchKernelGGL((k_act_to_16<true>), dim3((unsigned)((mmq_kp(p.ne10) + 1023)/1024), (unsigned) p.ne11, (unsigned) nbatch), dim3(256), 0, stream, pa);
     mmq_args a = { (const char *) p.a, p.nb01, p.nb02, p.nb03, (int) p.ne01, (int) p.ne00, xb, (int) p.ne11, (char *) p.dst, p.nb1, p.nb2, p.nb3,
-                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, 0, nullptr, nullptr, 0, 0, 0 };
+                   (int) p.ne12, (int)(p.ne12/p.ne02), (int)(p.ne13/p.ne03), 1, 0, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 0 };
     const dim3 grid((unsigned)((p.ne11 + MQ_BN - 1)/MQ_BN), (unsigned)((p.ne01 + MQ_BM - 1)/MQ_BM), (unsigned) nbatch);
     hipLaunchKernelGGL((k_mmq<T_F16>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
 }

@@ -493,6 +493,41 @@ def test_prefill_gate_up_glu_fused(name, ff, k, n, gate_first):
     assert orc.nmse(res[0], res[1]) <= 1e-9, orc.nmse(res[0], res[1])
 
 
+@pytest.mark.parametrize("t_ff,t_down,k,ff,n", [("q4_K", "q6_K", 512, 10240, 512), ("q8_0", "q4_K", 256, 10496, 300), ("q4_0", "q4_0", 1024, 20480, 256)])
+def test_prefill_ffn_chain(t_ff, t_down, k, ff, n):
+    """build_ffn for many tokens (src/llama-graph.cpp:632-774): norm -> gate / up -> swiglu -> down -> + residual. With fusion on: the norm
+    writes the bf16 copy gate / up read, ONE kernel does gate, up and SwiGLU and writes — instead of the f32 tensor — the bf16 copy that
+    ffn_down reads, and down adds the residual in its epilogue / combine pass: 3 kernels for 7 nodes."""
+    rng = np.random.default_rng(ff + n)
+    x = rng.standard_normal((1, 1, n, k)).astype(np.float32)
+    wn = rng.uniform(0.5, 1.5, size=(1, 1, 1, k)).astype(np.float32)
+    wg = orc.random_blocks(rng, QTYPES[t_ff], (ff,), k, scale=1.0 / np.sqrt(k)); wu = orc.random_blocks(rng, QTYPES[t_ff], (ff,), k, scale=1.0 / np.sqrt(k))
+    wd = orc.random_blocks(rng, QTYPES[t_down], (k,), ff, scale=1.0 / np.sqrt(ff))
+    res = {}
+    for fusion in (1, 0):
+        be = backend(); be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            xt = ctx.new_tensor(gg.F32, (k, n)); wt = ctx.new_tensor(gg.F32, (k,))
+            g_ = ctx.new_tensor(QTYPES[t_ff], (k, ff)); u_ = ctx.new_tensor(QTYPES[t_ff], (k, ff)); d_ = ctx.new_tensor(QTYPES[t_down], (ff, k))
+            nm = L.ggml_mul(ctx.ctx, L.ggml_rms_norm(ctx.ctx, xt, 1e-5), wt)
+            gate = L.ggml_mul_mat(ctx.ctx, g_, nm); up = L.ggml_mul_mat(ctx.ctx, u_, nm)
+            act = L.ggml_swiglu_split(ctx.ctx, gate, up)
+            out = L.ggml_add(ctx.ctx, L.ggml_mul_mat(ctx.ctx, d_, act), xt)
+            assert ctx.alloc(be)
+            gg.tensor_set(xt, x); gg.tensor_set(wt, wn); gg.tensor_set(g_, wg); gg.tensor_set(u_, wu); gg.tensor_set(d_, wd)
+            c0 = be.counters(); be.compute(gg.graph_of(ctx, out)); c1 = be.counters()
+            res[fusion] = gg.tensor_get(out)[0, 0].copy()
+        be.set_option("fusion", 1)
+        if fusion:
+            assert c1["mmq_launches"] - c0["mmq_launches"] == 2, "norm | gate+up+swiglu | down+residual"
+    h = (ref.rms_norm(x[0, 0], 1e-5) * wn[0, 0, 0]).astype(np.float32)
+    a = ref.swiglu(orc.mul_mat_2d(wg, QTYPES[t_ff], h, "exact"), orc.mul_mat_2d(wu, QTYPES[t_ff], h, "exact")).astype(np.float32)
+    exact = orc.mul_mat_2d(wd, QTYPES[t_down], a, "exact") + x[0, 0]
+    assert np.isfinite(res[1]).all()
+    assert orc.nmse(exact, res[1]) <= 5e-5, orc.nmse(exact, res[1])
+    assert orc.nmse(res[0], res[1]) <= 1e-8, orc.nmse(res[0], res[1])
+
+
 @pytest.mark.parametrize("types,ms,k,n,hd", [(("q4_K", "q4_K", "q6_K"), (4096, 1024, 1024), 4096, 512, 128), (("q4_K", "q4_K", "q4_K"), (2048, 512, 512), 4096, 300, 64),
                                             (("q6_K", "q5_K", "q5_K"), (7000, 7000, 7200), 256, 257, 8), (("q8_0", "q8_0"), (2048, 2048), 2048, 1000, 64),
                                             (("mxfp4", "mxfp4", "mxfp4"), (14336, 4096, 4096), 2880, 256, 64), (("q4_0", "q4_K", "q4_0"), (4096, 1024, 1024), 1024, 512, 64)])
