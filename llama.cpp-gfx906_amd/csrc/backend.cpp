@@ -507,7 +507,7 @@ static act_q8 get_act(mi_backend_ctx * c, const void * x, int64_t k, int64_t n_i
 static constexpr int ACT_KIND_BF16 = -16;   // aq.kind of the dense bf16 copy the MFMA prefill kernel reads
 
 // out/res: the prefill residual fusion (try_fused_prefill_add) writes W.x + res into `out` instead of W.x into dst
-static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml_tensor * out = nullptr, const struct ggml_tensor * res = nullptr) {
+static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml_tensor * out = nullptr, const struct ggml_tensor * res = nullptr, mmq_deferred * defer = nullptr) {
     const struct ggml_tensor * a = dst->src[0];
     const struct ggml_tensor * b = dst->src[1];
     if (ggml_is_quantized(a->type)) {
@@ -530,7 +530,7 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml
                                        c->aq.s_inner == b->nb[1];
                     void * scr = (char *) c->scratch + (ready ? c->aq.off : 0);
                     if (out) mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, scr, ready, (float *) out->data, out->nb[1],
-                                       (const float *) res->data, res->nb[1], c->stream);
+                                       (const float *) res->data, res->nb[1], c->stream, defer);
                     else     mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, scr, ready, d, dst->nb[1], nullptr, 0, c->stream);
                     if (ready) c->cnt.act_quant_reused++;
                     else c->aq = { bp, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
@@ -1179,8 +1179,42 @@ static int try_fused_prefill_add(mi_backend_ctx * c, struct ggml_cgraph * g, int
     if (nx->op != GGML_OP_ADD || (nx->src[0] != n && nx->src[1] != n) || nx->type != GGML_TYPE_F32 || !ggml_is_contiguous(nx) || !ggml_are_same_shape(nx, n)) return 0;
     const struct ggml_tensor * other = nx->src[0] == n ? nx->src[1] : nx->src[0];
     if (other == n || other->type != GGML_TYPE_F32 || !ggml_are_same_shape(other, n) || other->nb[0] != 4) return 0;
-    op_mul_mat(c, n, nx, other);
-    return j - i + 1;
+    // the sum is the residual stream; if RMS_NORM -> MUL(w) reads it next (ffn_norm, the next layer's attn_norm: build_norm, src/llama-graph.cpp:597-630)
+    // and the mat-mul splits k, ONE pass adds the planes and the residual, writes the sum and normalises it
+    static const bool norm_on = !getenv("GGML_MI355X_PREFILL_COMBINE_NORM") || atoi(getenv("GGML_MI355X_PREFILL_COMBINE_NORM")) != 0;
+    struct ggml_tensor * nrm = nullptr; struct ggml_tensor * mul = nullptr; const struct ggml_tensor * w = nullptr;
+    const int jn = next_real(g, j);
+    if (norm_on && jn > 0 && jn + 1 < g->n_nodes && g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0] == nx && g->nodes[jn + 1]->op == GGML_OP_MUL) {
+        nrm = g->nodes[jn]; mul = g->nodes[jn + 1];
+        w = mul->src[0] == nrm ? mul->src[1] : (mul->src[1] == nrm ? mul->src[0] : nullptr);
+        const int64_t M = n->ne[0];
+        const bool ok = w && is_internal(c, nrm) && w->type == GGML_TYPE_F32 && ggml_nelements(w) == M && w->ne[0] == M && w->nb[0] == 4 && ((uintptr_t) w->data % 16) == 0 &&
+                        mul->type == GGML_TYPE_F32 && ggml_are_same_shape(mul, nx) && mul->nb[0] == 4 && mul->nb[1] % 16 == 0 && ((uintptr_t) mul->data % 16) == 0 &&
+                        M % 4 == 0 && other->nb[1] % 16 == 0 && ((uintptr_t) other->data % 16) == 0 && nx->nb[1] % 16 == 0 && ((uintptr_t) nx->data % 16) == 0 &&
+                        nrm->ne[2] == 1 && nrm->ne[3] == 1;
+        if (!ok) { nrm = nullptr; mul = nullptr; }
+    }
+    mmq_deferred df = { 0, nullptr };
+    op_mul_mat(c, n, nx, other, nrm ? &df : nullptr);
+    if (!nrm || df.np == 0) return j - i + 1;          // no k split: the epilogue has added the residual; the norm runs as usual
+    const int64_t M = n->ne[0], N = n->ne[1];
+    // the mat-mul after the norm reads bf16: written here too (the planes sit above the activation copy's slot only if that slot is this launch's own x:
+    // the copy goes to offset 0, which the finished mat-mul no longer needs — but the PLANES live right after its x region, so the new copy must not reach them)
+    const int jm = next_real(g, jn + 1);
+    const struct ggml_tensor * mm = jm > 0 ? g->nodes[jm] : nullptr;
+    uint16_t * y16 = nullptr;
+    if (mm && mm->op == GGML_OP_MUL_MAT && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) && N > MMVQ_MAX_N && mul->ne[2] == 1 && mul->ne[3] == 1 &&
+        (const char *) c->scratch + (c->aq.valid ? c->aq.off : 0) + mul_mat_q_x_bytes(M, N) <= (const char *) df.planes) {
+        y16 = (uint16_t *) c->scratch;
+    }
+    combine_rms_norm(df.planes, df.np, M, N, (const float *) other->data, other->nb[1], (float *) nx->data, nx->nb[1], (const float *) w->data,
+                     (float *) mul->data, mul->nb[1], y16, op_f32(nrm, 0), c->stream);
+    c->cnt.kernels_launched++;
+    if (y16) {
+        c->aq = { mul->data, M, N, 1, mul->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*mul->nb[1] + (size_t) M*4, 0 };
+        c->aq_fresh = true;
+    } else c->aq.valid = false;
+    return jn + 1 - i + 1;
 }
 
 // returns the number of graph nodes consumed (>= 1)

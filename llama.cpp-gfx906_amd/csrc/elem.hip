@@ -152,6 +152,47 @@ void rms_norm_mul(const tensor_desc & src, const tensor_desc & w, const tensor_d
     else     hipLaunchKernelGGL((k_rms_norm<true, false>), g, b, 0, stream, mk(src), mk(w), td{},     mk(dst), eps, y16, kp16);
 }
 
+// ---- the pass that adds a split-k mat-mul's planes (+ residual), fused with the RMS_NORM * w that reads the sum next (prefill: wo -> ADD ->
+//      ffn_norm, ffn_down -> ADD -> next layer's attn_norm): x = plane 0 + plane 1 [+ ...] + res in mmq.hip k_combine's order; x is written
+//      (the residual stream), y = x / sqrt(mean(x^2) + eps) * w, and y's bf16 copy for the mat-mul after the norm ----
+template <int NP>
+__global__ void __launch_bounds__(256) k_combine_rms_norm(const float * planes, int64_t plane_elems, const char * res, size_t res_nb1, char * sum_out, size_t sum_nb1,
+                                                          const float * w, char * y, size_t y_nb1, uint16_t * y16, int kp16, int m, float eps) {
+    __shared__ float sh[4];
+    const int64_t row = blockIdx.x;
+    const float * pl = planes + row*m;
+    const char * rr = res + row*res_nb1; char * so = sum_out + row*sum_nb1; char * yo = y + row*y_nb1;
+    float ss = 0.0f;
+    for (int i = threadIdx.x*4; i < m; i += 256*4) {
+        float4v a = *(const float4v *) (pl + i);
+#pragma unroll
+        for (int p = 1; p < NP; p++) { const float4v b = *(const float4v *) (pl + (int64_t) p*plane_elems + i); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        { const float4v b = *(const float4v *) (rr + (size_t) i*4); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+        *(float4v *) (so + (size_t) i*4) = a;
+        ss += a.x*a.x + a.y*a.y + a.z*a.z + a.w*a.w;
+    }
+    ss = block_sum(ss, sh);
+    const float scale = 1.0f/sqrtf(ss/(float) m + eps);
+    for (int i = threadIdx.x*4; i < m; i += 256*4) {
+        float4v v = *(const float4v *) (so + (size_t) i*4);          // written by this thread above
+        const float4v t = *(const float4v *) (w + i);
+        v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
+        v.x *= t.x; v.y *= t.y; v.z *= t.z; v.w *= t.w;
+        *(float4v *) (yo + (size_t) i*4) = v;
+        if (y16) *(uint2 *) (y16 + (size_t) row*kp16 + i) = uint2{ pack_bf16(v.x, v.y), pack_bf16(v.z, v.w) };
+    }
+    if (y16) for (int i = m + threadIdx.x*4; i < kp16; i += 256*4) *(uint2 *) (y16 + (size_t) row*kp16 + i) = uint2{ 0u, 0u };
+}
+void combine_rms_norm(const float * planes, int np, int64_t m, int64_t n, const float * res, size_t res_nb1, float * sum_out, size_t sum_nb1,
+                      const float * w, float * y, size_t y_nb1, uint16_t * y16, float eps, hipStream_t stream) {
+    if (m == 0 || n == 0) return;
+    const int kp16 = (int)((m + 63) & ~(int64_t) 63);
+#define MI_CRN(NP_) hipLaunchKernelGGL((k_combine_rms_norm<NP_>), dim3((unsigned) n), dim3(256), 0, stream, planes, m*n, (const char *) res, res_nb1, (char *) sum_out, sum_nb1, \
+                                       w, (char *) y, y_nb1, y16, kp16, (int) m, eps)
+    if (np == 2) MI_CRN(2); else if (np == 4) MI_CRN(4); else MI_CRN(8);
+#undef MI_CRN
+}
+
 // ---- ADD / MUL / DIV / SUB with ggml repeat-broadcast — tests/test-backend-ops.cpp:2469 ----------------
 template <int OP>
 __global__ void __launch_bounds__(256) k_bin_bcast(const td a, const td b, const td dst, int64_t n) {

@@ -58,7 +58,10 @@ void mul_mat_vec_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m);
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes,
-               const float * res, size_t res_row_stride, hipStream_t stream);
+               const float * res, size_t res_row_stride, hipStream_t stream, struct mmq_deferred * defer = nullptr);
+// defer != NULL: when the launch splits k, the pass that adds the planes (and res) is left to the caller (who fuses it with the norm that
+// follows): np = number of planes (0: nothing deferred, dst is complete), planes = dense [np][n][m] f32 in the scratch
+struct mmq_deferred { int np; const float * planes; };
 
 struct mmvq_rope;
 // 2 or 3 mat-muls on the same activations (wq / wk / wv) as one launch of 256-token tiles; false = not done, run them one by one
@@ -108,6 +111,10 @@ void rms_norm(const tensor_desc & src, const tensor_desc & dst, float eps, hipSt
 // (rows of ne0 rounded up to 64 elements, zero tail), so that its activation pre-pass is skipped
 bool rms_norm_mul_bf16_supported(const tensor_desc & src, const tensor_desc & w, const tensor_desc & dst);
 void rms_norm_mul(const tensor_desc & src, const tensor_desc & w, const tensor_desc * add, const tensor_desc & dst, float eps, hipStream_t stream, uint16_t * y16 = nullptr);
+// the split-k planes of a prefill mat-mul (mul_mat_q with `defer`) + residual -> sum_out, and RMS_NORM(sum) * w -> y (+ its bf16 copy y16, or NULL);
+// m % 4 == 0, all rows 16-byte aligned, np = 2 | 4 | 8
+void combine_rms_norm(const float * planes, int np, int64_t m, int64_t n, const float * res, size_t res_nb1, float * sum_out, size_t sum_nb1,
+                      const float * w, float * y, size_t y_nb1, uint16_t * y16, float eps, hipStream_t stream);
 enum bin_op { BIN_ADD = 0, BIN_MUL = 1, BIN_DIV = 2, BIN_SUB = 3 };
 void bin_bcast(int op, const tensor_desc & a, const tensor_desc & b, const tensor_desc & dst, hipStream_t stream);
 void add_id(const tensor_desc & a, const tensor_desc & bias, const tensor_desc & ids, const tensor_desc & dst, hipStream_t stream);

@@ -628,7 +628,8 @@ __global__ void __launch_bounds__(256) k_combine(char * dst, size_t dst_nb1, con
 
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes,
-               const float * res, size_t res_row_stride, hipStream_t stream) {
+               const float * res, size_t res_row_stride, hipStream_t stream, mmq_deferred * defer) {
+    if (defer) { defer->np = 0; defer->planes = nullptr; }
     if (m == 0 || n == 0) return;
     uint16_t * xb = (uint16_t *) scratch;
     if (!scratch_ready) {
@@ -666,6 +667,7 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
         default: fprintf(stderr, "mmq: unsupported type %d\n", type_a); abort();
     }
 #undef MI_MMQ
+    if (defer && a.ksplit > 1) { defer->np = a.ksplit; defer->planes = planes; return; }
     const unsigned cgrid = (unsigned)((m/4*n + 255)/256);
     if (a.ksplit == 4)      hipLaunchKernelGGL(k_combine<4>, dim3(cgrid), dim3(256), 0, stream, (char *) dst, dst_col_stride_bytes, planes, (const char *) res, res_row_stride, m/4, n);
     else if (a.ksplit == 2) hipLaunchKernelGGL(k_combine<2>, dim3(cgrid), dim3(256), 0, stream, (char *) dst, dst_col_stride_bytes, planes, (const char *) res, res_row_stride, m/4, n);

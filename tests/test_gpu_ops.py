@@ -493,6 +493,40 @@ def test_prefill_gate_up_glu_fused(name, ff, k, n, gate_first):
     assert orc.nmse(res[0], res[1]) <= 1e-9, orc.nmse(res[0], res[1])
 
 
+@pytest.mark.parametrize("name,m,k,n", [("q4_K", 1024, 2048, 512), ("q4_K", 4096, 4096, 512), ("q6_K", 512, 8192, 300), ("q8_0", 1024, 288, 64)])
+def test_prefill_residual_norm_chain(name, m, k, n):
+    """wo (or ffn_down) -> + residual -> RMS_NORM * w -> the next mat-mul, many tokens (src/llama-model.cpp:6057-6070): when the first mat-mul
+    splits k, ONE pass adds its planes and the residual, writes the sum (the residual stream, read again later) and the normalised rows plus
+    their bf16 copy for the next mat-mul. Shapes: k split in 2 (128-token tiles), in 4 (256-token tiles), ragged n, and no split at all."""
+    rng = np.random.default_rng(m + k + n)
+    x = rng.uniform(-1, 1, size=(1, 1, n, k)).astype(np.float32)
+    r = rng.uniform(-1, 1, size=(1, 1, n, m)).astype(np.float32)
+    wn = rng.uniform(0.5, 1.5, size=(1, 1, 1, m)).astype(np.float32)
+    w1 = orc.random_blocks(rng, QTYPES[name], (m,), k, scale=1.0 / np.sqrt(k))
+    w2 = orc.random_blocks(rng, QTYPES["q8_0"], (256,), m, scale=1.0 / np.sqrt(m))
+    res = {}
+    for fusion in (1, 0):
+        be = backend(); be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            xt = ctx.new_tensor(gg.F32, (k, n)); rt = ctx.new_tensor(gg.F32, (m, n)); wt = ctx.new_tensor(gg.F32, (m,))
+            a1 = ctx.new_tensor(QTYPES[name], (k, m)); a2 = ctx.new_tensor(QTYPES["q8_0"], (m, 256))
+            s_ = L.ggml_add(ctx.ctx, L.ggml_mul_mat(ctx.ctx, a1, xt), rt)
+            y = L.ggml_mul(ctx.ctx, L.ggml_rms_norm(ctx.ctx, s_, 1e-5), wt)
+            o2 = L.ggml_mul_mat(ctx.ctx, a2, y)
+            o3 = L.ggml_scale(ctx.ctx, s_, 2.0)                         # a second reader of the residual stream
+            assert ctx.alloc(be)
+            gg.tensor_set(xt, x); gg.tensor_set(rt, r); gg.tensor_set(wt, wn); gg.tensor_set(a1, w1); gg.tensor_set(a2, w2)
+            be.compute(gg.graph_of(ctx, o2, o3))
+            res[fusion] = (gg.tensor_get(o2)[0, 0].copy(), gg.tensor_get(o3)[0, 0].copy())
+        be.set_option("fusion", 1)
+    s_ref = orc.mul_mat_2d(w1, QTYPES[name], x[0, 0], "exact") + r[0, 0]
+    y_ref = (ref.rms_norm(s_ref.astype(np.float32), 1e-5) * wn[0, 0, 0]).astype(np.float32)
+    o_ref = orc.mul_mat_2d(w2, QTYPES["q8_0"], y_ref, "exact")
+    assert orc.nmse(2.0 * s_ref, res[1][1]) <= 2e-5 and orc.nmse(o_ref, res[1][0]) <= 1e-4, (orc.nmse(2.0 * s_ref, res[1][1]), orc.nmse(o_ref, res[1][0]))
+    assert np.array_equal(res[0][1], res[1][1]), "the residual stream: same kernels, same summation order"
+    assert orc.nmse(res[0][0], res[1][0]) <= 1e-9
+
+
 @pytest.mark.parametrize("t_ff,t_down,k,ff,n", [("q4_K", "q6_K", 512, 10240, 512), ("q8_0", "q4_K", 256, 10496, 300), ("q4_0", "q4_0", 1024, 20480, 256)])
 def test_prefill_ffn_chain(t_ff, t_down, k, ff, n):
     """build_ffn for many tokens (src/llama-graph.cpp:632-774): norm -> gate / up -> swiglu -> down -> + residual. With fusion on: the norm
