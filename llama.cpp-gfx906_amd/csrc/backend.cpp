@@ -1151,12 +1151,38 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
     const int64_t K = b->ne[0], N = b->ne[1];
     const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == N && c->aq.s_inner == b->nb[1] && c->aq.off == 0;
     prof_begin(c, types[0], m[0] + m[1] + (nc > 2 ? m[2] : 0), K, N, wbytes);
-    bool roped = fuse_rope;
-    bool done = fuse_rope && mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, &rd, seg_rope, c->stream);
+    // the KV-cache writes that follow (SET_ROWS of rope(k) as f16 rows, SET_ROWS of v as an element scatter into the transposed cache — the pair
+    // try_fused_kv_store takes) ride on the same combine pass
+    mmq_kv_store kvs = {}; bool have_kvs = false; int kv_last = -1;
+    if (fuse_rope) {
+        const int j1 = next_real(g, ch[nc - 1].end), j2 = j1 > 0 ? next_real(g, j1) : -1;
+        if (j2 > 0 && g->nodes[j1]->op == GGML_OP_SET_ROWS && g->nodes[j2]->op == GGML_OP_SET_ROWS) {
+            struct ggml_tensor * sk = g->nodes[j1]; struct ggml_tensor * sv = g->nodes[j2];
+            const struct ggml_tensor * ks = sk->src[0]; const struct ggml_tensor * ki = sk->src[1];
+            const struct ggml_tensor * vs = sv->src[0]; const struct ggml_tensor * vi = sv->src[1];
+            int qk = -1, qv = -1;
+            for (int q = 0; q < nc; q++) { if (ks->data == (void *) dst[q]) qk = q; if (vs->data == (void *) dst[q]) qv = q; }
+            const bool ok = qk >= 0 && qv >= 0 && qk != qv && sk->type == GGML_TYPE_F16 && sv->type == GGML_TYPE_F16 && ks->type == GGML_TYPE_F32 && vs->type == GGML_TYPE_F32 &&
+                ki->type == GGML_TYPE_I64 && vi->type == GGML_TYPE_I64 && ggml_is_contiguous(ki) && ggml_is_contiguous(vi) &&
+                ks->ne[0] == m[qk] && ks->ne[1] == N && ks->ne[2] == 1 && ks->ne[3] == 1 && ks->nb[0] == 4 && ks->nb[1] == (size_t) m[qk]*4 && dstride[qk] == (size_t) m[qk]*4 &&
+                sk->nb[0] == 2 && sk->nb[1] % 8 == 0 && ((uintptr_t) sk->data % 8) == 0 && ggml_nelements(ki) == N && m[qk] % 4 == 0 &&
+                vs->ne[0] == 1 && vs->ne[1] == m[qv]*N && vs->ne[2] == 1 && vs->ne[3] == 1 && vs->nb[1] == 4 && dstride[qv] == (size_t) m[qv]*4 &&
+                sv->ne[0] == 1 && sv->nb[1] == 2 && ggml_nelements(vi) == m[qv]*N &&
+                !ranges_overlap(sk->data, ggml_nbytes(sk), b->data, ggml_nbytes(b)) && !ranges_overlap(sv->data, ggml_nbytes(sv), b->data, ggml_nbytes(b));
+            if (ok) {
+                kvs.st16[qk] = (uint16_t *) sk->data; kvs.st_idx[qk] = (const int64_t *) ki->data; kvs.st_row_elems[qk] = (int64_t)(sk->nb[1]/2); kvs.st_mode[qk] = 1;
+                kvs.st16[qv] = (uint16_t *) sv->data; kvs.st_idx[qv] = (const int64_t *) vi->data; kvs.st_row_elems[qv] = 0; kvs.st_mode[qv] = 2;
+                have_kvs = true; kv_last = j2;
+            }
+        }
+    }
+    bool roped = fuse_rope, stored = have_kvs;
+    bool done = fuse_rope && mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, &rd, seg_rope,
+                                             have_kvs ? &kvs : nullptr, c->stream);
     if (!done) {
-        roped = false;
+        roped = false; stored = false;
         for (int q = 0; q < nc; q++) { dst[q] = (float *) g->nodes[ch[q].mm]->data; dstride[q] = g->nodes[ch[q].mm]->nb[1]; }
-        done = mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, nullptr, nullptr, c->stream);
+        done = mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, nullptr, nullptr, nullptr, c->stream);
     }
     prof_end(c);
     if (!done) { if (c->profiling && !c->prof_suspend) c->prof.pop_back(); return 0; }
@@ -1164,7 +1190,7 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
     else c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
     c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 1 : 2; c->cnt.weight_bytes += wbytes;
     if (!roped) for (int q = 0; q < nc; q++) if (ch[q].rope >= 0) compute_node(c, g, ch[q].rope);
-    return ch[nc - 1].end - i + 1;
+    return (stored ? kv_last : ch[nc - 1].end) - i + 1;
 }
 
 // Prefill: MUL_MAT -> ADD(residual) (build_attn's wo, build_ffn's down: src/llama-model.cpp:6057,6096) — the residual is added in the

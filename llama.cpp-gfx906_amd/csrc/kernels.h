@@ -64,10 +64,13 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
 struct mmq_deferred { int np; const float * planes; };
 
 struct mmvq_rope;
+// KV-cache writes done by the pass that combines the launch's split-k planes: per segment, mode 0 none | 1 f16 rows st16[idx[token]*st_row_elems + col] |
+// 2 element scatter st16[idx[token*m + col]] (the transposed V cache)
+struct mmq_kv_store { uint16_t * st16[3]; const int64_t * st_idx[3]; int64_t st_row_elems[3]; int st_mode[3]; };
 // 2 or 3 mat-muls on the same activations (wq / wk / wv) as one launch of 256-token tiles; false = not done, run them one by one
 bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const size_t * w_row_stride, const int64_t * m, float * const * dst, const size_t * dst_stride,
                      int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready,
-                     const struct mmvq_rope * rope, const int * seg_rope, hipStream_t stream);     // rope != NULL: NORM rotary embedding on the segments flagged in seg_rope
+                     const struct mmvq_rope * rope, const int * seg_rope, const struct mmq_kv_store * kvs, hipStream_t stream);     // rope != NULL: NORM rotary embedding on the segments flagged in seg_rope
 
 // gate / up + SwiGLU for many tokens in one kernel: dst[n][m] = silu(Wg.x) * (Wu.x) (both weight tensors of one type and shape);
 // supported when the 256-token tiles fill the chip

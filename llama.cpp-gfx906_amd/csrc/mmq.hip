@@ -165,6 +165,9 @@ template <> __device__ __forceinline__ void decode4<T_Q6_K>(const raw32 & r, con
 }
 
 // ---- the tiled kernel ----
+#ifndef MI_DUAL_ORDER
+#define MI_DUAL_ORDER 1
+#endif
 constexpr int MQ_BM = 128, MQ_BN = 128, MQ_BK = 64, MQ_LD = MQ_BK*2 + 16;   // LDS row stride in bytes (padded)
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -333,11 +336,16 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
             for (int kk = 0; kk < MQ_BK/16; kk++) {
                 frags & f = (!DUAL && (kk & 1)) ? f1 : f0; frags & fn = (kk & 1) ? f0 : f1;
-                if (DUAL) read_frags(f, buf, kk);
-                else if (kk + 1 < MQ_BK/16) read_frags(fn, buf, kk + 1);
-                mfma_row(f, 0);
-                if (!DUAL) { __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); }
-                else       { commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); }
+                if (DUAL) {         // the slice's operand reads go out first and the decode piece runs under their latency (no registers to read ahead)
+                    static_assert(true, "");
+                    read_frags(f, buf, kk);
+                    if (MI_DUAL_ORDER == 1) { commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); __builtin_amdgcn_sched_barrier(0); mfma_row(f, 0); mfma_row(f, 1); }
+                    else                    { mfma_row(f, 0); commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); }
+                } else {
+                    if (kk + 1 < MQ_BK/16) read_frags(fn, buf, kk + 1);
+                    mfma_row(f, 0);
+                    __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             __syncthreads();
@@ -674,7 +682,10 @@ void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64
 }
 
 // ---- several mat-muls on the same activations as one launch (wq / wk / wv of build_attn, src/llama-model.cpp:6017-6040) ----
-struct combine_seg_args { const float * planes; int64_t m4_tot, n; int nseg; char * dst[3]; size_t dst_nb1[3]; int col4[3]; int rope_seg[3]; fused_rope rope; };
+// st_*: the KV-cache writes that follow wk / wv (SET_ROWS, src/llama-kv-cache-unified.cpp:1123,1157-1167) done by the same pass — mode 1: f16 row
+// idx[token] of the K cache (st_row_elems apart); mode 2: element scatter into the transposed V cache, st16[idx[token*m_seg + col]]
+struct combine_seg_args { const float * planes; int64_t m4_tot, n; int nseg; char * dst[3]; size_t dst_nb1[3]; int col4[3]; int rope_seg[3]; fused_rope rope;
+                          uint16_t * st16[3]; const int64_t * st_idx[3]; int64_t st_row_elems[3]; int st_mode[3]; int m_seg[3]; };
 template <int NP>
 __global__ void __launch_bounds__(256) k_combine_seg(const combine_seg_args p) {
     const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
@@ -692,6 +703,13 @@ __global__ void __launch_bounds__(256) k_combine_seg(const combine_seg_args p) {
         a = float4v{ x0, x1, x2, x3 };
     }
     *(float4v *) (p.dst[si] + (size_t) row*p.dst_nb1[si] + (size_t)(c4 - p.col4[si])*16) = a;
+    if (p.st_mode[si] == 1) {
+        uint16_t * q = p.st16[si] + p.st_idx[si][row]*p.st_row_elems[si] + (size_t)(c4 - p.col4[si])*4;
+        *(uint2 *) q = uint2{ (uint32_t) f32_to_f16_bits(a.x) | ((uint32_t) f32_to_f16_bits(a.y) << 16), (uint32_t) f32_to_f16_bits(a.z) | ((uint32_t) f32_to_f16_bits(a.w) << 16) };
+    } else if (p.st_mode[si] == 2) {
+        const int64_t * ix = p.st_idx[si] + row*p.m_seg[si] + (size_t)(c4 - p.col4[si])*4;
+        p.st16[si][ix[0]] = f32_to_f16_bits(a.x); p.st16[si][ix[1]] = f32_to_f16_bits(a.y); p.st16[si][ix[2]] = f32_to_f16_bits(a.z); p.st16[si][ix[3]] = f32_to_f16_bits(a.w);
+    }
 }
 
 template <int T_, int T2_>
@@ -717,7 +735,7 @@ static void launch_mmq_multi(dim3 grid, const mmq_args & a, hipStream_t stream) 
 // false: not done (too few tiles for 256-token tiles, an unsupported mix of types, scratch too small) — the caller runs them one by one
 bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const size_t * w_row_stride, const int64_t * m, float * const * dst, const size_t * dst_stride,
                      int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready,
-                     const mmvq_rope * rope, const int * seg_rope, hipStream_t stream) {
+                     const mmvq_rope * rope, const int * seg_rope, const mmq_kv_store * kvs, hipStream_t stream) {
     if (nseg < 2 || nseg > 3 || n < 256) return false;
     static const bool w16 = !getenv("GGML_MI355X_MMQ16") || atoi(getenv("GGML_MI355X_MMQ16")) != 0;
     if (rope) {        // epilogue / combine-pass ROPE: 16-wave kernel only, heads of an even size that start at column multiples of 4
@@ -750,7 +768,7 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
     else return false;
     // the rotation rides on the combine pass (one sincos per pair, no lane exchange); in the mat-mul epilogue both lanes of a pair would
     // evaluate it (measured: pp2048 -2.6 % against separate ROPE kernels), so without a k split the caller keeps its ROPE launches
-    if (rope && a.ksplit == 1) return false;
+    if ((rope || kvs) && a.ksplit == 1) return false;
     if (mmq_x_bytes(k, n) + (a.ksplit > 1 ? (size_t) a.ksplit*m_tot*n*4 : 0) + 512 > scratch_size) return false;
     if (!scratch_ready) {
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, (uint16_t *) scratch };
@@ -771,7 +789,9 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
         default: fprintf(stderr, "mmq_multi: unsupported type %d\n", t1); abort();
     }
     if (a.ksplit > 1) {
-        combine_seg_args ca = { planes, m_tot/4, n, nseg, { nullptr, nullptr, nullptr }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, a.rope };
+        combine_seg_args ca = { planes, m_tot/4, n, nseg, { nullptr, nullptr, nullptr }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 }, a.rope,
+                                { nullptr, nullptr, nullptr }, { nullptr, nullptr, nullptr }, { 0, 0, 0 }, { 0, 0, 0 }, { 0, 0, 0 } };
+        if (kvs) for (int s = 0; s < nseg; s++) { ca.st16[s] = kvs->st16[s]; ca.st_idx[s] = kvs->st_idx[s]; ca.st_row_elems[s] = kvs->st_row_elems[s]; ca.st_mode[s] = kvs->st_mode[s]; ca.m_seg[s] = (int) m[s]; }
         for (int s = 0; s < 3; s++) { const int q = s < nseg ? s : nseg - 1; ca.dst[s] = a.seg[q].dst; ca.dst_nb1[s] = a.seg[q].dst_nb1; ca.col4[s] = a.seg[q].col0/4; ca.rope_seg[s] = a.seg[q].rope; }
         const unsigned cgrid = (unsigned)((m_tot/4*n + 255)/256);
         if (a.ksplit == 4) hipLaunchKernelGGL(k_combine_seg<4>, dim3(cgrid), dim3(256), 0, stream, ca);

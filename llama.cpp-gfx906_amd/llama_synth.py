@@ -49,6 +49,10 @@ MODELS = {
     # head size 128 with GQA 4:1 at test size (the fused attention kernels are instantiated for 64 and 128)
     "tiny-hd128": dict(n_embd=512, n_ff=512, n_layer=2, n_head=4, n_head_kv=1, n_embd_head=128, n_vocab=512,
                        rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
+    # ONE Llama-3-8B-shaped layer with a small vocabulary: the prefill fusions (grouped QKV with ROPE and KV store in its combine pass, 16-wave
+    # tiles, gate/up/SwiGLU, split-k combine + norm) only engage at these sizes with >= 256 tokens
+    "llama3-8b-1l": dict(n_embd=4096, n_ff=14336, n_layer=1, n_head=32, n_head_kv=8, n_embd_head=128, n_vocab=512,
+                         rope_freq_base=500000.0, n_ctx_orig=8192, is_70b=0),
     # small model for graph-level parity tests (oracle finishes in seconds)
     "tiny": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                  rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),

@@ -275,6 +275,32 @@ def test_graph_replay_is_bitwise_neutral_and_fusion_stays_within_tolerance():
     assert orc.nmse(outs[(0, 0)], outs[(0, 1)]) <= 5e-4
 
 
+@pytest.mark.parametrize("ftype,n_prompt,fa", [("Q4_K_M", 512, 0), ("Q4_K_M", 300, 0), ("Q8_0", 512, 0), ("Q4_K_M", 512, 1)])
+def test_prefill_fusions_at_model_size(ftype, n_prompt, fa):
+    """One Llama-3-8B-shaped layer, a prompt of 300 / 512 tokens, then two single-token steps that read the KV cache the prompt pass wrote.
+    With fusion on the prompt pass runs 9 kernels per layer (grouped QKV whose combine pass also rotates q / k and stores k / v into the
+    cache, attention, wo and ffn_down with combine + norm, gate/up/SwiGLU); with fusion off one kernel per graph node. Same arithmetic, same
+    summation orders: the logits must agree far inside the reference gate, and the cache contents (seen through the next steps) too."""
+    be = backend()
+    toks = np.random.default_rng(n_prompt).integers(0, 512, size=n_prompt).astype(np.int32)
+    outs = {}
+    for fusion in (1, 0):
+        be.set_option("fusion", fusion)
+        m = ls.SynthLlama(be, "llama3-8b-1l", ftype, n_ctx=n_prompt + 32, seed=11, flash_attn=fa)
+        be.reset_counters()
+        res = [m.decode(toks), m.decode([7]), m.decode([9])]
+        outs[fusion] = np.stack(res); cnt = be.counters()
+        if fusion:
+            assert cnt["kernels_launched"] < 60, cnt
+        m.free()
+    be.set_option("fusion", 1)
+    assert np.isfinite(outs[1]).all()
+    # the prompt pass: the fused attention kernel (online softmax, probabilities in f16) against soft_max + two f16 mat-muls: the reference gate
+    assert orc.nmse(outs[0][0], outs[1][0]) <= 5e-4, orc.nmse(outs[0][0], outs[1][0])
+    # the steps after it read the cache the prompt pass wrote (k rotated and stored by the QKV combine pass when fused): same f16 values
+    assert orc.nmse(outs[0][1:], outs[1][1:]) <= 1e-4, orc.nmse(outs[0][1:], outs[1][1:])     # (a wrong cache row gives O(1))
+
+
 def test_kv_clear_restarts_sequence():
     be = backend()
     m = ls.SynthLlama(be, "tiny", "Q4_K_M", n_ctx=64, seed=9)
