@@ -236,6 +236,13 @@ def main():
                 mp.kv_clear(); torch.cuda.synchronize(); t0 = time.perf_counter(); mp.decode(ptoks); torch.cuda.synchronize()
                 reps.append(args.pp / (time.perf_counter() - t0))
             extra[f"pp{args.pp}_tok_s"] = round(float(np.mean(reps)), 1)
+            # the prompt pass against the matrix cores: 2 FLOP per token and weight element of the layers' mat-muls (MoE: the used experts), the attention
+            # products on top; dense bf16 MFMA peak from MI355X_MICROARCH.md (2.5 PFLOP/s)
+            hd, nh, nkv, ne, nff = cfg["n_embd_head"], cfg["n_head"], cfg["n_head_kv"], cfg["n_embd"], cfg["n_ff"]
+            w_layer = ne*(nh*hd + 2*nkv*hd) + nh*hd*ne + 3*ne*nff*max(1, cfg.get("n_expert_used", 0))
+            flop = 2.0*args.pp*w_layer*cfg["n_layer"] + 2.0*2.0*nh*hd*cfg["n_layer"]*args.pp*(args.pp + 1)/2
+            tfs = flop*float(np.mean(reps))/args.pp/1e12
+            extra[f"pp{args.pp}_mfma"] = {"TFLOP_per_pass": round(flop/1e12, 3), "achieved_TFLOPs": round(tfs, 1), "peak_TFLOPs": 2500.0, "frac": round(tfs/2500.0, 4)}
             mp.free()
         result["extra"] = extra
         result["roofline"] = roof
