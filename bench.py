@@ -37,6 +37,33 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
+def perplexity_delta(be, ls, gg, ftype, n_pos=200):
+    """checker leg (north_star: perplexity delta vs the CPU reference, <= 1e-3): perplexity of a synthetic token stream under the small synthetic
+    model from this backend's logits — token by token (decode kernels) and one prompt pass per position (prefill kernels) — against the
+    CPU-style oracle (oracle/ref_llama.py, mode cpu16) on the same weights; |delta ln PPL| (the per-position differences are zero-mean noise of the two
+    roundings: the mean over 200 positions is what settles below the target; a real perplexity run averages thousands). Same procedure, three
+    formats, in tests/test_gpu_llama_graph.py::test_perplexity_delta_vs_cpu_reference."""
+    sys.path.insert(0, str(ROOT / "oracle"))
+    import ref_llama
+    ft = ftype if ftype in ("Q4_K_M", "Q4_0", "Q8_0", "Q6_K") else "Q4_K_M"
+    toks = np.random.default_rng(77).integers(0, 512, size=n_pos + 1).astype(np.int32)
+    m = ls.SynthLlama(be, "tiny", ft, n_ctx=n_pos + 24, seed=21)
+    try:
+        rc = ref_llama.RefLlama(m.cfg, ref_llama.read_weights(m, gg), n_pos + 24, "cpu16")
+        nc, nd, npre = [], [], []
+        for t in range(n_pos):
+            nd.append(ref_llama.nll(m.decode([int(toks[t])]), toks[t + 1]))
+            nc.append(ref_llama.nll(rc.decode(np.stack([m.embedding(int(toks[t]))])), toks[t + 1]))
+        for t in range(8, n_pos):
+            m.kv_clear()
+            npre.append(ref_llama.nll(m.decode([int(x) for x in toks[: t + 1]]), toks[t + 1]))
+    finally:
+        m.free()
+    return {"model": f"tiny {ft} (random init)", "positions": n_pos, "ppl_cpu_reference": round(float(np.exp(np.mean(nc))), 3),
+            "delta_ln_ppl_decode_path": round(abs(float(np.mean(nd)) - float(np.mean(nc))), 6),
+            "delta_ln_ppl_prefill_path": round(abs(float(np.mean(npre)) - float(np.mean(nc[8:]))), 6), "target": 1e-3}
+
+
 def cpu_baseline(model_cfg, ftype, budget_s=20.0):
     """Time the oracle (CPU restatement, OpenMP) on the same mat-vec work: a bounded sample of layers + the lm_head."""
     sys.path.insert(0, str(ROOT / "oracle"))
@@ -247,6 +274,10 @@ def main():
         result["extra"] = extra
         result["roofline"] = roof
         if not args.no_cpu_baseline:
+            try:
+                extra["perplexity"] = perplexity_delta(be, ls, gg, args.ftype)
+            except Exception as e:
+                extra["perplexity"] = {"failed": str(e)}
             try:
                 result["cpu_baseline"] = cpu_baseline(cfg, args.ftype)
             except Exception as e:   # the baseline is reporting only; never let it take the bench line down

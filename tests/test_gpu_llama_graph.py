@@ -14,137 +14,12 @@ pytestmark = pytest.mark.gpu
 ls = pkg.llama_synth
 
 
+from ref_llama import RefLlama, mm, nll as _nll     # oracle/ref_llama.py
+import ref_llama
+
+
 def read_weights(m):
-    W = {}
-    moe = m.cfg.get("n_expert", 0) > 0
-    oai = m.cfg.get("arch", 0) == 1
-    names = ["attn_norm.weight", "attn_q.weight", "attn_k.weight", "attn_v.weight", "attn_output.weight", "ffn_norm.weight"]
-    names += ["ffn_gate_inp.weight", "ffn_gate_exps.weight", "ffn_up_exps.weight", "ffn_down_exps.weight"] if moe else \
-             ["ffn_gate.weight", "ffn_up.weight", "ffn_down.weight"]
-    if oai:
-        names += ["attn_q.bias", "attn_k.bias", "attn_v.bias", "attn_output.bias", "attn_sinks.weight",
-                  "ffn_gate_inp.bias", "ffn_gate_exps.bias", "ffn_up_exps.bias", "ffn_down_exps.bias"]
-    for il in range(m.cfg["n_layer"]):
-        for nm in names:
-            t = m.tensor(f"blk.{il}.{nm}")
-            a = gg.tensor_get(t)[0]
-            key = nm[:-7] if nm.endswith(".weight") else nm
-            W[(il, key)] = (t.contents.type, (a if t.contents.ne[2] > 1 else a[0]).copy())
-    for nm in ("output_norm", "output"):
-        t = m.tensor(f"{nm}.weight")
-        W[nm] = (t.contents.type, gg.tensor_get(t)[0, 0].copy())
-    return W
-
-
-def mm(W, key, x, mode):
-    qt, data = W[key]
-    return orc.mul_mat_2d(data, qt, x.astype(np.float32), mode).astype(np.float32)
-
-
-class RefLlama:
-    """numpy restatement of the graph llm_build_llama emits (src/llama-model.cpp:5969-6123), of its MoE branch (build_moe_ffn,
-    src/llama-graph.cpp:811-1023) and of llm_build_openai_moe_iswa (src/llama-model.cpp:17610-17738; within its 128-token window)"""
-
-    def __init__(self, cfg, W, kv_size, mode):
-        self.f16_attn = mode == "cpu16"
-        mode = "cpu" if mode == "cpu16" else mode
-        self.c, self.W, self.mode = cfg, W, mode
-        hd, hkv = cfg["n_embd_head"], cfg["n_head_kv"]
-        self.k = np.zeros((cfg["n_layer"], kv_size, hkv, hd), np.float16)
-        self.v = np.zeros((cfg["n_layer"], kv_size, hkv, hd), np.float16)
-        self.n_past = 0
-        self.selected = []      # expert choices, so that a test can tell a routing flip from an arithmetic error
-
-    def moe_ffn(self, il, h):
-        c, W, mode = self.c, self.W, self.mode
-        n_used, oai = c["n_expert_used"], c.get("arch", 0) == 1
-        logits = (h.astype(np.float64) @ W[(il, "ffn_gate_inp")][1].astype(np.float64).T).astype(np.float32)
-        if oai:
-            logits = logits + W[(il, "ffn_gate_inp.bias")][1]
-        probs = logits if oai else ref.soft_max(logits[None, None])[0, 0]
-        sel = ref.argsort_desc(probs[None, None])[0, 0][:, :n_used]
-        self.selected.append(sel.copy())
-        w = np.take_along_axis(probs, sel, axis=1).astype(np.float32)
-        if oai:
-            w = ref.soft_max(w[None, None])[0, 0]
-        else:
-            w = (w / w.sum(-1, keepdims=True, dtype=np.float32)).astype(np.float32)
-        qt_u, up_w = W[(il, "ffn_up_exps")]; qt_g, gate_w = W[(il, "ffn_gate_exps")]; qt_d, down_w = W[(il, "ffn_down_exps")]
-        x3 = h[:, None, :].astype(np.float32)
-        up = orc.mul_mat_id(up_w, qt_u, x3, sel, mode).astype(np.float32)
-        gate = orc.mul_mat_id(gate_w, qt_g, x3, sel, mode).astype(np.float32)
-        if oai:
-            up = up + W[(il, "ffn_up_exps.bias")][1][sel]; gate = gate + W[(il, "ffn_gate_exps.bias")][1][sel]
-            act = ref.swiglu_oai(gate, up).astype(np.float32)
-        else:
-            act = ref.swiglu(gate, up).astype(np.float32)
-        ex = orc.mul_mat_id(down_w, qt_d, act, sel, mode).astype(np.float32)
-        if oai:
-            ex = ex + W[(il, "ffn_down_exps.bias")][1][sel]
-        ex = (ex * w[:, :, None]).astype(np.float32)
-        out = ex[:, 0]
-        for i in range(1, n_used):
-            out = out + ex[:, i]
-        return out
-
-    def decode(self, emb):
-        c, W = self.c, self.W
-        n_tok = emb.shape[0]
-        hd, nh, hkv = c["n_embd_head"], c["n_head"], c["n_head_kv"]
-        oai, moe, rmode = c.get("arch", 0) == 1, c.get("n_expert", 0) > 0, c.get("rope_type", 0)
-        pos = np.arange(self.n_past, self.n_past + n_tok).astype(np.int32)
-        x = emb.astype(np.float32)
-        for il in range(c["n_layer"]):
-            last = il == c["n_layer"] - 1
-            h = (ref.rms_norm(x, 1e-5) * W[(il, "attn_norm")][1]).astype(np.float32)
-            q = mm(W, (il, "attn_q"), h, self.mode); k = mm(W, (il, "attn_k"), h, self.mode); v = mm(W, (il, "attn_v"), h, self.mode)
-            if oai:
-                q = q + W[(il, "attn_q.bias")][1]; k = k + W[(il, "attn_k.bias")][1]; v = v + W[(il, "attn_v.bias")][1]
-            q = q.reshape(1, n_tok, nh, hd); k = k.reshape(1, n_tok, hkv, hd); v = v.reshape(n_tok, hkv, hd)
-            q = ref.rope(q, pos, hd, rmode, c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
-            k = ref.rope(k, pos, hd, rmode, c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
-            self.k[il, pos] = k.astype(np.float16)
-            self.v[il, pos] = v.astype(np.float16)
-            n_kv = self.n_past + n_tok
-            K = self.k[il, :n_kv].astype(np.float32); V = self.v[il, :n_kv].astype(np.float32)
-            out = np.zeros((n_tok, nh, hd), np.float32)
-            for hh in range(nh):
-                kvh = hh // (nh // hkv)
-                # the CPU backend's mat-mul with an F16 src0 converts src1 to its vec_dot_type, F16 (ggml_compute_forward_mul_mat): q, and below
-                # the probabilities, are rounded to f16 before the dot; sums in f32. Mode "cpu16" restates that too (used where the CPU path as
-                # a whole is the yardstick: the perplexity delta); "cpu" and "exact" keep q and p in f32, as this backend's decode kernel does.
-                qh = q[:, hh, :].astype(np.float16).astype(np.float64) if self.f16_attn else q[:, hh, :].astype(np.float64)
-                s = (qh @ K[:, kvh, :].T.astype(np.float64)).astype(np.float32)   # kq (f32 result)
-                s = s.astype(np.float64) / np.sqrt(hd)
-                causal = np.arange(n_kv)[None, :] <= pos[:, None]
-                s = np.where(causal, s, -np.inf)
-                mx = s.max(-1, keepdims=True)
-                if oai:     # attention sink: one more logit per head in the max and the denominator (src/llama-graph.cpp:1313)
-                    sink = float(W[(il, "attn_sinks")][1].reshape(-1)[hh])
-                    mx = np.maximum(mx, sink)
-                p = np.exp(s - mx); den = p.sum(-1, keepdims=True)
-                if oai:
-                    den = den + np.exp(sink - mx)
-                p = (p / den).astype(np.float32)
-                if self.f16_attn:
-                    p = p.astype(np.float16).astype(np.float32)
-                out[:, hh, :] = (p.astype(np.float64) @ V[:, kvh, :].astype(np.float64)).astype(np.float32)
-            a = mm(W, (il, "attn_output"), out.reshape(n_tok, nh * hd), self.mode)
-            if oai:
-                a = a + W[(il, "attn_output.bias")][1]
-            if last:
-                a = a[-1:]; x = x[-1:]
-            ffn_inp = a + x
-            h = (ref.rms_norm(ffn_inp, 1e-5) * W[(il, "ffn_norm")][1]).astype(np.float32)
-            if moe:
-                x = self.moe_ffn(il, h) + ffn_inp
-            else:
-                up = mm(W, (il, "ffn_up"), h, self.mode); gate = mm(W, (il, "ffn_gate"), h, self.mode)
-                act = ref.swiglu(gate, up).astype(np.float32)
-                x = mm(W, (il, "ffn_down"), act, self.mode) + ffn_inp
-        h = (ref.rms_norm(x, 1e-5) * W["output_norm"][1]).astype(np.float32)
-        self.n_past += n_tok
-        return mm(W, "output", h, self.mode)[0]
+    return ref_llama.read_weights(m, gg)
 
 
 @pytest.mark.parametrize("ftype", ["Q4_K_M", "Q4_0", "Q8_0", "Q6_K"])
@@ -166,11 +41,6 @@ def test_synthetic_llama_matches_oracle(ftype):
             assert orc.nmse(exp_e, got) <= 2e-3, (toks, orc.nmse(exp_e, got))     # the reference's whole-graph gate
     finally:
         m.free()
-
-
-def _nll(logits, tok):
-    z = logits.astype(np.float64); z = z - z.max()
-    return float(np.log(np.exp(z).sum()) - z[tok])
 
 
 @pytest.mark.parametrize("ftype", ["Q4_K_M", "Q8_0", "Q4_0"])
