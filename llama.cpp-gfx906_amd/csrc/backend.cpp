@@ -251,6 +251,7 @@ struct mi_backend_ctx {
 
     void * scratch = nullptr;      // quantized activations
     size_t scratch_size = 0;
+    float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
     // activation-quantisation reuse inside one graph_compute
     struct { const void * data; int64_t k, n_inner, n_outer; size_t s_inner, s_outer; int kind; act_q8 q; bool valid; size_t span;
@@ -311,6 +312,7 @@ static void be_free(ggml_backend_t backend) {
     if (c->stream) (void) hipStreamSynchronize(c->stream);
     for (auto & e : c->graphs) if (e.exec) (void) hipGraphExecDestroy(e.exec);
     if (c->scratch) (void) hipFree(c->scratch);
+    if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     delete backend;
@@ -410,7 +412,7 @@ static bool mi_supports_op(const struct ggml_tensor * op) {
             if (op_f32(op, 1) != 0.0f || op_f32(op, 2) != 0.0f) return false;
             if (mask && (mask->type != GGML_TYPE_F16 || mask->ne[2] != 1 || mask->ne[3] != 1)) return false;
             if (s0->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || s0->nb[1] % 16 || s0->nb[2] % 16 || k->nb[1] % 16 || k->nb[2] % 16 || v->nb[1] % 16 || v->nb[2] % 16) return false;
-            return s0->ne[1] <= 8 ? attn_decode_supported(k->ne[0], k->ne[1]) : attn_prefill_supported(k->ne[0], k->ne[1]);
+            return s0->ne[1] <= 8 ? (attn_decode_supported(k->ne[0], k->ne[1]) || attn_decode_supported_split(k->ne[0], k->ne[1])) : attn_prefill_supported(k->ne[0], k->ne[1]);
         }
         case GGML_OP_RMS_NORM:
             return s0->type == GGML_TYPE_F32 && op->type == GGML_TYPE_F32 && s0->nb[0] == sizeof(float);
@@ -823,7 +825,7 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     if (k->type != GGML_TYPE_F16 || q->type != GGML_TYPE_F32 || k->ne[3] != 1 || q->ne[3] != 1) return 0;
     const int64_t hd = k->ne[0], n_kv = k->ne[1], n_head_kv = k->ne[2], T = q->ne[1], n_head = q->ne[2];
     const bool prefill = T > 8;      // many tokens: the matrix-core kernel with online softmax (attn_prefill.hip)
-    if (n_head % n_head_kv != 0 || !(prefill ? attn_prefill_supported(hd, n_kv) : attn_decode_supported(hd, n_kv))) return 0;
+    if (n_head % n_head_kv != 0 || !(prefill ? attn_prefill_supported(hd, n_kv) : (attn_decode_supported(hd, n_kv) || (c->attn_part && attn_decode_supported_split(hd, n_kv) && attn_decode_part_bytes(hd, n_kv, n_head, T) <= c->attn_part_bytes)))) return 0;
     if (k->nb[0] != 2 || q->nb[0] != 4 || k->nb[1] % 16 || k->nb[2] % 16 || (uintptr_t) k->data % 16 || q->nb[1] % 16 || q->nb[2] % 16 || (uintptr_t) q->data % 16) return 0;
     const int j1 = next_real(g, i); if (j1 < 0) return 0;
     struct ggml_tensor * sm = g->nodes[j1];
@@ -863,7 +865,7 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2],
                 mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, mask && mask->type == GGML_TYPE_F16,
                 sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
-                hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream);
+                hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream, true, c->attn_part, c->attn_part_bytes);
     c->cnt.kernels_launched++;
     return j3 - i + 1;
 }
@@ -1283,7 +1285,8 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             GGML_ASSERT(node->nb[1] == (size_t) hd*4 && ((uintptr_t) q->data % 16) == 0 && ((uintptr_t) k->data % 16) == 0 && ((uintptr_t) v->data % 16) == 0);
             GGML_ASSERT(!mask || (mask->ne[0] == n_kv && mask->ne[1] >= T && ((uintptr_t) mask->data % 16) == 0 && mask->nb[1] % 16 == 0));
             if (T <= 8) attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
-                                    sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false);
+                                    sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false,
+                                    c->attn_part, c->attn_part_bytes);
             else        attn_prefill(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
                                      sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false);
             c->cnt.kernels_launched++;
@@ -1468,6 +1471,10 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
     set_device(c->device);
     c->cnt.graphs_computed++;
 
+    if (!c->attn_part) {     // <= 8 tokens x 128 heads x 32 ranges x (128 + 2) floats: allocated once, outside any capture
+        const size_t pb = (size_t) 8*128*32*130*4;
+        if (hipMalloc((void **) &c->attn_part, pb) == hipSuccess) c->attn_part_bytes = pb; else (void) hipGetLastError();
+    }
     const size_t need = graph_scratch_need(g);
     if (need > c->scratch_size) {
         MI_CHECK(hipStreamSynchronize(c->stream));

@@ -161,6 +161,10 @@ struct attn_args {
     float * dst; size_t dst_nb1;                        // [hd*n_head, T]
     int n_kv, n_head, n_head_kv, T;
     float scale;
+    // long contexts: blockIdx.z splits the cells into nsplit ranges of kv_chunk (a multiple of 32); each workgroup writes its range's
+    // soft_max-weighted V sum (normalised within the range) + its max and denominator to part[(t*n_head + h)*nsplit + z][HD + 2];
+    // k_attn_merge combines them (and adds the sink). nsplit = 1: the kernel finishes the row itself.
+    int kv_chunk, nsplit; float * part;
 };
 
 static __device__ __forceinline__ float dot8_f16_f32(const int4v kv, const float4v a, const float4v b) {
@@ -184,6 +188,8 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     __shared__ float sh[4];
     const int h = blockIdx.x, t = blockIdx.y;
     const int hk = h/(p.n_head/p.n_head_kv);
+    const bool split = p.nsplit > 1;
+    const int kv_lo = split ? (int) blockIdx.z*p.kv_chunk : 0, kv_n = split ? min(p.n_kv - kv_lo, p.kv_chunk) : p.n_kv;   // this workgroup's cells
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int LPC = HD/8;                            // lanes per K row (8 f16 = 16 B each)
     constexpr int CPW = 64/LPC;                          // K rows per wave step
@@ -193,14 +199,14 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     // ---- scores: s[j] = scale * K[j].q + mask[j] ----
     const float * qp = (const float *) (p.q + (size_t) t*p.q_nb1 + (size_t) h*p.q_nb2) + sub*8;
     const float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
-    const char * kbase = p.k + (size_t) hk*p.k_nb2 + sub*16;
-    const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 : nullptr;
-    float mx = p.sinks ? p.sinks[h] : -INFINITY;
-    for (int j0 = wave*CPW + cw; j0 < p.n_kv; j0 += 4*CPW*U) {
+    const char * kbase = p.k + (size_t) hk*p.k_nb2 + sub*16 + (size_t) kv_lo*p.k_nb1;
+    const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 + (size_t) kv_lo*(p.mask_f16 ? 2 : 4) : nullptr;
+    float mx = (p.sinks && !split) ? p.sinks[h] : -INFINITY;
+    for (int j0 = wave*CPW + cw; j0 < kv_n; j0 += 4*CPW*U) {
         int4v kreg[U]; float mreg[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const int j = min(j0 + u*4*CPW, p.n_kv - 1);
+            const int j = min(j0 + u*4*CPW, kv_n - 1);
             kreg[u] = *(const int4v *) (kbase + (size_t) j*p.k_nb1);
             mreg[u] = 0.0f;
             if (mrow) mreg[u] = p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (mrow + (size_t) j*2)) : *(const float *) (mrow + (size_t) j*4);
@@ -211,7 +217,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
             float acc = dot8_f16_f32(kreg[u], q0, q1);
             acc += dpp_f<0xB1>(acc); acc += dpp_f<0x4E>(acc); acc += dpp_f<0x141>(acc);   // sum over the LPC lanes of the row
             if (LPC == 16) acc += dpp_f<0x140>(acc);
-            if (j < p.n_kv) {
+            if (j < kv_n) {
                 const float v = acc*p.scale + mreg[u];
                 if (sub == 0) s[j] = v;
                 mx = fmaxf(mx, v);
@@ -224,27 +230,31 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     mx = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
     __syncthreads();
     float sum = 0.0f;
-    for (int j = threadIdx.x; j < p.n_kv; j += 256) { const float e = expf(s[j] - mx); s[j] = e; sum += e; }
+    const float mxs = mx == -INFINITY ? 0.0f : mx;      // a range whose cells are all masked (split only): every e = 0
+    for (int j = threadIdx.x; j < kv_n; j += 256) { const float e = expf(s[j] - mxs); s[j] = e; sum += e; }
     sum = block_sum4(sum, sh);
-    if (p.sinks) sum += expf(p.sinks[h] - mx);
-    const float inv = 1.0f/sum;
-    for (int j = threadIdx.x; j < p.n_kv; j += 256) s[j] *= inv;   // the unfused SOFT_MAX normalises before V.p
+    if (p.sinks && !split) sum += expf(p.sinks[h] - mx);
+    const float inv = sum > 0.0f ? 1.0f/sum : 0.0f;
+    for (int j = threadIdx.x; j < kv_n; j += 256) s[j] *= inv;   // the unfused SOFT_MAX normalises before V.p
     __syncthreads();
+    // where the result goes: the output row, or this range's slot of the partial buffer (+ its max and denominator)
+    float * orow = split ? p.part + ((size_t)(t*p.n_head + h)*p.nsplit + blockIdx.z)*(HD + 2) : (float *) ((char *) p.dst + (size_t) t*p.dst_nb1) + (size_t) h*HD;
+    if (split && threadIdx.x == 0) { orow[HD] = mx; orow[HD + 1] = sum; }
 
     if (!VT) {
         // ---- out[d] = sum_j p[j]*V[j][d]: a thread owns 8 dims of every NGR-th cell; partial sums meet in LDS ----
         constexpr int DCH = HD/8, NGR = 256/DCH, UV = 4;
-        float * red = (float *) (smem + (((size_t) p.n_kv*4 + 15) & ~(size_t) 15));     // [NGR][HD]
+        float * red = (float *) (smem + (((size_t)(split ? p.kv_chunk : p.n_kv)*4 + 15) & ~(size_t) 15));     // [NGR][HD]
         const int dch = threadIdx.x % DCH, cg = threadIdx.x / DCH;
-        const char * vb = p.v + (size_t) hk*p.v_nb2 + (size_t) dch*16;
+        const char * vb = p.v + (size_t) hk*p.v_nb2 + (size_t) dch*16 + (size_t) kv_lo*p.v_nb1;
         float a8[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
-        for (int j0 = cg; j0 < p.n_kv; j0 += NGR*UV) {
+        for (int j0 = cg; j0 < kv_n; j0 += NGR*UV) {
             int4v vr[UV]; float pj[UV];
 #pragma unroll
             for (int u = 0; u < UV; u++) {
-                const int j = min(j0 + u*NGR, p.n_kv - 1);
+                const int j = min(j0 + u*NGR, kv_n - 1);
                 vr[u] = *(const int4v *) (vb + (size_t) j*p.v_nb1);
-                pj[u] = j0 + u*NGR < p.n_kv ? s[j] : 0.0f;
+                pj[u] = j0 + u*NGR < kv_n ? s[j] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < UV; u++) {
@@ -261,18 +271,18 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
         if (threadIdx.x < HD) {
             float r = 0.0f;
             for (int gq = 0; gq < NGR; gq++) r += red[gq*HD + threadIdx.x];
-            *(float *) ((char *) p.dst + (size_t) t*p.dst_nb1 + (size_t)(h*HD + threadIdx.x)*4) = r;
+            orow[threadIdx.x] = r;
         }
         return;
     }
     // ---- out[d] = sum_j V[d][j]*p[j]: 16 lanes per V row, 4 rows per wave, HD/16 row groups per workgroup ----
     constexpr int NG = HD/16;                            // row groups: d = g*16 + wave*4 + rw
     const int l16 = lane & 15, rw = lane >> 4;
-    const char * vbase = p.v + (size_t) hk*p.v_nb2 + (size_t)(wave*4 + rw)*p.v_nb1;
+    const char * vbase = p.v + (size_t) hk*p.v_nb2 + (size_t)(wave*4 + rw)*p.v_nb1 + (size_t) kv_lo*2;
     float acc[NG];
 #pragma unroll
     for (int g = 0; g < NG; g++) acc[g] = 0.0f;
-    const int nchunk = p.n_kv >> 3;                      // n_kv % 8 == 0
+    const int nchunk = kv_n >> 3;                        // n_kv % 8 == 0 (and kv_chunk % 32 == 0)
     for (int c = l16; c < nchunk; c += 16) {
         int4v vreg[NG];
 #pragma unroll
@@ -284,26 +294,66 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
 #pragma unroll
     for (int g = 0; g < NG; g++) {
         const float r = row16_sum(acc[g]);
-        if (l16 == 0) *(float *) ((char *) p.dst + (size_t) t*p.dst_nb1 + (size_t)(h*HD + g*16 + wave*4 + rw)*4) = r;
+        if (l16 == 0) orow[g*16 + wave*4 + rw] = r;
     }
 }
 
+// combine the cell ranges of one (token, head): out = sum_i w_i o_i / (sum_i w_i [+ e^(sink - M)]), w_i = l_i e^(m_i - M), M = max(m_i [, sink])
+template <int HD>
+__global__ void __launch_bounds__(HD) k_attn_merge(const attn_args p) {
+    const int h = blockIdx.x, t = blockIdx.y, d = threadIdx.x;
+    const float * pr = p.part + (size_t)(t*p.n_head + h)*p.nsplit*(HD + 2);
+    float M = p.sinks ? p.sinks[h] : -INFINITY;
+    for (int i = 0; i < p.nsplit; i++) M = fmaxf(M, pr[(size_t) i*(HD + 2) + HD]);
+    float den = p.sinks ? expf(p.sinks[h] - M) : 0.0f, acc = 0.0f;
+    for (int i = 0; i < p.nsplit; i++) {
+        const float mi = pr[(size_t) i*(HD + 2) + HD], li = pr[(size_t) i*(HD + 2) + HD + 1];
+        const float w = li > 0.0f ? li*expf(mi - M) : 0.0f;
+        den += w; acc += w*pr[(size_t) i*(HD + 2) + d];
+    }
+    *(float *) ((char *) p.dst + (size_t) t*p.dst_nb1 + (size_t)(h*HD + d)*4) = acc/den;
+}
+
+// without a partial buffer the whole row of scores must fit the workgroup's LDS
 bool attn_decode_supported(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv % 8 == 0 && n_kv*4 <= 48*1024; }
+bool attn_decode_supported_split(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv >= 1024 && n_kv % 32 == 0; }
+size_t attn_decode_part_bytes(int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t T) {     // 0: no split for this shape
+    if (n_kv < 1024 || n_kv % 32 != 0) return 0;
+    const int64_t ns = (n_kv + 255)/256 < 32 ? (n_kv + 255)/256 : 32;
+    return (size_t) T*n_head*ns*(head_dim + 2)*4;
+}
 
 void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                  const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
-                 int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans) {
+                 int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans,
+                 float * part, size_t part_bytes) {
     attn_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
-                    (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
-    const dim3 grid((unsigned) n_head, (unsigned) T);
-    const size_t lds = (((size_t) n_kv*4 + 15) & ~(size_t) 15) + (v_trans ? 0 : 8192);     // !v_trans: + [256/(hd/8)][hd] partial sums
+                    (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale, 0, 1, nullptr };
+    // long contexts: one workgroup per (head, token) walks every cell alone — 32 workgroups on 256 CUs. With a partial buffer the cells
+    // are split into ranges of >= 256 (at most 32 ranges) that run side by side and a small second kernel merges them.
+    static const bool split_on = !getenv("GGML_MI355X_ATTN_SPLIT") || atoi(getenv("GGML_MI355X_ATTN_SPLIT")) != 0;
+    const size_t need = attn_decode_part_bytes(head_dim, n_kv, n_head, T);
+    if (part && need && need <= part_bytes && (split_on || n_kv*4 > 48*1024)) {
+        int64_t ns = (n_kv + 255)/256 < 32 ? (n_kv + 255)/256 : 32;
+        const int64_t chunk = ((n_kv + ns - 1)/ns + 31)/32*32;          // the KV cache pads n_kv to 32 (256 with flash attention)
+        ns = (n_kv + chunk - 1)/chunk;
+        a.kv_chunk = (int) chunk; a.nsplit = (int) ns; a.part = part;
+    }
+    const dim3 grid((unsigned) n_head, (unsigned) T, (unsigned) a.nsplit);
+    const size_t lds = (((size_t)(a.nsplit > 1 ? a.kv_chunk : n_kv)*4 + 15) & ~(size_t) 15) + (v_trans ? 0 : 8192);     // !v_trans: + [256/(hd/8)][hd] partial sums
     if (!v_trans) {
         if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, false>), grid, dim3(256), lds, stream, a);
         else                 hipLaunchKernelGGL((k_attn_decode<64, false>),  grid, dim3(256), lds, stream, a);
-        return;
     }
-    if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128>), grid, dim3(256), lds, stream, a);
-    else                 hipLaunchKernelGGL((k_attn_decode<64>),  grid, dim3(256), lds, stream, a);
+    if (v_trans) {
+        if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128>), grid, dim3(256), lds, stream, a);
+        else                 hipLaunchKernelGGL((k_attn_decode<64>),  grid, dim3(256), lds, stream, a);
+    }
+    if (a.nsplit > 1) {
+        const dim3 mg((unsigned) n_head, (unsigned) T);
+        if (head_dim == 128) hipLaunchKernelGGL((k_attn_merge<128>), mg, dim3(128), 0, stream, a);
+        else                 hipLaunchKernelGGL((k_attn_merge<64>),  mg, dim3(64),  0, stream, a);
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -222,6 +222,23 @@ def test_prefill_fusions_at_model_size(ftype, n_prompt, fa):
     assert orc.nmse(outs[0][1:], outs[1][1:]) <= 1e-4, orc.nmse(outs[0][1:], outs[1][1:])     # (a wrong cache row gives O(1))
 
 
+@pytest.mark.parametrize("fa", [0, 1])
+def test_long_context_decode_attention_split(fa):
+    """Decode steps at > 1024 cached cells: the attention kernel splits the cells into ranges that run on several workgroups and a second
+    kernel merges them (decode_fused.hip k_attn_merge). Checked against the node-by-node path (soft_max over the whole row)."""
+    be = backend()
+    toks = np.random.default_rng(5).integers(0, 512, size=1290).astype(np.int32)
+    outs = {}
+    for fusion in (1, 0):
+        be.set_option("fusion", fusion)
+        m = ls.SynthLlama(be, "tiny", "Q8_0", n_ctx=1536, seed=9, flash_attn=fa)
+        res = [m.decode(toks[:1280])] + [m.decode([int(t)]) for t in toks[1280:1290]]
+        outs[fusion] = np.stack(res); m.free()
+    be.set_option("fusion", 1)
+    assert np.isfinite(outs[1]).all()
+    assert orc.nmse(outs[0], outs[1]) <= 5e-4, orc.nmse(outs[0], outs[1])
+
+
 def test_kv_clear_restarts_sequence():
     be = backend()
     m = ls.SynthLlama(be, "tiny", "Q4_K_M", n_ctx=64, seed=9)

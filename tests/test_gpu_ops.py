@@ -343,7 +343,10 @@ def test_mul_mat_f32_f16_generic_strided():
                                                             # ratio that is no power of two (3), idle waves in the last workgroup, a sliding window
                                                             # (T = 130: cells more than 100 back are masked, so whole blocks at the START are skipped)
                                                             (64, 4, 4, 256, 70, False), (128, 8, 4, 256, 100, True), (128, 16, 2, 512, 130, False),
-                                                            (64, 6, 2, 256, 45, True), (128, 32, 8, 1024, 300, False)])
+                                                            (64, 6, 2, 256, 45, True), (128, 32, 8, 1024, 300, False),
+                                                            # long contexts, few tokens: the cells are split into ranges over several workgroups and merged
+                                                            # (16384 cells of scores do not fit one workgroup's LDS: only the split form can run it)
+                                                            (128, 8, 2, 2048, 1, True), (64, 8, 2, 4096, 3, False), (128, 8, 8, 16384, 2, True)])
 def test_flash_attn_ext(hd, n_head, n_head_kv, n_kv, T, sinks):
     """FLASH_ATTN_EXT as build_attn_mha emits it with -fa (src/llama-graph.cpp:1245-1265; tests/test-backend-ops.cpp:4559, NMSE 5e-4):
     q F32 permuted view, K and V F16 views of the cache with rows = cells (V NOT transposed), F16 mask padded in the token dimension,
