@@ -316,10 +316,14 @@ __global__ void __launch_bounds__(HD) k_attn_merge(const attn_args p) {
 
 // without a partial buffer the whole row of scores must fit the workgroup's LDS
 bool attn_decode_supported(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv % 8 == 0 && n_kv*4 <= 48*1024; }
-static int64_t attn_split_min() { static const int64_t v = getenv("GGML_MI355X_ATTN_SPLIT_MIN") ? atoll(getenv("GGML_MI355X_ATTN_SPLIT_MIN")) : 512; return v < 256 ? 256 : v; }
-bool attn_decode_supported_split(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv >= attn_split_min() && n_kv % 32 == 0; }
+// measured (tg1024 / --fa 1 tg128): the transposed-V kernel gains from 384-512 cells on, the row-V (flash attention) one already at 256
+static int64_t attn_split_min(bool v_trans = true) {
+    static const int64_t v = getenv("GGML_MI355X_ATTN_SPLIT_MIN") ? atoll(getenv("GGML_MI355X_ATTN_SPLIT_MIN")) : 0;
+    return v ? (v < 256 ? 256 : v) : (v_trans ? 384 : 256);
+}
+bool attn_decode_supported_split(int64_t head_dim, int64_t n_kv) { return (head_dim == 128 || head_dim == 64) && n_kv >= attn_split_min(true) && n_kv % 32 == 0; }
 size_t attn_decode_part_bytes(int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t T) {     // 0: no split for this shape
-    if (n_kv < attn_split_min() || n_kv % 32 != 0) return 0;
+    if (n_kv < attn_split_min(false) || n_kv % 32 != 0) return 0;
     const int64_t ns = (n_kv + 127)/128 < 32 ? (n_kv + 127)/128 : 32;
     return (size_t) T*n_head*ns*(head_dim + 2)*4;
 }
@@ -334,7 +338,7 @@ void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, siz
     // are split into ranges of >= 256 (at most 32 ranges) that run side by side and a small second kernel merges them.
     static const bool split_on = !getenv("GGML_MI355X_ATTN_SPLIT") || atoi(getenv("GGML_MI355X_ATTN_SPLIT")) != 0;
     const size_t need = attn_decode_part_bytes(head_dim, n_kv, n_head, T);
-    if (part && need && need <= part_bytes && (split_on || n_kv*4 > 48*1024)) {
+    if (part && need && need <= part_bytes && n_kv >= attn_split_min(v_trans) && (split_on || n_kv*4 > 48*1024)) {
         int64_t ns = (n_kv + 127)/128 < 32 ? (n_kv + 127)/128 : 32;       // ranges of >= 128 cells
         const int64_t chunk = ((n_kv + ns - 1)/ns + 31)/32*32;          // the KV cache pads n_kv to 32 (256 with flash attention)
         ns = (n_kv + chunk - 1)/chunk;
