@@ -686,9 +686,11 @@ static const struct ggml_tensor * base_of(const struct ggml_tensor * t) {   // s
 //   norm/normw != NULL: the activation is MUL(RMS_NORM(norm->src[0]), normw) and the caller has checked that every consumer of
 //   that product is a mat-vec; if they all fit into this launch the norm is computed in the prologue (PRO_NORM).
 // Returns the index of the last node consumed (-1 = not fused).
+static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i);
 static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm, const struct ggml_tensor * normw) {
     struct ggml_tensor * n = g->nodes[i];
     if (!fusable_mmv(n)) return -1;
+    int deferred[MMVQ_MAX_GROUPS]; int n_def = 0;      // ROPE nodes between the grouped mat-vecs that the epilogue cannot do (NEOX): run after the launch
     const struct ggml_tensor * b = n->src[1];
     const int kind = act_kind_for((int) n->src[0]->type);
     mmv_chain chains[MMVQ_MAX_GROUPS];
@@ -697,9 +699,20 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     last = chains[0].last;
     n_mm += chains[0].grp.epi == EPI_GLU ? 2 : 1;
     while (nc < MMVQ_MAX_GROUPS && chains[0].grp.epi != EPI_GLU) {
-        const int j = next_real(g, last);
+        int j = next_real(g, last);
         if (j < 0) break;
         struct ggml_tensor * m = g->nodes[j];
+        int def_j = -1;
+        if (m->op == GGML_OP_ROPE && !chains[nc - 1].has_rope && m->src[0] && base_of(m->src[0])->data == chains[nc - 1].out_ptr && n_def < MMVQ_MAX_GROUPS) {
+            // gpt-oss: wq -> + bias -> RESHAPE -> ROPE(NEOX) ; wk -> ... ; wv (src/llama-model.cpp:17636-17660): the rotation of the chain just matched
+            // only needs that chain — if the next mat-vec on the same activation follows it, it joins the launch and the ROPE runs afterwards
+            const int j2 = next_real(g, j);
+            if (j2 < 0 || !fusable_mmv(g->nodes[j2]) || g->nodes[j2]->src[1] != b) break;
+            bool okr = !ranges_overlap(m->data, ggml_nbytes(m), b->data, ggml_nbytes(b));
+            for (int q = 0; q < nc && okr; q++) okr = m->data == chains[q].out_ptr ? q == nc - 1 : !ranges_overlap(m->data, ggml_nbytes(m), chains[q].out_ptr, chains[q].out_bytes);
+            if (!okr) break;
+            def_j = j; j = j2; m = g->nodes[j];
+        }
         if (!fusable_mmv(m) || m->src[1] != b || act_kind_for((int) m->src[0]->type) != kind) break;
         mmv_chain ch = match_mmv_chain(c, g, j);
         if (ch.grp.epi == EPI_GLU) break;   // the dual (GLU) kernel runs alone
@@ -717,7 +730,13 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
             if (ok && chains[q].grp.res) ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, chains[q].grp.res, (size_t) chains[q].grp.m*4);
             if (ok && ch.grp.res)       ok = !ranges_overlap(chains[q].out_ptr, chains[q].out_bytes, ch.grp.res, (size_t) ch.grp.m*4);
         }
+        // ... nor what a ROPE that now runs after the launch still has to write (its own chain's buffer excepted: in-place rotation)
+        for (int r = 0; r < n_def + (def_j >= 0 ? 1 : 0) && ok; r++) {
+            const struct ggml_tensor * rp = g->nodes[r < n_def ? deferred[r] : def_j];
+            ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, rp->data, ggml_nbytes(rp));
+        }
         if (!ok) break;
+        if (def_j >= 0) deferred[n_def++] = def_j;
         chains[nc++] = ch;
         last = ch.last;
         n_mm++;
@@ -783,6 +802,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     }
     mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream);     // may be held back as a position of the per-layer chain (profile events: prof_hook_*)
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++; c->cnt.weight_bytes += wbytes;
+    for (int r = 0; r < n_def; r++) compute_node(c, g, deferred[r]);       // (flushes a held-back launch first)
     return last;
 }
 
