@@ -251,6 +251,7 @@ struct mi_backend_ctx {
 
     void * scratch = nullptr;      // quantized activations
     size_t scratch_size = 0;
+    float * moe_ws = nullptr;                                   // logits + arrival counter of the multi-workgroup router kernel (moe_route)
     float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
     // activation-quantisation reuse inside one graph_compute
@@ -313,6 +314,7 @@ static void be_free(ggml_backend_t backend) {
     for (auto & e : c->graphs) if (e.exec) (void) hipGraphExecDestroy(e.exec);
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
+    if (c->moe_ws) (void) hipFree(c->moe_ws);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     delete backend;
@@ -1065,7 +1067,7 @@ static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i
     }
     if (nd->op != GGML_OP_ARGSORT || nd->src[0] != cur || nd->op_params[0] != GGML_SORT_ORDER_DESC || nd->type != GGML_TYPE_I32 ||
         !ggml_is_contiguous(nd) || ggml_nelements(nd) != E) return 0;
-    moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream);
+    moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws);
     c->cnt.kernels_launched++;
     return j - i + 1;
 }
@@ -1491,6 +1493,10 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
     set_device(c->device);
     c->cnt.graphs_computed++;
 
+    if (!c->moe_ws) {
+        if (hipMalloc((void **) &c->moe_ws, 1088) == hipSuccess) { MI_CHECK(hipMemsetAsync(c->moe_ws, 0, 1088, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream)); }
+        else { (void) hipGetLastError(); c->moe_ws = nullptr; }
+    }
     if (!c->attn_part) {     // <= 8 tokens x 128 heads x 32 ranges x (128 + 2) floats: allocated once, outside any capture
         const size_t pb = (size_t) 8*128*32*130*4;
         if (hipMalloc((void **) &c->attn_part, pb) == hipSuccess) c->attn_part_bytes = pb; else (void) hipGetLastError();

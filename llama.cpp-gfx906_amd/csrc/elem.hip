@@ -633,10 +633,66 @@ __global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
         p.sorted[rank] = e;
     }
 }
+// Many experts (gpt-oss: 32 rows of 2880 floats = 368 KB): one workgroup streams the router matrix at ONE CU's rate (13 us). Here 4 experts per
+// workgroup; every workgroup publishes its logits (release fence + counter), and the one that arrives last (acquire) does the soft_max / ranking
+// and re-arms the counter. ws = [256 floats of logits | 1 int counter], zero-initialised once.
+__global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, float * ws) {
+    __shared__ float v[256];
+    __shared__ int is_last;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int e0 = blockIdx.x*4 + wave;
+    if (e0 < p.n_expert) {
+        const char * row = (const char *) p.w + (size_t) e0*p.w_nb1;
+        float acc = 0.0f, acc2 = 0.0f;
+        int i = lane*4;
+        for (; i + 256 < p.k; i += 512) {
+            const float4v a = *(const float4v *) (row + (size_t) i*4), b = *(const float4v *) (p.x + i);
+            const float4v a2 = *(const float4v *) (row + (size_t)(i + 256)*4), b2 = *(const float4v *) (p.x + i + 256);
+            acc  += (a.x*b.x + a.y*b.y) + (a.z*b.z + a.w*b.w);
+            acc2 += (a2.x*b2.x + a2.y*b2.y) + (a2.z*b2.z + a2.w*b2.w);
+        }
+        if (i < p.k) {
+            const float4v a = *(const float4v *) (row + (size_t) i*4), b = *(const float4v *) (p.x + i);
+            acc += (a.x*b.x + a.y*b.y) + (a.z*b.z + a.w*b.w);
+        }
+        acc += acc2;                        // the same summation order as k_moe_route: identical logits
+        acc = wave_sum(acc);
+        if (lane == 0) { if (p.bias) acc += p.bias[e0]; ws[e0] = acc; if (p.logits) p.logits[e0] = acc; }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();                                                     // release: this workgroup's logits before its ticket
+        const int t = atomicAdd((int *) (ws + 256), 1);
+        is_last = t == (int) gridDim.x - 1;
+        if (is_last) { __threadfence(); *(int *) (ws + 256) = 0; }          // acquire; re-arm for the next launch
+    }
+    __syncthreads();
+    if (!is_last) return;
+    const int e = threadIdx.x;
+    if (e < p.n_expert) v[e] = __builtin_nontemporal_load(ws + e);
+    __syncthreads();
+    if (p.softmax) {
+        float mx = -INFINITY, sum = 0.0f;
+        for (int j = 0; j < p.n_expert; j++) mx = fmaxf(mx, v[j]);
+        for (int j = 0; j < p.n_expert; j++) sum += expf(v[j] - mx);
+        const float pe = e < p.n_expert ? expf(v[e] - mx)*(1.0f/sum) : 0.0f;
+        __syncthreads();
+        if (e < p.n_expert) { v[e] = pe; p.probs[e] = pe; }
+        __syncthreads();
+    }
+    if (e < p.n_expert) {      // rank = how many values sort before this one (descending, index breaks ties)
+        int rank = 0;
+        const float me = v[e];
+        for (int j = 0; j < p.n_expert; j++) rank += (v[j] > me) || (v[j] == me && j < e);
+        p.sorted[rank] = e;
+    }
+}
 void moe_route(const float * w, size_t w_nb1, const float * x, const float * bias, int64_t k, int64_t n_expert, bool softmax,
-               float * logits, float * probs, int32_t * sorted, hipStream_t stream) {
+               float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws) {
     moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted };
-    hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(1024), 0, stream, a);
+    static const bool wide_on = !getenv("GGML_MI355X_MOE_ROUTE_WIDE") || atoi(getenv("GGML_MI355X_MOE_ROUTE_WIDE")) != 0;
+    if (ws && wide_on && n_expert >= 16 && n_expert <= 256) hipLaunchKernelGGL(k_moe_route_wide, dim3((unsigned)((n_expert + 3)/4)), dim3(256), 0, stream, a, ws);
+    else hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(1024), 0, stream, a);
 }
 
 // ---- MoE combine, one token (decode): the tail of build_moe_ffn as ONE kernel (src/llama-graph.cpp:887-1012) ----

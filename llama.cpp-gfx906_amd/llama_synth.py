@@ -44,6 +44,9 @@ MODELS = {
     # small MoE models for graph-level parity tests
     "tiny-moe": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                      rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=8, n_expert_used=2),
+    # 32 experts top-4: from 16 experts on the one-token router runs on several workgroups (elem.hip k_moe_route_wide)
+    "tiny-moe32": dict(n_embd=256, n_ff=256, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
+                       rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=32, n_expert_used=4),
     "tiny-oai": dict(n_embd=128, n_ff=128, n_layer=2, n_head=8, n_head_kv=2, n_embd_head=32, n_vocab=512,
                      rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=8, n_expert_used=4, arch=1, rope_type=2),
     # head size 128 with GQA 4:1 at test size (the fused attention kernels are instantiated for 64 and 128)

@@ -81,7 +81,7 @@ def test_perplexity_delta_vs_cpu_reference(ftype, record_property):
         m.free()
 
 
-@pytest.mark.parametrize("model,ftype", [("tiny-moe", "Q4_K_M"), ("tiny-oai", "MXFP4_MOE")])
+@pytest.mark.parametrize("model,ftype", [("tiny-moe", "Q4_K_M"), ("tiny-oai", "MXFP4_MOE"), ("tiny-moe32", "Q4_K_M")])
 def test_synthetic_moe_matches_oracle(model, ftype):
     """SURVEY.md §8 a5/a10 + Appendix B config 5: a Mixtral-shaped layer stack (router soft_max, top-k, MUL_MAT_ID experts, weighted sum;
     8-expert type bumps) and a gpt-oss-shaped one (biases, sinks, NEOX rope, SOFTMAX_WEIGHT gating, swiglu_oai, MXFP4 experts + Q8_0)"""
@@ -91,13 +91,18 @@ def test_synthetic_moe_matches_oracle(model, ftype):
     try:
         W = read_weights(m)
         rc = RefLlama(m.cfg, W, 64, "cpu"); re_ = RefLlama(m.cfg, W, 64, "exact")
+        same_route = True
         for toks in [[5, 9, 200, 17, 3], [7], [8], [300], [2]]:
             emb = np.stack([m.embedding(t) for t in toks])
             got = m.decode(toks)
             exp_c = rc.decode(emb); exp_e = re_.decode(emb)
             assert np.isfinite(got).all()
             assert orc.nmse(exp_c, got) <= 5e-4, (toks, orc.nmse(exp_c, got))
-            assert orc.nmse(exp_e, got) <= 2e-3, (toks, orc.nmse(exp_e, got))
+            # the exact oracle may route a near-tie to another expert than the CPU-style arithmetic does (32 experts, top-4: it happens): from
+            # then on the two oracles describe different computations (the caches differ too), and only the CPU-style one is the yardstick
+            same_route = same_route and len(rc.selected) == len(re_.selected) and all(np.array_equal(a, b_) for a, b_ in zip(rc.selected, re_.selected))
+            if same_route:
+                assert orc.nmse(exp_e, got) <= 2e-3, (toks, orc.nmse(exp_e, got))
     finally:
         m.free()
 
