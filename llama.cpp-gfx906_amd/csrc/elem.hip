@@ -633,15 +633,16 @@ __global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
         p.sorted[rank] = e;
     }
 }
-// Many experts (gpt-oss: 32 rows of 2880 floats = 368 KB): one workgroup streams the router matrix at ONE CU's rate (13 us). Here 4 experts per
-// workgroup; every workgroup publishes its logits (release fence + counter), and the one that arrives last (acquire) does the soft_max / ranking
+// One workgroup streams the whole router matrix at ONE CU's rate (gpt-oss: 32 rows of 2880 floats = 368 KB: 13 us; Mixtral: 8 x 4096: 8 us). Here one
+// expert row per wave, MR_EPW rows per workgroup; every workgroup publishes its logits (release fence + counter), and the one that arrives last (acquire) does the soft_max / ranking
 // and re-arms the counter. ws = [256 floats of logits | 1 int counter], zero-initialised once.
+constexpr int MR_EPW = 2;
 __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, float * ws) {
     __shared__ float v[256];
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int e0 = blockIdx.x*4 + wave;
-    if (e0 < p.n_expert) {
+    const int e0 = blockIdx.x*MR_EPW + wave;
+    if (wave < MR_EPW && e0 < p.n_expert) {
         const char * row = (const char *) p.w + (size_t) e0*p.w_nb1;
         float acc = 0.0f, acc2 = 0.0f;
         int i = lane*4;
@@ -691,7 +692,7 @@ void moe_route(const float * w, size_t w_nb1, const float * x, const float * bia
                float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws) {
     moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted };
     static const bool wide_on = !getenv("GGML_MI355X_MOE_ROUTE_WIDE") || atoi(getenv("GGML_MI355X_MOE_ROUTE_WIDE")) != 0;
-    if (ws && wide_on && n_expert >= 16 && n_expert <= 256) hipLaunchKernelGGL(k_moe_route_wide, dim3((unsigned)((n_expert + 3)/4)), dim3(256), 0, stream, a, ws);
+    if (ws && wide_on && n_expert >= 4 && n_expert <= 256) hipLaunchKernelGGL(k_moe_route_wide, dim3((unsigned)((n_expert + MR_EPW - 1)/MR_EPW)), dim3(256), 0, stream, a, ws);
     else hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(1024), 0, stream, a);
 }
 
