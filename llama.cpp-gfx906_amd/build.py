@@ -15,17 +15,22 @@ from pathlib import Path
 HERE = Path(__file__).resolve().parent
 ROOT = HERE.parent
 CSRC = HERE / "csrc"
-LIB = HERE / "lib"
-OBJ = HERE / "build"
+# MI355X_BUILD_VARIANT=<tag>: a second build beside the product (lib-<tag>/, build-<tag>/), e.g. the -DMI_STAMPS diagnostic build
+VARIANT = os.environ.get("MI355X_BUILD_VARIANT", "")
+LIB = HERE / ("lib-" + VARIANT if VARIANT else "lib")
+OBJ = HERE / ("build-" + VARIANT if VARIANT else "build")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 ARCH = "gfx950"
 
 INC = ["-I", str(ROOT / "include"), "-I", str(ROOT / "include" / "ggml-compat"), "-I", str(CSRC)]
 COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-parameter", "-Wno-unused-function",
-          "-Wno-missing-field-initializers"]
+          "-Wno-missing-field-initializers", "-Wno-array-bounds"]
 HIPFLAGS = [f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"] + os.environ.get("MI_EXTRA_HIPFLAGS", "").split()
 
-KERNEL_SRCS = ["quantize_act.hip", "mmvq.hip", "mmq.hip", "mm_dense.hip", "elem.hip", "decode_fused.hip", "attn_prefill.hip"]
+KERNEL_SRCS = ["quantize_act.hip", "mmvq.hip", "mmq.hip", "mm_dense.hip", "elem.hip", "decode_fused.hip", "attn_prefill.hip", "mmvq_fused.hip",
+               # the persistent grouped mat-vec, one translation unit per weight format (they compile in parallel)
+               "mmvq_fused_q4_K.hip", "mmvq_fused_q5_K.hip", "mmvq_fused_q6_K.hip", "mmvq_fused_q8_0.hip", "mmvq_fused_q4_0.hip", "mmvq_fused_mxfp4.hip",
+               "mmvq_fused_q4_K_q5_K.hip", "mmvq_fused_q4_K_q6_K.hip", "mmvq_fused_q5_K_q6_K.hip"]
 
 
 def run(cmd):
@@ -57,7 +62,7 @@ def build(verbose=True):
     LIB.mkdir(exist_ok=True)
     OBJ.mkdir(exist_ok=True)
     jobs = []
-    with ThreadPoolExecutor(max_workers=6) as ex:
+    with ThreadPoolExecutor(max_workers=8) as ex:
         jobs.append(ex.submit(compile_obj, CSRC / "compat" / "ggml-compat.cpp", ["-x", "c++"]))
         for s in KERNEL_SRCS:
             jobs.append(ex.submit(compile_obj, CSRC / s, HIPFLAGS))

@@ -111,6 +111,17 @@ static __device__ __forceinline__ int2v ld_b64(const void * p) {
     const u32x2_u t = *(const u32x2_u *) p;
     return int2v{ (int) t.x, (int) t.y };
 }
+// 8 bytes at a 2-byte-aligned address as ONE dword-aligned 12-byte load + a per-lane byte funnel shift (v_alignbyte_b32): a
+// global_load_dwordx2 at 2 or 6 bytes past a dword boundary is split by the address unit into several accesses per lane (Q6_K's
+// 210-byte blocks put three quarters of their fragments there: tools/stamp_timeline.py showed the workgroups of a Q6_K group issue
+// their first weight step 2 us slower than their Q4_K neighbours)
+struct __attribute__((packed, aligned(4))) u32x3_a { uint32_t x, y, z; };
+static __device__ __forceinline__ int2v ld_b64_a2(const void * p) {
+    const uintptr_t a = (uintptr_t) p;
+    const u32x3_a t = *(const u32x3_a *) (a & ~(uintptr_t) 3);
+    const uint32_t sh = (uint32_t)(a & 3);
+    return int2v{ (int) __builtin_amdgcn_alignbyte(t.y, t.x, sh), (int) __builtin_amdgcn_alignbyte(t.z, t.y, sh) };
+}
 // 16-byte aligned weight bytes. Measured on the tg128 bench (profiles/r01_*): plain loads 500 tok/s vs nontemporal 482,
 // so plain is the default; -DMI_NT_WEIGHTS switches the streamed-once hint back on for experiments.
 static __device__ __forceinline__ int4v ld_b128_nt(const void * p) {

@@ -1,0 +1,487 @@
+// mmvq_fused.h — the PERSISTENT grouped quantized mat-vec (n = 1) with prologues and epilogues: device code shared by the
+// per-format translation units (mmvq_fused_<type>.hip, one each so that they compile in parallel) and the host side (mmvq_fused.hip).
+//
+// A launch has ONE workgroup of 8 (or 16) waves per CU; each workgroup belongs to one group (weight tensor) and its waves walk that
+// tensor's row pairs (single rows for the dual GLU stream) with a grid stride, so that
+//   * the activation is prepared ONCE per workgroup (copy / quantize / rms-norm + quantize into LDS) instead of once per 8 rows,
+//   * the packed-weight stream never stops: loads run D steps ahead across row boundaries in a STATIC ring of register sets (the
+//     loop is unrolled D times; a rotating copy w0 = w1 makes the compiler wait for every outstanding load at the top of each step,
+//     measured: tools/stamp_timeline.py), and the DPP reduction + epilogue of one row pair overlaps the loads of the next.
+// Order of issue: (1) activation loads by every wave, workgroup barrier (a CU returns loads in request order: nothing HBM-bound
+// may be queued in front of them), (2) norm weights, then the D steps of weight loads one at a time BETWEEN the phases of
+// (3) the prologue into LDS (a wave that cannot queue a load cannot do its share of the prologue either) + barrier,
+// (4) integer dots, (5) reduction + epilogue per row pair.
+// Every load is unconditional (clamped address) so that the number of outstanding loads is the same on every path.
+//
+// Head latency (round 2, tools/stamp_timeline.py + the ISA): the first version reached its activation loads through ~10 DEPENDENT
+// scalar loads of the kernel-argument block (group lookup loop, per-group descriptor, type switch, eid / pos / st_idx pointer chases,
+// each behind its own s_waitcnt) — 1.3-1.5 us before the first vector load. Now everything the head needs sits in a flat header that
+// arrives with the first scalar-load batch (group of this workgroup = compares + selects, no memory), the per-group descriptor and the
+// pointer chases overlap the activation round trip, and the operands of a row pair's epilogue (residual, KV-cache indices, rope
+// frequency factor) are requested when the pair STARTS instead of after its last dot product (each was a dependent global load
+// at the tail of the launch: the V-cache element scatter alone held the norm+QKV launch 3.5 us after every other workgroup had finished).
+#pragma once
+
+#include "mmvq_core.h"
+#include "quant_core.h"
+#include "rope_dev.h"
+
+#include <math.h>
+
+namespace mi355x {
+
+// The header occupies the first four 64-byte lines of the kernel-argument block; the kernel fetches them with ONE batch of scalar
+// loads (k_mmvq_fused) and picks its group's entries with compares and selects.
+struct fused_mmvq_args {
+    // line 0
+    int block_end[MMVQ_MAX_GROUPS];       // cumulative workgroup counts; unused entries = INT_MAX
+    int x_off[MMVQ_MAX_GROUPS];           // = g[i].x_off
+    int gtype[MMVQ_MAX_GROUPS];           // = g[i].type
+    int gm[MMVQ_MAX_GROUPS];              // = g[i].m
+    // line 1
+    const char * gW[MMVQ_MAX_GROUPS];     // = g[i].W, g[i].W2
+    const char * gW2[MMVQ_MAX_GROUPS];
+    // line 2
+    const int32_t * geid[MMVQ_MAX_GROUPS];// = g[i].eid (NULL: a plain weight tensor)
+    const int64_t * kidx[MMVQ_MAX_GROUPS];// = g[i].st_idx where st_mode == 1 (the K-cache row index), else NULL
+    // line 3
+    uint32_t grow_stride[MMVQ_MAX_GROUPS];// = g[i].row_stride
+    uint32_t gestride[MMVQ_MAX_GROUPS];   // = g[i].estride
+    // PRO_Q8: quantized activation column as ONE contiguous image in global memory (qs | d | bsums at the offsets
+    // act_q8_carve gives for n = 1), staged verbatim into LDS. PRO_QUANT / PRO_NORM build the same image in LDS from x.
+    const char * act;
+    const float * x; const float * norm_w;
+    const int32_t * pos;                  // = rope.pos when a group has EPI_ROPE, else NULL
+    // line 4 (first half)
+    int n_groups;
+    int k;
+    int act_kind;
+    int act_chunks;                       // 16-byte chunks
+    int off_d, off_bs;                    // byte offsets of d / bsums inside the image
+    float eps; int pad0;
+    // ---- end of the header ----
+    fused_rope rope;
+    mmvq_group g[MMVQ_MAX_GROUPS];
+#ifdef MI_STAMPS
+    unsigned long long * stamps;          // [workgroup][MI_STAMP_N] stamps (tools/stamp_timeline.py), NULL = off
+#endif
+};
+static_assert(MMVQ_MAX_GROUPS == 4, "the header layout is written for four groups");
+static_assert(offsetof(fused_mmvq_args, gW) == 64 && offsetof(fused_mmvq_args, geid) == 128 && offsetof(fused_mmvq_args, grow_stride) == 192 &&
+              offsetof(fused_mmvq_args, n_groups) == 256 && offsetof(fused_mmvq_args, k) == 260 && offsetof(fused_mmvq_args, act_chunks) == 268 &&
+              offsetof(fused_mmvq_args, eps) == 280, "fused_mmvq_args: the header must be four 64-byte lines");
+
+// what a workgroup picks out of the header
+struct fused_sel {
+    int gi, wg_in_group, nwg_group, x_off, type, m;
+    const char * W; const char * W2; const int32_t * eid; const int64_t * kidx;
+    uint32_t row_stride, estride;
+    const char * act; const float * x; const float * norm_w; const int32_t * pos;
+    int k, act_chunks, off_d, off_bs; float eps;
+    const void * dummy;                   // a readable address for the loads of absent operands
+};
+
+typedef int int16v __attribute__((ext_vector_type(16)));
+typedef int int8v  __attribute__((ext_vector_type(8)));
+
+// a pointer from two header dwords: made in the GLOBAL address space so that the loads through it stay global_load (a pointer made
+// from integers is generic: every load became flat_load, which also counts on lgkmcnt and returns out of order)
+template <typename P>
+static __device__ __forceinline__ P mk_ptr(int lo, int hi) {
+    typedef const char __attribute__((address_space(1))) * gptr;
+    return (P) (const char *) (gptr) (((unsigned long long)(unsigned) hi << 32) | (unsigned long long)(unsigned) lo);
+}
+static __device__ __forceinline__ int pick4(int a0, int a1, int a2, int a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
+
+// ONE batch of scalar loads for the whole header (the compiler's own loads of by-value struct fields came out as a chain of
+// dependent loads, each behind its own wait: ISA of round 1's kernel), then compares and selects
+static __device__ __forceinline__ fused_sel load_header(int b) {
+    const void * ka = (const void *) __builtin_amdgcn_kernarg_segment_ptr();
+    int16v h0, h1, h2, h3; int8v h4;
+    asm volatile("s_nop 4\n\ts_load_dwordx16 %0, %5, 0x0\n\ts_load_dwordx16 %1, %5, 0x40\n\ts_load_dwordx16 %2, %5, 0x80\n\t"
+                 "s_load_dwordx16 %3, %5, 0xc0\n\ts_load_dwordx8 %4, %5, 0x100\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(h0), "=&s"(h1), "=&s"(h2), "=&s"(h3), "=&s"(h4) : "s"(ka) : "memory");
+    fused_sel s;
+    const int be0 = h0[0], be1 = h0[1], be2 = h0[2], be3 = h0[3];
+    const int gi = (b >= be0 ? 1 : 0) + (b >= be1 ? 1 : 0) + (b >= be2 ? 1 : 0);
+    const int first = gi == 0 ? 0 : (gi == 1 ? be0 : (gi == 2 ? be1 : be2));
+    const int last  = pick4(be0, be1, be2, be3, gi);
+    s.gi = gi; s.wg_in_group = b - first; s.nwg_group = last - first;
+    s.x_off = pick4(h0[4], h0[5], h0[6], h0[7], gi);
+    s.type  = pick4(h0[8], h0[9], h0[10], h0[11], gi);
+    s.m     = pick4(h0[12], h0[13], h0[14], h0[15], gi);
+    s.W   = mk_ptr<const char *>(pick4(h1[0], h1[2], h1[4], h1[6], gi), pick4(h1[1], h1[3], h1[5], h1[7], gi));
+    s.W2  = mk_ptr<const char *>(pick4(h1[8], h1[10], h1[12], h1[14], gi), pick4(h1[9], h1[11], h1[13], h1[15], gi));
+    s.eid = mk_ptr<const int32_t *>(pick4(h2[0], h2[2], h2[4], h2[6], gi), pick4(h2[1], h2[3], h2[5], h2[7], gi));
+    s.kidx = mk_ptr<const int64_t *>(pick4(h2[8], h2[10], h2[12], h2[14], gi), pick4(h2[9], h2[11], h2[13], h2[15], gi));
+    s.row_stride = (uint32_t) pick4(h3[0], h3[1], h3[2], h3[3], gi);
+    s.estride    = (uint32_t) pick4(h3[4], h3[5], h3[6], h3[7], gi);
+    s.act = mk_ptr<const char *>(h3[8], h3[9]);
+    s.x = mk_ptr<const float *>(h3[10], h3[11]);
+    s.norm_w = mk_ptr<const float *>(h3[12], h3[13]);
+    s.pos = mk_ptr<const int32_t *>(h3[14], h3[15]);
+    s.k = h4[1]; s.act_chunks = h4[3]; s.off_d = h4[4]; s.off_bs = h4[5]; s.eps = __builtin_bit_cast(float, (int) h4[6]);
+    s.dummy = (const void *) ka;
+    return s;
+}
+
+// the three device values a workgroup needs besides its descriptor — the expert index of a MUL_MAT_ID group, the K-cache row, the
+// rope position — in ONE batch of scalar loads (absent ones read the kernel-argument block and are ignored)
+static __device__ __forceinline__ void load_chased(const fused_sel & s, int & eid0, long long & idx0, int & pos0) {
+    const void * pe = s.eid ? (const void *) s.eid : s.dummy;
+    const void * pk = s.kidx ? (const void *) s.kidx : s.dummy;
+    const void * pp = s.pos ? (const void *) s.pos : s.dummy;
+    int e, q; long long i;
+    asm volatile("s_nop 4\n\ts_load_dword %0, %3, 0x0\n\ts_load_dwordx2 %1, %4, 0x0\n\ts_load_dword %2, %5, 0x0\n\ts_waitcnt lgkmcnt(0)"
+                 : "=&s"(e), "=&s"(i), "=&s"(q) : "s"(pe), "s"(pk), "s"(pp) : "memory");
+    eid0 = s.eid ? e : 0; idx0 = s.kidx ? i : 0; pos0 = s.pos ? q : 0;
+}
+
+#ifdef MI_STAMPS
+#define MI_STAMP_N 16
+#define MI_STAMP(i_) do { if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x*MI_STAMP_N + (i_)] = wall_clock64(); } while (0)
+#define MI_STAMP_CYC(i_) do { if (p.stamps && threadIdx.x == 0) p.stamps[blockIdx.x*MI_STAMP_N + (i_)] = clock64(); } while (0)
+#else
+#define MI_STAMP(i_) do { } while (0)
+#define MI_STAMP_CYC(i_) do { } while (0)
+#endif
+
+// operands of one row pair's epilogue, requested when the pair starts (all lanes load the same addresses: one line, broadcast)
+struct pair_pre { float r0, r1; long long i0, i1; float ff; };
+
+// Branch-free: an absent operand is read from `dummy` (a readable device address, the group's weights) and ignored — loads inside
+// branches made the compiler wait for EVERY outstanding load (vmcnt(0)) where the branches join.
+template <bool GLU>
+static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, const fused_rope & rope, const char * dummy, int m, int row0, int rows) {
+    pair_pre e = { 0.0f, 0.0f, 0, 0, 1.0f };
+    if (GLU) return e;
+    const int ra = min(row0, m - 1), rb = min(row0 + (rows > 1 ? 1 : 0), m - 1);
+    const bool has_res = g.epi == EPI_ADD, has_ff = g.epi == EPI_ROPE && rope.ff != nullptr, has_idx = g.st_mode == 2;
+    const float * rp = has_res ? g.res : (const float *) dummy;
+    e.r0 = rp[has_res ? ra : 0]; e.r1 = rp[has_res ? rb : 0];
+    const float * fp = has_ff ? rope.ff : (const float *) dummy;
+    e.ff = fp[has_ff ? (min(ra % rope.head_dim, rope.n_dims - 1) >> 1) : 0];
+    const int64_t * ip = has_idx ? g.st_idx : (const int64_t *) dummy;
+    e.i0 = ip[has_idx ? ra : 0]; e.i1 = ip[has_idx ? rb : 0];
+    return e;
+}
+
+// NORM rope on the pair (2i, 2i+1) with the frequency factor already fetched — same formulas as rope_pair / elem.hip k_rope<false>
+static __device__ __forceinline__ void rope_pair_ff(const fused_rope & r, int pos, int row_in_head, float ff, float & x0, float & x1) {
+    if (row_in_head >= r.n_dims) return;
+    const int ip = row_in_head >> 1;
+    const float theta_base = (float) pos*powf(r.theta_scale, (float) ip);
+    const float theta_extrap = theta_base/(r.ff ? ff : 1.0f);
+    float theta_interp = r.freq_scale*theta_extrap, theta = theta_interp, mscale = r.attn_factor;
+    if (r.ext_factor != 0.0f) {
+        const float y = ((float) ip - r.corr_lo)/fmaxf(0.001f, r.corr_hi - r.corr_lo);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y)))*r.ext_factor;
+        theta = theta_interp*(1.0f - ramp_mix) + theta_extrap*ramp_mix;
+        mscale *= 1.0f + 0.1f*logf(1.0f/r.freq_scale);
+    }
+    const float c = cosf(theta)*mscale, s = sinf(theta)*mscale;
+    const float a = x0, b = x1;
+    x0 = a*c - b*s;
+    x1 = a*s + b*c;
+}
+
+// what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers)
+static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, float s0, float s1, int row0, int pos0, long long idx0,
+                                                   const pair_pre & e, const int g_m, const int rows) {
+    const int m = rows > 1 ? g_m : row0 + 1;      // rows == 1: the unit has no second row
+    if (g.epi == EPI_ADD) {
+        s0 += e.r0;
+        if (row0 + 1 < m) s1 += e.r1;
+    } else if (g.epi == EPI_ROPE) {
+        rope_pair_ff(rope, pos0, row0 % rope.head_dim, e.ff, s0, s1);   // m is even on this path
+    }
+    g.dst[row0] = s0;
+    if (row0 + 1 < m) g.dst[row0 + 1] = s1;
+    if (g.st_mode == 1) {
+        uint16_t * q = g.st16 + idx0*g.st_row_elems + row0;
+        q[0] = f32_to_f16_bits(s0);
+        if (row0 + 1 < m) q[1] = f32_to_f16_bits(s1);
+    } else if (g.st_mode == 2) {
+        g.st16[e.i0] = f32_to_f16_bits(s0);
+        if (row0 + 1 < m) g.st16[e.i1] = f32_to_f16_bits(s1);
+    }
+}
+
+//   PRO  : where the activation comes from (mmvq_prologue)
+//   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*256*waves)
+//   D    : ring depth (2; 4 for the one-row GLU units and for long single-tensor streams)
+//   FWT  : waves per workgroup
+template <int TYPE, bool GLU, int PRO, int NA, int D, int FWT>
+static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, const fused_sel & sel, char * smem, int lane, int wave) {
+    typedef mmvq_t<TYPE> T;
+    // rows per unit of work: a pair for single-tensor groups; ONE row (of gate and of up) for the dual GLU stream, so that n_ff = 14336
+    // rows split evenly over 2048 waves (7 each; as pairs it was 4 for half the waves and 3 for the rest — tools/stamp_timeline.py)
+    constexpr int R = GLU ? 1 : 2, LPB = T::LPB, BPW = 64/LPB, ACT = T::ACT;
+    const int nb = sel.k / T::QK;
+    const int iters = (nb + BPW - 1)/BPW;
+    const int slot = lane % LPB, ibl = lane / LPB;
+
+    MI_STAMP(0); MI_STAMP_CYC(8);
+    const float * gx = sel.x + sel.x_off;
+    int4v areg[PRO == PRO_Q8 ? NA : 1];
+    float4v xv[PRO != PRO_Q8 ? NA : 1], wv[PRO == PRO_NORM ? NA : 1];
+    const int nchunk = (sel.k + 255) >> 8;     // the last chunk may be partial (k % 32 == 0 with Q8_0 activations: gpt-oss's 2880)
+    // element offset of this lane's 4 floats in chunk slot i: clamped into the vector; `live` tells whether they exist
+#define MI_XOFF(i_) min(min(wave + FWT*(i_), nchunk - 1)*256 + lane*4, sel.k - 4)
+#define MI_XLIVE(i_) ((wave + FWT*(i_))*256 + lane*4 < sel.k)
+
+    // ---- (1) activation loads: their addresses come from the header alone ----
+    if (PRO == PRO_Q8) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = min((int) threadIdx.x + i*(FWT*64), sel.act_chunks - 1);
+            areg[i] = *(const int4v *) (sel.act + (size_t) idx*16);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < NA; i++) { xv[i] = *(const float4v *) (gx + MI_XOFF(i)); if (!MI_XLIVE(i)) xv[i] = float4v{ 0.0f, 0.0f, 0.0f, 0.0f }; }
+    }
+    // A CU's L1 returns data in request order across all its waves: a load that hits L2 (the activation, just written) queued
+    // behind one that goes to HBM (weights, norm weights) of ANY wave comes back with HBM latency — 1-4 us instead of ~0.5 us,
+    // and the whole prologue hangs on it (measured, tools/stamp_timeline.py: the second workgroup on a CU saw its activation 2 us
+    // after the first). So: every wave issues its activation loads, the workgroup meets at a barrier (issue order = request
+    // order), and only then are norm weights and the weight stream requested. The asm statements are compiler barriers too.
+    asm volatile("" ::: "memory");
+    // the device values behind pointers (expert index, K-cache row, rope position): one scalar-load batch beside the activation round trip
+    int eid0, pos0; long long idx0;
+    load_chased(sel, eid0, idx0, pos0);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
+    const mmvq_group & g = p.g[sel.gi];                  // the cold part of the descriptor (epilogue operands): loaded when first used
+    const int g_m = sel.m;
+    const size_t g_row_stride = sel.row_stride;
+    const int P = (g_m + R - 1)/R;                       // row pairs in this group
+    const int stride = sel.nwg_group*FWT;
+    const int p_first = sel.wg_in_group*FWT + wave;
+    int p_cur = p_first;
+    // an expert of a stack (MUL_MAT_ID, one token): the index is a device value, workgroup-uniform
+    const size_t eoff = (size_t) eid0*sel.estride;
+    const char * gW = sel.W + eoff; const char * gW2 = GLU ? sel.W2 + eoff : nullptr;
+    if (PRO == PRO_NORM) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) wv[i] = *(const float4v *) (sel.norm_w + min(wave + FWT*i, nchunk - 1)*256 + lane*4);
+    }
+    // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch.
+    // Past the end of the stream the loads go to the wave's own first block (an L1 hit), not to a line every wave would share.
+    int p_pf = p_cur, it_pf = 0;
+    typename T::wfrag w[D][R], u[GLU ? D : 1][R];
+#define MI_FETCH(d_) { \
+        const bool live = p_pf < P; \
+        const int pp = live ? p_pf : min(p_first, P - 1); \
+        const int ibf = live ? min(it_pf*BPW + ibl, nb - 1) : 0; \
+        _Pragma("unroll") for (int r = 0; r < R; r++) { \
+            const size_t off = (size_t) min(pp*R + r, g_m - 1)*g_row_stride; \
+            w[d_][r] = T::load_w(gW + off, ibf, slot); \
+            if (GLU) u[GLU ? d_ : 0][r] = T::load_w(gW2 + off, ibf, slot); \
+        } \
+        if (++it_pf == iters) { it_pf = 0; p_pf += stride; } }
+#define MI_FENCE asm volatile("" ::: "memory")
+
+    // ---- (2) weight prefetch: the first D steps of this wave's stream ----
+    // A wave blocks at a load it cannot queue (the CU's request queue is finite) and then cannot run its share of the prologue
+    // either, so the D steps are not issued in one burst: one step now, the others between the phases of the prologue (FENCE keeps
+    // the compiler from hoisting them back up). HBM then has work from the first 0.2 us on and the prologue math starts as soon as
+    // the activation is there.
+    MI_FETCH(0)
+    MI_FENCE;
+    pair_pre epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, p_cur*R, R);      // behind the first weight step: needed only after the pair's last dot
+    MI_FENCE;
+
+    // ---- (3) prologue: build the quantized activation image in LDS ----
+    int8_t * l_qs = (int8_t *) smem; float * l_d = (float *) (smem + sel.off_d); int16_t * l_bs = (int16_t *) (smem + sel.off_bs);
+    if (PRO == PRO_Q8) {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int idx = threadIdx.x + i*(FWT*64);
+            if (idx < sel.act_chunks) *(int4v *) (smem + (size_t) idx*16) = areg[i];
+        }
+    } else {
+        float scale = 1.0f;
+        if (PRO == PRO_NORM) {
+            float * red = (float *) (smem + sel.off_bs + (((sel.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15));   // FWT floats after the image
+            float ss = 0.0f;
+#pragma unroll
+            for (int i = 0; i < NA; i++) if (wave + FWT*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
+            ss = wave_sum(ss);
+            MI_STAMP(4);
+            if (lane == 0) red[wave] = ss;
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+            if (FWT == 16) ss += ((red[8] + red[9]) + (red[10] + red[11])) + ((red[12] + red[13]) + (red[14] + red[15]));
+            scale = 1.0f/sqrtf(ss/(float) sel.k + sel.eps);
+            MI_STAMP(7);
+            MI_FENCE;
+            MI_FETCH(1)
+            MI_FENCE;
+        }
+        // all chunks of this wave are quantized first (independent chains the scheduler can interleave; a chunk past the end is
+        // quantized too — its lanes hold a clamped duplicate — and simply not stored), then stored
+        uint32_t qp[NA]; float qd[NA]; int qb[NA];
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            float4v v = xv[i];
+            if (PRO == PRO_NORM) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
+            qp[i] = quant_chunk256<ACT>(v, qd[i], qb[i]);
+        }
+        MI_STAMP(5);
+        MI_FENCE;
+        // the steps must be fetched in ring order: set d holds stream step d
+        if (PRO == PRO_QUANT) { MI_FETCH(1) }
+        else if (D > 2)       { MI_FETCH(2) }
+        MI_FENCE;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int c = wave + FWT*i;
+            if (c < nchunk) store_chunk256<ACT>(qp[i], qd[i], qb[i], c, lane, l_qs, l_d, l_bs);
+        }
+    }
+    MI_FENCE;
+    if (PRO == PRO_Q8) { MI_FETCH(1) }
+    if (D > 2 && PRO != PRO_NORM) { MI_FETCH(2) }
+    if (D > 3) { MI_FETCH(3) }
+    MI_FENCE;
+    MI_STAMP(6);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    act_view av;
+    av.qs = l_qs; av.d = l_d; av.bs = l_bs;
+    MI_STAMP(1);
+
+    // ---- (4)+(5) stream: D steps per trip, each consuming one register set and refilling it for D steps later ----
+    const int my_pairs = p_cur < P ? (P - 1 - p_cur)/stride + 1 : 0;
+    const int total = my_pairs*iters;
+    int it = 0;
+    float acc[2] = { 0.0f, 0.0f }, acu[2] = { 0.0f, 0.0f };
+#ifdef MI_STAMPS
+    bool first_pair = true;
+#endif
+    for (int s = 0; s < total; s += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+            if (s + d < total) {        // wave-uniform
+                const int ib = it*BPW + ibl;
+                if (ib < nb) {
+                    const typename T::afrag a = T::load_a(av, ib, slot);
+#pragma unroll
+                    for (int r = 0; r < R; r++) { acc[r] += T::dot(w[d][r], a, slot); if (GLU) acu[r] += T::dot(u[GLU ? d : 0][r], a, slot); }
+                }
+                MI_FETCH(d)
+                if (++it == iters) {
+#ifdef MI_STAMPS
+                    if (first_pair) { MI_STAMP(2); first_pair = false; }
+#endif
+                    float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
+                    if (GLU) {
+                        float up_s = wave_sum(acu[0]);
+                        if (g.b_gate) {     // + bias rows of this group's expert (ADD_ID), wave-uniform addresses
+                            const size_t brow = (size_t) eid0*g_m + p_cur;
+                            s0 += g.b_gate[brow]; up_s += g.b_up[brow];
+                        }
+                        if (g.glu_alpha != 0.0f) {      // swiglu_oai, as elem.hip k_glu
+                            const float xc = fminf(s0, g.glu_limit), gc = fmaxf(fminf(up_s, g.glu_limit), -g.glu_limit);
+                            s0 = (xc/(1.0f + expf(-xc*g.glu_alpha)))*(gc + 1.0f);
+                        } else {
+                            s0 = (s0/(1.0f + expf(-s0)))*up_s;      // silu(gate)*up, as elem.hip k_glu
+                        }
+                    }
+                    if (lane == 0) finish_pair(g, p.rope, s0, s1, p_cur*R, pos0, idx0, epre, g_m, R);
+                    it = 0; p_cur += stride;
+                    acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
+                    if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, p_cur*R, R);     // the next pair's epilogue operands
+                }
+            }
+        }
+    }
+    MI_STAMP(3); MI_STAMP_CYC(9);
+#undef MI_FETCH
+#undef MI_FENCE
+#undef MI_XOFF
+#undef MI_XLIVE
+}
+
+// One instantiation per {weight type or pair of types} x {GLU} x {prologue} x {activation size class}: a single kernel switching
+// over all six formats at run time allocates registers for the fattest path (227 VGPRs -> 2 waves/SIMD), which starves the HBM stream.
+// FWT = waves per workgroup: 8, or 16 for launches with more row pairs than 8 waves x CUs but no more than 16 x CUs (norm + QKV:
+// 3072 pairs) — ONE 1024-thread workgroup per CU shares one prologue (two 8-wave workgroups on a CU ran the second one's prologue
+// ~2x slower), every wave owns a single pair, and the prologue has one 256-chunk per wave instead of two
+template <int TA, int TB, bool GLU, int PRO, int NA, int D, int FWT = 8>
+__global__ void __launch_bounds__(FWT*64, FWT == 8 ? 2 : 1) k_mmvq_fused(const fused_mmvq_args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const fused_sel sel = load_header((int) blockIdx.x);
+    if (TA == TB || sel.type == TA) fused_body<TA, GLU, PRO, NA, D, FWT>(p, sel, smem, lane, wave);
+    else                            fused_body<TB, GLU, PRO, NA, D, FWT>(p, sel, smem, lane, wave);
+}
+
+// a grouped launch, prepared on the host
+struct fused_launch { fused_mmvq_args a; int blocks; size_t lds; int ta, tb; bool glu; int mode, na; bool deep; int64_t k; uint64_t wbytes; int fw; };
+
+// the launcher of one {TA, TB} kernel family: picks the instantiation for L's prologue / activation size class / ring depth
+#define MI_DEFINE_FUSED_LAUNCHER(NAME_, TA_, TB_, HAS_GLU_) \
+void NAME_(const fused_launch & L, hipStream_t stream) { \
+    const fused_mmvq_args & a = L.a; \
+    const dim3 grid((unsigned) L.blocks); \
+    const size_t lds = L.lds; \
+    const int mode = L.mode, na = L.na; \
+    const bool deep = L.deep; \
+    constexpr int FW = 8; \
+    if (L.fw == 16) { hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 1, 2, 16>), grid, dim3(1024), lds, stream, a); return; } \
+    if (HAS_GLU_ && L.glu) {     /* one-row units: 4 steps = the bytes 2 steps of pairs held */ \
+        if (mode == PRO_Q8) { \
+            if (na == 1)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_Q8, 1, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_Q8, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else              hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_Q8, 4, 4>), grid, dim3(FW*64), lds, stream, a); \
+        } else if (mode == PRO_NORM) { \
+            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_NORM, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_NORM, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+        } else { \
+            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_QUANT, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_QUANT, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+        } \
+        return; \
+    } \
+    if (deep) { \
+        if (mode == PRO_Q8) { \
+            if (na == 1)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 1, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else              hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 4, 4>), grid, dim3(FW*64), lds, stream, a); \
+        } else if (mode == PRO_NORM) { \
+            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+        } else { \
+            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
+            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+        } \
+        return; \
+    } \
+    if (mode == PRO_Q8) { \
+        if (na == 1)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 1, 2>), grid, dim3(FW*64), lds, stream, a); \
+        else if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 2, 2>), grid, dim3(FW*64), lds, stream, a); \
+        else              hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 4, 2>), grid, dim3(FW*64), lds, stream, a); \
+    } else if (mode == PRO_NORM) { \
+        if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 2, 2>), grid, dim3(FW*64), lds, stream, a); \
+        else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 8, 2>), grid, dim3(FW*64), lds, stream, a); \
+    } else { \
+        if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 2, 2>), grid, dim3(FW*64), lds, stream, a); \
+        else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 8, 2>), grid, dim3(FW*64), lds, stream, a); \
+    } \
+}
+
+void launch_fused_q4_K(const fused_launch & L, hipStream_t stream);
+void launch_fused_q5_K(const fused_launch & L, hipStream_t stream);
+void launch_fused_q6_K(const fused_launch & L, hipStream_t stream);
+void launch_fused_q8_0(const fused_launch & L, hipStream_t stream);
+void launch_fused_q4_0(const fused_launch & L, hipStream_t stream);
+void launch_fused_mxfp4(const fused_launch & L, hipStream_t stream);
+void launch_fused_q4_K_q5_K(const fused_launch & L, hipStream_t stream);
+void launch_fused_q4_K_q6_K(const fused_launch & L, hipStream_t stream);
+void launch_fused_q5_K_q6_K(const fused_launch & L, hipStream_t stream);
+
+} // namespace mi355x

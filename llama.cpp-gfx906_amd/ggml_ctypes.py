@@ -10,12 +10,13 @@ raises: there is no fallback path.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from pathlib import Path
 
 import numpy as np
 
 HERE = Path(__file__).resolve().parent
-LIBDIR = HERE / "lib"
+LIBDIR = HERE / ("lib-" + os.environ["MI355X_BUILD_VARIANT"] if os.environ.get("MI355X_BUILD_VARIANT") else "lib")   # build.py: variant builds
 
 GGML_MAX_DIMS, GGML_MAX_SRC, GGML_MAX_NAME, GGML_MAX_OP_PARAMS = 4, 10, 64, 64
 
