@@ -252,6 +252,9 @@ struct mi_backend_ctx {
     void * scratch = nullptr;      // quantized activations
     size_t scratch_size = 0;
     float * moe_ws = nullptr;                                   // logits + arrival counter of the multi-workgroup router kernel (moe_route)
+    // producer-side activation quantization (mmvq_fin): the image a GLU launch writes for the mat-vec that follows + its arrival counters
+    void * fin_img = nullptr; unsigned * fin_cnt = nullptr;
+    static constexpr size_t FIN_IMG_BYTES = 64*1024; static constexpr int FIN_COUNTERS = 256;
     float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
     // activation-quantisation reuse inside one graph_compute
@@ -315,6 +318,8 @@ static void be_free(ggml_backend_t backend) {
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
+    if (c->fin_img) (void) hipFree(c->fin_img);
+    if (c->fin_cnt) (void) hipFree(c->fin_cnt);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     delete backend;
@@ -802,7 +807,30 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
         mul_mat_vec_q_fused_flush(c->stream);     // the quantizer below reads what a held-back launch writes
         in.mode = PRO_Q8; in.act = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);
     }
-    mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream);     // may be held back as a position of the per-layer chain (profile events: prof_hook_*)
+    // gate/up/SwiGLU whose output the down projection reads next (build_ffn, src/llama-graph.cpp:691-748): the launch also writes the quantized
+    // image of its output (mmvq_fin) — the f32 tensor is written as always, so any other reader still finds it
+    mmvq_fin fin = {}; act_q8 fin_q = {}; const struct ggml_tensor * fin_t = nullptr;
+    static const bool fin_env = !getenv("GGML_MI355X_FIN") || atoi(getenv("GGML_MI355X_FIN")) != 0;
+    if (fin_env && nc == 1 && grp[0].epi == EPI_GLU && !grp[0].eid && c->fin_img) {
+        const int jn = next_real(g, last);
+        const struct ggml_tensor * gl = g->nodes[last];
+        const struct ggml_tensor * mm = jn > 0 ? g->nodes[jn] : nullptr;
+        if (mm && fusable_mmv(mm) && mm->src[1] == gl && (void *) grp[0].dst == gl->data) {
+            const int kind2 = act_kind_for((int) mm->src[0]->type);
+            const int64_t M = grp[0].m;
+            if (kind2 > 0 && mul_mat_vec_q_fused_fin_supported(M, K) && mul_mat_vec_q_fused_supported(M, kind2) && M/256 <= mi_backend_ctx::FIN_COUNTERS &&
+                act_q8_bytes(kind2, M, 1) <= mi_backend_ctx::FIN_IMG_BYTES) {
+                fin_q = act_q8_carve(c->fin_img, kind2, M, 1);
+                fin = { kind2, 0, fin_q.qs, fin_q.d, fin_q.bsums, c->fin_cnt };
+                fin_t = gl;
+            }
+        }
+    }
+    mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin_t ? &fin : nullptr);
+    if (fin_t) {
+        c->aq = { fin_t->data, grp[0].m, 1, 1, fin_t->nb[1], 0, fin.kind, fin_q, true, (size_t) grp[0].m*4, 0 };
+        c->aq_fresh = true;
+    }
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++; c->cnt.weight_bytes += wbytes;
     for (int r = 0; r < n_def; r++) compute_node(c, g, deferred[r]);       // (flushes a held-back launch first)
     return last;
@@ -1334,7 +1362,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                         if (mm && fusable_mmv(mm) && mm->src[1] == mul && node->ne[1] == 1 && w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] &&
                             is_row_vec_f32(s0) && !(mul->flags & GGML_TENSOR_FLAG_OUTPUT)) {
                             const int l = try_fused_mmv(c, g, jn, node, w);
-                            if (l >= 0) { consumed = l - i + 1; break; }
+                            if (l >= 0) { consumed = l - i + 1; fresh_aq = c->aq_fresh; c->aq_fresh = false; break; }
                         }
                         mul_mat_vec_q_fused_flush(c->stream);
                         if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&
@@ -1496,6 +1524,12 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
     if (!c->moe_ws) {
         if (hipMalloc((void **) &c->moe_ws, 1088) == hipSuccess) { MI_CHECK(hipMemsetAsync(c->moe_ws, 0, 1088, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
+    }
+    if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
+        if (hipMalloc(&c->fin_img, mi_backend_ctx::FIN_IMG_BYTES) != hipSuccess) { (void) hipGetLastError(); c->fin_img = nullptr; }
+        if (c->fin_img && hipMalloc((void **) &c->fin_cnt, mi_backend_ctx::FIN_COUNTERS*4) == hipSuccess) {
+            MI_CHECK(hipMemsetAsync(c->fin_cnt, 0, mi_backend_ctx::FIN_COUNTERS*4, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream));
+        } else if (c->fin_img) { (void) hipGetLastError(); (void) hipFree(c->fin_img); c->fin_img = nullptr; c->fin_cnt = nullptr; }
     }
     if (!c->attn_part) {     // <= 8 tokens x 128 heads x 32 ranges x (128 + 2) floats: allocated once, outside any capture
         const size_t pb = (size_t) 8*128*32*130*4;

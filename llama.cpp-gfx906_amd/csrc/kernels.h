@@ -196,6 +196,9 @@ struct mmvq_group {
     // row `eid[0]` of [m, n_expert] f32 tensors) and swiglu_oai(alpha, limit) instead of swiglu when glu_alpha != 0
     const float * b_gate; const float * b_up; float glu_alpha, glu_limit;
 };
+// GLU launches only: the launch also writes its f32 output as the quantized image (act_q8 layout for n = 1) the next mat-vec reads;
+// counters: >= m/256 words, zero between launches (the kernel re-arms them). m % 256 == 0, one group, no expert stack.
+struct mmvq_fin { int kind; int pad; int8_t * qs; float * d; int16_t * bs; unsigned * counters; };
 struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; };   // EPI_ROPE (NORM pairs)
 
 // where the activation vector comes from
@@ -211,7 +214,9 @@ struct mmvq_input {
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind);        // PRO_QUANT / PRO_NORM limits (k % 256, or k % 32 with Q8_0 activations)
 bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);   // may these two weight types share one grouped launch
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream);
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
+                         const mmvq_fin * fin = nullptr);
+bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);      // may a GLU launch with m output rows carry an mmvq_fin
 // Launches that fit a position of the per-layer chain (decode_fused.hip: k_mmvq_chain) are held back until the chain is complete
 // or broken. EVERY other use of the stream must call flush first; `pending` tells how many launches (and weight bytes) are held.
 void mul_mat_vec_q_fused_flush(hipStream_t stream);

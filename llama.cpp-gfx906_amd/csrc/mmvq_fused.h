@@ -61,6 +61,7 @@ struct fused_mmvq_args {
     float eps; int pad0;
     // ---- end of the header ----
     fused_rope rope;
+    mmvq_fin fin;                         // GLU launches: the producer quantizes its own output for the mat-vec that reads it next (kind == 0: off)
     mmvq_group g[MMVQ_MAX_GROUPS];
 #ifdef MI_STAMPS
     unsigned long long * stamps;          // [workgroup][MI_STAMP_N] stamps (tools/stamp_timeline.py), NULL = off
@@ -145,6 +146,16 @@ static __device__ __forceinline__ void load_chased(const fused_sel & s, int & ei
 #define MI_STAMP(i_) do { } while (0)
 #define MI_STAMP_CYC(i_) do { } while (0)
 #endif
+
+// ---- bytes handed from one workgroup to another INSIDE a launch (MI355X guide, inter-workgroup visibility): write-through (`sc1`)
+// stores, drained by every storing wave before its workgroup signals; every load of them an `sc1` load (served by L2, never by the
+// reading CU's L1, which another CU's stores do not refresh) ----
+static __device__ __forceinline__ void st_f32_sc1(float * p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+static __device__ __forceinline__ float4v ld_f4_sc1(const float * p) {      // the wait is part of the statement: hipcc does not count asm loads
+    float4v v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
 
 // operands of one row pair's epilogue, requested when the pair starts (all lanes load the same addresses: one line, broadcast)
 struct pair_pre { float r0, r1; long long i0, i1; float ff; };
@@ -256,10 +267,16 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     const mmvq_group & g = p.g[sel.gi];                  // the cold part of the descriptor (epilogue operands): loaded when first used
     const int g_m = sel.m;
     const size_t g_row_stride = sel.row_stride;
-    const int P = (g_m + R - 1)/R;                       // row pairs in this group
-    const int stride = sel.nwg_group*FWT;
-    const int p_first = sel.wg_in_group*FWT + wave;
-    int p_cur = p_first;
+    const int P = (g_m + R - 1)/R;                       // units (row pairs; rows of the dual GLU stream) in this group
+    // which units this wave owns: unit j of the wave is u_base + j*u_step, j < n_mine. Grid-strided by default; a GLU launch that
+    // finalises its output (p.fin) gives every wave a CONTIGUOUS run of rows instead, so that a 256-row chunk of the output — the unit
+    // the activation quantizer works on — comes from five or six workgroups, not from all of them
+    const bool fin_on = GLU && p.fin.kind != 0;
+    const int fin_rpw = (P + sel.nwg_group*FWT - 1)/(sel.nwg_group*FWT);       // rows per wave (contiguous ownership)
+    const int u_step = fin_on ? 1 : sel.nwg_group*FWT;
+    const int u_base = fin_on ? (sel.wg_in_group*FWT + wave)*fin_rpw : sel.wg_in_group*FWT + wave;
+    const int n_mine = fin_on ? max(0, min(fin_rpw, P - u_base)) : (u_base < P ? (P - 1 - u_base)/u_step + 1 : 0);
+    int p_cur = u_base;
     // an expert of a stack (MUL_MAT_ID, one token): the index is a device value, workgroup-uniform
     const size_t eoff = (size_t) eid0*sel.estride;
     const char * gW = sel.W + eoff; const char * gW2 = GLU ? sel.W2 + eoff : nullptr;
@@ -269,18 +286,18 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     }
     // the stream is the sequence of (row pair, k-step) this wave will consume; (p_pf, it_pf) is the next step to fetch.
     // Past the end of the stream the loads go to the wave's own first block (an L1 hit), not to a line every wave would share.
-    int p_pf = p_cur, it_pf = 0;
+    int j_pf = 0, it_pf = 0;
     typename T::wfrag w[D][R], u[GLU ? D : 1][R];
 #define MI_FETCH(d_) { \
-        const bool live = p_pf < P; \
-        const int pp = live ? p_pf : min(p_first, P - 1); \
+        const bool live = j_pf < n_mine; \
+        const int pp = live ? u_base + j_pf*u_step : min(u_base, P - 1); \
         const int ibf = live ? min(it_pf*BPW + ibl, nb - 1) : 0; \
         _Pragma("unroll") for (int r = 0; r < R; r++) { \
             const size_t off = (size_t) min(pp*R + r, g_m - 1)*g_row_stride; \
             w[d_][r] = T::load_w(gW + off, ibf, slot); \
             if (GLU) u[GLU ? d_ : 0][r] = T::load_w(gW2 + off, ibf, slot); \
         } \
-        if (++it_pf == iters) { it_pf = 0; p_pf += stride; } }
+        if (++it_pf == iters) { it_pf = 0; j_pf++; } }
 #define MI_FENCE asm volatile("" ::: "memory")
 
     // ---- (2) weight prefetch: the first D steps of this wave's stream ----
@@ -355,8 +372,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     MI_STAMP(1);
 
     // ---- (4)+(5) stream: D steps per trip, each consuming one register set and refilling it for D steps later ----
-    const int my_pairs = p_cur < P ? (P - 1 - p_cur)/stride + 1 : 0;
-    const int total = my_pairs*iters;
+    const int total = n_mine*iters;
     int it = 0;
     float acc[2] = { 0.0f, 0.0f }, acu[2] = { 0.0f, 0.0f };
 #ifdef MI_STAMPS
@@ -391,12 +407,46 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
                             s0 = (s0/(1.0f + expf(-s0)))*up_s;      // silu(gate)*up, as elem.hip k_glu
                         }
                     }
-                    if (lane == 0) finish_pair(g, p.rope, s0, s1, p_cur*R, pos0, idx0, epre, g_m, R);
-                    it = 0; p_cur += stride;
+                    if (GLU && fin_on) { if (lane == 0) st_f32_sc1(g.dst + p_cur, s0); }      // handed to the workgroup that quantizes the chunk
+                    else if (lane == 0) finish_pair(g, p.rope, s0, s1, p_cur*R, pos0, idx0, epre, g_m, R);
+                    it = 0; p_cur += u_step;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
                     if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, p_cur*R, R);     // the next pair's epilogue operands
                 }
             }
+        }
+    }
+    if (GLU && fin_on) {
+        // ---- producer-side activation quantization (round 2): the mat-vec that reads this launch's output next needs it as int8 blocks
+        // (Q8_K / Q8_0, 256-element chunks). Instead of every one of its 256 workgroups quantizing all of it again in its prologue
+        // (5.5 us of a 15 us ffn_down launch, instruction-bound), the workgroup that completes a chunk here quantizes that chunk once.
+        // Per chunk: an arrival counter; each workgroup whose rows touch the chunk adds 1 after its rows are stored (sc1) and drained;
+        // the one whose add came last (by the returned value) loads the chunk (sc1), quantizes it and stores the image piece.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int * fin_list = (int *) (smem + sel.off_bs + (((sel.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15) + 64);      // [0] = count, [1..] = chunks (after the RMS scratch)
+        const int RW = FWT*fin_rpw, ra = sel.wg_in_group*RW, rb = min(ra + RW, g_m);
+        if (threadIdx.x == 0) {
+            int n = 0;
+            if (ra < g_m) {
+                for (int c = ra >> 8; c <= (rb - 1) >> 8; c++) {
+                    const int expect = min((c << 8) + 255, g_m - 1)/RW - (c << 8)/RW + 1;
+                    const unsigned old = __hip_atomic_fetch_add(p.fin.counters + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if ((int) old == expect - 1) {
+                        __hip_atomic_store(p.fin.counters + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
+                        fin_list[1 + n++] = c;
+                    }
+                }
+            }
+            fin_list[0] = n;
+        }
+        __syncthreads();
+        const int nfin = fin_list[0];
+        for (int j = wave; j < nfin; j += FWT) {
+            const int c = fin_list[1 + j];
+            const float4v v = ld_f4_sc1(g.dst + c*256 + lane*4);
+            if (p.fin.kind == T_Q8_0) quant_store_chunk256<T_Q8_0>(v, c, lane, p.fin.qs, p.fin.d, p.fin.bs);
+            else                      quant_store_chunk256<T_Q8_K>(v, c, lane, p.fin.qs, p.fin.d, p.fin.bs);
         }
     }
     MI_STAMP(3); MI_STAMP_CYC(9);

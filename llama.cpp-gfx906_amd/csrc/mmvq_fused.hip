@@ -60,9 +60,16 @@ static int device_cu_count() {
     return n_cu;
 }
 
-static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope) {
+bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in) {
+    // chunks are 256 rows; a workgroup's contiguous run (8 waves x rows per wave, one workgroup per CU) may touch at most 7 of them
+    const int64_t rpw = (m + (int64_t) device_cu_count()*8 - 1)/((int64_t) device_cu_count()*8);
+    return m % 256 == 0 && m >= 256 && 8*rpw <= 1024 && k_in % 256 == 0;
+}
+
+static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin) {
     fused_launch L = {};
     fused_mmvq_args & a = L.a;
+    if (fin && fin->kind && n_groups == 1 && groups[0].epi == EPI_GLU && !groups[0].eid && mul_mat_vec_q_fused_fin_supported(groups[0].m, k)) a.fin = *fin;
     a.n_groups = n_groups; a.k = (int) k; a.act_kind = in.act_kind;
     // share the persistent workgroups among the groups in proportion to their rows (never more than one row pair per wave)
     static int wpc = 0, glu_wpc = 1;   // measured (tools/stamp_timeline.py): the second workgroup on a CU runs its prologue ~2x slower
@@ -117,7 +124,7 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         a.rope = make_fused_rope(*rope);
         a.pos = rope->pos;
     }
-    const size_t lds = bytes + 64;     // + FW floats for the RMS reduction
+    const size_t lds = bytes + 64 + 64;     // + FW floats for the RMS reduction + the finaliser's chunk list
     int ta = groups[0].type, tb = groups[0].type;
     for (int i = 1; i < n_groups; i++) if (groups[i].type != ta) tb = groups[i].type;
     if (tb < ta) { const int t = ta; ta = tb; tb = t; }
@@ -179,13 +186,14 @@ static void fused_launch_kernel(const fused_launch & L, hipStream_t stream) {
 int mul_mat_vec_q_fused_pending(uint64_t * wbytes) { if (wbytes) *wbytes = 0; return 0; }     // nothing is ever held back (the round-1 chained launch is gone)
 void mul_mat_vec_q_fused_flush(hipStream_t) { }
 
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream) {
-    const fused_launch L = fused_prepare(groups, n_groups, k, in, rope);
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
+                         const mmvq_fin * fin) {
+    const fused_launch L = fused_prepare(groups, n_groups, k, in, rope, fin);
     if (g_hook.pre) g_hook.pre(g_hook.ctx, L.ta, L.wbytes, 1, L.k);
     fused_launch_kernel(L, stream);
     static const int dup = getenv("GGML_MI355X_DEBUG_DUP_LAUNCH") ? atoi(getenv("GGML_MI355X_DEBUG_DUP_LAUNCH")) : 0;     // timing experiments only (results are wrong where dst aliases the residual)
     if (dup) {
-        fused_launch L2 = fused_prepare(groups, n_groups, k, in, rope);      // (its own stamp slot in the -DMI_STAMPS build)
+        fused_launch L2 = fused_prepare(groups, n_groups, k, in, rope, fin);      // (its own stamp slot in the -DMI_STAMPS build)
         fused_launch_kernel(L2, stream);
     }
     if (g_hook.post) g_hook.post(g_hook.ctx, L.ta, L.wbytes, 1, L.k);
