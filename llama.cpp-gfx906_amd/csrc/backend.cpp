@@ -16,6 +16,7 @@
 #include "ggml-impl.h"
 
 #include "kernels.h"
+#include "decode_mega.h"
 
 #include <hip/hip_runtime.h>
 
@@ -238,6 +239,7 @@ struct node_sig {
 
 struct graph_entry {
     std::vector<node_sig> sig;
+    std::vector<void *> owned_dev;      // device buffers a captured graph refers to (persistent-decode program tables and their signal words)
     hipGraphExec_t exec = nullptr;
     uint64_t last_use = 0;
     int seen = 0;              // identical submissions observed (capture on the 2nd)
@@ -271,6 +273,26 @@ struct mi_backend_ctx {
     uint64_t graph_tick = 0;
 
     struct ggml_backend_mi355x_counters cnt = {};
+
+    // ---- persistent decode (decode_mega.hip): the single-token launches of a graph are recorded instead of launched; at the next op that
+    // is not one of them (or at the end of the graph) the recorded run becomes ONE launch if it has the shape the kernel serves,
+    // else its items go out one by one ----
+    struct rec_item {
+        int kind;                                   // 0: grouped mat-vec, 1: attention
+        mmvq_group grp[MMVQ_MAX_GROUPS]; int nc; int64_t K; mmvq_input in; bool has_rope; mmvq_rope rope;
+        float * norm_out;                           // PRO_NORM: the RMS_NORM*w tensor (the launch path leaves it unwritten; the finaliser writes it)
+        struct { const void * q; size_t q_nb1, q_nb2; const void * k; size_t k_nb1, k_nb2; const void * v; size_t v_nb1, v_nb2; const void * mask; size_t m_nb1;
+                 bool mask_f16; const float * sinks; float * dst; size_t dst_nb1; int64_t hd, n_kv, n_head, n_head_kv, T; float scale; bool v_trans; } at;
+    };
+    std::vector<rec_item> rec;
+    bool use_mega = true, rec_on = false, capturing = false;
+    void * mega_img[2] = { nullptr, nullptr };       // the two activation images the phases alternate between
+    unsigned * mega_err = nullptr;                   // host-mapped word: a bounded wait inside the kernel gave up
+    void * mega_prog_dev = nullptr; void * mega_prog_host = nullptr; unsigned * mega_ws = nullptr;    // eager runs (captured graphs own theirs)
+    struct pending_upload { void * dev; std::vector<char> host; };
+    std::vector<pending_upload> mega_uploads;        // program tables built during a capture: copied once the capture has ended
+    graph_entry * cap_entry = nullptr; size_t cap_prog_used = 0, cap_ws_used = 0;
+    static constexpr size_t MEGA_IMG_BYTES = 64*1024; static constexpr int MEGA_MAX_PHASES = 1024;
 
     // "profile" option: every quantized mat-mul launch is bracketed by a hipEvent pair on this stream (eager mode)
     struct prof_rec { int type; int64_t m, k, n; uint64_t bytes; hipEvent_t e0, e1; };
@@ -314,10 +336,15 @@ static void be_free(ggml_backend_t backend) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    for (auto & e : c->graphs) if (e.exec) (void) hipGraphExecDestroy(e.exec);
+    for (auto & e : c->graphs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); for (void * p : e.owned_dev) (void) hipFree(p); }
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
+    for (int i = 0; i < 2; i++) if (c->mega_img[i]) (void) hipFree(c->mega_img[i]);
+    if (c->mega_prog_dev) (void) hipFree(c->mega_prog_dev);
+    if (c->mega_prog_host) (void) hipHostFree(c->mega_prog_host);
+    if (c->mega_ws) (void) hipFree(c->mega_ws);
+    if (c->mega_err) (void) hipHostFree(c->mega_err);
     if (c->fin_img) (void) hipFree(c->fin_img);
     if (c->fin_cnt) (void) hipFree(c->fin_cnt);
     if (c->stream) (void) hipStreamDestroy(c->stream);
@@ -373,6 +400,11 @@ static void be_synchronize(ggml_backend_t backend) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     MI_CHECK(hipStreamSynchronize(c->stream));
+    if (c->mega_err && c->mega_err[0] != 0) {
+        // a bounded wait inside the persistent decode kernel gave up (a workgroup was not resident, e.g. the device was shared): the results of
+        // that graph are not valid. Hard internal error (GGML_ABORT), reported instead of hanging the device.
+        GGML_ABORT("MI355X backend: the persistent decode kernel timed out waiting for a hand-off (GGML_MI355X_MEGA=0 selects the launch-per-phase path)");
+    }
 }
 
 // ---- op support -----------------------------------------------------------------------------------
@@ -597,6 +629,219 @@ static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// persistent decode: recorder and program builder (decode_mega.h)
+// ---------------------------------------------------------------------------------------------------------------
+static size_t mega_pad256(size_t x) { return (x + 255) & ~(size_t) 255; }
+static void mega_image_layout(int kind, int64_t k, int & off_d, int & off_bs, int & chunks16) {      // = act_q8_carve(…, n = 1)
+    const int64_t nd = kind == T_Q8_0 ? k/32 : k/256, nbs = kind == T_Q8_0 ? k/32 : k/16;
+    off_d = (int) mega_pad256((size_t) k); off_bs = (int)(mega_pad256((size_t) k) + mega_pad256((size_t) nd*4));
+    chunks16 = (int)((off_bs + ((nbs*2 + 15) & ~(int64_t) 15))/16);
+}
+
+static void launch_rec_item(mi_backend_ctx * c, const mi_backend_ctx::rec_item & it) {
+    if (it.kind == 0) {
+        mul_mat_vec_q_fused(it.grp, it.nc, it.K, it.in, it.has_rope ? &it.rope : nullptr, c->stream, nullptr);
+    } else {
+        attn_decode(it.at.q, it.at.q_nb1, it.at.q_nb2, it.at.k, it.at.k_nb1, it.at.k_nb2, it.at.v, it.at.v_nb1, it.at.v_nb2, it.at.mask, it.at.m_nb1, it.at.mask_f16,
+                    it.at.sinks, it.at.dst, it.at.dst_nb1, it.at.hd, it.at.n_kv, it.at.n_head, it.at.n_head_kv, it.at.T, it.at.scale, c->stream, it.at.v_trans,
+                    c->attn_part, c->attn_part_bytes);
+    }
+    c->cnt.kernels_launched++;
+}
+
+// the recorded run as a program of the persistent kernel; false: it does not have the shape the kernel serves
+static bool build_mega_program(mi_backend_ctx * c, std::vector<mega_phase> & prog, size_t & lds_bytes, int & n_chunk_phases) {
+    const auto & rec = c->rec;
+    const int n = (int) rec.size();
+    if (n < 3 || n + 2 > mi_backend_ctx::MEGA_MAX_PHASES || !c->mega_img[0]) return false;
+    const int n_cu = mega_max_workgroups();
+    if (n_cu < 32) return false;
+    prog.clear(); lds_bytes = 1024; n_chunk_phases = 0;
+    int cur = 0;                       // which image the next mat-vec phase reads
+    // indices instead of pointers while building: wait/signal/arrive hold (phase index + 1), chunk counters (chunk phase index + 1)
+    auto as_ptr = [](size_t v) { return (unsigned *) v; };
+    for (int j = 0; j < n; j++) {
+        const auto & it = rec[j];
+        mega_phase ph = {};
+        for (int q = 0; q < 4; q++) ph.block_end[q] = INT_MAX;
+        if (it.kind == 0) {
+            if (it.nc > MEGA_MAX_GROUPS) return false;
+            int types[MMVQ_MAX_GROUPS];
+            for (int q = 0; q < it.nc; q++) {
+                const mmvq_group & g = it.grp[q];
+                types[q] = g.type;
+                if (g.eid || g.b_gate || g.b_up || g.glu_alpha != 0.0f || g.x_off != 0 || g.row_stride > 0xFFFFFFFFull) return false;
+                if (g.epi == EPI_GLU && it.nc != 1) return false;
+            }
+            if (!mega_supported_types(types, it.nc)) return false;
+            const int kind = it.in.act_kind;
+            if (it.K % 256 != 0 || it.K > 16384) return false;
+            ph.kind = MEGA_MM; ph.n_groups = it.nc; ph.glu = it.grp[0].epi == EPI_GLU ? 1 : 0;
+            ph.n_active = mul_mat_vec_q_fused_share(it.grp, it.nc, 8, ph.block_end);
+            if (ph.n_active > n_cu) return false;
+            ph.k = (int) it.K; ph.act_kind = kind;
+            mega_image_layout(kind, it.K, ph.off_d, ph.off_bs, ph.act_chunks);
+            if ((size_t) ph.act_chunks*16 > mi_backend_ctx::MEGA_IMG_BYTES) return false;
+            lds_bytes = std::max(lds_bytes, (size_t) ph.act_chunks*16 + 512);
+            for (int q = 0; q < it.nc; q++) {
+                const mmvq_group & g = it.grp[q];
+                ph.g[q] = { g.W, g.W2, g.dst, g.res, g.st16, g.st_idx, g.st_row_elems, (uint32_t) g.row_stride, g.m, g.type, g.epi, g.st_mode, 0 };
+            }
+            if (it.has_rope) { ph.rope = make_fused_rope(it.rope); ph.pos = it.rope.pos; }
+            // where the input comes from
+            if (j == 0) {
+                if (it.in.mode == PRO_NORM) {
+                    if (it.K > 8192) return false;
+                    mega_phase f = {};
+                    for (int q = 0; q < 4; q++) f.block_end[q] = INT_MAX;
+                    f.kind = MEGA_FIN; f.n_active = 1; f.fin_mode = MFIN_NORM; f.fin_k = (int) it.K; f.fin_kind = kind; f.fin_eps = it.in.eps;
+                    f.fin_x = it.in.x; f.fin_norm_w = it.in.norm_w; f.fin_norm_out = it.norm_out;
+                    f.fin_img = (char *) c->mega_img[0]; f.fin_off_d = ph.off_d; f.fin_off_bs = ph.off_bs;
+                    f.signal = as_ptr(prog.size() + 1);
+                    prog.push_back(f);
+                    cur = 0;
+                    ph.act = (const char *) c->mega_img[0]; ph.wait = as_ptr(prog.size()); ph.wait_target = 1;
+                } else if (it.in.mode == PRO_Q8) {
+                    ph.act = (const char *) it.in.act.qs; ph.wait = nullptr; cur = 0;      // an image some earlier kernel made
+                    if ((const char *) it.in.act.d - (const char *) it.in.act.qs != ph.off_d || (const char *) it.in.act.bsums - (const char *) it.in.act.qs != ph.off_bs) return false;
+                } else return false;
+            } else {
+                mega_phase & pr = prog.back();             // the producer: patched to deliver what this consumer reads
+                const auto & pit = rec[j - 1];
+                ph.act = (const char *) c->mega_img[cur];
+                if (pit.kind == 1) {                       // attention -> quantize + this mat-vec (wo)
+                    if (it.in.mode != PRO_QUANT || it.in.x != pit.at.dst || it.K != pit.at.hd*pit.at.n_head) return false;
+                    pr.fin_kind = kind; pr.fin_off_d = ph.off_d; pr.fin_off_bs = ph.off_bs;
+                    ph.wait = pr.signal; ph.wait_target = (unsigned) pr.n_active;
+                } else {
+                    const mmvq_group & pg = pit.grp[0];
+                    if (pit.nc != 1 || it.K != pg.m) return false;
+                    pr.fin_k = (int) it.K; pr.fin_kind = kind; pr.fin_off_d = ph.off_d; pr.fin_off_bs = ph.off_bs;
+                    pr.fin_img = (char *) c->mega_img[cur];
+                    if (it.in.mode == PRO_NORM) {          // residual stream -> RMS_NORM * w -> quantize -> this mat-vec
+                        if (it.in.x != pg.dst || pg.epi == EPI_GLU || it.K > 8192) return false;
+                        pr.fin_mode = MFIN_NORM; pr.fin_x = it.in.x; pr.fin_norm_w = it.in.norm_w; pr.fin_eps = it.in.eps; pr.fin_norm_out = it.norm_out;
+                        pr.arrive = as_ptr(prog.size());   // (the producer's own index + 1)
+                        ph.wait = pr.signal; ph.wait_target = 1;
+                    } else if (it.in.mode == PRO_QUANT && pg.epi == EPI_GLU) {      // gate/up/SwiGLU -> quantize -> down
+                        const int nwg = pr.n_active;
+                        if (it.in.x != pg.dst || pg.m % 256 != 0 || nwg % 32 != 0 || pg.m/256 > MEGA_CHUNK_WORDS || (pg.m + nwg*8 - 1)/(nwg*8) > 63) return false;
+                        pr.fin_mode = MFIN_CHUNK;
+                        pr.arrive = as_ptr((size_t) 0x10000 + (size_t) n_chunk_phases); n_chunk_phases++;
+                        ph.wait = pr.signal; ph.wait_target = (unsigned)(pg.m/256);
+                    } else return false;
+                }
+            }
+            ph.signal = as_ptr(prog.size() + 1);
+            ph.fin_mode = MFIN_NONE;
+            prog.push_back(ph);
+            cur ^= 1;                  // what this phase (its finaliser, or the attention phase behind it) produces goes to the other image
+        } else {
+            // attention: reads q / the KV cache the previous phase (QKV) wrote, writes the image wo reads
+            if (j == 0 || rec[j - 1].kind != 0) return false;
+            const auto & a = it.at;
+            if (a.T != 1 || a.hd != 128 || !a.v_trans || a.sinks || a.n_head % 2 != 0 || a.n_head % a.n_head_kv != 0 || a.n_kv % 8 != 0 || (a.n_head/2) > n_cu) return false;
+            if (a.k_nb1 % 16 || a.k_nb2 % 16 || a.v_nb1 % 16 || a.v_nb2 % 16 || ((uintptr_t) a.q % 16) || a.q_nb2 % 16 || ((uintptr_t) a.k % 16) || ((uintptr_t) a.v % 16)) return false;
+            const size_t lds = ((size_t) 2*((a.n_kv + 3) & ~(int64_t) 3) + 16 + 256)*4;
+            if (lds > 60*1024) return false;
+            lds_bytes = std::max(lds_bytes, lds);
+            bool q_found = false;
+            for (int q = 0; q < rec[j - 1].nc; q++) if ((const void *) rec[j - 1].grp[q].dst == a.q) q_found = true;
+            if (!q_found) return false;
+            mega_phase & pr = prog.back();
+            pr.fin_mode = MFIN_NONE;
+            ph.kind = MEGA_ATTN; ph.n_active = (int)(a.n_head/2);
+            ph.wait = pr.signal; ph.wait_target = (unsigned) pr.n_active;
+            ph.q = (const char *) a.q; ph.q_nb2 = a.q_nb2; ph.kc = (const char *) a.k; ph.k_nb1 = a.k_nb1; ph.k_nb2 = a.k_nb2;
+            ph.vc = (const char *) a.v; ph.v_nb1 = a.v_nb1; ph.v_nb2 = a.v_nb2; ph.mask = (const char *) a.mask; ph.mask_f16 = a.mask_f16 ? 1 : 0;
+            ph.attn_dst = a.dst; ph.scale = a.scale; ph.n_kv = (int) a.n_kv; ph.n_head = (int) a.n_head; ph.n_head_kv = (int) a.n_head_kv; ph.head_dim = (int) a.hd;
+            ph.fin_kind = T_Q8_K; ph.fin_img = (char *) c->mega_img[cur];
+            mega_image_layout(T_Q8_K, a.hd*a.n_head, ph.fin_off_d, ph.fin_off_bs, ph.act_chunks);
+            ph.signal = as_ptr(prog.size() + 1);
+            prog.push_back(ph);
+        }
+    }
+    // the last phase signals nobody
+    prog.back().signal = nullptr;
+    return true;
+}
+
+static void rec_flush(mi_backend_ctx * c) {
+    if (c->rec.empty()) return;
+    std::vector<mega_phase> prog; size_t lds = 0; int n_chunk = 0;
+    bool ok = c->use_mega && c->mega_err && build_mega_program(c, prog, lds, n_chunk);
+    static const bool dbg = getenv("GGML_MI355X_MEGA_DEBUG") != nullptr;
+    if (dbg) fprintf(stderr, "ggml-mi355x: recorded run of %d launches -> %s (%d phases, %zu B LDS)%s\n", (int) c->rec.size(), ok ? "persistent kernel" : "separate launches",
+                     (int) prog.size(), lds, c->capturing ? " [capture]" : "");
+    void * prog_dev = nullptr; unsigned * ws = nullptr;
+    const size_t prog_bytes = prog.size()*sizeof(mega_phase);
+    const size_t ws_words = prog.size()*MEGA_SIG_WORDS + (size_t) n_chunk*MEGA_CHUNK_WORDS;
+    if (ok) {
+        if (c->capturing) {       // a captured graph owns its tables and signal words: carved from buffers allocated before the capture began
+            const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*(MEGA_SIG_WORDS + MEGA_CHUNK_WORDS)*4;
+            if (c->cap_entry->owned_dev.size() != 2 || c->cap_prog_used + prog_bytes > pcap || c->cap_ws_used + ws_words*4 > wcap) ok = false;
+            else {
+                prog_dev = (char *) c->cap_entry->owned_dev[0] + c->cap_prog_used; ws = (unsigned *) ((char *) c->cap_entry->owned_dev[1] + c->cap_ws_used);
+                c->cap_prog_used += (prog_bytes + 255) & ~(size_t) 255; c->cap_ws_used += (ws_words*4 + 255) & ~(size_t) 255;
+            }
+        } else {
+            if (!c->mega_prog_dev) {
+                const size_t cap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*(MEGA_SIG_WORDS + MEGA_CHUNK_WORDS)*4;
+                if (hipMalloc(&c->mega_prog_dev, cap) != hipSuccess || hipHostMalloc(&c->mega_prog_host, cap, hipHostMallocDefault) != hipSuccess ||
+                    hipMalloc((void **) &c->mega_ws, wcap) != hipSuccess) { (void) hipGetLastError(); ok = false; }
+            }
+            prog_dev = c->mega_prog_dev; ws = c->mega_ws;
+        }
+    }
+    if (!ok) {
+        for (const auto & it : c->rec) launch_rec_item(c, it);
+        c->rec.clear();
+        return;
+    }
+    // patch the signalling indices into addresses
+    auto fix = [&](unsigned * & p) {
+        const size_t v = (size_t) p;
+        if (v == 0) return;
+        if (v >= 0x10000) p = ws + prog.size()*MEGA_SIG_WORDS + (v - 0x10000)*MEGA_CHUNK_WORDS;
+        else p = ws + (v - 1)*MEGA_SIG_WORDS + 4;      // a phase's signal word
+    };
+    for (size_t i = 0; i < prog.size(); i++) {
+        mega_phase & ph = prog[i];
+        { unsigned * w = (unsigned *) ph.wait; fix(w); ph.wait = w; }
+        fix(ph.signal);
+        if (ph.fin_mode == MFIN_NORM && ph.kind == MEGA_MM) ph.arrive = ws + i*MEGA_SIG_WORDS;      // its own arrival counter
+        else if (ph.fin_mode == MFIN_CHUNK) fix(ph.arrive);
+        else ph.arrive = nullptr;
+    }
+    if (c->capturing) {
+        mi_backend_ctx::pending_upload up; up.dev = prog_dev; up.host.assign((const char *) prog.data(), (const char *) prog.data() + prog_bytes);
+        c->mega_uploads.push_back(std::move(up));     // copied when the capture has ended (be_graph_compute), before the graph's first launch
+    } else {
+        MI_CHECK(hipStreamSynchronize(c->stream));    // the staging copy of the previous eager run may still be in flight
+        memcpy(c->mega_prog_host, prog.data(), prog_bytes);
+        MI_CHECK(hipMemcpyAsync(prog_dev, c->mega_prog_host, prog_bytes, hipMemcpyHostToDevice, c->stream));
+    }
+    MI_CHECK(hipMemsetAsync(ws, 0, ws_words*4, c->stream));
+    unsigned * err_dev = nullptr;
+    MI_CHECK(hipHostGetDevicePointer((void **) &err_dev, c->mega_err, 0));
+    mega_launch((const mega_phase *) prog_dev, (int) prog.size(), mega_max_workgroups(), err_dev, lds, c->stream);
+    c->cnt.kernels_launched += 2;
+    c->rec.clear();
+}
+
+static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin, float * norm_out) {
+    if (!c->rec_on) {
+        mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
+        c->cnt.kernels_launched++;
+        return;
+    }
+    mi_backend_ctx::rec_item it = {};
+    it.kind = 0; it.nc = nc; it.K = K; it.in = in; it.has_rope = rope != nullptr; if (rope) it.rope = *rope; it.norm_out = norm_out;
+    for (int q = 0; q < nc; q++) it.grp[q] = grp[q];
+    c->rec.push_back(it);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // decode fusions (decode_fused.hip). Each matcher checks op, type, shape, layout AND that every skipped intermediate
 // has exactly one consumer and is not a graph output; anything else falls back to node-by-node execution.
 // ---------------------------------------------------------------------------------------------------------------
@@ -792,6 +1037,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
         wbytes += (uint64_t) grp[q].m*grp[q].row_stride*(grp[q].epi == EPI_GLU ? 2 : 1);
     }
     const int64_t K = n->src[0]->ne[0];
+    void * norm_mul_data = b->data;      // with `norm`: b is the RMS_NORM*w tensor the launch path never writes
     mmvq_input in = {};
     in.act_kind = kind;
     const bool cached = c->aq.valid && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == 1 && c->aq.n_outer == 1 && c->aq.kind == kind;
@@ -804,14 +1050,14 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     } else if (mul_mat_vec_q_fused_prologue_supported(K, kind)) {
         in.mode = PRO_QUANT; in.x = (const float *) b->data;
     } else {
-        mul_mat_vec_q_fused_flush(c->stream);     // the quantizer below reads what a held-back launch writes
+        rec_flush(c);     // the quantizer below reads what a recorded launch writes
         in.mode = PRO_Q8; in.act = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);
     }
     // gate/up/SwiGLU whose output the down projection reads next (build_ffn, src/llama-graph.cpp:691-748): the launch also writes the quantized
     // image of its output (mmvq_fin) — the f32 tensor is written as always, so any other reader still finds it
     mmvq_fin fin = {}; act_q8 fin_q = {}; const struct ggml_tensor * fin_t = nullptr;
     static const bool fin_env = !getenv("GGML_MI355X_FIN") || atoi(getenv("GGML_MI355X_FIN")) != 0;
-    if (fin_env && nc == 1 && grp[0].epi == EPI_GLU && !grp[0].eid && c->fin_img) {
+    if (fin_env && !c->rec_on && nc == 1 && grp[0].epi == EPI_GLU && !grp[0].eid && c->fin_img) {
         const int jn = next_real(g, last);
         const struct ggml_tensor * gl = g->nodes[last];
         const struct ggml_tensor * mm = jn > 0 ? g->nodes[jn] : nullptr;
@@ -826,12 +1072,12 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
             }
         }
     }
-    mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin_t ? &fin : nullptr);
+    emit_mmv(c, grp, nc, K, in, rope, fin_t ? &fin : nullptr, in.mode == PRO_NORM && normw ? (float *) norm_mul_data : nullptr);
     if (fin_t) {
         c->aq = { fin_t->data, grp[0].m, 1, 1, fin_t->nb[1], 0, fin.kind, fin_q, true, (size_t) grp[0].m*4, 0 };
         c->aq_fresh = true;
     }
-    c->cnt.mmvq_launches++; c->cnt.kernels_launched++; c->cnt.weight_bytes += wbytes;
+    c->cnt.mmvq_launches++; c->cnt.weight_bytes += wbytes;
     for (int r = 0; r < n_def; r++) compute_node(c, g, deferred[r]);       // (flushes a held-back launch first)
     return last;
 }
@@ -896,6 +1142,7 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     if (pm->ne[0] != hd || pm->ne[1] != n_head || pm->ne[2] != T || pm->ne[3] != 1) return 0;
     if (ct->type != GGML_TYPE_F32 || !ggml_is_contiguous(ct) || ggml_nelements(ct) != hd*n_head*T) return 0;
     if (prefill) {
+        rec_flush(c);
         if (mask && (mask->ne[1] < T || ((uintptr_t) mask->data % 16) || mask->nb[1] % 16)) return 0;
         if (v->nb[1] % 8 || v->nb[2] % 8 || ((uintptr_t) v->data % 8)) return 0;
         // wo reads the result next: hand it the bf16 copy directly (nothing reads the scratch's offset 0 during this kernel)
@@ -912,11 +1159,14 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         c->cnt.kernels_launched++;
         return j3 - i + 1;
     }
-    attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2],
-                mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, mask && mask->type == GGML_TYPE_F16,
-                sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
-                hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream, true, c->attn_part, c->attn_part_bytes);
-    c->cnt.kernels_launched++;
+    {
+        mi_backend_ctx::rec_item it = {};
+        it.kind = 1;
+        it.at = { q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0,
+                  mask && mask->type == GGML_TYPE_F16, sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
+                  hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), true };
+        if (c->rec_on) c->rec.push_back(it); else launch_rec_item(c, it);
+    }
     return j3 - i + 1;
 }
 
@@ -1047,6 +1297,7 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
                                bg ? (const float *) bg->src[1]->data : nullptr, bu ? (const float *) bu->src[1]->data : nullptr,
                                oai ? op_f32(gl, 2) : 0.0f, oai ? op_f32(gl, 3) : 0.0f };
                 }
+                rec_flush(c);
                 mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
                 c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
                 c->cnt.weight_bytes += (uint64_t) 2*n_used*M*ggml_row_size(as->type, K);
@@ -1060,6 +1311,7 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
         grp[u] = { (const char *) as->data, nullptr, as->nb[1], (int) M, (int) as->type, (float *) ((char *) up->data + (size_t) u*up->nb[1]), EPI_NONE,
                    nullptr, nullptr, nullptr, 0, 0, (const int32_t *) ids->data + u, as->nb[2], b->ne[1] > 1 ? (int)((size_t) u*b->nb[1]/4) : 0 };
     }
+    rec_flush(c);
     mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
     c->cnt.weight_bytes += (uint64_t) n_used*M*ggml_row_size(as->type, K);
@@ -1308,13 +1560,13 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         int f = 0;
         if (node->op == GGML_OP_MUL_MAT) {
             const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0;
-            if (!f) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_attn(c, g, i); }
-            if (!f) f = try_fused_moe_route(c, g, i);
+            if (!f) f = try_fused_attn(c, g, i);       // (one token: recorded; many tokens: flushes, then launches)
+            if (!f) { rec_flush(c); f = try_fused_moe_route(c, g, i); }
             if (!f) f = try_fused_prefill_glu(c, g, i);
             if (!f) f = try_fused_prefill_qkv(c, g, i);
             if (!f) f = try_fused_prefill_add(c, g, i);
-        } else if (node->op == GGML_OP_SET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_kv_store(c, g, i); }
-        else if (node->op == GGML_OP_GET_ROWS) { mul_mat_vec_q_fused_flush(c->stream); f = try_fused_moe_combine(c, g, i); }
+        } else if (node->op == GGML_OP_SET_ROWS) { rec_flush(c); f = try_fused_kv_store(c, g, i); }
+        else if (node->op == GGML_OP_GET_ROWS) { rec_flush(c); f = try_fused_moe_combine(c, g, i); }
         else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);
         if (f) {
             consumed = f;
@@ -1324,7 +1576,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     }
     // held-back grouped launches (decode_fused.hip: the per-layer chain) go out before anything else touches the stream; only an
     // RMS_NORM may still be absorbed into the next grouped launch's prologue
-    if (node->op != GGML_OP_RMS_NORM) mul_mat_vec_q_fused_flush(c->stream);
+    if (node->op != GGML_OP_RMS_NORM) rec_flush(c);
     switch (node->op) {
         case GGML_OP_MUL_MAT:    op_mul_mat(c, node); break;
         case GGML_OP_MUL_MAT_ID: op_mul_mat_id(c, node); break;
@@ -1364,7 +1616,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                             const int l = try_fused_mmv(c, g, jn, node, w);
                             if (l >= 0) { consumed = l - i + 1; fresh_aq = c->aq_fresh; c->aq_fresh = false; break; }
                         }
-                        mul_mat_vec_q_fused_flush(c->stream);
+                        rec_flush(c);
                         if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&
                             act_kind_for((int) mm->src[0]->type) > 0 && rms_norm_mul_quant_supported(node->ne[0]) && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 &&
                             w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] && s0->nb[0] == 4 &&
@@ -1399,7 +1651,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                     }
                 }
             }
-            mul_mat_vec_q_fused_flush(c->stream);
+            rec_flush(c);
             rms_norm(desc(s0), desc(node), op_f32(node, 0), c->stream);
             c->cnt.kernels_launched++;
         } break;
@@ -1458,13 +1710,16 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
     mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
     c->aq.valid = false;
     c->uses.clear();
+    c->rec.clear();
+    c->rec_on = c->use_mega && c->use_fusion && !c->profiling && c->mega_err != nullptr;
     if (c->use_fusion) {
         for (int i = 0; i < g->n_nodes; i++) {
             for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[i]->src[s]) c->uses[g->nodes[i]->src[s]]++;
         }
     }
     for (int i = 0; i < g->n_nodes; ) i += compute_node(c, g, i);
-    mul_mat_vec_q_fused_flush(c->stream);
+    rec_flush(c);
+    c->rec_on = false;
     c->aq.valid = false;
 }
 
@@ -1486,7 +1741,7 @@ static inline void fill_sig(node_sig & s, const struct ggml_tensor * n) {
 }
 
 static void drop_graphs(mi_backend_ctx * c) {
-    for (auto & e : c->graphs) if (e.exec) (void) hipGraphExecDestroy(e.exec);
+    for (auto & e : c->graphs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); for (void * p : e.owned_dev) (void) hipFree(p); }
     c->graphs.clear();
 }
 
@@ -1506,6 +1761,7 @@ static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph *
     if (best) { best->last_use = ++c->graph_tick; best->seen++; return *best; }
     if ((int) c->graphs.size() >= MI_MAX_GRAPHS) {
         if (lru->exec) { MI_CHECK(hipStreamSynchronize(c->stream)); MI_CHECK(hipGraphExecDestroy(lru->exec)); }
+        for (void * p : lru->owned_dev) (void) hipFree(p);
         *lru = graph_entry();
         lru->sig = c->cur_sig; lru->last_use = ++c->graph_tick; lru->seen = 1;
         return *lru;
@@ -1524,6 +1780,12 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
     if (!c->moe_ws) {
         if (hipMalloc((void **) &c->moe_ws, 1088) == hipSuccess) { MI_CHECK(hipMemsetAsync(c->moe_ws, 0, 1088, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
+    }
+    if (!c->mega_err && c->use_mega) {     // persistent decode: images, the error word (host-mapped)
+        bool ok = hipMalloc(&c->mega_img[0], mi_backend_ctx::MEGA_IMG_BYTES) == hipSuccess && hipMalloc(&c->mega_img[1], mi_backend_ctx::MEGA_IMG_BYTES) == hipSuccess;
+        ok = ok && hipHostMalloc((void **) &c->mega_err, 64, hipHostMallocMapped) == hipSuccess;
+        if (ok) { c->mega_err[0] = 0; }
+        else { (void) hipGetLastError(); c->use_mega = false; }
     }
     if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
         if (hipMalloc(&c->fin_img, mi_backend_ctx::FIN_IMG_BYTES) != hipSuccess) { (void) hipGetLastError(); c->fin_img = nullptr; }
@@ -1559,11 +1821,21 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
         }
         if (e.seen >= 2) {
             hipGraph_t graph = nullptr;
+            if (c->use_mega && c->mega_err && e.owned_dev.empty()) {       // room for the persistent-decode programs of this graph (no allocation inside a capture)
+                void * pd = nullptr; void * wd = nullptr;
+                const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*(MEGA_SIG_WORDS + MEGA_CHUNK_WORDS)*4;
+                if (hipMalloc(&pd, pcap) == hipSuccess && hipMalloc(&wd, wcap) == hipSuccess) { e.owned_dev.push_back(pd); e.owned_dev.push_back(wd); }
+                else { (void) hipGetLastError(); if (pd) (void) hipFree(pd); }
+            }
             MI_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             c->prof_suspend = false;
+            c->capturing = true; c->cap_entry = &e; c->mega_uploads.clear(); c->cap_prog_used = 0; c->cap_ws_used = 0;
             run_nodes(c, g);
+            c->capturing = false; c->cap_entry = nullptr;
             c->prof_suspend = c->prof_in_graph;
             MI_CHECK(hipStreamEndCapture(c->stream, &graph));
+            for (auto & up : c->mega_uploads) MI_CHECK(hipMemcpy(up.dev, up.host.data(), up.host.size(), hipMemcpyHostToDevice));     // the program tables the captured launches read
+            c->mega_uploads.clear();
             hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
             MI_CHECK(hipGraphDestroy(graph));
             if (err == hipSuccess) {
@@ -1793,6 +2065,7 @@ ggml_backend_t ggml_backend_mi355x_init(int device) {
     MI_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->use_fusion = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_MEGA")) c->use_mega = atoi(e) != 0;
     ggml_backend_t backend = new ggml_backend{ mi_guid(), mi_backend_iface, &d.dev, c };
     return backend;
 }
@@ -1824,6 +2097,12 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
         c->prof.clear();
         c->profiling = value != 0; c->prof_in_graph = value == 2; c->prof_suspend = false;
         mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
+        return 0;
+    }
+    if (strcmp(key, "mega") == 0) {
+        c->use_mega = value != 0;
+        MI_CHECK(hipStreamSynchronize(c->stream));
+        drop_graphs(c);
         return 0;
     }
     if (strcmp(key, "fusion") == 0) {

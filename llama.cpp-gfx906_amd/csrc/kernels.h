@@ -216,7 +216,8 @@ bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind);        // 
 bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);   // may these two weight types share one grouped launch
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                          const mmvq_fin * fin = nullptr);
-bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);      // may a GLU launch with m output rows carry an mmvq_fin
+bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);
+int  mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end);   // workgroups per group (one workgroup per CU in all)      // may a GLU launch with m output rows carry an mmvq_fin
 // Launches that fit a position of the per-layer chain (decode_fused.hip: k_mmvq_chain) are held back until the chain is complete
 // or broken. EVERY other use of the stream must call flush first; `pending` tells how many launches (and weight bytes) are held.
 void mul_mat_vec_q_fused_flush(hipStream_t stream);

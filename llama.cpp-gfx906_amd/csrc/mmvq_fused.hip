@@ -60,6 +60,23 @@ static int device_cu_count() {
     return n_cu;
 }
 
+// how the persistent workgroups (one per CU) are shared among the groups of a launch: in proportion to their rows, at least one each,
+// never more than one unit (row pair; row of the dual GLU stream) per wave. Returns the grid size; block_end[i] = cumulative counts.
+int mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end) {
+    const int budget = device_cu_count();
+    int64_t rows_total = 0;
+    for (int i = 0; i < n_groups; i++) rows_total += (int64_t) groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1);
+    int blocks = 0;
+    for (int i = 0; i < n_groups; i++) {
+        const int max_wg = groups[i].epi == EPI_GLU ? (int)((groups[i].m + fw - 1)/fw) : (int)(((groups[i].m + 1)/2 + fw - 1)/fw);
+        int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1))/rows_total);
+        share = share < 1 ? 1 : (share > max_wg ? max_wg : share);
+        blocks += share;
+        block_end[i] = blocks;
+    }
+    return blocks;
+}
+
 bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in) {
     // chunks are 256 rows; a workgroup's contiguous run (8 waves x rows per wave, one workgroup per CU) may touch at most 7 of them
     const int64_t rpw = (m + (int64_t) device_cu_count()*8 - 1)/((int64_t) device_cu_count()*8);
