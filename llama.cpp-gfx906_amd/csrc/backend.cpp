@@ -286,7 +286,7 @@ struct mi_backend_ctx {
     };
     std::vector<rec_item> rec;
     bool use_mega = true, rec_on = false, capturing = false;
-    void * mega_img[2] = { nullptr, nullptr };       // the two activation images the phases alternate between
+    void * mega_gran = nullptr; unsigned * mega_epoch = nullptr;      // hand-off granules (decode_mega.h) and the launch counter their tags derive from
     unsigned * mega_err = nullptr;                   // host-mapped word: a bounded wait inside the kernel gave up
     void * mega_prog_dev = nullptr; void * mega_prog_host = nullptr; unsigned * mega_ws = nullptr;    // eager runs (captured graphs own theirs)
     struct pending_upload { void * dev; std::vector<char> host; };
@@ -340,7 +340,8 @@ static void be_free(ggml_backend_t backend) {
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
-    for (int i = 0; i < 2; i++) if (c->mega_img[i]) (void) hipFree(c->mega_img[i]);
+    if (c->mega_gran) (void) hipFree(c->mega_gran);
+    if (c->mega_epoch) (void) hipFree(c->mega_epoch);
     if (c->mega_prog_dev) (void) hipFree(c->mega_prog_dev);
     if (c->mega_prog_host) (void) hipHostFree(c->mega_prog_host);
     if (c->mega_ws) (void) hipFree(c->mega_ws);
@@ -649,21 +650,32 @@ static void launch_rec_item(mi_backend_ctx * c, const mi_backend_ctx::rec_item &
     c->cnt.kernels_launched++;
 }
 
-// the recorded run as a program of the persistent kernel; false: it does not have the shape the kernel serves
-static bool build_mega_program(mi_backend_ctx * c, std::vector<mega_phase> & prog, size_t & lds_bytes, int & n_chunk_phases) {
+// the recorded run as a program of the persistent kernel; false: it does not have the shape the kernel serves.
+// Signalling words are kept as (phase index + 1) (+ 0x10000 for a phase's second counter) while building and patched by rec_flush.
+static bool build_mega_program(mi_backend_ctx * c, std::vector<mega_phase> & prog, size_t & lds_bytes) {
     const auto & rec = c->rec;
     const int n = (int) rec.size();
-    if (n < 3 || n + 2 > mi_backend_ctx::MEGA_MAX_PHASES || !c->mega_img[0]) return false;
+    static const int min_items = getenv("GGML_MI355X_MEGA_DBG_NOLAST") ? 2 : 3;
+    if (n < min_items || n + 2 > mi_backend_ctx::MEGA_MAX_PHASES || !c->mega_gran) return false;
     const int n_cu = mega_max_workgroups();
     if (n_cu < 32) return false;
-    prog.clear(); lds_bytes = 1024; n_chunk_phases = 0;
-    int cur = 0;                       // which image the next mat-vec phase reads
-    // indices instead of pointers while building: wait/signal/arrive hold (phase index + 1), chunk counters (chunk phase index + 1)
+    prog.clear(); lds_bytes = 1024;
     auto as_ptr = [](size_t v) { return (unsigned *) v; };
+    // granule buffers (decode_mega.h): three for the residual stream (rotating), q / k / v, the GLU output, two sets of pieces
+    unsigned long long * gbase = (unsigned long long *) c->mega_gran;
+    unsigned long long * x_gran[3] = { gbase, gbase + 8192, gbase + 2*8192 };
+    unsigned long long * q_gran = gbase + 3*8192, * k_gran = gbase + 4*8192, * v_gran = gbase + 5*8192;
+    unsigned long long * act_gran = gbase + 6*8192;                               // 32768 rows
+    unsigned long long * pieces_a = act_gran + 32768, * pieces_b = pieces_a + 128*MEGA_PIECE_WORDS;
+    int xi = 0;
+    const void * gran_of_ptr[3] = { nullptr, nullptr, nullptr };                  // which f32 vector each residual-stream buffer holds
+    auto find_gran = [&](const void * p) -> unsigned long long * { for (int q = 0; q < 3; q++) if (gran_of_ptr[q] == p && p) return x_gran[q]; return nullptr; };
     for (int j = 0; j < n; j++) {
         const auto & it = rec[j];
         mega_phase ph = {};
+        const int self = (int) prog.size();
         for (int q = 0; q < 4; q++) ph.block_end[q] = INT_MAX;
+        ph.hint = as_ptr((size_t) self + 1);
         if (it.kind == 0) {
             if (it.nc > MEGA_MAX_GROUPS) return false;
             int types[MMVQ_MAX_GROUPS];
@@ -675,110 +687,131 @@ static bool build_mega_program(mi_backend_ctx * c, std::vector<mega_phase> & pro
             }
             if (!mega_supported_types(types, it.nc)) return false;
             const int kind = it.in.act_kind;
-            if (it.K % 256 != 0 || it.K > 16384) return false;
+            if (kind != T_Q8_K || it.K % 256 != 0 || it.K > 32768) return false;
             ph.kind = MEGA_MM; ph.n_groups = it.nc; ph.glu = it.grp[0].epi == EPI_GLU ? 1 : 0;
             ph.n_active = mul_mat_vec_q_fused_share(it.grp, it.nc, 8, ph.block_end);
             if (ph.n_active > n_cu) return false;
             ph.k = (int) it.K; ph.act_kind = kind;
             mega_image_layout(kind, it.K, ph.off_d, ph.off_bs, ph.act_chunks);
-            if ((size_t) ph.act_chunks*16 > mi_backend_ctx::MEGA_IMG_BYTES) return false;
-            lds_bytes = std::max(lds_bytes, (size_t) ph.act_chunks*16 + 512);
+            lds_bytes = std::max(lds_bytes, (size_t) ph.act_chunks*16 + 256);
             for (int q = 0; q < it.nc; q++) {
                 const mmvq_group & g = it.grp[q];
-                ph.g[q] = { g.W, g.W2, g.dst, g.res, g.st16, g.st_idx, g.st_row_elems, (uint32_t) g.row_stride, g.m, g.type, g.epi, g.st_mode, 0 };
+                ph.g[q] = { g.W, g.W2, g.dst, g.res, nullptr, nullptr, g.st16, g.st_idx, g.st_row_elems, (uint32_t) g.row_stride, g.m, g.type, g.epi, g.st_mode, 0 };
+                if (g.epi == EPI_ADD) ph.g[q].res_gran = find_gran(g.res);      // a vector an earlier phase of this launch produced, or a graph input (plain)
             }
             if (it.has_rope) { ph.rope = make_fused_rope(it.rope); ph.pos = it.rope.pos; }
+            // the RMS_NORM*w tensor itself is written (by workgroup 0, at the start of the phase) only when that cannot collide with what the phase
+            // writes: the graph allocator may have placed an output of the fused nodes (rope result, SwiGLU result) in the memory the norm
+            // tensor occupied until its last reader — the launch path never writes it, so it never noticed
+            float * norm_out = getenv("GGML_MI355X_MEGA_DBG_NONORMOUT") ? nullptr : it.norm_out;
+            for (int q = 0; q < it.nc && norm_out; q++) if (ranges_overlap(norm_out, (size_t) it.K*4, it.grp[q].dst, (size_t) it.grp[q].m*4)) norm_out = nullptr;
             // where the input comes from
             if (j == 0) {
                 if (it.in.mode == PRO_NORM) {
                     if (it.K > 8192) return false;
-                    mega_phase f = {};
-                    for (int q = 0; q < 4; q++) f.block_end[q] = INT_MAX;
-                    f.kind = MEGA_FIN; f.n_active = 1; f.fin_mode = MFIN_NORM; f.fin_k = (int) it.K; f.fin_kind = kind; f.fin_eps = it.in.eps;
-                    f.fin_x = it.in.x; f.fin_norm_w = it.in.norm_w; f.fin_norm_out = it.norm_out;
-                    f.fin_img = (char *) c->mega_img[0]; f.fin_off_d = ph.off_d; f.fin_off_bs = ph.off_bs;
-                    f.signal = as_ptr(prog.size() + 1);
-                    prog.push_back(f);
-                    cur = 0;
-                    ph.act = (const char *) c->mega_img[0]; ph.wait = as_ptr(prog.size()); ph.wait_target = 1;
+                    ph.in_mode = MIN_NORM_PLAIN; ph.x = it.in.x; ph.norm_w = it.in.norm_w; ph.eps = it.in.eps; ph.norm_out = norm_out;
                 } else if (it.in.mode == PRO_Q8) {
-                    ph.act = (const char *) it.in.act.qs; ph.wait = nullptr; cur = 0;      // an image some earlier kernel made
+                    ph.in_mode = MIN_IMAGE; ph.act = (const char *) it.in.act.qs;      // an image some earlier kernel made
                     if ((const char *) it.in.act.d - (const char *) it.in.act.qs != ph.off_d || (const char *) it.in.act.bsums - (const char *) it.in.act.qs != ph.off_bs) return false;
                 } else return false;
             } else {
                 mega_phase & pr = prog.back();             // the producer: patched to deliver what this consumer reads
                 const auto & pit = rec[j - 1];
-                ph.act = (const char *) c->mega_img[cur];
-                if (pit.kind == 1) {                       // attention -> quantize + this mat-vec (wo)
+                const int pidx = (int) prog.size() - 1;
+                if (pit.kind == 1) {                       // attention -> pieces -> this mat-vec (wo)
                     if (it.in.mode != PRO_QUANT || it.in.x != pit.at.dst || it.K != pit.at.hd*pit.at.n_head) return false;
-                    pr.fin_kind = kind; pr.fin_off_d = ph.off_d; pr.fin_off_bs = ph.off_bs;
-                    ph.wait = pr.signal; ph.wait_target = (unsigned) pr.n_active;
+                    ph.in_mode = MIN_PIECES; ph.pieces = pieces_a; ph.n_pieces = (int)(it.K/256); ph.pieces_tag_phase = pidx;
+                    ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active;
                 } else {
                     const mmvq_group & pg = pit.grp[0];
                     if (pit.nc != 1 || it.K != pg.m) return false;
-                    pr.fin_k = (int) it.K; pr.fin_kind = kind; pr.fin_off_d = ph.off_d; pr.fin_off_bs = ph.off_bs;
-                    pr.fin_img = (char *) c->mega_img[cur];
-                    if (it.in.mode == PRO_NORM) {          // residual stream -> RMS_NORM * w -> quantize -> this mat-vec
+                    if (it.in.mode == PRO_NORM) {          // residual stream -> RMS_NORM * w -> quantize, in every consumer workgroup
                         if (it.in.x != pg.dst || pg.epi == EPI_GLU || it.K > 8192) return false;
-                        pr.fin_mode = MFIN_NORM; pr.fin_x = it.in.x; pr.fin_norm_w = it.in.norm_w; pr.fin_eps = it.in.eps; pr.fin_norm_out = it.norm_out;
-                        pr.arrive = as_ptr(prog.size());   // (the producer's own index + 1)
-                        ph.wait = pr.signal; ph.wait_target = 1;
-                    } else if (it.in.mode == PRO_QUANT && pg.epi == EPI_GLU) {      // gate/up/SwiGLU -> quantize -> down
-                        const int nwg = pr.n_active;
-                        if (it.in.x != pg.dst || pg.m % 256 != 0 || nwg % 32 != 0 || pg.m/256 > MEGA_CHUNK_WORDS || (pg.m + nwg*8 - 1)/(nwg*8) > 63) return false;
-                        pr.fin_mode = MFIN_CHUNK;
-                        pr.arrive = as_ptr((size_t) 0x10000 + (size_t) n_chunk_phases); n_chunk_phases++;
-                        ph.wait = pr.signal; ph.wait_target = (unsigned)(pg.m/256);
+                        pr.g[0].gran = x_gran[xi]; gran_of_ptr[xi] = pg.dst; xi = (xi + 1) % 3;
+                        ph.in_mode = MIN_NORM_GRAN; ph.x_gran = pr.g[0].gran; ph.in_tag_phase = pidx;
+                        ph.norm_w = it.in.norm_w; ph.eps = it.in.eps; ph.norm_out = norm_out;
+                        ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active;
+                    } else if (it.in.mode == PRO_QUANT && pg.epi == EPI_GLU && it.K <= 8192 && getenv("GGML_MI355X_MEGA_DBG_GATHER")) {      // (debugging aid)
+                        if (it.in.x != pg.dst) return false;
+                        pr.g[0].gran = act_gran;
+                        ph.in_mode = MIN_QUANT_GRAN; ph.x_gran = act_gran; ph.in_tag_phase = pidx;
+                        ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active;
+                    } else if (it.in.mode == PRO_QUANT && pg.epi == EPI_GLU) {      // gate/up/SwiGLU -> chunk owners quantize -> pieces -> down
+                        const int n_ch = pg.m/256;
+                        if (it.in.x != pg.dst || pg.m % 256 != 0 || n_ch > 128 || n_ch > ph.n_active || pg.m > 32768) return false;
+                        pr.g[0].gran = act_gran;
+                        ph.n_own = n_ch; ph.own_src = act_gran; ph.own_src_tag_phase = pidx; ph.own_wait = pr.hint; ph.own_wait_target = (unsigned) pr.n_active;
+                        ph.own_pieces = pieces_b; ph.hint2 = as_ptr((size_t) 0x10000 + self + 1);
+                        ph.in_mode = MIN_PIECES; ph.pieces = pieces_b; ph.n_pieces = n_ch; ph.pieces_tag_phase = self;
+                        ph.wait = ph.hint2; ph.wait_target = (unsigned) n_ch;
                     } else return false;
                 }
             }
-            ph.signal = as_ptr(prog.size() + 1);
-            ph.fin_mode = MFIN_NONE;
             prog.push_back(ph);
-            cur ^= 1;                  // what this phase (its finaliser, or the attention phase behind it) produces goes to the other image
         } else {
-            // attention: reads q / the KV cache the previous phase (QKV) wrote, writes the image wo reads
+            // attention: reads q / k / v granules of the previous phase (QKV) + the cache of older cells, publishes the pieces wo reads
             if (j == 0 || rec[j - 1].kind != 0) return false;
+            static const bool no_attn = getenv("GGML_MI355X_MEGA_NOATTN") != nullptr;      // (debugging aid: runs with attention stay on the launch path)
+            if (no_attn) return false;
             const auto & a = it.at;
+            const auto & pit = rec[j - 1];
             if (a.T != 1 || a.hd != 128 || !a.v_trans || a.sinks || a.n_head % 2 != 0 || a.n_head % a.n_head_kv != 0 || a.n_kv % 8 != 0 || (a.n_head/2) > n_cu) return false;
-            if (a.k_nb1 % 16 || a.k_nb2 % 16 || a.v_nb1 % 16 || a.v_nb2 % 16 || ((uintptr_t) a.q % 16) || a.q_nb2 % 16 || ((uintptr_t) a.k % 16) || ((uintptr_t) a.v % 16)) return false;
-            const size_t lds = ((size_t) 2*((a.n_kv + 3) & ~(int64_t) 3) + 16 + 256)*4;
+            const int64_t gqa = a.n_head/a.n_head_kv;
+            if (gqa != 1 && gqa % 2 != 0) return false;
+            if (a.hd*a.n_head > 8192 || a.hd*a.n_head_kv > 8192) return false;
+            if (a.k_nb1 % 16 || a.k_nb2 % 16 || a.v_nb1 % 16 || a.v_nb2 % 16 || ((uintptr_t) a.k % 16) || ((uintptr_t) a.v % 16)) return false;
+            const size_t lds = ((size_t) 2*((a.n_kv + 3) & ~(int64_t) 3) + 16 + 1024)*4;
             if (lds > 60*1024) return false;
             lds_bytes = std::max(lds_bytes, lds);
-            bool q_found = false;
-            for (int q = 0; q < rec[j - 1].nc; q++) if ((const void *) rec[j - 1].grp[q].dst == a.q) q_found = true;
-            if (!q_found) return false;
             mega_phase & pr = prog.back();
-            pr.fin_mode = MFIN_NONE;
+            // the QKV phase's groups: q = the rope output attention reads; k = the group that stores K rows; v = the one that scatters into the V cache
+            int qg = -1, kg = -1, vg = -1;
+            for (int q = 0; q < pit.nc; q++) {
+                if ((const void *) pit.grp[q].dst == a.q) qg = q;
+                else if (pit.grp[q].st_mode == 1) kg = q;
+                else if (pit.grp[q].st_mode == 2) vg = q;
+            }
+            if (qg < 0 || kg < 0 || vg < 0 || pit.grp[qg].m != a.hd*a.n_head || pit.grp[kg].m != a.hd*a.n_head_kv || pit.grp[vg].m != a.hd*a.n_head_kv) return false;
+            if (a.q_nb2 != (size_t) a.hd*4) return false;                      // q rows of head h at h*hd
+            // the cache rows K / V are written to must be the cache attention reads
+            pr.g[qg].gran = q_gran; pr.g[kg].gran = k_gran; pr.g[vg].gran = v_gran;
             ph.kind = MEGA_ATTN; ph.n_active = (int)(a.n_head/2);
-            ph.wait = pr.signal; ph.wait_target = (unsigned) pr.n_active;
-            ph.q = (const char *) a.q; ph.q_nb2 = a.q_nb2; ph.kc = (const char *) a.k; ph.k_nb1 = a.k_nb1; ph.k_nb2 = a.k_nb2;
-            ph.vc = (const char *) a.v; ph.v_nb1 = a.v_nb1; ph.v_nb2 = a.v_nb2; ph.mask = (const char *) a.mask; ph.mask_f16 = a.mask_f16 ? 1 : 0;
+            ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active; ph.in_tag_phase = (int) prog.size() - 1;
+            ph.q_gran = q_gran; ph.k_gran = k_gran; ph.v_gran = v_gran;
+            ph.kc = (const char *) a.k; ph.k_nb1 = a.k_nb1; ph.k_nb2 = a.k_nb2; ph.vc = (const char *) a.v; ph.v_nb1 = a.v_nb1; ph.v_nb2 = a.v_nb2;
+            ph.cell_idx = pit.grp[kg].st_idx;
+            ph.mask = (const char *) a.mask; ph.mask_f16 = a.mask_f16 ? 1 : 0;
             ph.attn_dst = a.dst; ph.scale = a.scale; ph.n_kv = (int) a.n_kv; ph.n_head = (int) a.n_head; ph.n_head_kv = (int) a.n_head_kv; ph.head_dim = (int) a.hd;
-            ph.fin_kind = T_Q8_K; ph.fin_img = (char *) c->mega_img[cur];
-            mega_image_layout(T_Q8_K, a.hd*a.n_head, ph.fin_off_d, ph.fin_off_bs, ph.act_chunks);
-            ph.signal = as_ptr(prog.size() + 1);
+            ph.own_pieces = pieces_a;
             prog.push_back(ph);
         }
     }
-    // the last phase signals nobody
-    prog.back().signal = nullptr;
+    prog.back().hint = nullptr;        // nobody waits for the last phase
     return true;
 }
 
 static void rec_flush(mi_backend_ctx * c) {
     if (c->rec.empty()) return;
-    std::vector<mega_phase> prog; size_t lds = 0; int n_chunk = 0;
-    bool ok = c->use_mega && c->mega_err && build_mega_program(c, prog, lds, n_chunk);
+    // (debugging aid) GGML_MI355X_MEGA_DBG_NOLAST: the last recorded launch stays a launch of its own
+    static const bool dbg_nolast = getenv("GGML_MI355X_MEGA_DBG_NOLAST") != nullptr;
+    if (dbg_nolast && c->rec.size() >= 3) {
+        const mi_backend_ctx::rec_item last = c->rec.back();
+        c->rec.pop_back();
+        rec_flush(c);
+        launch_rec_item(c, last);
+        return;
+    }
+    std::vector<mega_phase> prog; size_t lds = 0;
+    bool ok = c->use_mega && c->mega_err && build_mega_program(c, prog, lds);
     static const bool dbg = getenv("GGML_MI355X_MEGA_DEBUG") != nullptr;
     if (dbg) fprintf(stderr, "ggml-mi355x: recorded run of %d launches -> %s (%d phases, %zu B LDS)%s\n", (int) c->rec.size(), ok ? "persistent kernel" : "separate launches",
                      (int) prog.size(), lds, c->capturing ? " [capture]" : "");
     void * prog_dev = nullptr; unsigned * ws = nullptr;
     const size_t prog_bytes = prog.size()*sizeof(mega_phase);
-    const size_t ws_words = prog.size()*MEGA_SIG_WORDS + (size_t) n_chunk*MEGA_CHUNK_WORDS;
+    const size_t ws_words = prog.size()*MEGA_SIG_WORDS;
+    const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*MEGA_SIG_WORDS*4;
     if (ok) {
         if (c->capturing) {       // a captured graph owns its tables and signal words: carved from buffers allocated before the capture began
-            const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*(MEGA_SIG_WORDS + MEGA_CHUNK_WORDS)*4;
             if (c->cap_entry->owned_dev.size() != 2 || c->cap_prog_used + prog_bytes > pcap || c->cap_ws_used + ws_words*4 > wcap) ok = false;
             else {
                 prog_dev = (char *) c->cap_entry->owned_dev[0] + c->cap_prog_used; ws = (unsigned *) ((char *) c->cap_entry->owned_dev[1] + c->cap_ws_used);
@@ -786,8 +819,7 @@ static void rec_flush(mi_backend_ctx * c) {
             }
         } else {
             if (!c->mega_prog_dev) {
-                const size_t cap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*(MEGA_SIG_WORDS + MEGA_CHUNK_WORDS)*4;
-                if (hipMalloc(&c->mega_prog_dev, cap) != hipSuccess || hipHostMalloc(&c->mega_prog_host, cap, hipHostMallocDefault) != hipSuccess ||
+                if (hipMalloc(&c->mega_prog_dev, pcap) != hipSuccess || hipHostMalloc(&c->mega_prog_host, pcap, hipHostMallocDefault) != hipSuccess ||
                     hipMalloc((void **) &c->mega_ws, wcap) != hipSuccess) { (void) hipGetLastError(); ok = false; }
             }
             prog_dev = c->mega_prog_dev; ws = c->mega_ws;
@@ -798,20 +830,15 @@ static void rec_flush(mi_backend_ctx * c) {
         c->rec.clear();
         return;
     }
-    // patch the signalling indices into addresses
-    auto fix = [&](unsigned * & p) {
+    // patch the signalling indices into addresses: a phase's hint = its first counter, hint2 = its second
+    auto fix = [&](unsigned * p) -> unsigned * {
         const size_t v = (size_t) p;
-        if (v == 0) return;
-        if (v >= 0x10000) p = ws + prog.size()*MEGA_SIG_WORDS + (v - 0x10000)*MEGA_CHUNK_WORDS;
-        else p = ws + (v - 1)*MEGA_SIG_WORDS + 4;      // a phase's signal word
+        if (v == 0) return nullptr;
+        if (v >= 0x10000) return ws + (v - 0x10000 - 1)*MEGA_SIG_WORDS + 128;
+        return ws + (v - 1)*MEGA_SIG_WORDS;
     };
-    for (size_t i = 0; i < prog.size(); i++) {
-        mega_phase & ph = prog[i];
-        { unsigned * w = (unsigned *) ph.wait; fix(w); ph.wait = w; }
-        fix(ph.signal);
-        if (ph.fin_mode == MFIN_NORM && ph.kind == MEGA_MM) ph.arrive = ws + i*MEGA_SIG_WORDS;      // its own arrival counter
-        else if (ph.fin_mode == MFIN_CHUNK) fix(ph.arrive);
-        else ph.arrive = nullptr;
+    for (auto & ph : prog) {
+        ph.wait = fix((unsigned *) ph.wait); ph.hint = fix(ph.hint); ph.hint2 = fix(ph.hint2); ph.own_wait = fix((unsigned *) ph.own_wait);
     }
     if (c->capturing) {
         mi_backend_ctx::pending_upload up; up.dev = prog_dev; up.host.assign((const char *) prog.data(), (const char *) prog.data() + prog_bytes);
@@ -824,7 +851,7 @@ static void rec_flush(mi_backend_ctx * c) {
     MI_CHECK(hipMemsetAsync(ws, 0, ws_words*4, c->stream));
     unsigned * err_dev = nullptr;
     MI_CHECK(hipHostGetDevicePointer((void **) &err_dev, c->mega_err, 0));
-    mega_launch((const mega_phase *) prog_dev, (int) prog.size(), mega_max_workgroups(), err_dev, lds, c->stream);
+    mega_launch((const mega_phase *) prog_dev, (int) prog.size(), mega_max_workgroups(), c->mega_epoch, err_dev, lds, c->stream);
     c->cnt.kernels_launched += 2;
     c->rec.clear();
 }
@@ -1782,9 +1809,13 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
     }
     if (!c->mega_err && c->use_mega) {     // persistent decode: images, the error word (host-mapped)
-        bool ok = hipMalloc(&c->mega_img[0], mi_backend_ctx::MEGA_IMG_BYTES) == hipSuccess && hipMalloc(&c->mega_img[1], mi_backend_ctx::MEGA_IMG_BYTES) == hipSuccess;
+        const size_t gran_bytes = ((size_t) 6*8192 + 32768 + 2*128*MEGA_PIECE_WORDS)*8;
+        bool ok = hipMalloc(&c->mega_gran, gran_bytes) == hipSuccess && hipMalloc((void **) &c->mega_epoch, 256) == hipSuccess;
         ok = ok && hipHostMalloc((void **) &c->mega_err, 64, hipHostMallocMapped) == hipSuccess;
-        if (ok) { c->mega_err[0] = 0; }
+        if (ok) {
+            c->mega_err[0] = 0;
+            MI_CHECK(hipMemsetAsync(c->mega_gran, 0, gran_bytes, c->stream)); MI_CHECK(hipMemsetAsync(c->mega_epoch, 0, 256, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream));
+        }
         else { (void) hipGetLastError(); c->use_mega = false; }
     }
     if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
@@ -1823,7 +1854,7 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
             hipGraph_t graph = nullptr;
             if (c->use_mega && c->mega_err && e.owned_dev.empty()) {       // room for the persistent-decode programs of this graph (no allocation inside a capture)
                 void * pd = nullptr; void * wd = nullptr;
-                const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*(MEGA_SIG_WORDS + MEGA_CHUNK_WORDS)*4;
+                const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*MEGA_SIG_WORDS*4;
                 if (hipMalloc(&pd, pcap) == hipSuccess && hipMalloc(&wd, wcap) == hipSuccess) { e.owned_dev.push_back(pd); e.owned_dev.push_back(wd); }
                 else { (void) hipGetLastError(); if (pd) (void) hipFree(pd); }
             }

@@ -30,5 +30,7 @@ for mode in (0, 1):
     out[mode] = np.stack(res)
     print(f"mega={mode}: {n_tok/dt:.1f} tok/s, kernels/token {be.counters()['kernels_launched'] if hasattr(be, 'counters') else '?'}", flush=True)
 d = np.abs(out[0] - out[1])
+bad = d > 1e-3*np.abs(out[0]).max()
+print("tokens with differences:", [int(i) for i in np.nonzero(bad.any(axis=1))[0]], "fraction of logits off per token:", [round(float(b.mean()), 3) for b in bad])
 print("finite:", np.isfinite(out[1]).all(), "max|diff|", float(d.max()), "max|ref|", float(np.abs(out[0]).max()), "bitwise equal:", bool((out[0] == out[1]).all()))
 m.free(); be.free()

@@ -44,6 +44,13 @@ for p in range(min(P, 14)):
     print(f"{p:4d} {a.sum():4d} {med(0):9.2f} {med(1)-med(0):7.2f} {med(2)-med(0):9.2f} {med(3)-med(0):7.2f}   {np.nanmin(e[:,4])-med(0):6.2f}/{med(4)-med(0):6.2f}/{np.nanmax(e[:,4])-med(0):6.2f}   "
           f"{med(5)-med(0):7.2f}/{np.nanmax(e[:,5])-med(0):7.2f}   {np.nanmax(e[:,5]) - prev:7.2f}")
     prev = np.nanmax(e[:, 5])
+# the chunk owners of the down phases (stamps 6: previous phase hinted complete, 7: piece published), relative to the phase's median entry
+for p in range(min(P, 14)):
+    a = us[p, :, 6]
+    if (~np.isnan(a)).any():
+        e0 = np.nanmedian(us[p, :, 0])
+        print(f"phase {p}: owners: prev-phase-complete seen {np.nanmin(a)-e0:.2f}/{np.nanmedian(a)-e0:.2f}/{np.nanmax(a)-e0:.2f}  piece published {np.nanmin(us[p,:,7])-e0:.2f}/{np.nanmedian(us[p,:,7])-e0:.2f}/{np.nanmax(us[p,:,7])-e0:.2f}"
+              f"  consumers hinted {np.nanmin(us[p,:,2])-e0:.2f}/{np.nanmedian(us[p,:,2])-e0:.2f}/{np.nanmax(us[p,:,2])-e0:.2f}; prev phase rows done max {np.nanmax(us[p-1,:,4])-e0:.2f} end max {np.nanmax(us[p-1,:,5])-e0:.2f}")
 # per-layer period
 ends = np.array([np.nanmax(us[p, :, 5]) if (~np.isnan(us[p, :, 5])).any() else np.nan for p in range(P)])
 print("layer period (us):", [round(float(ends[1 + 5*(l+1)] - ends[1 + 5*l]), 2) for l in range(0, min(6, (P - 2)//5 - 1))])
