@@ -285,7 +285,9 @@ struct mi_backend_ctx {
                  bool mask_f16; const float * sinks; float * dst; size_t dst_nb1; int64_t hd, n_kv, n_head, n_head_kv, T; float scale; bool v_trans; } at;
     };
     std::vector<rec_item> rec;
-    bool use_mega = true, rec_on = false, capturing = false;
+    // opt-in (GGML_MI355X_MEGA=1 / option "mega"): bit-identical to the launch path, but at the end of round 2 still slower than it
+    // (every hand-off hop costs ~2 us beside streaming CUs and a layer has nine of them)
+    bool use_mega = false, rec_on = false, capturing = false;
     void * mega_gran = nullptr; unsigned * mega_epoch = nullptr;      // hand-off granules (decode_mega.h) and the launch counter their tags derive from
     unsigned * mega_err = nullptr;                   // host-mapped word: a bounded wait inside the kernel gave up
     void * mega_prog_dev = nullptr; void * mega_prog_host = nullptr; unsigned * mega_ws = nullptr;    // eager runs (captured graphs own theirs)
@@ -721,7 +723,7 @@ static bool build_mega_program(mi_backend_ctx * c, std::vector<mega_phase> & pro
                 if (pit.kind == 1) {                       // attention -> pieces -> this mat-vec (wo)
                     if (it.in.mode != PRO_QUANT || it.in.x != pit.at.dst || it.K != pit.at.hd*pit.at.n_head) return false;
                     ph.in_mode = MIN_PIECES; ph.pieces = pieces_a; ph.n_pieces = (int)(it.K/256); ph.pieces_tag_phase = pidx;
-                    ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active;
+                    ph.wait = nullptr;      // no hint hop: the pieces are 10 KB, the consumers poll by the data
                 } else {
                     const mmvq_group & pg = pit.grp[0];
                     if (pit.nc != 1 || it.K != pg.m) return false;

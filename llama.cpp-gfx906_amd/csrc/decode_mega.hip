@@ -58,17 +58,32 @@ static __device__ __forceinline__ void mega_give_up(unsigned * err, unsigned cod
 static __device__ __forceinline__ void mega_hint_add(unsigned * hint) {
     if (hint) __hip_atomic_fetch_add(hint + ((unsigned) blockIdx.x & 7u)*16u, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// Four polls are kept in flight, issued ~0.15 us apart: a poll's round trip is ~1 us beside streaming CUs, and one poll at a time sees a
+// change 1.5 round trips late on average (2-3 us per hop measured, tools/mega_stamps.py).
+static __device__ __forceinline__ unsigned mega_hint_ld(const unsigned * ptr, int lane) {
+    return lane < 8 ? __hip_atomic_load(ptr + lane*16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+}
+static __device__ __forceinline__ bool mega_hint_done(unsigned v, unsigned target) {
+    return (int)((unsigned) __builtin_amdgcn_readfirstlane(group8_sum_i((int) v)) - target) >= 0;
+}
 static __device__ __forceinline__ void mega_hint_wait(const unsigned * ptr, unsigned target, unsigned * err, int lane) {
     if (!ptr) return;
-    int spins = 0;
-    for (;;) {
-        const unsigned v = lane < 8 ? __hip_atomic_load(ptr + lane*16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-        const unsigned tot = (unsigned) __builtin_amdgcn_readfirstlane(group8_sum_i((int) v));
-        if ((int)(tot - target) >= 0) return;
-        __builtin_amdgcn_s_sleep(2);
-        if ((++spins & 1023) == 0) {
+    unsigned v0 = mega_hint_ld(ptr, lane); __builtin_amdgcn_s_sleep(6);
+    unsigned v1 = mega_hint_ld(ptr, lane); __builtin_amdgcn_s_sleep(6);
+    unsigned v2 = mega_hint_ld(ptr, lane); __builtin_amdgcn_s_sleep(6);
+    unsigned v3 = mega_hint_ld(ptr, lane);
+    for (int spins = 0;; spins++) {
+        if (mega_hint_done(v0, target)) return;
+        v0 = mega_hint_ld(ptr, lane); __builtin_amdgcn_s_sleep(6);
+        if (mega_hint_done(v1, target)) return;
+        v1 = mega_hint_ld(ptr, lane); __builtin_amdgcn_s_sleep(6);
+        if (mega_hint_done(v2, target)) return;
+        v2 = mega_hint_ld(ptr, lane); __builtin_amdgcn_s_sleep(6);
+        if (mega_hint_done(v3, target)) return;
+        v3 = mega_hint_ld(ptr, lane); __builtin_amdgcn_s_sleep(6);
+        if ((spins & 255) == 255) {
             if (mega_gave_up(err)) return;      // somebody gave up: do not add a second timeout to it
-            if (spins >= MEGA_SPIN_LIMIT) { mega_give_up(err, 1u); return; }
+            if (spins >= (MEGA_SPIN_LIMIT >> 2)) { mega_give_up(err, 1u); return; }
         }
     }
 }
@@ -109,8 +124,7 @@ struct mega_pre { float r0, r1; long long i0, i1; float ff; };
 // ---- chunk owner (wave 0 of workgroup j < n_own, before the phase's own wait): chunk j of the previous phase's output -> piece ----
 static __device__ __forceinline__ void mega_own_chunk(const mega_phase & ph, uint32_t tag_base, int phase_index, int lane, unsigned * err MG_STAMP_ARGS) {
     const int c = (int) blockIdx.x;
-    mega_hint_wait(ph.own_wait, ph.own_wait_target, err, lane);
-    MG_STAMP(6);
+    MG_STAMP(6);        // (no hint hop: an owner's sweep is 2 KB; it polls by the data itself)
     const uint32_t src_tag = tag_base + (uint32_t) ph.own_src_tag_phase + 1u;
     const mg_rsrc rs = mg_make_rsrc(ph.own_src);
     const unsigned off = (unsigned)(c*256 + lane*4)*8u;
@@ -403,9 +417,7 @@ static __device__ __forceinline__ void mega_attn(const mega_phase & ph, char * s
     constexpr int LPC = HD/8, CPW = 64/LPC, U = 4;
     const int sub = lane % LPC, cw = lane / LPC;
 
-    if (tid < 64) mega_hint_wait(ph.wait, ph.wait_target, err, tid);
-    __syncthreads();
-    MG_STAMP(2);
+    MG_STAMP(2);        // (no hint hop: 16 workgroups sweep 4 KB each; they poll by the data itself)
 
     // ---- q (2 x 128) and the new cell's k, v (128 each per local head) ----
     {
