@@ -117,6 +117,64 @@ template <> struct mmvq_t<T_Q5_K> {
 };
 
 // ---- Q6_K ---------------------------------------------------------------------------------------
+// Four lanes per 210-byte block (round 2; MI_Q6K_LPB8 keeps round 1's eight): lane slot j: half n = j>>1 (128 elements each), l0 = 16*(j&1):
+// the lane owns l = l0..l0+15 of that half, i.e. elements 128n + {0,32,64,96} + l (quants.py:554-572): ql[64n+l] lo/hi nibble,
+// ql[64n+32+l] lo/hi nibble, qh[32n+l] 2-bit fields — three 16-byte loads + the scales + d per lane, half the load instructions per byte
+// of the eight-lane split (whose 8-byte loads kept the CU's address unit busy: the workgroups of a Q6_K group ran every phase of the
+// norm+QKV launch ~1.7x slower than their Q4_K neighbours, tools/stamp_timeline.py).
+#ifndef MI_Q6K_LPB8
+template <> struct mmvq_t<T_Q6_K> {
+    static constexpr int LPB = 4, BLOCK_BYTES = 210, QK = 256, ACT = T_Q8_K;
+    struct afrag { int4v a[4]; int s[4]; float d8; };   // s[i] = sum of the 16 int8 of a[i] (for the -32 offset)
+    struct wfrag { int4v qla, qlb, qh; int2v sc; uint32_t d; };
+    static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int slot) {
+        const int n = slot >> 1, l0 = 16*(slot & 1);
+        afrag f;
+        const int8_t * p = a.qs + ib*256 + 128*n + l0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            f.a[i] = lds_or_global_b128(p + 32*i);
+            f.s[i] = dot4(0x01010101, f.a[i].x, dot4(0x01010101, f.a[i].y, dot4(0x01010101, f.a[i].z, dot4(0x01010101, f.a[i].w, 0))));
+        }
+        f.d8 = a.d[ib];
+        return f;
+    }
+    static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int slot) {
+        const int n = slot >> 1, l0 = 16*(slot & 1);
+        const char * b = row + ib*BLOCK_BYTES;   // only 2-byte aligned: unaligned-mode global loads
+        wfrag w;
+        w.qla = ld_b128(b + 64*n + l0);
+        w.qlb = ld_b128(b + 64*n + 32 + l0);
+        w.qh  = ld_b128(b + 128 + 32*n + l0);
+        w.sc  = ld_b64(b + 192 + 8*n);           // scales[8n .. 8n+7]
+        w.d   = ld_u16(b + 208);
+        return w;
+    }
+    static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int slot) {
+        const int is = slot & 1;                 // l0/16
+        // the four scales this lane needs are bytes is, is+2, is+4, is+6 of sc
+        const uint32_t sx = (uint32_t) w.sc.x >> (8*is), sy = (uint32_t) w.sc.y >> (8*is);
+        const int sc0 = (int8_t)(sx & 0xFF), sc1 = (int8_t)((sx >> 16) & 0xFF), sc2 = (int8_t)(sy & 0xFF), sc3 = (int8_t)((sy >> 16) & 0xFF);
+        int acc[4];
+#define MI_Q6(c, A0, A1, A2, A3) { \
+        const uint32_t qa = (uint32_t) w.qla.c, qb = (uint32_t) w.qlb.c, qh = (uint32_t) w.qh.c; \
+        const int v0 = (int)((qa & 0x0F0F0F0F)        | ((qh << 4) & 0x30303030)); \
+        const int v1 = (int)((qb & 0x0F0F0F0F)        | ((qh << 2) & 0x30303030)); \
+        const int v2 = (int)(((qa >> 4) & 0x0F0F0F0F) | ( qh       & 0x30303030)); \
+        const int v3 = (int)(((qb >> 4) & 0x0F0F0F0F) | ((qh >> 2) & 0x30303030)); \
+        A0 = dot4(v0, a.a[0].c, A0); A1 = dot4(v1, a.a[1].c, A1); A2 = dot4(v2, a.a[2].c, A2); A3 = dot4(v3, a.a[3].c, A3); }
+        acc[0] = acc[1] = acc[2] = acc[3] = 0;
+        MI_Q6(x, acc[0], acc[1], acc[2], acc[3])
+        MI_Q6(y, acc[0], acc[1], acc[2], acc[3])
+        MI_Q6(z, acc[0], acc[1], acc[2], acc[3])
+        MI_Q6(w, acc[0], acc[1], acc[2], acc[3])
+#undef MI_Q6
+        // sum (q-32)*a = sum q*a - 32*sum a
+        const int isum = sc0*(acc[0] - 32*a.s[0]) + sc1*(acc[1] - 32*a.s[1]) + sc2*(acc[2] - 32*a.s[2]) + sc3*(acc[3] - 32*a.s[3]);
+        return (f16_bits_to_f32((uint16_t) w.d)*a.d8)*(float) isum;
+    }
+};
+#else
 // lane slot j: half n = j>>2 (128 elements each), l0 = 8*(j&3): the lane owns l = l0..l0+7 of that half, i.e.
 // elements 128n + {0,32,64,96} + l (quants.py:554-572): ql[64n+l] lo/hi nibble, ql[64n+32+l] lo/hi nibble,
 // qh[32n+l] 2-bit fields. 24 bytes of quants per lane.
@@ -176,6 +234,7 @@ template <> struct mmvq_t<T_Q6_K> {
         return (f16_bits_to_f32((uint16_t) w.d)*a.d8)*(float) isum;
     }
 };
+#endif
 
 // ---- Q8_0 ---------------------------------------------------------------------------------------
 template <> struct mmvq_t<T_Q8_0> {

@@ -218,6 +218,55 @@ static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const f
     }
 }
 
+// ---- batched finish of the dual GLU stream (round 2). The kernels are bound by instruction issue, not by HBM (ISA count: ~690 instructions per
+// k-step in the gate/up loop; 22 GB/s per CU is what four SIMDs issue), and for k = 4096 almost half of them were the per-row finish — two
+// full-wave reductions, expf, a division, address arithmetic — repeated for each of a wave's 7 rows. Now a wave keeps the lane-partial sums of
+// its finished rows (8 gate + 8 up registers), and reduces all 16 together: v_permlane32_swap / v_permlane16_swap fold two (then four) rows
+// into one register, so that after 40 instructions four registers hold the 16 totals, four rows (16 lanes each) per register; silu(gate)*up
+// then runs once per register instead of once per row, and the first lane of each 16-lane row stores its row.
+// Summation order per row: lane i + lane i+32, then + the other 16-lane half, then the 16 lanes (DPP) — every partial sum is still f32.
+typedef unsigned mi_u2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ float mi_fold32(float a, float b) {      // lanes 0-31: a summed over its halves; lanes 32-63: b likewise
+    const mi_u2 r = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+static __device__ __forceinline__ float mi_fold16(float a, float b) {      // 16-lane rows 0..3: a.row0+a.row1, b.row0+b.row1, a.row2+a.row3, b.row2+b.row3
+    const mi_u2 r = __builtin_amdgcn_permlane16_swap(__builtin_bit_cast(unsigned, a), __builtin_bit_cast(unsigned, b), false, false);
+    const unsigned r0 = r.x, r1 = r.y;
+    return __builtin_bit_cast(float, r0) + __builtin_bit_cast(float, r1);
+}
+// hg / hu: lane-partial sums of the last `nh` (<= 8) finished rows, entry 0 the most recent = row p_last, entry e = row p_last - e*u_step
+static __device__ __forceinline__ void glu_flush8(const float (&hg)[8], const float (&hu)[8], int nh, int p_last, int u_step, const mmvq_group & g,
+                                                  int g_m, int eid0, bool sc1_store, int lane) {
+    float tg[2], tu[2];
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        // register m: 16-lane rows 0..3 = entries 4m + {0, 2, 1, 3}
+        tg[m] = row16_sum(mi_fold16(mi_fold32(hg[4*m], hg[4*m + 1]), mi_fold32(hg[4*m + 2], hg[4*m + 3])));
+        tu[m] = row16_sum(mi_fold16(mi_fold32(hu[4*m], hu[4*m + 1]), mi_fold32(hu[4*m + 2], hu[4*m + 3])));
+    }
+    const int r = lane >> 4, perm = (r == 1) ? 2 : ((r == 2) ? 1 : r);
+#pragma unroll
+    for (int m = 0; m < 2; m++) {
+        const int e = 4*m + perm;
+        const int row = p_last - e*u_step;
+        const bool live = e < nh && (lane & 15) == 0;
+        float s0 = tg[m], up_s = tu[m];
+        if (g.b_gate) {     // + bias rows of this group's expert (ADD_ID)
+            const size_t brow = (size_t) eid0*g_m + (live ? row : 0);
+            s0 += g.b_gate[brow]; up_s += g.b_up[brow];
+        }
+        if (g.glu_alpha != 0.0f) {      // swiglu_oai, as elem.hip k_glu
+            const float xc = fminf(s0, g.glu_limit), gc = fmaxf(fminf(up_s, g.glu_limit), -g.glu_limit);
+            s0 = (xc/(1.0f + expf(-xc*g.glu_alpha)))*(gc + 1.0f);
+        } else {
+            s0 = (s0/(1.0f + expf(-s0)))*up_s;      // silu(gate)*up, as elem.hip k_glu
+        }
+        if (live) { if (sc1_store) st_f32_sc1(g.dst + row, s0); else g.dst[row] = s0; }
+    }
+}
+
 //   PRO  : where the activation comes from (mmvq_prologue)
 //   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*256*waves)
 //   D    : ring depth (2; 4 for the one-row GLU units and for long single-tensor streams)
@@ -375,6 +424,9 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     const int total = n_mine*iters;
     int it = 0;
     float acc[2] = { 0.0f, 0.0f }, acu[2] = { 0.0f, 0.0f };
+    float hg[GLU ? 8 : 1], hu[GLU ? 8 : 1]; int nh = 0;      // the dual GLU stream: lane-partial sums of finished rows, reduced eight at a time (glu_flush8)
+#pragma unroll
+    for (int q = 0; q < (GLU ? 8 : 1); q++) { hg[q] = 0.0f; hu[q] = 0.0f; }
 #ifdef MI_STAMPS
     bool first_pair = true;
 #endif
@@ -393,22 +445,15 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
 #ifdef MI_STAMPS
                     if (first_pair) { MI_STAMP(2); first_pair = false; }
 #endif
-                    float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
                     if (GLU) {
-                        float up_s = wave_sum(acu[0]);
-                        if (g.b_gate) {     // + bias rows of this group's expert (ADD_ID), wave-uniform addresses
-                            const size_t brow = (size_t) eid0*g_m + p_cur;
-                            s0 += g.b_gate[brow]; up_s += g.b_up[brow];
-                        }
-                        if (g.glu_alpha != 0.0f) {      // swiglu_oai, as elem.hip k_glu
-                            const float xc = fminf(s0, g.glu_limit), gc = fmaxf(fminf(up_s, g.glu_limit), -g.glu_limit);
-                            s0 = (xc/(1.0f + expf(-xc*g.glu_alpha)))*(gc + 1.0f);
-                        } else {
-                            s0 = (s0/(1.0f + expf(-s0)))*up_s;      // silu(gate)*up, as elem.hip k_glu
-                        }
+#pragma unroll
+                        for (int q = 7; q > 0; q--) { hg[GLU ? q : 0] = hg[GLU ? q - 1 : 0]; hu[GLU ? q : 0] = hu[GLU ? q - 1 : 0]; }
+                        hg[0] = acc[0]; hu[0] = acu[0];
+                        if (++nh == 8) { glu_flush8((const float (&)[8]) hg, (const float (&)[8]) hu, 8, p_cur, u_step, g, g_m, eid0, fin_on, lane); nh = 0; }
+                    } else {
+                        const float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
+                        if (lane == 0) finish_pair(g, p.rope, s0, s1, p_cur*R, pos0, idx0, epre, g_m, R);
                     }
-                    if (GLU && fin_on) { if (lane == 0) st_f32_sc1(g.dst + p_cur, s0); }      // handed to the workgroup that quantizes the chunk
-                    else if (lane == 0) finish_pair(g, p.rope, s0, s1, p_cur*R, pos0, idx0, epre, g_m, R);
                     it = 0; p_cur += u_step;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
                     if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, p_cur*R, R);     // the next pair's epilogue operands
@@ -416,6 +461,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
             }
         }
     }
+    if (GLU && nh > 0) glu_flush8((const float (&)[8]) hg, (const float (&)[8]) hu, nh, p_cur - u_step, u_step, g, g_m, eid0, fin_on, lane);
     if (GLU && fin_on) {
         // ---- producer-side activation quantization (round 2): the mat-vec that reads this launch's output next needs it as int8 blocks
         // (Q8_K / Q8_0, 256-element chunks). Instead of every one of its 256 workgroups quantizing all of it again in its prologue
