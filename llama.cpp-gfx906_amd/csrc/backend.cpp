@@ -37,6 +37,13 @@ using namespace mi355x;
 
 #define MI_LOG(...) do { fprintf(stderr, "ggml-mi355x: " __VA_ARGS__); } while (0)
 
+// On the graph path (be_graph_compute and what it calls) a HIP error is not fatal: it unwinds to be_graph_compute, which ends a capture in
+// progress and returns GGML_STATUS_FAILED — llama_context::decode maps that and rolls the KV cells of the batch back
+// (src/llama-context.cpp:1078-1107). Everywhere else (buffer and device entry points, which have no status to return) MI_CHECK aborts.
+struct mi_graph_error { hipError_t err; const char * file; int line; };
+#define MI_CHECK_G(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) throw mi_graph_error{ e_, __FILE__, __LINE__ }; } while (0)
+#define MI_REQUIRE_G(cond) do { if (!(cond)) throw mi_graph_error{ hipErrorInvalidValue, __FILE__, __LINE__ }; } while (0)
+
 static constexpr size_t MI_BUFFER_ALIGN = 128;
 static constexpr size_t MI_TENSOR_PAD   = 256;   // readable slack after quantized tensors (wave-wide 16 B loads may run past the last block)
 
@@ -233,7 +240,7 @@ struct node_sig {
     const void * node; const void * data;
     int32_t op, type;
     int64_t ne[4]; size_t nb[3];
-    const void * src_data[4]; int64_t src_ne1[2];
+    const void * src_data[GGML_MAX_SRC]; uint32_t src_hash[GGML_MAX_SRC];      // every source: placement + a hash of its type, shape and strides
     uint32_t params_hash; uint32_t flags;
 };
 
@@ -452,7 +459,11 @@ static bool mi_supports_op(const struct ggml_tensor * op) {
             if (s0->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
             if (s0->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1 || v->ne[0] != k->ne[0] || s0->ne[2] % k->ne[2] != 0) return false;
             if (op_f32(op, 1) != 0.0f || op_f32(op, 2) != 0.0f) return false;
-            if (mask && (mask->type != GGML_TYPE_F16 || mask->ne[2] != 1 || mask->ne[3] != 1)) return false;
+            if (mask && (mask->type != GGML_TYPE_F16 || mask->ne[2] != 1 || mask->ne[3] != 1 || mask->ne[0] != k->ne[1] || mask->ne[1] < s0->ne[1] || mask->nb[1] % 16)) return false;
+            if (op->nb[1] != (size_t) k->ne[0]*4) return false;
+            // few tokens: the whole score row in LDS, or the cell ranges through the fixed partial-result buffer (8 tokens x 128 heads x 32 ranges)
+            if (s0->ne[1] <= 8 && !attn_decode_supported(k->ne[0], k->ne[1]) &&
+                !(attn_decode_supported_split(k->ne[0], k->ne[1]) && attn_decode_part_bytes(k->ne[0], k->ne[1], s0->ne[2], s0->ne[1]) <= (size_t) 8*128*32*130*4)) return false;
             if (s0->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || s0->nb[1] % 16 || s0->nb[2] % 16 || k->nb[1] % 16 || k->nb[2] % 16 || v->nb[1] % 16 || v->nb[2] % 16) return false;
             return s0->ne[1] <= 8 ? (attn_decode_supported(k->ne[0], k->ne[1]) || attn_decode_supported_split(k->ne[0], k->ne[1])) : attn_prefill_supported(k->ne[0], k->ne[1]);
         }
@@ -846,13 +857,13 @@ static void rec_flush(mi_backend_ctx * c) {
         mi_backend_ctx::pending_upload up; up.dev = prog_dev; up.host.assign((const char *) prog.data(), (const char *) prog.data() + prog_bytes);
         c->mega_uploads.push_back(std::move(up));     // copied when the capture has ended (be_graph_compute), before the graph's first launch
     } else {
-        MI_CHECK(hipStreamSynchronize(c->stream));    // the staging copy of the previous eager run may still be in flight
+        MI_CHECK_G(hipStreamSynchronize(c->stream));    // the staging copy of the previous eager run may still be in flight
         memcpy(c->mega_prog_host, prog.data(), prog_bytes);
-        MI_CHECK(hipMemcpyAsync(prog_dev, c->mega_prog_host, prog_bytes, hipMemcpyHostToDevice, c->stream));
+        MI_CHECK_G(hipMemcpyAsync(prog_dev, c->mega_prog_host, prog_bytes, hipMemcpyHostToDevice, c->stream));
     }
-    MI_CHECK(hipMemsetAsync(ws, 0, ws_words*4, c->stream));
+    MI_CHECK_G(hipMemsetAsync(ws, 0, ws_words*4, c->stream));
     unsigned * err_dev = nullptr;
-    MI_CHECK(hipHostGetDevicePointer((void **) &err_dev, c->mega_err, 0));
+    MI_CHECK_G(hipHostGetDevicePointer((void **) &err_dev, c->mega_err, 0));
     mega_launch((const mega_phase *) prog_dev, (int) prog.size(), mega_max_workgroups(), c->mega_epoch, err_dev, lds, c->stream);
     c->cnt.kernels_launched += 2;
     c->rec.clear();
@@ -1070,7 +1081,13 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     mmvq_input in = {};
     in.act_kind = kind;
     const bool cached = c->aq.valid && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == 1 && c->aq.n_outer == 1 && c->aq.kind == kind;
-    if (norm && n_mm == n_uses(c, b) && mul_mat_vec_q_fused_prologue_supported(K, kind) && ((uintptr_t) normw->data % 16) == 0) {
+    // The norm's product is left unwritten only where nobody else can look at it: not when the view handed to graph_compute ENDS at one of
+    // its consumers (the scheduler's eval-callback cuts the graph there and the callback — tools/imatrix/imatrix.cpp:223-247 — reads the mat-mul's
+    // src1), and not for result_norm, which llama_context reads back as the embeddings without an OUTPUT flag (src/llama-context.cpp:1137-1151)
+    bool view_ends_here = false;
+    for (int q = 0; q < g->n_nodes; q++) if (g->nodes[q]->op == GGML_OP_MUL_MAT && g->nodes[q]->src[1] == b && q == g->n_nodes - 1) view_ends_here = true;
+    const bool keep_norm = norm && (view_ends_here || strncmp(b->name, "result_norm", 11) == 0 || strncmp(b->name, "result_embd", 11) == 0);
+    if (norm && !keep_norm && n_mm == n_uses(c, b) && mul_mat_vec_q_fused_prologue_supported(K, kind) && ((uintptr_t) normw->data % 16) == 0) {
         in.mode = PRO_NORM; in.x = (const float *) norm->src[0]->data; in.norm_w = (const float *) normw->data; in.eps = op_f32(norm, 0);
     } else if (norm) {
         return -1;      // the caller runs the norm (+ quantization) as its own kernel, then comes back without `norm`
@@ -1116,7 +1133,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
 static const struct ggml_tensor * prefill_mm_consumer(mi_backend_ctx * c, const struct ggml_cgraph * g, int last, const struct ggml_tensor * t) {
     static const bool on = !getenv("GGML_MI355X_PREFILL_BF16_OUT") || atoi(getenv("GGML_MI355X_PREFILL_BF16_OUT")) != 0;
     const int j = next_real(g, last);
-    if (!on || j < 0) return nullptr;
+    if (!on || j < 0 || j == g->n_nodes - 1) return nullptr;      // (a view that ends at the consumer: the eval-callback case — its src1 must exist as f32)
     const struct ggml_tensor * n = g->nodes[j];
     if (n->op != GGML_OP_MUL_MAT || n->src[1] != t || !ggml_is_quantized(n->src[0]->type) || t->type != GGML_TYPE_F32 || t->ne[1] <= MMVQ_MAX_N || t->ne[2] != 1 || t->ne[3] != 1 ||
         n->src[0]->ne[2] != 1 || n->src[0]->ne[3] != 1 || t->nb[0] != 4 || t->ne[0] % 64 != 0 || !is_internal(c, t)) return nullptr;
@@ -1613,8 +1630,10 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             const struct ggml_tensor * q = s0; const struct ggml_tensor * k = node->src[1]; const struct ggml_tensor * v = node->src[2];
             const struct ggml_tensor * mask = node->src[3]; const struct ggml_tensor * sinks = node->src[4];
             const int64_t hd = k->ne[0], n_kv = k->ne[1], T = q->ne[1];
-            GGML_ASSERT(node->nb[1] == (size_t) hd*4 && ((uintptr_t) q->data % 16) == 0 && ((uintptr_t) k->data % 16) == 0 && ((uintptr_t) v->data % 16) == 0);
-            GGML_ASSERT(!mask || (mask->ne[0] == n_kv && mask->ne[1] >= T && ((uintptr_t) mask->data % 16) == 0 && mask->nb[1] % 16 == 0));
+            // what supports_op cannot see (data alignment of the views handed in) fails the graph instead of the process
+            MI_REQUIRE_G(node->nb[1] == (size_t) hd*4 && ((uintptr_t) q->data % 16) == 0 && ((uintptr_t) k->data % 16) == 0 && ((uintptr_t) v->data % 16) == 0);
+            MI_REQUIRE_G(!mask || (mask->ne[0] == n_kv && mask->ne[1] >= T && ((uintptr_t) mask->data % 16) == 0 && mask->nb[1] % 16 == 0));
+            MI_REQUIRE_G(T > 8 || attn_decode_supported(hd, n_kv) || (c->attn_part && attn_decode_supported_split(hd, n_kv) && attn_decode_part_bytes(hd, n_kv, q->ne[2], T) <= c->attn_part_bytes));
             if (T <= 8) attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
                                     sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false,
                                     c->attn_part, c->attn_part_bytes);
@@ -1762,9 +1781,17 @@ static inline void fill_sig(node_sig & s, const struct ggml_tensor * n) {
     s.node = n; s.data = n->data; s.op = (int32_t) n->op; s.type = (int32_t) n->type;
     for (int d = 0; d < 4; d++) s.ne[d] = n->ne[d];
     for (int d = 0; d < 3; d++) s.nb[d] = n->nb[d + 1];
-    for (int j = 0; j < 4; j++) s.src_data[j] = n->src[j] ? n->src[j]->data : NULL;
-    s.src_ne1[0] = n->src[0] ? n->src[0]->ne[1] : 0;
-    s.src_ne1[1] = n->src[1] ? n->src[1]->ne[1] : 0;
+    for (int j = 0; j < GGML_MAX_SRC; j++) {
+        const struct ggml_tensor * t = n->src[j];
+        s.src_data[j] = t ? t->data : NULL;
+        uint32_t h = 2166136261u;
+        if (t) {
+            auto mix = [&](uint64_t v) { h ^= (uint32_t) v; h *= 16777619u; h ^= (uint32_t)(v >> 32); h *= 16777619u; };
+            mix((uint64_t) t->type);
+            for (int d = 0; d < 4; d++) { mix((uint64_t) t->ne[d]); mix((uint64_t) t->nb[d]); }
+        }
+        s.src_hash[j] = t ? h : 0u;
+    }
     s.params_hash = hash_params(n->op_params);
     s.flags = (uint32_t) n->flags;
 }
@@ -1789,7 +1816,7 @@ static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph *
     }
     if (best) { best->last_use = ++c->graph_tick; best->seen++; return *best; }
     if ((int) c->graphs.size() >= MI_MAX_GRAPHS) {
-        if (lru->exec) { MI_CHECK(hipStreamSynchronize(c->stream)); MI_CHECK(hipGraphExecDestroy(lru->exec)); }
+        if (lru->exec) { MI_CHECK_G(hipStreamSynchronize(c->stream)); MI_CHECK_G(hipGraphExecDestroy(lru->exec)); }
         for (void * p : lru->owned_dev) (void) hipFree(p);
         *lru = graph_entry();
         lru->sig = c->cur_sig; lru->last_use = ++c->graph_tick; lru->seen = 1;
@@ -1801,13 +1828,35 @@ static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph *
     return e;
 }
 
+static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggml_cgraph * g);
 static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgraph * g) {
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    try {
+        const enum ggml_status st = be_graph_compute_impl(backend, g);
+        // a kernel launch that failed (bad configuration, out of resources) shows up as the runtime's last error
+        const hipError_t le = hipGetLastError();
+        if (st == GGML_STATUS_SUCCESS && le != hipSuccess) { MI_LOG("graph_compute: %s (%s)\n", hipGetErrorName(le), hipGetErrorString(le)); return GGML_STATUS_FAILED; }
+        return st;
+    } catch (const mi_graph_error & e) {
+        MI_LOG("graph_compute failed: HIP error %s (%s) at %s:%d\n", hipGetErrorName(e.err), hipGetErrorString(e.err), e.file, e.line);
+        if (c->capturing) {       // leave the stream usable: end the capture, drop what was recorded
+            hipGraph_t graph = nullptr;
+            (void) hipStreamEndCapture(c->stream, &graph);
+            if (graph) (void) hipGraphDestroy(graph);
+            c->capturing = false; c->cap_entry = nullptr; c->mega_uploads.clear();
+        }
+        c->rec.clear(); c->rec_on = false; c->aq.valid = false;
+        (void) hipGetLastError();
+        return GGML_STATUS_FAILED;
+    }
+}
+static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggml_cgraph * g) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     c->cnt.graphs_computed++;
 
     if (!c->moe_ws) {
-        if (hipMalloc((void **) &c->moe_ws, 1088) == hipSuccess) { MI_CHECK(hipMemsetAsync(c->moe_ws, 0, 1088, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream)); }
+        if (hipMalloc((void **) &c->moe_ws, 1088) == hipSuccess) { MI_CHECK_G(hipMemsetAsync(c->moe_ws, 0, 1088, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
     }
     if (!c->mega_err && c->use_mega) {     // persistent decode: images, the error word (host-mapped)
@@ -1816,14 +1865,14 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
         ok = ok && hipHostMalloc((void **) &c->mega_err, 64, hipHostMallocMapped) == hipSuccess;
         if (ok) {
             c->mega_err[0] = 0;
-            MI_CHECK(hipMemsetAsync(c->mega_gran, 0, gran_bytes, c->stream)); MI_CHECK(hipMemsetAsync(c->mega_epoch, 0, 256, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream));
+            MI_CHECK_G(hipMemsetAsync(c->mega_gran, 0, gran_bytes, c->stream)); MI_CHECK_G(hipMemsetAsync(c->mega_epoch, 0, 256, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream));
         }
         else { (void) hipGetLastError(); c->use_mega = false; }
     }
     if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
         if (hipMalloc(&c->fin_img, mi_backend_ctx::FIN_IMG_BYTES) != hipSuccess) { (void) hipGetLastError(); c->fin_img = nullptr; }
         if (c->fin_img && hipMalloc((void **) &c->fin_cnt, mi_backend_ctx::FIN_COUNTERS*4) == hipSuccess) {
-            MI_CHECK(hipMemsetAsync(c->fin_cnt, 0, mi_backend_ctx::FIN_COUNTERS*4, c->stream)); MI_CHECK(hipStreamSynchronize(c->stream));
+            MI_CHECK_G(hipMemsetAsync(c->fin_cnt, 0, mi_backend_ctx::FIN_COUNTERS*4, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream));
         } else if (c->fin_img) { (void) hipGetLastError(); (void) hipFree(c->fin_img); c->fin_img = nullptr; c->fin_cnt = nullptr; }
     }
     if (!c->attn_part) {     // <= 8 tokens x 128 heads x 32 ranges x (128 + 2) floats: allocated once, outside any capture
@@ -1832,8 +1881,8 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
     }
     const size_t need = graph_scratch_need(g);
     if (need > c->scratch_size) {
-        MI_CHECK(hipStreamSynchronize(c->stream));
-        if (c->scratch) MI_CHECK(hipFree(c->scratch));
+        MI_CHECK_G(hipStreamSynchronize(c->stream));
+        if (c->scratch) MI_CHECK_G(hipFree(c->scratch));
         c->scratch = nullptr; c->scratch_size = 0;
         drop_graphs(c);   // captured graphs hold the old scratch pointer
         const size_t sz = need + (need >> 2);
@@ -1848,7 +1897,7 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
     if (try_graph) {
         graph_entry & e = graph_lookup(c, g);
         if (e.exec) {
-            MI_CHECK(hipGraphLaunch(e.exec, c->stream));
+            MI_CHECK_G(hipGraphLaunch(e.exec, c->stream));
             c->cnt.graph_replays++;
             return GGML_STATUS_SUCCESS;
         }
@@ -1860,20 +1909,20 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
                 if (hipMalloc(&pd, pcap) == hipSuccess && hipMalloc(&wd, wcap) == hipSuccess) { e.owned_dev.push_back(pd); e.owned_dev.push_back(wd); }
                 else { (void) hipGetLastError(); if (pd) (void) hipFree(pd); }
             }
-            MI_CHECK(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            MI_CHECK_G(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             c->prof_suspend = false;
             c->capturing = true; c->cap_entry = &e; c->mega_uploads.clear(); c->cap_prog_used = 0; c->cap_ws_used = 0;
             run_nodes(c, g);
             c->capturing = false; c->cap_entry = nullptr;
             c->prof_suspend = c->prof_in_graph;
-            MI_CHECK(hipStreamEndCapture(c->stream, &graph));
-            for (auto & up : c->mega_uploads) MI_CHECK(hipMemcpy(up.dev, up.host.data(), up.host.size(), hipMemcpyHostToDevice));     // the program tables the captured launches read
+            MI_CHECK_G(hipStreamEndCapture(c->stream, &graph));
+            for (auto & up : c->mega_uploads) MI_CHECK_G(hipMemcpy(up.dev, up.host.data(), up.host.size(), hipMemcpyHostToDevice));     // the program tables the captured launches read
             c->mega_uploads.clear();
             hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
-            MI_CHECK(hipGraphDestroy(graph));
+            MI_CHECK_G(hipGraphDestroy(graph));
             if (err == hipSuccess) {
                 c->cnt.graph_captures++;
-                MI_CHECK(hipGraphLaunch(e.exec, c->stream));
+                MI_CHECK_G(hipGraphLaunch(e.exec, c->stream));
                 return GGML_STATUS_SUCCESS;
             }
             fprintf(stderr, "ggml-mi355x: hipGraphInstantiate failed (%s): staying eager\n", hipGetErrorString(err));
@@ -1983,7 +2032,7 @@ static ggml_backend_dev_t reg_get_device(ggml_backend_reg_t, size_t index) {
 
 static struct ggml_backend_feature * mi_get_features(ggml_backend_reg_t) {
     static struct ggml_backend_feature features[] = {
-        { "ARCH", "gfx950" }, { "WAVE", "64" }, { "MMVQ", "sdot4+dpp" }, { "MMQ", "mfma_i32_32x32x32_i8" }, { "GRAPHS", "1" }, { NULL, NULL },
+        { "ARCH", "gfx950" }, { "WAVE", "64" }, { "MMVQ", "sdot4+dpp" }, { "MMQ", "dequant_bf16+mfma_f32_32x32x16_bf16" }, { "GRAPHS", "1" }, { NULL, NULL },
     };
     return features;
 }

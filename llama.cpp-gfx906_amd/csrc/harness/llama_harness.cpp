@@ -389,6 +389,7 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
     if (last_rank) {
         cur = ggml_rms_norm(ctx0, cur, hp.f_norm_rms_eps);
         cur = ggml_mul(ctx0, cur, m->output_norm);
+        ggml_set_name(cur, "result_norm");            // res->t_embd (src/llama-model.cpp:6113): read back by llama_context for embeddings, no OUTPUT flag
         cur = ggml_mul_mat(ctx0, m->output, cur);     // lm_head
     }
     ggml_set_output(cur);

@@ -56,6 +56,10 @@ MODELS = {
     # tiles, gate/up/SwiGLU, split-k combine + norm) only engage at these sizes with >= 256 tokens
     "llama3-8b-1l": dict(n_embd=4096, n_ff=14336, n_layer=1, n_head=32, n_head_kv=8, n_embd_head=128, n_vocab=512,
                          rope_freq_base=500000.0, n_ctx_orig=8192, is_70b=0),
+    # TWO Llama-3-70B-shaped layers (BASELINE.json configs[3] shapes: k = 8192 / 28672, 64 heads over 8 KV heads; layer 0 takes the LLM_TYPE_70B
+    # Q5_K bump of attn_v, layer 1 the use_more_bits Q6_K) with a small vocabulary
+    "llama3-70b-2l": dict(n_embd=8192, n_ff=28672, n_layer=2, n_head=64, n_head_kv=8, n_embd_head=128, n_vocab=512,
+                          rope_freq_base=500000.0, n_ctx_orig=8192, is_70b=1),
     # small model for graph-level parity tests (oracle finishes in seconds)
     "tiny": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                  rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),

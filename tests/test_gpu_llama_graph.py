@@ -43,6 +43,56 @@ def test_synthetic_llama_matches_oracle(ftype):
         m.free()
 
 
+def test_stories15m_shaped_q8_0_matches_oracle():
+    """BASELINE.json configs[0] (stories15M Q8_0, llama-bench pp64/tg32): the stand-in of SURVEY.md Appendix B — the synthetic model of that
+    shape (288/768/6 layers/6 heads x 48) — through the same protocol: one 64-token prompt pass, then 32 single-token steps. Head size 48 has no
+    fused attention kernel: the graph runs on the generic kernels (the plumbing the config is about)."""
+    be = backend()
+    be.set_option("graphs", 1); be.set_option("fusion", 1)
+    m = ls.SynthLlama(be, "stories15m", "Q8_0", n_ctx=128, seed=15)
+    try:
+        W = read_weights(m)
+        rc = RefLlama(m.cfg, W, 128, "cpu"); re_ = RefLlama(m.cfg, W, 128, "exact")
+        rng = np.random.default_rng(1)
+        prompt = [int(t) for t in rng.integers(0, m.cfg["n_vocab"], size=64)]
+        steps = [prompt] + [[int(t)] for t in rng.integers(0, m.cfg["n_vocab"], size=32)]
+        for toks in steps:
+            emb = np.stack([m.embedding(t) for t in toks])
+            got = m.decode(toks)
+            exp_c = rc.decode(emb); exp_e = re_.decode(emb)
+            assert np.isfinite(got).all()
+            # the 64-token pass multiplies bf16 activations on MFMA (not the CPU's int8 activations) and leaves ITS keys/values in the cache
+            # the later steps read, so both oracles are independent approximations of this run: the reference's whole-graph gate against
+            # each, and no further from the exact product than the CPU-style evaluation itself is (x3 + a floor)
+            e_got, e_cpu = orc.nmse(exp_e, got), orc.nmse(exp_e, exp_c)
+            assert e_got <= 2e-3, (len(toks), e_got)
+            assert orc.nmse(exp_c, got) <= 2e-3, (len(toks), orc.nmse(exp_c, got))
+            assert e_got <= 3 * e_cpu + 1e-4, (len(toks), e_got, e_cpu)
+    finally:
+        m.free()
+
+
+def test_llama3_70b_shaped_layers_match_oracle():
+    """BASELINE.json configs[3] shapes on one GPU: two Llama-3-70B-shaped layers (k = 8192 / 28672, GQA 64:8, the Q5_K attn_v bump of
+    src/llama-quant.cpp:305-310 in layer 0 and the Q6_K use_more_bits tensors in layer 1), Q4_K_M"""
+    be = backend()
+    be.set_option("graphs", 1); be.set_option("fusion", 1)
+    m = ls.SynthLlama(be, "llama3-70b-2l", "Q4_K_M", n_ctx=32, seed=70)
+    try:
+        W = read_weights(m)
+        rc = RefLlama(m.cfg, W, 32, "cpu")
+        # single-token steps first (they follow the CPU arithmetic: the tight gate), then a 12-token pass (bf16 activations on MFMA:
+        # the reference's whole-graph gate) and one more step on top of the cache that pass wrote
+        for toks, gate in (([9], 5e-4), ([7], 5e-4), ([9], 5e-4), ([3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8], 2e-3), ([2], 2e-3)):
+            emb = np.stack([m.embedding(t) for t in toks])
+            got = m.decode(toks)
+            exp_c = rc.decode(emb)
+            assert np.isfinite(got).all()
+            assert orc.nmse(exp_c, got) <= gate, (len(toks), orc.nmse(exp_c, got))
+    finally:
+        m.free()
+
+
 @pytest.mark.parametrize("ftype", ["Q4_K_M", "Q8_0", "Q4_0"])
 def test_perplexity_delta_vs_cpu_reference(ftype, record_property):
     """BASELINE.json north_star: "<= 1e-3 perplexity delta vs CPU reference". Perplexity of a synthetic token stream under the synthetic

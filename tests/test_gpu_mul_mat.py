@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 import oracle as orc
-from gpu_util import QTYPES, backend, gg, proc, run_mul_mat
+from gpu_util import QTYPES, backend, gg, proc, run_mul_mat, run_mul_mat_bcast
 
 pytestmark = pytest.mark.gpu
 
@@ -107,6 +107,24 @@ def test_mul_mat_model_shapes(name, m, k, n):
     x = rng.uniform(-1, 1, size=(n, k)).astype(np.float32)
     got = run_mul_mat(QTYPES[name], w, x, m, k)
     check(QTYPES[name], w, x, got)
+
+
+# batch / broadcast dimensions on quantized weights (tests/test-backend-ops.cpp:5716-5762: bs in {[1,1],[3,1],[3,2]}, nr in {[1,1],[2,1],[1,2],[2,2]}),
+# mat-vec widths and a prefill width
+@pytest.mark.parametrize("n", [1, 4, 16])
+@pytest.mark.parametrize("bs,nr", [((3, 1), (1, 1)), ((3, 1), (2, 1)), ((3, 2), (1, 1)), ((3, 2), (1, 2)), ((3, 2), (2, 2)), ((1, 1), (2, 2))])
+@pytest.mark.parametrize("name", ["q8_0", "q4_0", "q4_K", "mxfp4"])
+def test_mul_mat_batch_broadcast(name, bs, nr, n):
+    rng = np.random.default_rng(bs[0]*100 + bs[1]*10 + nr[0]*3 + nr[1] + n)
+    m, k = 16, 256
+    w = orc.random_blocks(rng, QTYPES[name], (bs[1], bs[0], m), k)
+    x = rng.uniform(-1, 1, size=(bs[1]*nr[1], bs[0]*nr[0], n, k)).astype(np.float32)
+    got = run_mul_mat_bcast(QTYPES[name], w, x, m, k, bs, nr)
+    assert got.shape == (bs[1]*nr[1], bs[0]*nr[0], n, m)
+    for i3 in range(bs[1]*nr[1]):
+        for i2 in range(bs[0]*nr[0]):
+            wi = w[i3 // nr[1], i2 // nr[0]]                # dst[.., i2, i3] = a[.., i2/r2, i3/r3] . b[.., i2, i3]  
+            check(QTYPES[name], wi, x[i3, i2], got[i3, i2])
 
 
 def test_mul_mat_zero_and_outlier_activations():
