@@ -37,31 +37,29 @@ def log(*a):
     print(*a, file=sys.stderr, flush=True)
 
 
-def perplexity_delta(be, ls, gg, ftype, n_pos=200):
-    """checker leg (north_star: perplexity delta vs the CPU reference, <= 1e-3): perplexity of a synthetic token stream under the small synthetic
-    model from this backend's logits — token by token (decode kernels) and one prompt pass per position (prefill kernels) — against the
-    CPU-style oracle (oracle/ref_llama.py, mode cpu16) on the same weights; |delta ln PPL| (the per-position differences are zero-mean noise of the two
-    roundings: the mean over 200 positions is what settles below the target; a real perplexity run averages thousands). Same procedure, three
-    formats, in tests/test_gpu_llama_graph.py::test_perplexity_delta_vs_cpu_reference."""
+def perplexity_delta(be, ls, gg, ftype, n_seq=8, seq_len=128):
+    """checker leg (north_star: perplexity delta vs the CPU reference, <= 1e-3): what llama-perplexity --kl-divergence reports (ln PPL ratio,
+    mean KL divergence, per-position RMS delta logit, top-1 agreement, each mean with its standard error) between this backend's logits —
+    token by token (decode kernels) and one prompt pass per position (prefill kernels) — and the oracle (oracle/ref_llama.py: "cpu16" = the CPU
+    backend's arithmetic incl. its f16 rounding of q / p, "cpu" = the same with q / p in f32, "exact" = dequantized weights) on the same
+    synthetic model and 8 x 128 = 1024 positions; the oracle-vs-oracle rows are the yardsticks. Same procedure with gates in
+    tests/test_gpu_llama_graph.py::test_logit_parity_statistics_1024_positions."""
     sys.path.insert(0, str(ROOT / "oracle"))
     import ref_llama
     ft = ftype if ftype in ("Q4_K_M", "Q4_0", "Q8_0", "Q6_K") else "Q4_K_M"
-    toks = np.random.default_rng(77).integers(0, 512, size=n_pos + 1).astype(np.int32)
-    m = ls.SynthLlama(be, "tiny", ft, n_ctx=n_pos + 24, seed=21)
+    m = ls.SynthLlama(be, "tiny", ft, n_ctx=seq_len + 32, seed=21)
     try:
-        rc = ref_llama.RefLlama(m.cfg, ref_llama.read_weights(m, gg), n_pos + 24, "cpu16")
-        nc, nd, npre = [], [], []
-        for t in range(n_pos):
-            nd.append(ref_llama.nll(m.decode([int(toks[t])]), toks[t + 1]))
-            nc.append(ref_llama.nll(rc.decode(np.stack([m.embedding(int(toks[t]))])), toks[t + 1]))
-        for t in range(8, n_pos):
-            m.kv_clear()
-            npre.append(ref_llama.nll(m.decode([int(x) for x in toks[: t + 1]]), toks[t + 1]))
+        r = ref_llama.logit_parity(m, gg, n_seq=n_seq, seq_len=seq_len)
     finally:
         m.free()
-    return {"model": f"tiny {ft} (random init)", "positions": n_pos, "ppl_cpu_reference": round(float(np.exp(np.mean(nc))), 3),
-            "delta_ln_ppl_decode_path": round(abs(float(np.mean(nd)) - float(np.mean(nc))), 6),
-            "delta_ln_ppl_prefill_path": round(abs(float(np.mean(npre)) - float(np.mean(nc[8:]))), 6), "target": 1e-3}
+    keep = ("positions", "kl_mean", "kl_se", "rms_dlogit_mean", "rms_dlogit_over_logit_std", "delta_ln_ppl", "delta_ln_ppl_se", "top1_agree")
+    def cut(e):
+        return {k: (round(e[k], 8) if isinstance(e[k], float) else e[k]) for k in keep}
+    return {"model": f"tiny {ft} (random init)", "positions": r["positions"], "target_abs_delta_ln_ppl": 1e-3,
+            "ppl_cpu_reference": round(float(np.exp(r["decode_path"]["cpu16"]["ln_ppl_base"])), 3),
+            "decode_path_vs_cpu_backend": cut(r["decode_path"]["cpu16"]), "decode_path_vs_same_arithmetic": cut(r["decode_path"]["cpu"]),
+            "prefill_path_vs_cpu_backend": cut(r["prefill_path"]["cpu16"]), "prefill_path_vs_exact": cut(r["prefill_path"]["exact"]),
+            "yardstick_cpu_f16_rounding": cut(r["oracle"]["cpu16_vs_cpu"]), "yardstick_weight_format": cut(r["oracle"]["cpu_vs_exact"])}
 
 
 def cpu_baseline(model_cfg, ftype, budget_s=20.0):
@@ -214,10 +212,11 @@ def main():
 
         roof = None
         if not args.no_profile:
-            # dominant kernel, timed live with HIP events on the backend stream (option "profile": eager, event pair per launch)
-            # option "profile" = 1: eager launches with an event pair around each (the host launch gap is inside the pair: 18.6 us
-            # where rocprofv3's kernel trace says 16.5 us). = 2 (BENCH_PROFILE_MODE=2) captures the pairs into the hipGraphs, but on
-            # ROCm 7.2 events recorded by graph nodes cannot be read back (hipEventElapsedTime fails), so it falls back to 1.
+            # dominant kernel, timed live with HIP events on the backend stream. Option "profile" = 1: eager launches, each grouped mat-vec
+            # dispatch carrying its own start/stop event pair (hipExtLaunchKernelGGL), i.e. kernel start -> kernel end by the packet's
+            # timestamps, the same interval rocprofv3's kernel trace reports (round 1 recorded an event either side of the launch call,
+            # which put the host launch gap inside the pair: 20.7 us where the trace says 14.8 us). = 2 (BENCH_PROFILE_MODE=2) captures
+            # record-event nodes into the hipGraphs, but on ROCm 7.2 those cannot be read back (hipEventElapsedTime fails): falls back to 1.
             pmode = int(os.environ.get("BENCH_PROFILE_MODE", "1"))
             be.set_option("profile", pmode); m.kv_clear(); run_tokens(min(K, 32)); prof = be.profile()
             if not prof and pmode == 2:
@@ -229,10 +228,12 @@ def main():
             ach = top["bytes_per_launch"] / avg_s / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
                     "traffic": None, "traffic_source": None,
-                    "kernel": f"k_mmvq<{TYPE_NAMES.get(top['type'], top['type'])}> m={top['m']} k={top['k']} n={top['n']}",
+                    "kernel": top.get("kernel") or f"k_mmvq<{TYPE_NAMES.get(top['type'], top['type'])}> m={top['m']} k={top['k']} n={top['n']}",
+                    "timing": "eager launches, each dispatch's own start/stop events (hipExtLaunchKernelGGL) on the backend stream = the interval "
+                              "rocprofv3 --kernel-trace reports for that kernel name",
                     "bytes_per_launch": top["bytes_per_launch"], "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": top["launches"],
                     "all": [{"type": TYPE_NAMES.get(e["type"], e["type"]), "m": e["m"], "k": e["k"], "n": e["n"], "launches": e["launches"],
-                             "avg_us": round(e["total_ms"] / e["launches"] * 1e3, 2),
+                             "kernel": e.get("kernel", ""), "avg_us": round(e["total_ms"] / e["launches"] * 1e3, 2),
                              "GBps": round(e["bytes_per_launch"] / (e["total_ms"] / e["launches"] * 1e-3) / 1e9, 1)} for e in prof]}
             # HBM bytes per launch of that kernel from the PMC pass (a separate rocprofv3 --pmc FETCH_SIZE run, doubled as the guide's
             # gfx950 correction prescribes; tools/pmc_traffic.py) — it cannot be collected inside this run, so the committed summary
@@ -289,6 +290,12 @@ def main():
         send_buf = [torch.empty(n_embd, dtype=torch.float32, device=buf_dev) for _ in range(lsp.N_BUF)]
         recv_work = [None] * lsp.N_BUF; send_work = [None] * lsp.N_BUF
         tcur = torch.cuda.current_stream()
+        if transport == "gloo":                        # device-side staging buffers the model reads / writes
+            recv_dev = [torch.empty(n_embd, dtype=torch.float32, device="cuda") for _ in range(lsp.N_BUF)]
+            send_dev = [torch.empty(n_embd, dtype=torch.float32, device="cuda") for _ in range(lsp.N_BUF)]
+        # BENCH_DUMP_LOGITS=<file.npz>: the last rank keeps the logits of every timed step (tests/test_gpu_layer_split.py compares them
+        # with a single-process run of the same token streams)
+        dump = {"on": False, "rows": []} if os.environ.get("BENCH_DUMP_LOGITS") else None
 
         def post_recv(j):
             recv_work[j % lsp.N_BUF] = dist.irecv(recv_buf[j % lsp.N_BUF], src=rank - 1, group=pg)
@@ -309,10 +316,16 @@ def main():
             b = j % lsp.N_BUF
             if send_work[b] is not None:          # buffer reuse: the send issued N_BUF steps ago must be done
                 send_work[b].wait(); tcur.synchronize(); send_work[b] = None
-            m.decode(tokens[j % len(tokens):j % len(tokens) + 1] if not has_input else None, n_tokens=1, seq=seq,
-                     dev_act_in=recv_buf[b].data_ptr() if has_input else None,
-                     dev_result_out=send_buf[b].data_ptr() if rank < world - 1 else None,
-                     want_host=has_out, sync=True)
+            if has_input and transport == "gloo":      # debug transport: the hand-off was received into host memory
+                recv_dev[b].copy_(recv_buf[b]); tcur.synchronize()
+            out = m.decode(tokens[j % len(tokens):j % len(tokens) + 1] if not has_input else None, n_tokens=1, seq=seq,
+                           dev_act_in=(recv_dev[b] if transport == "gloo" else recv_buf[b]).data_ptr() if has_input else None,
+                           dev_result_out=(send_dev[b] if transport == "gloo" else send_buf[b]).data_ptr() if rank < world - 1 else None,
+                           want_host=has_out, sync=True)
+            if rank < world - 1 and transport == "gloo":
+                send_buf[b].copy_(send_dev[b]); tcur.synchronize()
+            if dump is not None and has_out and dump["on"]:
+                dump["rows"].append((seq, pos[seq], out.copy()))
             pos[seq] += 1
         log(f"[rank {rank}] warm-up: {W} pipeline steps")
         lsp.run_steps(tr, W, stage, 0, n_seq)
@@ -320,6 +333,10 @@ def main():
         log(f"[rank {rank}] warm-up done")
         if os.environ.get("BENCH_DEBUG"):
             import faulthandler; faulthandler.dump_traceback_later(int(os.environ["BENCH_DEBUG"]), exit=True)
+        for i in range(n_seq):
+            pos[i] = 0
+        if dump is not None:
+            dump["on"] = True
         sync_all(); t0 = time.perf_counter()
         log(f"[rank {rank}] timed region: {K} pipeline steps")
         lsp.run_steps(tr, K, stage, 0, n_seq)
@@ -331,6 +348,9 @@ def main():
         result.update(value=K / dt, ms_per_step=dt / K * 1e3)
         result["extra"] = {"layers": [list(r) for r in ranges], "sequences_in_flight": n_seq, "handoff_bytes": n_embd * 4}
         result["roofline"] = None
+        if dump is not None and has_out:
+            np.savez(os.environ["BENCH_DUMP_LOGITS"], seq=np.array([r[0] for r in dump["rows"]]), pos=np.array([r[1] for r in dump["rows"]]),
+                     logits=np.stack([r[2] for r in dump["rows"]]), tokens=tokens, n_seq=n_seq)
         m.free()
 
     if rank == 0:

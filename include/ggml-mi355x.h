@@ -85,8 +85,10 @@ struct ggml_backend_mi355x_prof_entry {
     int32_t  n;                 // activation columns
     int64_t  m, k;              // weight rows, row length
     uint64_t launches;
-    double   total_ms;          // sum over launches of (end event - start event) on the backend's stream
+    double   total_ms;          // sum over launches of (stop event - start event); for the grouped mat-vec launches the pair is the
+                                // dispatch's own start / stop (hipExtLaunchKernelGGL): the interval rocprofv3's kernel trace reports
     uint64_t bytes_per_launch;  // algorithmic weight bytes: m * row_size(type, k)
+    char     kernel[96];        // grouped launches: the instantiation as rocprofv3 spells it ("k_mmvq_fused<12, 12, true, 2, 2, 4, 8>"), else ""
 };
 GGML_BACKEND_API int ggml_backend_mi355x_get_profile(ggml_backend_t backend, struct ggml_backend_mi355x_prof_entry * out, int cap);
 

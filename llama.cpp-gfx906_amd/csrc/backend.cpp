@@ -304,7 +304,7 @@ struct mi_backend_ctx {
     static constexpr size_t MEGA_IMG_BYTES = 64*1024; static constexpr int MEGA_MAX_PHASES = 1024;
 
     // "profile" option: every quantized mat-mul launch is bracketed by a hipEvent pair on this stream (eager mode)
-    struct prof_rec { int type; int64_t m, k, n; uint64_t bytes; hipEvent_t e0, e1; };
+    struct prof_rec { int type; int64_t m, k, n; uint64_t bytes; hipEvent_t e0, e1; const char * kernel = nullptr; };
     bool profiling = false;
     bool prof_in_graph = false;      // option "profile" = 2: the event pairs are captured into the hipGraphs as event-record nodes
     bool prof_suspend = false;       //   ... and eager passes (before a graph's capture) are not recorded
@@ -329,9 +329,20 @@ static void prof_end(mi_backend_ctx * c) {
 // the grouped mat-vec module launches (possibly several graph nodes later, possibly several launches merged into one): it calls back
 static void prof_hook_pre(void * ctx, int type, uint64_t wbytes, int n_merged, int64_t k) {
     // m < 0: grouped launch, |m| = KiB of weights; n = launches merged into this kernel
-    prof_begin((mi_backend_ctx *) ctx, type, -(int64_t)(wbytes/1024), k, n_merged, wbytes);
+    mi_backend_ctx * c = (mi_backend_ctx *) ctx;
+    if (!c->profiling || c->prof_suspend) return;
+    if (c->prof_in_graph) { prof_begin(c, type, -(int64_t)(wbytes/1024), k, n_merged, wbytes); return; }
+    // eager: the pair rides on the dispatch itself (kernel start -> kernel end, the interval rocprofv3's kernel trace reports)
+    mi_backend_ctx::prof_rec r = { type, -(int64_t)(wbytes/1024), k, n_merged, wbytes, prof_event(c), prof_event(c) };
+    mul_mat_vec_q_fused_set_launch_events(r.e0, r.e1);
+    c->prof.push_back(r);
 }
-static void prof_hook_post(void * ctx, int, uint64_t, int, int64_t) { prof_end((mi_backend_ctx *) ctx); }
+static void prof_hook_post(void * ctx, int, uint64_t, int, int64_t) {
+    mi_backend_ctx * c = (mi_backend_ctx *) ctx;
+    if (!c->profiling || c->prof_suspend) return;
+    if (c->prof_in_graph) prof_end(c);
+    c->prof.back().kernel = mul_mat_vec_q_fused_last_kernel();
+}
 
 
 static ggml_guid_t mi_guid(void) {
@@ -2212,7 +2223,8 @@ int ggml_backend_mi355x_get_profile(ggml_backend_t backend, struct ggml_backend_
         for (; j < n; j++) if (out[j].type == r.type && out[j].m == r.m && out[j].k == r.k && out[j].n == r.n) break;
         if (j == n) {
             if (n == cap) continue;
-            out[n] = { r.type, (int32_t) r.n, r.m, r.k, 0, 0.0, r.bytes };
+            out[n] = { r.type, (int32_t) r.n, r.m, r.k, 0, 0.0, r.bytes, {0} };
+            if (r.kernel) snprintf(out[n].kernel, sizeof(out[n].kernel), "%s", r.kernel);
             n++;
         }
         out[j].launches++; out[j].total_ms += ms;

@@ -122,6 +122,17 @@ static __device__ __forceinline__ int2v ld_b64_a2(const void * p) {
     const uint32_t sh = (uint32_t)(a & 3);
     return int2v{ (int) __builtin_amdgcn_alignbyte(t.y, t.x, sh), (int) __builtin_amdgcn_alignbyte(t.z, t.y, sh) };
 }
+// 16 bytes at a 2-byte-aligned address from dword-aligned loads: five dwords (b128 + b32) and four v_alignbyte
+struct __attribute__((packed, aligned(4))) u32x4_a { uint32_t x, y, z, w; };
+static __device__ __forceinline__ int4v ld_b128_a2(const void * p) {
+    const uintptr_t a = (uintptr_t) p;
+    const uintptr_t base = a & ~(uintptr_t) 3;
+    const u32x4_a t = *(const u32x4_a *) base;
+    const uint32_t t4 = *(const uint32_t *) (base + 16);
+    const uint32_t sh = (uint32_t)(a & 3);
+    return int4v{ (int) __builtin_amdgcn_alignbyte(t.y, t.x, sh), (int) __builtin_amdgcn_alignbyte(t.z, t.y, sh),
+                  (int) __builtin_amdgcn_alignbyte(t.w, t.z, sh), (int) __builtin_amdgcn_alignbyte(t4, t.w, sh) };
+}
 // 16-byte aligned weight bytes. Measured on the tg128 bench (profiles/r01_*): plain loads 500 tok/s vs nontemporal 482,
 // so plain is the default; -DMI_NT_WEIGHTS switches the streamed-once hint back on for experiments.
 static __device__ __forceinline__ int4v ld_b128_nt(const void * p) {

@@ -489,7 +489,10 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
             ggml_backend_tensor_set(t, ff.data(), 0, ggml_nbytes(t));
             continue;
         }
-        upload_random(m, t, 1.0f/sqrtf((float) t->ne[0]), s++, tmp);
+        // seeded by the tensor's NAME: a rank that holds only some layers (-sm layer) generates the same bytes for them as a whole model does
+        uint64_t h = 1469598103934665603ull;
+        for (const char * c = ggml_get_name(t); *c; c++) h = (h ^ (uint8_t) *c)*1099511628211ull;
+        upload_random(m, t, 1.0f/sqrtf((float) t->ne[0]), s ^ h, tmp);
     }
 
     // pinned staging for per-step inputs

@@ -223,6 +223,9 @@ int  mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, 
 void mul_mat_vec_q_fused_flush(hipStream_t stream);
 // called right before / after every kernel this module puts on the stream (type of the first group, weight bytes, launches merged, k)
 typedef void (*mmvq_launch_hook)(void * ctx, int type, uint64_t weight_bytes, int n_merged, int64_t k);
+// the NEXT grouped launch carries (e0, e1) as its dispatch's start / stop events (hipExtLaunchKernelGGL); consumed by that launch
+void mul_mat_vec_q_fused_set_launch_events(hipEvent_t e0, hipEvent_t e1);
+const char * mul_mat_vec_q_fused_last_kernel(void);     // name of the instantiation the last grouped launch used
 void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx);
 int  mul_mat_vec_q_fused_pending(uint64_t * weight_bytes);
 

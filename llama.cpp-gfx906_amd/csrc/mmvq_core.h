@@ -143,10 +143,17 @@ template <> struct mmvq_t<T_Q6_K> {
         const int n = slot >> 1, l0 = 16*(slot & 1);
         const char * b = row + ib*BLOCK_BYTES;   // only 2-byte aligned: unaligned-mode global loads
         wfrag w;
+#ifndef MI_Q6K_A2
         w.qla = ld_b128(b + 64*n + l0);
         w.qlb = ld_b128(b + 64*n + 32 + l0);
         w.qh  = ld_b128(b + 128 + 32*n + l0);
         w.sc  = ld_b64(b + 192 + 8*n);           // scales[8n .. 8n+7]
+#else
+        w.qla = ld_b128_a2(b + 64*n + l0);
+        w.qlb = ld_b128_a2(b + 64*n + 32 + l0);
+        w.qh  = ld_b128_a2(b + 128 + 32*n + l0);
+        w.sc  = ld_b64_a2(b + 192 + 8*n);        // scales[8n .. 8n+7]
+#endif
         w.d   = ld_u16(b + 208);
         return w;
     }

@@ -21,6 +21,7 @@
 // frequency factor) are requested when the pair STARTS instead of after its last dot product (each was a dependent global load
 // at the tail of the launch: the V-cache element scatter alone held the norm+QKV launch 3.5 us after every other workgroup had finished).
 #pragma once
+#include <hip/hip_ext.h>
 
 #include "mmvq_core.h"
 #include "quant_core.h"
@@ -323,7 +324,10 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     const bool fin_on = GLU && p.fin.kind != 0;
     const int fin_rpw = (P + sel.nwg_group*FWT - 1)/(sel.nwg_group*FWT);       // rows per wave (contiguous ownership)
     const int u_step = fin_on ? 1 : sel.nwg_group*FWT;
-    const int u_base = fin_on ? (sel.wg_in_group*FWT + wave)*fin_rpw : sel.wg_in_group*FWT + wave;
+    // 16-wave workgroups: unit = wave*nwg + wg, so that a group may spread over MORE workgroups than units/16 (its high waves then own
+    // nothing): the Q6_K group of a norm+QKV launch needs ~3 us to queue its first weight loads at 16 pairs per CU (every Q6_K launch
+    // does: tools/stamp_timeline.py on a Q6_K model), 64 CUs of that launch were idle
+    const int u_base = fin_on ? (sel.wg_in_group*FWT + wave)*fin_rpw : (FWT == 16 ? wave*sel.nwg_group + sel.wg_in_group : sel.wg_in_group*FWT + wave);
     const int n_mine = fin_on ? max(0, min(fin_rpw, P - u_base)) : (u_base < P ? (P - 1 - u_base)/u_step + 1 : 0);
     int p_cur = u_base;
     // an expert of a stack (MUL_MAT_ID, one token): the index is a device value, workgroup-uniform
@@ -384,7 +388,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
             scale = 1.0f/sqrtf(ss/(float) sel.k + sel.eps);
             MI_STAMP(7);
             MI_FENCE;
-            MI_FETCH(1)
+            if constexpr (D > 1) { MI_FETCH(1) }
             MI_FENCE;
         }
         // all chunks of this wave are quantized first (independent chains the scheduler can interleave; a chunk past the end is
@@ -399,8 +403,8 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
         MI_STAMP(5);
         MI_FENCE;
         // the steps must be fetched in ring order: set d holds stream step d
-        if (PRO == PRO_QUANT) { MI_FETCH(1) }
-        else if (D > 2)       { MI_FETCH(2) }
+        if constexpr (PRO == PRO_QUANT && D > 1) { MI_FETCH(1) }
+        else if constexpr (D > 2)               { MI_FETCH(2) }
         MI_FENCE;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
@@ -409,9 +413,9 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
         }
     }
     MI_FENCE;
-    if (PRO == PRO_Q8) { MI_FETCH(1) }
-    if (D > 2 && PRO != PRO_NORM) { MI_FETCH(2) }
-    if (D > 3) { MI_FETCH(3) }
+    if constexpr (PRO == PRO_Q8 && D > 1) { MI_FETCH(1) }
+    if constexpr (D > 2 && PRO != PRO_NORM) { MI_FETCH(2) }
+    if constexpr (D > 3) { MI_FETCH(3) }
     MI_FENCE;
     MI_STAMP(6);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -512,9 +516,30 @@ __global__ void __launch_bounds__(FWT*64, FWT == 8 ? 2 : 1) k_mmvq_fused(const f
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const fused_sel sel = load_header((int) blockIdx.x);
-    if (TA == TB || sel.type == TA) fused_body<TA, GLU, PRO, NA, D, FWT>(p, sel, smem, lane, wave);
-    else                            fused_body<TB, GLU, PRO, NA, D, FWT>(p, sel, smem, lane, wave);
+    // 16 waves: every wave owns ONE unit of k <= 4096; a format whose wave covers 16 blocks per step (Q6_K) finishes it in one step, and a
+    // second register set would only hold a dead fetch (the Q4_K + Q6_K norm+QKV kernel spilled 3 dwords at its 128-VGPR limit, and the
+    // reloads queued behind the weight stream: its Q6_K workgroups left the prologue 3.3 us late, tools/stamp_timeline.py)
+    constexpr int DA = (FWT == 16 && mmvq_t<TA>::QK == 256 && mmvq_t<TA>::LPB <= 4) ? 1 : D;
+    constexpr int DB = (FWT == 16 && mmvq_t<TB>::QK == 256 && mmvq_t<TB>::LPB <= 4) ? 1 : D;
+    if (TA == TB || sel.type == TA) fused_body<TA, GLU, PRO, NA, DA, FWT>(p, sel, smem, lane, wave);
+    else                            fused_body<TB, GLU, PRO, NA, DB, FWT>(p, sel, smem, lane, wave);
 }
+
+// Timing hook: when the host set an event pair (option "profile"), the launch carries it as the DISPATCH's own start / stop events
+// (hipExtLaunchKernelGGL): hipEventElapsedTime(ev0, ev1) is then the kernel's execution time by the same packet timestamps rocprofv3's
+// kernel trace reports — not "launch call to completion" as a pair of hipEventRecord around the launch measures
+extern hipEvent_t mi355x_fused_ev0, mi355x_fused_ev1;
+extern const char * mi355x_fused_last_kernel;       // the instantiation the last launch used, spelled as rocprofv3's kernel trace spells it
+template <int TA, int TB, bool GLU, int PRO, int NA, int D, int FWT = 8> static const char * fused_kname() {
+    static char name[96] = "";
+    if (!name[0]) snprintf(name, sizeof(name), "k_mmvq_fused<%d, %d, %s, %d, %d, %d, %d>", TA, TB, GLU ? "true" : "false", PRO, NA, D, FWT);
+    return name;
+}
+#define MI_UNP(...) __VA_ARGS__
+#define MI_FL(TARGS_, grid_, block_, lds_, stream_, a_) do { \
+    mi355x_fused_last_kernel = fused_kname<MI_UNP TARGS_>(); \
+    if (mi355x_fused_ev0) { hipExtLaunchKernelGGL((k_mmvq_fused<MI_UNP TARGS_>), grid_, block_, lds_, stream_, mi355x_fused_ev0, mi355x_fused_ev1, 0, a_); mi355x_fused_ev0 = nullptr; mi355x_fused_ev1 = nullptr; } \
+    else hipLaunchKernelGGL((k_mmvq_fused<MI_UNP TARGS_>), grid_, block_, lds_, stream_, a_); } while (0)
 
 // a grouped launch, prepared on the host
 struct fused_launch { fused_mmvq_args a; int blocks; size_t lds; int ta, tb; bool glu; int mode, na; bool deep; int64_t k; uint64_t wbytes; int fw; };
@@ -528,45 +553,45 @@ void NAME_(const fused_launch & L, hipStream_t stream) { \
     const int mode = L.mode, na = L.na; \
     const bool deep = L.deep; \
     constexpr int FW = 8; \
-    if (L.fw == 16) { hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 1, 2, 16>), grid, dim3(1024), lds, stream, a); return; } \
+    if (L.fw == 16) { MI_FL((TA_, TB_, false, PRO_NORM, 1, 2, 16), grid, dim3(1024), lds, stream, a); return; } \
     if (HAS_GLU_ && L.glu) {     /* one-row units: 4 steps = the bytes 2 steps of pairs held */ \
         if (mode == PRO_Q8) { \
-            if (na == 1)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_Q8, 1, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_Q8, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else              hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_Q8, 4, 4>), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 1)      MI_FL((TA_, TB_, HAS_GLU_, PRO_Q8, 1, 4), grid, dim3(FW*64), lds, stream, a); \
+            else if (na == 2) MI_FL((TA_, TB_, HAS_GLU_, PRO_Q8, 2, 4), grid, dim3(FW*64), lds, stream, a); \
+            else              MI_FL((TA_, TB_, HAS_GLU_, PRO_Q8, 4, 4), grid, dim3(FW*64), lds, stream, a); \
         } else if (mode == PRO_NORM) { \
-            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_NORM, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_NORM, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 2) MI_FL((TA_, TB_, HAS_GLU_, PRO_NORM, 2, 4), grid, dim3(FW*64), lds, stream, a); \
+            else         MI_FL((TA_, TB_, HAS_GLU_, PRO_NORM, 8, 4), grid, dim3(FW*64), lds, stream, a); \
         } else { \
-            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_QUANT, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, HAS_GLU_, PRO_QUANT, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 2) MI_FL((TA_, TB_, HAS_GLU_, PRO_QUANT, 2, 4), grid, dim3(FW*64), lds, stream, a); \
+            else         MI_FL((TA_, TB_, HAS_GLU_, PRO_QUANT, 8, 4), grid, dim3(FW*64), lds, stream, a); \
         } \
         return; \
     } \
     if (deep) { \
         if (mode == PRO_Q8) { \
-            if (na == 1)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 1, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else              hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 4, 4>), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 1)      MI_FL((TA_, TB_, false, PRO_Q8, 1, 4), grid, dim3(FW*64), lds, stream, a); \
+            else if (na == 2) MI_FL((TA_, TB_, false, PRO_Q8, 2, 4), grid, dim3(FW*64), lds, stream, a); \
+            else              MI_FL((TA_, TB_, false, PRO_Q8, 4, 4), grid, dim3(FW*64), lds, stream, a); \
         } else if (mode == PRO_NORM) { \
-            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 2) MI_FL((TA_, TB_, false, PRO_NORM, 2, 4), grid, dim3(FW*64), lds, stream, a); \
+            else         MI_FL((TA_, TB_, false, PRO_NORM, 8, 4), grid, dim3(FW*64), lds, stream, a); \
         } else { \
-            if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 2, 4>), grid, dim3(FW*64), lds, stream, a); \
-            else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 8, 4>), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 2) MI_FL((TA_, TB_, false, PRO_QUANT, 2, 4), grid, dim3(FW*64), lds, stream, a); \
+            else         MI_FL((TA_, TB_, false, PRO_QUANT, 8, 4), grid, dim3(FW*64), lds, stream, a); \
         } \
         return; \
     } \
     if (mode == PRO_Q8) { \
-        if (na == 1)      hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 1, 2>), grid, dim3(FW*64), lds, stream, a); \
-        else if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 2, 2>), grid, dim3(FW*64), lds, stream, a); \
-        else              hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_Q8, 4, 2>), grid, dim3(FW*64), lds, stream, a); \
+        if (na == 1)      MI_FL((TA_, TB_, false, PRO_Q8, 1, 2), grid, dim3(FW*64), lds, stream, a); \
+        else if (na == 2) MI_FL((TA_, TB_, false, PRO_Q8, 2, 2), grid, dim3(FW*64), lds, stream, a); \
+        else              MI_FL((TA_, TB_, false, PRO_Q8, 4, 2), grid, dim3(FW*64), lds, stream, a); \
     } else if (mode == PRO_NORM) { \
-        if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 2, 2>), grid, dim3(FW*64), lds, stream, a); \
-        else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_NORM, 8, 2>), grid, dim3(FW*64), lds, stream, a); \
+        if (na == 2) MI_FL((TA_, TB_, false, PRO_NORM, 2, 2), grid, dim3(FW*64), lds, stream, a); \
+        else         MI_FL((TA_, TB_, false, PRO_NORM, 8, 2), grid, dim3(FW*64), lds, stream, a); \
     } else { \
-        if (na == 2) hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 2, 2>), grid, dim3(FW*64), lds, stream, a); \
-        else         hipLaunchKernelGGL((k_mmvq_fused<TA_, TB_, false, PRO_QUANT, 8, 2>), grid, dim3(FW*64), lds, stream, a); \
+        if (na == 2) MI_FL((TA_, TB_, false, PRO_QUANT, 2, 2), grid, dim3(FW*64), lds, stream, a); \
+        else         MI_FL((TA_, TB_, false, PRO_QUANT, 8, 2), grid, dim3(FW*64), lds, stream, a); \
     } \
 }
 

@@ -48,6 +48,10 @@ bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind) { return (k
 // per host thread: one backend (stream) is driven by one thread at a time, different backends concurrently from different threads
 // (tests/test-thread-safety.cpp)
 static thread_local struct { mmvq_launch_hook pre = nullptr, post = nullptr; void * ctx = nullptr; } g_hook;
+hipEvent_t mi355x_fused_ev0 = nullptr, mi355x_fused_ev1 = nullptr;
+const char * mi355x_fused_last_kernel = "";
+const char * mul_mat_vec_q_fused_last_kernel(void) { return mi355x_fused_last_kernel; }
+void mul_mat_vec_q_fused_set_launch_events(hipEvent_t e0, hipEvent_t e1) { mi355x_fused_ev0 = e0; mi355x_fused_ev1 = e1; }
 void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx) { g_hook.pre = pre; g_hook.post = post; g_hook.ctx = ctx; }
 
 static int device_cu_count() {
@@ -62,19 +66,35 @@ static int device_cu_count() {
 
 // how the persistent workgroups (one per CU) are shared among the groups of a launch: in proportion to their rows, at least one each,
 // never more than one unit (row pair; row of the dual GLU stream) per wave. Returns the grid size; block_end[i] = cumulative counts.
-int mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end) {
-    const int budget = device_cu_count();
+static int share_groups(const mmvq_group * groups, int n_groups, int fw, int budget, int * block_end) {
+    int blocks = 0;
+    if (fw == 16) {
+        // 16-wave workgroups own units wave*nwg + wg: any count up to the group's units is balanced. Shares in proportion to units x a
+        // per-format weight (a Q6_K pair takes ~2x as long to queue and stream as a Q4_K pair), rounded down, the budget never exceeded
+        double tot = 0.0;
+        for (int i = 0; i < n_groups; i++) tot += (double)((groups[i].m + 1)/2)*(groups[i].type == T_Q6_K ? 2.0 : 1.0);
+        for (int i = 0; i < n_groups; i++) {
+            const int64_t units = (groups[i].m + 1)/2;
+            int share = (int)((double) budget*(double) units*(groups[i].type == T_Q6_K ? 2.0 : 1.0)/tot);
+            share = share < 1 ? 1 : (share > units ? (int) units : share);
+            blocks += share;
+            block_end[i] = blocks;
+        }
+        return blocks;
+    }
     int64_t rows_total = 0;
     for (int i = 0; i < n_groups; i++) rows_total += (int64_t) groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1);
-    int blocks = 0;
     for (int i = 0; i < n_groups; i++) {
-        const int max_wg = groups[i].epi == EPI_GLU ? (int)((groups[i].m + fw - 1)/fw) : (int)(((groups[i].m + 1)/2 + fw - 1)/fw);
-        int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1))/rows_total);
+        const int max_wg = groups[i].epi == EPI_GLU ? (int)((groups[i].m + fw - 1)/fw) : (int)(((groups[i].m + 1)/2 + fw - 1)/fw);   // units: rows (GLU) or row pairs
+        int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1))/rows_total);   // rounded down: the grid never exceeds the budget (one workgroup per CU)
         share = share < 1 ? 1 : (share > max_wg ? max_wg : share);
         blocks += share;
         block_end[i] = blocks;
     }
     return blocks;
+}
+int mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end) {
+    return share_groups(groups, n_groups, fw, device_cu_count(), block_end);
 }
 
 bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in) {
@@ -106,7 +126,6 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
                     ((rows_total + 1)/2 <= (int64_t) n_cu*16 + 64 || (rows_total + 1)/2 >= (int64_t) n_cu*64)) ? 16 : 8;   // or a long stream (lm_head: 101 -> 96 us)
     L.fw = FW;
     const int budget = n_cu*(groups[0].epi == EPI_GLU ? glu_wpc : wpc);   // the dual (GLU) kernels need > 128 VGPRs: one workgroup per CU
-    int blocks = 0;
     for (int i = 0; i < MMVQ_MAX_GROUPS; i++) {
         a.block_end[i] = INT_MAX; a.x_off[i] = 0; a.gtype[i] = groups[0].type; a.gm[i] = 1; a.gW[i] = groups[0].W; a.gW2[i] = groups[0].W2;
         a.geid[i] = nullptr; a.kidx[i] = nullptr; a.grow_stride[i] = 0; a.gestride[i] = 0;
@@ -117,12 +136,10 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         a.geid[i] = groups[i].eid; a.kidx[i] = groups[i].st_mode == 1 ? groups[i].st_idx : nullptr;
         if (groups[i].row_stride > 0xFFFFFFFFull || groups[i].estride > 0xFFFFFFFFull) { fprintf(stderr, "mul_mat_vec_q_fused: row / expert stride beyond 4 GiB\n"); abort(); }
         a.grow_stride[i] = (uint32_t) groups[i].row_stride; a.gestride[i] = (uint32_t) groups[i].estride;
-        const int max_wg = groups[i].epi == EPI_GLU ? (int)((groups[i].m + FW - 1)/FW) : (int)(((groups[i].m + 1)/2 + FW - 1)/FW);   // units: rows (GLU) or row pairs
-        int share = (int)(((int64_t) budget*groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1))/rows_total);   // rounded down: the grid never exceeds the budget (one workgroup per CU)
-        share = share < 1 ? 1 : (share > max_wg ? max_wg : share);
-        blocks += share;
-        a.block_end[i] = blocks;
     }
+    int be_[MMVQ_MAX_GROUPS];
+    const int blocks = share_groups(groups, n_groups, FW, budget, be_);
+    for (int i = 0; i < n_groups; i++) a.block_end[i] = be_[i];
     const int64_t nd = in.act_kind == T_Q8_0 ? k/32 : k/256;
     a.off_d = (int) pad256h(k);
     a.off_bs = (int)(pad256h(k) + pad256h(nd*4));

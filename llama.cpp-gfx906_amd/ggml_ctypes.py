@@ -70,7 +70,7 @@ class mi355x_counters(C.Structure):
 
 class mi355x_prof_entry(C.Structure):
     _fields_ = [("type", C.c_int32), ("n", C.c_int32), ("m", C.c_int64), ("k", C.c_int64), ("launches", C.c_uint64),
-                ("total_ms", C.c_double), ("bytes_per_launch", C.c_uint64)]
+                ("total_ms", C.c_double), ("bytes_per_launch", C.c_uint64), ("kernel", C.c_char * 96)]
 
 
 class dev_caps(C.Structure):
@@ -292,7 +292,8 @@ class Backend:
         """aggregated (type, m, k, n) -> launches / total_ms of the mat-mul launches recorded under option 'profile'"""
         arr = (mi355x_prof_entry * cap)()
         n = self._lib.ggml_backend_mi355x_get_profile(self.be, arr, cap)
-        return [dict(type=e.type, n=e.n, m=e.m, k=e.k, launches=e.launches, total_ms=e.total_ms, bytes_per_launch=e.bytes_per_launch)
+        return [dict(type=e.type, n=e.n, m=e.m, k=e.k, launches=e.launches, total_ms=e.total_ms, bytes_per_launch=e.bytes_per_launch,
+                     kernel=e.kernel.decode())
                 for e in arr[:n]]
 
     def supports_op(self, t):

@@ -63,6 +63,9 @@ MODELS = {
     # small model for graph-level parity tests (oracle finishes in seconds)
     "tiny": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                  rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
+    # the same with four layers: the smallest model both ranks of a 2-way layer split own layers of (tests/test_gpu_layer_split.py)
+    "tiny4": dict(n_embd=256, n_ff=512, n_layer=4, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
+                  rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
 }
 
 _hz = None

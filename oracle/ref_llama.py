@@ -145,3 +145,71 @@ def nll(logits, tok):
     """next-token negative log-likelihood from one row of logits"""
     z = logits.astype(np.float64); z = z - z.max()
     return float(np.log(np.exp(z).sum()) - z[tok])
+
+
+def _mean_se(a):
+    a = np.asarray(a, np.float64)
+    return float(a.mean()), float(a.std(ddof=1)/np.sqrt(len(a))) if len(a) > 1 else 0.0
+
+
+def logit_parity(m, gg, n_seq=8, seq_len=128, modes=("cpu", "cpu16", "exact"), seed=77, prefill=True, min_prefill=9, W=None):
+    """The statistics llama-perplexity --kl-divergence reports (tools/perplexity/perplexity.cpp:1743-2005: mean KL divergence, RMS of the
+    probability / logit differences, top-1 agreement, ln(PPL(Q)/PPL(base)), each with its standard error), between THIS backend's logits and
+    the oracle's on the same weights and tokens, over n_seq independent token streams of seq_len positions (the cache is cleared between
+    them, as between perplexity chunks). The backend's logits at a position are taken twice: token by token (decode kernels) and, for
+    prefixes of >= min_prefill tokens, from one prompt pass over the prefix (prefill kernels). Oracle modes: "cpu" = the CPU backend's mat-mul
+    arithmetic (int8 activation blocks, integer dots) with q and the attention probabilities kept in f32 (as this backend's decode kernel
+    keeps them); "cpu16" = the same with q and p rounded to f16 first, which is what the CPU backend's F16 mat-mul does — the yardstick
+    north_star names; "exact" = dequantized weights x f32. The oracles are also compared with each other: those rows are the yardsticks
+    (what the CPU backend's own f16 rounding, and what the weight format itself, do to the same statistics)."""
+    W = W if W is not None else read_weights(m, gg)
+    nv = m.cfg["n_vocab"]
+    rng = np.random.default_rng(seed)
+    rows = {}
+
+    def stats(lg, lc, nxt):
+        lg = lg.astype(np.float64); lc = lc.astype(np.float64)
+        zg = lg - lg.max(); zc = lc - lc.max()
+        lpg = zg - np.log(np.exp(zg).sum()); lpc = zc - np.log(np.exp(zc).sum())
+        pc = np.exp(lpc)
+        return (float((pc*(lpc - lpg)).sum()),                       # KL(P_base || P_other)
+                float(np.sqrt(np.mean((lg - lc)**2))),               # RMS delta logit at this position
+                float(np.std(lc)),                                   # scale of the logits themselves
+                float(-lpg[nxt]), float(-lpc[nxt]),                  # next-token NLL under each
+                float(np.exp(lpg[nxt]) - np.exp(lpc[nxt])),          # delta p(next token)
+                int(np.argmax(lg) == np.argmax(lc)))
+
+    for s in range(n_seq):
+        toks = rng.integers(0, nv, size=seq_len + 1).astype(np.int32)
+        refs = {k: RefLlama(m.cfg, W, seq_len + 8, k) for k in modes}
+        m.kv_clear()
+        ref_logits = {k: [] for k in modes}
+        for t in range(seq_len):
+            emb = np.stack([m.embedding(int(toks[t]))])
+            lg = m.decode([int(toks[t])])
+            for k in modes:
+                lc = refs[k].decode(emb)
+                ref_logits[k].append(lc)
+                rows.setdefault(("decode_path", k), []).append(stats(lg, lc, int(toks[t + 1])))
+            for a, b in (("cpu16", "cpu"), ("cpu", "exact")):
+                if a in modes and b in modes:
+                    rows.setdefault(("oracle", f"{a}_vs_{b}"), []).append(stats(ref_logits[a][t], ref_logits[b][t], int(toks[t + 1])))
+        if prefill:
+            for t in range(min_prefill - 1, seq_len):
+                m.kv_clear()
+                lg = m.decode([int(x) for x in toks[: t + 1]])
+                for k in modes:
+                    rows.setdefault(("prefill_path", k), []).append(stats(lg, ref_logits[k][t], int(toks[t + 1])))
+    m.kv_clear()
+    out = {"positions": n_seq*seq_len, "sequences": n_seq, "seq_len": seq_len}
+    for (path, k), r in rows.items():
+        a = np.array(r, np.float64)
+        kl, se_kl = _mean_se(a[:, 0])
+        dn, se_dn = _mean_se(a[:, 3] - a[:, 4])                      # paired: ln PPL(other) - ln PPL(base)
+        out.setdefault(path, {})[k] = {
+            "positions": int(len(a)), "kl_mean": kl, "kl_se": se_kl, "kl_max": float(a[:, 0].max()),
+            "rms_dlogit_mean": float(a[:, 1].mean()), "rms_dlogit_max": float(a[:, 1].max()),
+            "rms_dlogit_over_logit_std": float((a[:, 1]/a[:, 2]).mean()),
+            "delta_ln_ppl": dn, "delta_ln_ppl_se": se_dn, "ln_ppl_base": float(a[:, 4].mean()),
+            "rms_dp_next": float(np.sqrt(np.mean(a[:, 5]**2))), "top1_agree": float(a[:, 6].mean())}
+    return out

@@ -93,42 +93,49 @@ def test_llama3_70b_shaped_layers_match_oracle():
         m.free()
 
 
+def fmt_parity(tag, e):
+    return (f"logit parity[{tag}, {e['positions']} positions]: KL {e['kl_mean']:.3e} +- {e['kl_se']:.1e} (max {e['kl_max']:.2e}); "
+            f"RMS dlogit {e['rms_dlogit_mean']:.3e} (max {e['rms_dlogit_max']:.2e}; {e['rms_dlogit_over_logit_std']:.2e} of the logit std); "
+            f"d ln PPL {e['delta_ln_ppl']:+.2e} +- {e['delta_ln_ppl_se']:.1e}; RMS dp(next) {e['rms_dp_next']:.2e}; top-1 agreement {e['top1_agree']:.4f}")
+
+
 @pytest.mark.parametrize("ftype", ["Q4_K_M", "Q8_0", "Q4_0"])
-def test_perplexity_delta_vs_cpu_reference(ftype, record_property):
-    """BASELINE.json north_star: "<= 1e-3 perplexity delta vs CPU reference". Perplexity of a synthetic token stream under the synthetic
-    model = exp(mean next-token NLL), once from this backend's logits and once from the CPU-backend-style oracle (Q8 activations, integer
-    dots, q and the attention probabilities rounded to f16: what the reference CPU backend computes) on the same weights and tokens; the delta is |ln PPL_gpu - ln PPL_cpu|. Two ways to
-    get the backend's logits at a position: (a) token by token (the decode kernels), (b) one prompt pass over the prefix (the
-    matrix-core prefill kernels, for prefixes of more than 8 tokens) — the CPU reference gives the same numbers either way."""
+def test_logit_parity_statistics_1024_positions(ftype, record_property):
+    """What llama-perplexity --kl-divergence reports (tools/perplexity/perplexity.cpp:1743-2005), between this backend and the oracle, over
+    8 token streams x 128 positions = 1024 positions (decode path) and the 960 of them with a prefix of >= 9 tokens (prefill path):
+    mean KL divergence +- its standard error, per-position RMS delta logit, ln PPL ratio +- standard error, top-1 agreement."""
     be = backend(); be.set_option("graphs", 1); be.set_option("fusion", 1)
-    n_pos = 200
-    toks = np.random.default_rng(77).integers(0, 512, size=n_pos + 1).astype(np.int32)
-    m = ls.SynthLlama(be, "tiny", ftype, n_ctx=n_pos + 24, seed=21)
+    m = ls.SynthLlama(be, "tiny", ftype, n_ctx=160, seed=21)
     try:
-        W = read_weights(m)
-        rc = RefLlama(m.cfg, W, n_pos + 24, "cpu16"); re_ = RefLlama(m.cfg, W, n_pos + 24, "exact")
-        nll_cpu, nll_ex, nll_dec, nll_pre = [], [], [], []
-        for t in range(n_pos):                                   # (a) decode path + the two oracles, incrementally
-            emb = np.stack([m.embedding(int(toks[t]))])
-            nll_dec.append(_nll(m.decode([int(toks[t])]), toks[t + 1]))
-            nll_cpu.append(_nll(rc.decode(emb), toks[t + 1])); nll_ex.append(_nll(re_.decode(emb), toks[t + 1]))
-        for t in range(8, n_pos):                                # (b) prompt pass over tokens 0..t (t + 1 > 8 tokens)
-            m.kv_clear()
-            nll_pre.append(_nll(m.decode([int(x) for x in toks[: t + 1]]), toks[t + 1]))
-        mc, me = float(np.mean(nll_cpu)), float(np.mean(nll_ex))
-        d_dec = abs(float(np.mean(nll_dec)) - mc)
-        d_pre = abs(float(np.mean(nll_pre)) - float(np.mean(nll_cpu[8:]))); d_pre_ex = abs(float(np.mean(nll_pre)) - float(np.mean(nll_ex[8:])))
-        d_cpu_ex = abs(mc - me)
-        record_property("ln_ppl_cpu", mc); record_property("delta_ln_ppl_decode", d_dec); record_property("delta_ln_ppl_prefill", d_pre)
-        print(f"perplexity[{ftype}] over {n_pos} positions: cpu {np.exp(mc):.3f} exact {np.exp(me):.3f} (|d ln| cpu-exact {d_cpu_ex:.2e}); "
-              f"decode path |d ln| vs cpu {d_dec:.2e}; prefill path |d ln| vs cpu {d_pre:.2e}, vs exact {d_pre_ex:.2e}")
-        assert d_dec <= 1e-3, d_dec
-        # the prompt pass rounds activations to bf16 where the CPU path rounds them to int8 blocks: two different approximations of the exact
-        # product, so it is held to the CPU path's OWN distance from the exact result (plus the stated 1e-3)
-        assert d_pre <= 1e-3 + d_cpu_ex, (d_pre, d_cpu_ex)
-        assert d_pre_ex <= 1e-3 + d_cpu_ex, (d_pre_ex, d_cpu_ex)
+        r = ref_llama.logit_parity(m, gg, n_seq=8, seq_len=128)
     finally:
         m.free()
+    for path in ("decode_path", "prefill_path", "oracle"):
+        for k, e in r[path].items():
+            print(fmt_parity(f"{ftype}, {path} vs {k}" if path != "oracle" else f"{ftype}, oracle {k}", e))
+            for kk, v in e.items():
+                record_property(f"{path}_{k}_{kk}", v)
+    d, d16, p16 = r["decode_path"]["cpu"], r["decode_path"]["cpu16"], r["prefill_path"]["cpu16"]
+    y16, yfmt = r["oracle"]["cpu16_vs_cpu"], r["oracle"]["cpu_vs_exact"]
+    assert d["positions"] == 1024 and p16["positions"] == 8*120
+    # This model re-quantizes its activations to int8 blocks eight times between embedding and logits: a 1-ulp difference (f32 summation
+    # order) that flips one rounding is amplified by the next quantizer, so two runs of the SAME arithmetic either agree to ~1e-7 (the first
+    # positions of a stream: tools/diag_parity.py shows NMSE 1e-14) or sit apart by a fraction of the format's own noise. The yardsticks are
+    # therefore the oracle-vs-oracle rows: what the CPU backend's f16 rounding of q / p does (cpu16 vs cpu), what the format does (cpu vs exact).
+    # (1) decode path against the same arithmetic (int8 activation blocks, integer dots, q / p in f32): well inside both yardsticks
+    assert d["kl_mean"] <= 0.5*min(y16["kl_mean"], yfmt["kl_mean"]), (d["kl_mean"], y16["kl_mean"], yfmt["kl_mean"])
+    assert abs(d["delta_ln_ppl"]) <= 1e-3, d
+    # (2) against the CPU backend as it is (its F16 mat-mul rounds q and p to f16, this backend keeps them in f32): north_star's 1e-3 on
+    # ln PPL, and no further from it than the CPU backend's own f16 rounding moves the result
+    assert abs(d16["delta_ln_ppl"]) <= 1e-3, d16
+    assert d16["kl_mean"] <= 1.1*y16["kl_mean"] + 1e-6, (d16["kl_mean"], y16["kl_mean"])
+    # (3) prefill path: bf16 activations on MFMA instead of int8 blocks — a different approximation of the same product: closer to the
+    # exact product than the CPU arithmetic is, and within twice the yardsticks of the CPU backend; ln PPL within 1e-3 + 3 standard errors
+    # (960 positions resolve ln PPL to ~6e-4)
+    pe = r["prefill_path"]["exact"]
+    assert pe["kl_mean"] <= yfmt["kl_mean"], (pe["kl_mean"], yfmt["kl_mean"])
+    assert p16["kl_mean"] <= 2.0*max(yfmt["kl_mean"], y16["kl_mean"]), (p16["kl_mean"], yfmt["kl_mean"], y16["kl_mean"])
+    assert abs(p16["delta_ln_ppl"]) <= 1e-3 + 3*p16["delta_ln_ppl_se"], p16
 
 
 @pytest.mark.parametrize("model,ftype", [("tiny-moe", "Q4_K_M"), ("tiny-oai", "MXFP4_MOE"), ("tiny-moe32", "Q4_K_M")])
