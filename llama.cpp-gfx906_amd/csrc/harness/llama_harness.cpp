@@ -48,6 +48,9 @@ struct mi_llama_hparams {
     int32_t n_expert, n_expert_used;  // > 0: the FFN is build_moe_ffn (src/llama-graph.cpp:811-1023); n_ff is then the expert width
     int32_t arch;                     // 0 = llm_build_llama (dense or Mixtral-style MoE), 1 = llm_build_openai_moe_iswa (gpt-oss; src/llama-model.cpp:17610-17738)
     int32_t flash_attn;               // -fa 1: ggml_flash_attn_ext, V cache not transposed, n_kv padded to 256, F16 mask (src/llama-graph.cpp:1245-1265)
+    int32_t n_swa, swa_pattern;       // > 0: sliding-window attention on the layers il % swa_pattern < swa_pattern - 1 (llama_hparams::set_swa_pattern,
+                                      // src/llama-hparams.cpp:5-13; gpt-oss: 128 / 2), which get their own, smaller cache (llama_kv_cache_unified_iswa)
+    int32_t n_ubatch;                 // most tokens per decode call; sizes the window cache: min(n_ctx, PAD(n_swa + n_ubatch)) (src/llama-kv-cache-unified-iswa.cpp:46-60)
 };
 
 struct mi_llama;
@@ -150,6 +153,7 @@ struct layer {
     ggml_tensor * bq = nullptr, * bk = nullptr, * bv = nullptr, * bo = nullptr, * sinks = nullptr;
     ggml_tensor * gate_inp_b = nullptr, * gate_b = nullptr, * up_b = nullptr, * down_b = nullptr;
     std::vector<ggml_tensor *> k_cache, v_cache;   // one per sequence stream
+    bool swa = false;                              // attends through the window cache (its k_cache / v_cache have swa_size cells)
 };
 
 struct graph_inst {
@@ -157,6 +161,7 @@ struct graph_inst {
     ggml_backend_buffer_t buf = nullptr;
     ggml_cgraph * gf = nullptr;
     ggml_tensor * inp_embd = nullptr, * inp_pos = nullptr, * kq_mask = nullptr, * k_idxs = nullptr, * v_idxs = nullptr, * out_ids = nullptr;
+    ggml_tensor * kq_mask_swa = nullptr, * k_idxs_swa = nullptr, * v_idxs_swa = nullptr;     // the window cache's own inputs (llm_graph_input_attn_kv_unified_iswa)
     ggml_tensor * result = nullptr;    // logits (has_output) or the last layer's l_out
     int64_t last_use = 0;
 };
@@ -172,7 +177,9 @@ struct mi_llama {
     ggml_backend_buffer_t kvbuf = nullptr;
     std::vector<layer> layers;
     ggml_tensor * output_norm = nullptr, * output = nullptr, * rope_freqs = nullptr;
-    std::map<std::tuple<int, int, int>, graph_inst> graphs;   // (seq, n_tokens, n_kv) -> graph: the reuse of src/llama-context.cpp:728
+    std::map<std::tuple<int, int, int, int>, graph_inst> graphs;   // (seq, n_tokens, n_kv, n_kv of the window cache) -> graph: the reuse of src/llama-context.cpp:728
+    int swa_size = 0;                                   // cells of the window cache (0: the model has none)
+    std::vector<std::vector<int>> swa_cell_pos;         // [seq][cell] position held by a cell of the window cache, -1 = empty
     int64_t tick = 0;
     std::vector<int> n_past;                            // cells [0, n_past[s]) of sequence s are in use
     uint64_t weight_bytes = 0;                          // bytes of every dense MUL_MAT weight held here (all of them are read per token)
@@ -265,7 +272,7 @@ ggml_tensor * build_moe_ffn(ggml_context * ctx0, ggml_cgraph * gf, const mi_llam
 }
 
 // llm_build_llama for n_tokens tokens attending to n_kv cache cells
-graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
+graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_swa) {
     const mi_llama_hparams & hp = m->hp;
     graph_inst g;
     g.ctx = ggml_init({ 0, NULL, true });
@@ -273,7 +280,7 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
     g.gf = ggml_new_graph_custom(ctx0, 8192, false);
 
     const int64_t n_embd = hp.n_embd, hd = hp.n_embd_head, n_head = hp.n_head, n_head_kv = hp.n_head_kv;
-    const int64_t n_embd_k_gqa = hd*n_head_kv, n_embd_v_gqa = hd*n_head_kv, kv_size = hp.n_ctx;
+    const int64_t n_embd_k_gqa = hd*n_head_kv, n_embd_v_gqa = hd*n_head_kv;
     const float kq_scale = 1.0f/sqrtf((float) hd);
     const bool last_rank = hp.has_output != 0;
 
@@ -286,6 +293,13 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
     g.v_idxs   = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, hp.flash_attn ? n_tokens : n_tokens*n_embd_v_gqa); ggml_set_input(g.v_idxs);   // :1208 (v_trans: per element)
     // with flash attention the mask is cast to F16 once per graph (src/llama-graph.cpp:1423)
     ggml_tensor * kq_mask_f16 = hp.flash_attn ? ggml_cast(ctx0, g.kq_mask, GGML_TYPE_F16) : nullptr;
+    ggml_tensor * kq_mask_swa_f16 = nullptr;
+    if (m->swa_size > 0) {     // build_attn_inp_kv_unified_iswa (src/llama-graph.cpp:1568-1612): a second set of inputs for the window cache
+        g.kq_mask_swa = ggml_new_tensor_2d(ctx0, GGML_TYPE_F32, n_kv_swa, GGML_PAD(n_tokens, GGML_KQ_MASK_PAD)); ggml_set_input(g.kq_mask_swa);
+        g.k_idxs_swa  = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, n_tokens);                                         ggml_set_input(g.k_idxs_swa);
+        g.v_idxs_swa  = ggml_new_tensor_1d(ctx0, GGML_TYPE_I64, hp.flash_attn ? n_tokens : n_tokens*n_embd_v_gqa); ggml_set_input(g.v_idxs_swa);
+        if (hp.flash_attn) kq_mask_swa_f16 = ggml_cast(ctx0, g.kq_mask_swa, GGML_TYPE_F16);
+    }
     const int n_outputs = 1;                                                       // llama_batch_get_one: logits for the last token only
     g.out_ids  = ggml_new_tensor_1d(ctx0, GGML_TYPE_I32, n_outputs);                ggml_set_input(g.out_ids);
 
@@ -296,6 +310,11 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
         const layer & L = m->layers[li];
         const bool last_layer = last_rank && li == n_local - 1;
         ggml_tensor * inpSA = inpL;
+        // which cache / mask / indices this layer attends through (build_attn(inp_attn_kv_unified_iswa), src/llama-graph.cpp:1490-1560)
+        const int64_t kv_size = L.swa ? m->swa_size : hp.n_ctx;
+        const int64_t n_kv_l = L.swa ? n_kv_swa : n_kv;
+        ggml_tensor * l_mask = L.swa ? g.kq_mask_swa : g.kq_mask, * l_mask_f16 = L.swa ? kq_mask_swa_f16 : kq_mask_f16;
+        ggml_tensor * l_k_idxs = L.swa ? g.k_idxs_swa : g.k_idxs, * l_v_idxs = L.swa ? g.v_idxs_swa : g.v_idxs;
 
         // build_norm(inpL, attn_norm, NULL, LLM_NORM_RMS)
         cur = ggml_rms_norm(ctx0, inpL, hp.f_norm_rms_eps);
@@ -320,30 +339,30 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
         ggml_build_forward_expand(g.gf, Vcur);
         {   // store to KV cache: cpy_k / cpy_v with set_rows (src/llama-kv-cache-unified.cpp:1108-1190)
             ggml_tensor * k_cur2 = ggml_reshape_2d(ctx0, Kcur, n_embd_k_gqa, n_tokens);
-            ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, L.k_cache[seq], k_cur2, g.k_idxs));
+            ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, L.k_cache[seq], k_cur2, l_k_idxs));
             ggml_tensor * v_cur2 = ggml_reshape_2d(ctx0, Vcur, n_embd_v_gqa, n_tokens);
             if (hp.flash_attn) {      // !v_trans: a row scatter like K (:1154)
-                ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, L.v_cache[seq], v_cur2, g.v_idxs));
+                ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, L.v_cache[seq], v_cur2, l_v_idxs));
             } else {
                 ggml_tensor * v_view = ggml_reshape_2d(ctx0, L.v_cache[seq], 1, n_embd_v_gqa*kv_size);     // the row becomes a single element
                 v_cur2 = ggml_reshape_2d(ctx0, v_cur2, 1, n_embd_v_gqa*n_tokens);
-                ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, v_view, v_cur2, g.v_idxs));
+                ggml_build_forward_expand(g.gf, ggml_set_rows(ctx0, v_view, v_cur2, l_v_idxs));
             }
         }
         // get_k / get_v (:1056-1106), v_trans layout
-        ggml_tensor * k = ggml_view_4d(ctx0, L.k_cache[seq], hd, n_head_kv, n_kv, 1,
+        ggml_tensor * k = ggml_view_4d(ctx0, L.k_cache[seq], hd, n_head_kv, n_kv_l, 1,
                 ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa*kv_size), 0);
         ggml_tensor * v = hp.flash_attn
-            ? ggml_view_4d(ctx0, L.v_cache[seq], hd, n_head_kv, n_kv, 1,      // !v_trans (:1087-1096)
+            ? ggml_view_4d(ctx0, L.v_cache[seq], hd, n_head_kv, n_kv_l, 1,      // !v_trans (:1087-1096)
                 ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa*kv_size), 0)
-            : ggml_view_4d(ctx0, L.v_cache[seq], n_kv, n_head_kv, hd, 1,
+            : ggml_view_4d(ctx0, L.v_cache[seq], n_kv_l, n_head_kv, hd, 1,
                 ggml_row_size(GGML_TYPE_F16, kv_size*hd), ggml_row_size(GGML_TYPE_F16, kv_size), ggml_row_size(GGML_TYPE_F16, kv_size*n_embd_v_gqa), 0);
         if (hp.flash_attn) {   // build_attn_mha with flash attention (src/llama-graph.cpp:1245-1265, :1337): n_kv % 256 == 0 by the cache's padding
             ggml_tensor * q = ggml_reshape_4d(ctx0, Qcur, Qcur->ne[0], Qcur->ne[1], Qcur->ne[2], 1);
             q = ggml_permute(ctx0, q, 0, 2, 1, 3);
             k = ggml_permute(ctx0, k, 0, 2, 1, 3);
             v = ggml_permute(ctx0, v, 0, 2, 1, 3);
-            cur = ggml_flash_attn_ext(ctx0, q, k, v, kq_mask_f16, kq_scale, 0.0f, 0.0f);
+            cur = ggml_flash_attn_ext(ctx0, q, k, v, l_mask_f16, kq_scale, 0.0f, 0.0f);
             ggml_flash_attn_ext_add_sinks(cur, L.sinks);
             ggml_flash_attn_ext_set_prec(cur, GGML_PREC_F32);
             cur = ggml_reshape_2d(ctx0, cur, cur->ne[0]*cur->ne[1], cur->ne[2]*cur->ne[3]);
@@ -355,7 +374,7 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv) {
             v = ggml_permute(ctx0, v, 0, 2, 1, 3);
             ggml_tensor * kq = ggml_mul_mat(ctx0, k, q);
             ggml_mul_mat_set_prec(kq, GGML_PREC_F32);
-            kq = ggml_soft_max_ext(ctx0, kq, g.kq_mask, kq_scale, 0.0f);
+            kq = ggml_soft_max_ext(ctx0, kq, l_mask, kq_scale, 0.0f);
             if (L.sinks) ggml_soft_max_add_sinks(kq, L.sinks);       // build_attn_with_sinks, src/llama-graph.cpp:1313
             ggml_tensor * kqv = ggml_mul_mat(ctx0, v, kq);
             cur = ggml_permute(ctx0, kqv, 0, 2, 1, 3);
@@ -426,6 +445,11 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
     const int64_t n_embd_k_gqa = hd*hp.n_head_kv, n_embd_v_gqa = hd*hp.n_head_kv;
     const int kv_size = hp.n_ctx;
     if (kv_size % (hp.flash_attn ? 256 : KV_PAD) != 0) { fprintf(stderr, "mi_llama: n_ctx must be a multiple of %d\n", hp.flash_attn ? 256 : KV_PAD); delete m; return nullptr; }
+    if (hp.n_swa > 0) {    // llama_kv_cache_unified_iswa (src/llama-kv-cache-unified-iswa.cpp:46-60): size_swa = min(size_base, PAD(n_swa*n_seq + n_ubatch, n_pad)); one stream per sequence here
+        const int pad = hp.flash_attn ? 256 : KV_PAD;
+        m->swa_size = std::min(kv_size, (int) GGML_PAD(hp.n_swa + std::max(1, hp.n_ubatch), pad));
+        m->swa_cell_pos.assign(std::max(1, hp.n_seq_max), std::vector<int>(m->swa_size, -1));
+    }
 
     m->wctx = ggml_init({ 0, NULL, true });
     m->kvctx = ggml_init({ 0, NULL, true });
@@ -463,9 +487,10 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
             }
         }
         // KV cache on the layer's device, F16 (src/llama-kv-cache-unified.cpp:114-132)
+        L.swa = hp.n_swa > 0 && (hp.swa_pattern <= 0 || il % hp.swa_pattern < hp.swa_pattern - 1);     // llama_hparams::set_swa_pattern
         for (int sq = 0; sq < std::max(1, hp.n_seq_max); sq++) {
-            L.k_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_k_gqa, kv_size));
-            L.v_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_v_gqa, kv_size));
+            L.k_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_k_gqa, L.swa ? m->swa_size : kv_size));
+            L.v_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_v_gqa, L.swa ? m->swa_size : kv_size));
         }
         m->layers.push_back(L);
     }
@@ -499,7 +524,7 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
     ggml_backend_buffer_type_t hbt = ggml_backend_dev_host_buffer_type(ggml_backend_get_device(backend));
     {   // 4 slots, each large enough for the inputs of one decode of up to n_ctx tokens: embeddings, mask, K / V indices, positions
         const size_t nc = (size_t) hp.n_ctx;
-        const size_t slot = nc*hp.n_embd*4 + nc*GGML_PAD(nc, GGML_KQ_MASK_PAD)*4 + nc*(size_t) n_embd_v_gqa*8 + nc*16 + (64u << 10);
+        const size_t slot = nc*hp.n_embd*4 + (hp.n_swa > 0 ? 2 : 1)*(nc*GGML_PAD(nc, GGML_KQ_MASK_PAD)*4 + nc*(size_t) n_embd_v_gqa*8 + nc*16) + (64u << 10);
         m->hsize = 4*((slot + 4095) & ~(size_t) 4095);
     }
     if (hbt) {
@@ -527,7 +552,7 @@ GGML_API uint64_t mi_llama_weight_bytes(const struct mi_llama * m) {
     return m->weight_bytes + (m->hp.n_expert > 0 ? m->expert_bytes*(uint64_t) m->hp.n_expert_used/(uint64_t) m->hp.n_expert : 0);
 }
 GGML_API int      mi_llama_n_past(const struct mi_llama * m, int seq) { return m->n_past[seq]; }
-GGML_API void     mi_llama_kv_clear(struct mi_llama * m) { for (auto & p : m->n_past) p = 0; }   // llama_memory_clear(mem, false): metadata only (llama-bench.cpp:1974)
+GGML_API void     mi_llama_kv_clear(struct mi_llama * m) { for (auto & p : m->n_past) p = 0; for (auto & c : m->swa_cell_pos) std::fill(c.begin(), c.end(), -1); }   // llama_memory_clear(mem, false): metadata only (llama-bench.cpp:1974)
 GGML_API int      mi_llama_n_result(const struct mi_llama * m) { return (int) m->logits.size(); }
 
 // tensor access for graph-level parity tests
@@ -553,7 +578,18 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
     const int kv_pad = hp.flash_attn ? 256 : KV_PAD;                                                   // get_padding (:2407-2410)
     const int n_kv = std::min(hp.n_ctx, std::max(kv_pad, (int) GGML_PAD(head + n_tokens, kv_pad)));   // get_n_kv (:1040-1050)
 
-    auto key = std::make_tuple(seq, n_tokens, n_kv);
+    // the window cache: a token at position p lives in cell p % swa_size (the cell it overwrites held p - swa_size, out of every
+    // window that is still open since swa_size >= n_swa + n_tokens); n_kv covers the highest cell in use (get_n_kv)
+    int n_kv_swa = 0;
+    if (m->swa_size > 0) {
+        if (m->swa_size < hp.n_ctx && hp.n_swa + n_tokens > m->swa_size) return 1;      // a batch beyond n_ubatch would overwrite cells of its own window
+        std::vector<int> & cp = m->swa_cell_pos[seq];
+        for (int i = 0; i < n_tokens; i++) cp[(head + i) % m->swa_size] = head + i;
+        int used_max_p1 = 0;
+        for (int j = 0; j < m->swa_size; j++) if (cp[j] >= 0) used_max_p1 = j + 1;
+        n_kv_swa = std::min(m->swa_size, std::max(kv_pad, (int) GGML_PAD(used_max_p1, kv_pad)));
+    }
+    auto key = std::make_tuple(seq, n_tokens, n_kv, n_kv_swa);
     auto it = m->graphs.find(key);
     if (it == m->graphs.end()) {
         if (m->graphs.size() >= 6*m->n_past.size()) {   // bound the number of live compute buffers
@@ -563,7 +599,7 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
             free_graph(victim->second);
             m->graphs.erase(victim);
         }
-        it = m->graphs.emplace(key, build_graph(m, seq, n_tokens, n_kv)).first;
+        it = m->graphs.emplace(key, build_graph(m, seq, n_tokens, n_kv, n_kv_swa)).first;
     }
     graph_inst & g = it->second;
     g.last_use = ++m->tick;
@@ -611,6 +647,31 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
         for (int i = 0; i < n_tokens; i++)
             for (int64_t j = 0; j < n_embd_v_gqa; j++) p[(int64_t) i*n_embd_v_gqa + j] = j*kv_size + head + i;
         ggml_backend_tensor_set_async(m->backend, g.v_idxs, p, 0, ggml_nbytes(g.v_idxs));
+    }
+    if (m->swa_size > 0) {   // the same three inputs for the window cache (llm_graph_input_attn_kv_unified_iswa::set_input, src/llama-graph.cpp:353-369)
+        const std::vector<int> & cp = m->swa_cell_pos[seq];
+        const int64_t ne0 = g.kq_mask_swa->ne[0], ne1 = g.kq_mask_swa->ne[1], ssz = m->swa_size;
+        float * pm = (float *) stage((size_t) ne0*ne1*4);
+        for (int64_t i = 0; i < ne0*ne1; i++) pm[i] = -INFINITY;
+        for (int i = 0; i < n_tokens; i++) {
+            const int p1 = head + i;
+            // is_masked_swa, LLAMA_SWA_TYPE_STANDARD (src/llama-hparams.cpp / llama-kv-cache-unified.cpp:1337-1358): empty, future, or p1 - p0 >= n_swa
+            for (int j = 0; j < n_kv_swa; j++) if (cp[j] >= 0 && cp[j] <= p1 && p1 - cp[j] < hp.n_swa) pm[(int64_t) i*ne0 + j] = 0.0f;
+        }
+        ggml_backend_tensor_set_async(m->backend, g.kq_mask_swa, pm, 0, ggml_nbytes(g.kq_mask_swa));
+        int64_t * pk = (int64_t *) stage((size_t) n_tokens*8);
+        for (int i = 0; i < n_tokens; i++) pk[i] = (head + i) % ssz;
+        ggml_backend_tensor_set_async(m->backend, g.k_idxs_swa, pk, 0, ggml_nbytes(g.k_idxs_swa));
+        if (hp.flash_attn) {
+            int64_t * pv = (int64_t *) stage((size_t) n_tokens*8);
+            for (int i = 0; i < n_tokens; i++) pv[i] = (head + i) % ssz;
+            ggml_backend_tensor_set_async(m->backend, g.v_idxs_swa, pv, 0, ggml_nbytes(g.v_idxs_swa));
+        } else {
+            int64_t * pv = (int64_t *) stage((size_t) n_tokens*n_embd_v_gqa*8);
+            for (int i = 0; i < n_tokens; i++)
+                for (int64_t j = 0; j < n_embd_v_gqa; j++) pv[(int64_t) i*n_embd_v_gqa + j] = j*ssz + (head + i) % ssz;
+            ggml_backend_tensor_set_async(m->backend, g.v_idxs_swa, pv, 0, ggml_nbytes(g.v_idxs_swa));
+        }
     }
     {
         int32_t * p = (int32_t *) stage(4);

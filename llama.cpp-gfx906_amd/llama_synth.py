@@ -20,7 +20,8 @@ class hparams(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("n_embd", "n_ff", "n_layer", "n_head", "n_head_kv", "n_embd_head", "n_vocab", "n_ctx",
                                          "ftype", "rope_type", "n_ctx_orig", "has_rope_freqs", "is_70b")] + \
                [(n, C.c_float) for n in ("rope_freq_base", "rope_freq_scale", "f_norm_rms_eps")] + \
-               [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max", "n_expert", "n_expert_used", "arch", "flash_attn")]
+               [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max", "n_expert", "n_expert_used", "arch", "flash_attn",
+                                         "n_swa", "swa_pattern", "n_ubatch")]
 
 
 # model shapes used by the configs
@@ -37,18 +38,22 @@ MODELS = {
     # Mixtral-8x7B: 4096/14336/32/32/8/128/32000, 8 experts top-2 (llm_build_llama's MoE branch)
     "mixtral-8x7b": dict(n_embd=4096, n_ff=14336, n_layer=32, n_head=32, n_head_kv=8, n_embd_head=128, n_vocab=32000,
                          rope_freq_base=1000000.0, n_ctx_orig=32768, is_70b=0, n_expert=8, n_expert_used=2),
-    # gpt-oss-20b: n_embd=2880, n_ff_exp=2880, 24 layers, 64/8 heads x 64, 32 experts top-4, vocab 201088 (llm_build_openai_moe_iswa;
-    # the sliding window of its even layers is 128 tokens = the bench context, so the full causal mask is the same mask)
+    # gpt-oss-20b: n_embd=2880, n_ff_exp=2880, 24 layers, 64/8 heads x 64, 32 experts top-4, vocab 201088 (llm_build_openai_moe_iswa:
+    # even layers attend through a 128-token sliding window with their own cache of min(n_ctx, PAD(128 + n_ubatch)) cells)
     "gpt-oss-20b": dict(n_embd=2880, n_ff=2880, n_layer=24, n_head=64, n_head_kv=8, n_embd_head=64, n_vocab=201088,
-                        rope_freq_base=150000.0, n_ctx_orig=4096, is_70b=0, n_expert=32, n_expert_used=4, arch=1, rope_type=2),
+                        rope_freq_base=150000.0, n_ctx_orig=4096, is_70b=0, n_expert=32, n_expert_used=4, arch=1, rope_type=2,
+                        n_swa=128, swa_pattern=2),
     # small MoE models for graph-level parity tests
     "tiny-moe": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                      rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=8, n_expert_used=2),
     # 32 experts top-4: from 16 experts on the one-token router runs on several workgroups (elem.hip k_moe_route_wide)
     "tiny-moe32": dict(n_embd=256, n_ff=256, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                        rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=32, n_expert_used=4),
-    "tiny-oai": dict(n_embd=128, n_ff=128, n_layer=2, n_head=8, n_head_kv=2, n_embd_head=32, n_vocab=512,
-                     rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=8, n_expert_used=4, arch=1, rope_type=2),
+    # gpt-oss-shaped: head size 64 (the fused attention kernels' other instantiation), sinks, biases, and the iswa cache pair: even layers
+    # attend through a 16-token window held in a 32-cell ring (PAD(n_swa + n_ubatch, 32)), odd layers through the full cache
+    "tiny-oai": dict(n_embd=128, n_ff=128, n_layer=2, n_head=8, n_head_kv=2, n_embd_head=64, n_vocab=512,
+                     rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0, n_expert=8, n_expert_used=4, arch=1, rope_type=2,
+                     n_swa=16, swa_pattern=2, n_ubatch=8),
     # head size 128 with GQA 4:1 at test size (the fused attention kernels are instantiated for 64 and 128)
     "tiny-hd128": dict(n_embd=512, n_ff=512, n_layer=2, n_head=4, n_head_kv=1, n_embd_head=128, n_vocab=512,
                        rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
@@ -115,6 +120,7 @@ class SynthLlama:
         hp.rope_freq_base = cfg["rope_freq_base"]; hp.rope_freq_scale = 1.0; hp.f_norm_rms_eps = 1e-5
         hp.layer_begin, hp.layer_end, hp.has_output = layer_begin, layer_end, int(has_output)
         hp.n_seq_max = n_seq_max
+        hp.n_swa, hp.swa_pattern, hp.n_ubatch = cfg.get("n_swa", 0), cfg.get("swa_pattern", 0), cfg.get("n_ubatch", 512)
         self.hp = hp
         self.backend = backend
         self.L = harness()

@@ -37,7 +37,7 @@ def mm(W, key, x, mode):
 
 class RefLlama:
     """numpy restatement of the graph llm_build_llama emits (src/llama-model.cpp:5969-6123), of its MoE branch (build_moe_ffn,
-    src/llama-graph.cpp:811-1023) and of llm_build_openai_moe_iswa (src/llama-model.cpp:17610-17738; within its 128-token window)"""
+    src/llama-graph.cpp:811-1023) and of llm_build_openai_moe_iswa (src/llama-model.cpp:17610-17738, incl. the sliding window of its even layers)"""
 
     def __init__(self, cfg, W, kv_size, mode):
         self.f16_attn = mode == "cpu16"
@@ -111,6 +111,9 @@ class RefLlama:
                 s = (qh @ K[:, kvh, :].T.astype(np.float64)).astype(np.float32)   # kq (f32 result)
                 s = s.astype(np.float64) / np.sqrt(hd)
                 causal = np.arange(n_kv)[None, :] <= pos[:, None]
+                n_swa, pat = c.get("n_swa", 0), c.get("swa_pattern", 0)
+                if n_swa > 0 and (pat <= 0 or il % pat < pat - 1):      # sliding-window layer (llama_hparams::set_swa_pattern; is_masked_swa: p1 - p0 >= n_swa)
+                    causal = causal & (pos[:, None] - np.arange(n_kv)[None, :] < n_swa)
                 s = np.where(causal, s, -np.inf)
                 mx = s.max(-1, keepdims=True)
                 if oai:     # attention sink: one more logit per head in the max and the denominator (src/llama-graph.cpp:1313)

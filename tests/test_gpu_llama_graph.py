@@ -164,6 +164,39 @@ def test_synthetic_moe_matches_oracle(model, ftype):
         m.free()
 
 
+@pytest.mark.parametrize("fa", [0, 1])
+def test_sliding_window_layers_and_their_ring_cache(fa):
+    """llm_build_openai_moe_iswa's cache pair (src/llama-kv-cache-unified-iswa.cpp): the even layers of the gpt-oss-shaped model attend through a
+    16-token window held in their own 32-cell cache (a ring: position p lives in cell p % 32), the odd ones through the full cache — two
+    masks, two index sets, two n_kv in ONE graph; head size 64 with sinks. 8-token prompt, then single tokens past the window (16), past the
+    ring's wrap (32) and to the end of the context; also with flash attention (F16 masks, n_kv padded to 256). Fusion on vs off as well."""
+    be = backend()
+    outs = {}
+    for fusion in (1, 0):
+        be.set_option("graphs", 1); be.set_option("fusion", fusion)
+        m = ls.SynthLlama(be, "tiny-oai", "MXFP4_MOE", n_ctx=256 if fa else 64, seed=9, flash_attn=bool(fa))
+        try:
+            if fusion:
+                rc = RefLlama(m.cfg, read_weights(m), 64, "cpu")
+            rng = np.random.default_rng(12)
+            steps = [[int(t) for t in rng.integers(0, 512, size=8)]] + [[int(t)] for t in rng.integers(0, 512, size=52)]
+            res = []
+            for i, toks in enumerate(steps):
+                got = m.decode(toks)
+                assert np.isfinite(got).all()
+                if fusion:
+                    exp_c = rc.decode(np.stack([m.embedding(t) for t in toks]))
+                    # 5e-4 as everywhere; a routing near-tie that flips an expert would show as ~1e-1, a wrong window or cell as ~1
+                    assert orc.nmse(exp_c, got) <= 5e-4, (i, m.n_past, orc.nmse(exp_c, got))
+                res.append(got)
+            assert m.n_past == 60
+            outs[fusion] = res
+        finally:
+            m.free()
+    for a_, b_ in zip(outs[1], outs[0]):
+        assert orc.nmse(b_, a_) <= 1e-6
+
+
 @pytest.mark.parametrize("model,n_prompt", [("tiny", 40), ("tiny-hd128", 33), ("tiny-hd128", 64)])
 def test_prefill_attention_on_matrix_cores(model, n_prompt):
     """More than 8 tokens per step: K.q -> soft_max -> V.kq runs as one matrix-core kernel with an online softmax (attn_prefill.hip)
