@@ -100,6 +100,10 @@ def test_mul_mat_golden(name, k, golden_dir):
     ("q4_K", 1027, 4096, 1), ("q6_K", 515, 4096, 1), ("q5_K", 259, 2048, 2), ("q8_0", 130, 2880, 1),
     ("q4_0", 77, 4096, 3), ("mxfp4", 2880, 2880, 1), ("q4_K", 64, 14336, 1), ("q6_K", 64, 14336, 8),
     ("q4_K", 33, 768, 1), ("q8_0", 17, 288, 1), ("mxfp4", 9, 96, 4), ("q4_0", 5, 32, 1),
+    # 2..8 columns of a K-quant: the int8 matrix-core kernel (mmvq_cols_mfma.hip): more 16-row tiles than CUs, ragged last tile, fewer k
+    # blocks than waves, the reference's perf shape, and a k whose images do not fit in LDS at n = 8 (falls back)
+    ("q4_K", 5003, 4096, 5), ("q5_K", 4100, 1024, 7), ("q6_K", 515, 4096, 3), ("q4_K", 4096, 14336, 8), ("q6_K", 4096, 14336, 2),
+    ("q5_K", 64, 14336, 8), ("q4_K", 48, 28672, 8), ("q4_K", 48, 28672, 4), ("q6_K", 31, 512, 6),
 ])
 def test_mul_mat_model_shapes(name, m, k, n):
     rng = np.random.default_rng(m * 131 + k)
@@ -170,3 +174,18 @@ def test_mul_mat_prefill_mfma(name, m, k, n):
     assert orc.nmse(exact, got) <= 5e-4 and orc.nmse(cpu, got) <= 5e-4
     # bf16 operands, f32 accumulation: a far tighter bound than the gate holds against the exact product
     assert orc.nmse(exact, got) <= 2e-5, orc.nmse(exact, got)
+
+
+def test_mfma_column_kernel_forced_for_every_n_and_q6_k():
+    """mmvq_cols_mfma.hip is routed to only where it is faster (Q4_K / Q5_K, n >= 5); GGML_MI355X_MMVQ_COLS_MFMA=2 (read once per process)
+    sends every 2 <= n <= 8 and Q6_K through it: the small and the model-shape cases again, in a child process with that setting."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("MI_NESTED_PYTEST"):
+        pytest.skip("already the child run")
+    env = dict(os.environ, GGML_MI355X_MMVQ_COLS_MFMA="2", MI_NESTED_PYTEST="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_mul_mat_small or test_mul_mat_model_shapes"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
