@@ -881,7 +881,10 @@ static void rec_flush(mi_backend_ctx * c) {
 }
 
 static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin, float * norm_out) {
-    if (!c->rec_on) {
+    bool mega_ok = true;      // the persistent kernel knows NORM rotations without a bias only
+    for (int q = 0; q < nc; q++) if (grp[q].epi == EPI_ROPE && (grp[q].res || (rope && (rope->p.mode & 2)))) mega_ok = false;
+    if (!c->rec_on || !mega_ok) {
+        if (c->rec_on) rec_flush(c);
         mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
         c->cnt.kernels_launched++;
         return;
@@ -931,13 +934,25 @@ static mmv_chain match_mmv_chain(mi_backend_ctx * c, const struct ggml_cgraph * 
     ch.grp = { (const char *) a->data, nullptr, a->nb[1], (int) a->ne[1], (int) a->type, (float *) n->data, EPI_NONE, nullptr, nullptr, nullptr, 0, 0 };
     ch.last = i; ch.has_rope = false; ch.out_ptr = n->data; ch.out_bytes = ggml_nbytes(n);
 
-    // MUL_MAT -> RESHAPE -> ROPE (NORM pairs): src/llama-model.cpp:6017-6040
+    // MUL_MAT [-> ADD(bias)] -> RESHAPE -> ROPE: NORM pairs (src/llama-model.cpp:6017-6040), or NEOX pairs over a whole power-of-two head, with
+    // gpt-oss's bias in between (src/llama-model.cpp:17636-17660)
     if (i + 2 < g->n_nodes && is_internal(c, n)) {
-        struct ggml_tensor * rs = g->nodes[i + 1]; struct ggml_tensor * rp = g->nodes[i + 2];
-        if (rs->op == GGML_OP_RESHAPE && rs->src[0] == n && is_internal(c, rs) && rp->op == GGML_OP_ROPE && rp->src[0] == rs &&
-            rp->type == GGML_TYPE_F32 && ggml_is_contiguous(rp) && (rp->op_params[2] & ~0) == 0 /* NORM */ && rp->ne[2] == 1 && rp->ne[3] == 1 &&
+        int ir = i + 1;
+        const struct ggml_tensor * bias = nullptr; const struct ggml_tensor * pre = n;
+        if (g->nodes[ir]->op == GGML_OP_ADD && ir + 2 < g->n_nodes) {
+            const struct ggml_tensor * ad = g->nodes[ir];
+            const struct ggml_tensor * other = ad->src[0] == n ? ad->src[1] : (ad->src[1] == n ? ad->src[0] : nullptr);
+            if (other && other != n && other->type == GGML_TYPE_F32 && ad->type == GGML_TYPE_F32 && ggml_are_same_shape(other, n) && ggml_are_same_shape(ad, n) &&
+                ggml_is_contiguous(other) && ggml_is_contiguous(ad) && is_internal(c, ad)) { bias = other; pre = ad; ir++; }
+        }
+        struct ggml_tensor * rs = g->nodes[ir]; struct ggml_tensor * rp = g->nodes[ir + 1];
+        const int rmode = rp->op == GGML_OP_ROPE ? rp->op_params[2] : -1;
+        const bool neox_ok = rmode == 2 && rp->op_params[1] == rp->ne[0] && (rp->ne[0] & (rp->ne[0] - 1)) == 0 && rp->ne[0] >= 4 && a->ne[1] % rp->ne[0] == 0;
+        if (rs->op == GGML_OP_RESHAPE && rs->src[0] == pre && is_internal(c, rs) && rp->op == GGML_OP_ROPE && rp->src[0] == rs &&
+            rp->type == GGML_TYPE_F32 && ggml_is_contiguous(rp) && (rmode == 0 || neox_ok) && rp->ne[2] == 1 && rp->ne[3] == 1 &&
             rp->op_params[1] % 2 == 0 && rp->ne[0] % 2 == 0 && a->ne[1] % 2 == 0 && rp->src[1]->type == GGML_TYPE_I32) {
-            ch.grp.dst = (float *) rp->data; ch.grp.epi = EPI_ROPE; ch.last = i + 2; ch.has_rope = true;
+            ch.grp.dst = (float *) rp->data; ch.grp.epi = EPI_ROPE; ch.last = ir + 1; ch.has_rope = true;
+            ch.grp.res = bias ? (const float *) bias->data : nullptr;
             ch.rope.pos = (const int32_t *) rp->src[1]->data;
             ch.rope.freq_factors = rp->src[2] ? (const float *) rp->src[2]->data : nullptr;
             ch.rope.head_dim = (int) rp->ne[0];
@@ -1062,7 +1077,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
                 ks->type == GGML_TYPE_F32 && vs->type == GGML_TYPE_F32 && ki->type == GGML_TYPE_I64 && vi->type == GGML_TYPE_I64 &&
                 ggml_is_contiguous(ki) && ggml_is_contiguous(vi) && ggml_is_contiguous(ks) && ggml_is_contiguous(vs) &&
                 ks->ne[1] == 1 && ks->ne[2] == 1 && ks->ne[3] == 1 && ks->ne[0] == chains[qk].grp.m && sk->nb[0] == 2 && sk->nb[1] % 2 == 0 &&
-                vs->ne[2] == 1 && vs->ne[3] == 1 && qv >= 0 && chains[qv].grp.epi == EPI_NONE &&
+                vs->ne[2] == 1 && vs->ne[3] == 1 && qv >= 0 && (chains[qv].grp.epi == EPI_NONE || chains[qv].grp.epi == EPI_ADD) &&
                 // V: element scatter on the transposed cache's [1, N] view (v_trans), or — with flash attention — a row like K (:1154)
                 ((vs->ne[0] == 1 && vs->ne[1] == chains[qv].grp.m && sv->ne[0] == 1 && sv->nb[1] == 2 && ggml_nelements(vi) == chains[qv].grp.m) ||
                  (vs->ne[0] == chains[qv].grp.m && vs->ne[1] == 1 && sv->nb[0] == 2 && sv->nb[1] % 2 == 0 && ggml_nelements(vi) == 1)) &&

@@ -76,6 +76,7 @@ static_assert(offsetof(fused_mmvq_args, gW) == 64 && offsetof(fused_mmvq_args, g
 // what a workgroup picks out of the header
 struct fused_sel {
     int gi, wg_in_group, nwg_group, x_off, type, m;
+    int neox_hl;                          // 0: a unit is two adjacent rows; h + 1: NEOX rotation partners, rows i and i + 2^h of a 2^(h+1)-row head
     const char * W; const char * W2; const int32_t * eid; const int64_t * kidx;
     uint32_t row_stride, estride;
     const char * act; const float * x; const float * norm_w; const int32_t * pos;
@@ -110,7 +111,7 @@ static __device__ __forceinline__ fused_sel load_header(int b) {
     const int last  = pick4(be0, be1, be2, be3, gi);
     s.gi = gi; s.wg_in_group = b - first; s.nwg_group = last - first;
     s.x_off = pick4(h0[4], h0[5], h0[6], h0[7], gi);
-    s.type  = pick4(h0[8], h0[9], h0[10], h0[11], gi);
+    { const int gt = pick4(h0[8], h0[9], h0[10], h0[11], gi); s.type = gt & 0xFFFF; s.neox_hl = gt >> 16; }
     s.m     = pick4(h0[12], h0[13], h0[14], h0[15], gi);
     s.W   = mk_ptr<const char *>(pick4(h1[0], h1[2], h1[4], h1[6], gi), pick4(h1[1], h1[3], h1[5], h1[7], gi));
     s.W2  = mk_ptr<const char *>(pick4(h1[8], h1[10], h1[12], h1[14], gi), pick4(h1[9], h1[11], h1[13], h1[15], gi));
@@ -164,24 +165,26 @@ struct pair_pre { float r0, r1; long long i0, i1; float ff; };
 // Branch-free: an absent operand is read from `dummy` (a readable device address, the group's weights) and ignored — loads inside
 // branches made the compiler wait for EVERY outstanding load (vmcnt(0)) where the branches join.
 template <bool GLU>
-static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, const fused_rope & rope, const char * dummy, int m, int row0, int rows) {
+static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, const fused_rope & rope, const char * dummy, int m, int row0, int row1) {
     pair_pre e = { 0.0f, 0.0f, 0, 0, 1.0f };
     if (GLU) return e;
-    const int ra = min(row0, m - 1), rb = min(row0 + (rows > 1 ? 1 : 0), m - 1);
-    const bool has_res = g.epi == EPI_ADD, has_ff = g.epi == EPI_ROPE && rope.ff != nullptr, has_idx = g.st_mode == 2;
+    const int ra = min(row0, m - 1), rb = min(row1, m - 1);
+    // res: the residual of EPI_ADD, or the bias added before the rotation (EPI_ROPE: gpt-oss's wq / wk, src/llama-model.cpp:17636-17652)
+    const bool has_res = g.res != nullptr && (g.epi == EPI_ADD || g.epi == EPI_ROPE), has_ff = g.epi == EPI_ROPE && rope.ff != nullptr, has_idx = g.st_mode == 2;
     const float * rp = has_res ? g.res : (const float *) dummy;
     e.r0 = rp[has_res ? ra : 0]; e.r1 = rp[has_res ? rb : 0];
     const float * fp = has_ff ? rope.ff : (const float *) dummy;
-    e.ff = fp[has_ff ? (min(ra % rope.head_dim, rope.n_dims - 1) >> 1) : 0];
+    e.ff = fp[has_ff ? (rope.neox ? min(ra % rope.head_dim, (rope.n_dims >> 1) - 1) : (min(ra % rope.head_dim, rope.n_dims - 1) >> 1)) : 0];
     const int64_t * ip = has_idx ? g.st_idx : (const int64_t *) dummy;
     e.i0 = ip[has_idx ? ra : 0]; e.i1 = ip[has_idx ? rb : 0];
     return e;
 }
 
-// NORM rope on the pair (2i, 2i+1) with the frequency factor already fetched — same formulas as rope_pair / elem.hip k_rope<false>
+// rope on one rotation pair with the frequency factor already fetched: NORM (2i, 2i+1) or NEOX (i, i + n_dims/2), row_in_head = the
+// first of the two — same formulas as rope_pair / elem.hip k_rope
 static __device__ __forceinline__ void rope_pair_ff(const fused_rope & r, int pos, int row_in_head, float ff, float & x0, float & x1) {
     if (row_in_head >= r.n_dims) return;
-    const int ip = row_in_head >> 1;
+    const int ip = r.neox ? row_in_head : row_in_head >> 1;
     const float theta_base = (float) pos*powf(r.theta_scale, (float) ip);
     const float theta_extrap = theta_base/(r.ff ? ff : 1.0f);
     float theta_interp = r.freq_scale*theta_extrap, theta = theta_interp, mscale = r.attn_factor;
@@ -198,24 +201,25 @@ static __device__ __forceinline__ void rope_pair_ff(const fused_rope & r, int po
 }
 
 // what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers)
-static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, float s0, float s1, int row0, int pos0, long long idx0,
+static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, float s0, float s1, int row0, int row1, int pos0, long long idx0,
                                                    const pair_pre & e, const int g_m, const int rows) {
     const int m = rows > 1 ? g_m : row0 + 1;      // rows == 1: the unit has no second row
     if (g.epi == EPI_ADD) {
         s0 += e.r0;
-        if (row0 + 1 < m) s1 += e.r1;
+        if (row1 < m) s1 += e.r1;
     } else if (g.epi == EPI_ROPE) {
-        rope_pair_ff(rope, pos0, row0 % rope.head_dim, e.ff, s0, s1);   // m is even on this path
+        if (g.res) { s0 += e.r0; s1 += e.r1; }                          // bias first, then the rotation
+        rope_pair_ff(rope, pos0, row0 % rope.head_dim, e.ff, s0, s1);   // m is a multiple of the head size on this path
     }
     g.dst[row0] = s0;
-    if (row0 + 1 < m) g.dst[row0 + 1] = s1;
+    if (row1 < m) g.dst[row1] = s1;
     if (g.st_mode == 1) {
-        uint16_t * q = g.st16 + idx0*g.st_row_elems + row0;
-        q[0] = f32_to_f16_bits(s0);
-        if (row0 + 1 < m) q[1] = f32_to_f16_bits(s1);
+        uint16_t * q = g.st16 + idx0*g.st_row_elems;
+        q[row0] = f32_to_f16_bits(s0);
+        if (row1 < m) q[row1] = f32_to_f16_bits(s1);
     } else if (g.st_mode == 2) {
         g.st16[e.i0] = f32_to_f16_bits(s0);
-        if (row0 + 1 < m) g.st16[e.i1] = f32_to_f16_bits(s1);
+        if (row1 < m) g.st16[e.i1] = f32_to_f16_bits(s1);
     }
 }
 
@@ -330,6 +334,10 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     const int u_base = fin_on ? (sel.wg_in_group*FWT + wave)*fin_rpw : (FWT == 16 ? wave*sel.nwg_group + sel.wg_in_group : sel.wg_in_group*FWT + wave);
     const int n_mine = fin_on ? max(0, min(fin_rpw, P - u_base)) : (u_base < P ? (P - 1 - u_base)/u_step + 1 : 0);
     int p_cur = u_base;
+    // the two rows of unit pp (single-tensor groups): adjacent, or the NEOX rotation partners i and i + half of one head
+    const int nhl = GLU ? 0 : sel.neox_hl;
+#define MI_ROW_A(pp_) (nhl ? ((((pp_) >> (nhl - 1)) << nhl) + ((pp_) & ((1 << (nhl - 1)) - 1))) : (pp_)*R)
+#define MI_ROW_B(pp_) (MI_ROW_A(pp_) + (nhl ? (1 << (nhl - 1)) : 1))
     // an expert of a stack (MUL_MAT_ID, one token): the index is a device value, workgroup-uniform
     const size_t eoff = (size_t) eid0*sel.estride;
     const char * gW = sel.W + eoff; const char * gW2 = GLU ? sel.W2 + eoff : nullptr;
@@ -346,7 +354,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
         const int pp = live ? u_base + j_pf*u_step : min(u_base, P - 1); \
         const int ibf = live ? min(it_pf*BPW + ibl, nb - 1) : 0; \
         _Pragma("unroll") for (int r = 0; r < R; r++) { \
-            const size_t off = (size_t) min(pp*R + r, g_m - 1)*g_row_stride; \
+            const size_t off = (size_t) min(GLU ? pp : (r ? MI_ROW_B(pp) : MI_ROW_A(pp)), g_m - 1)*g_row_stride; \
             w[d_][r] = T::load_w(gW + off, ibf, slot); \
             if (GLU) u[GLU ? d_ : 0][r] = T::load_w(gW2 + off, ibf, slot); \
         } \
@@ -360,7 +368,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     // the activation is there.
     MI_FETCH(0)
     MI_FENCE;
-    pair_pre epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, p_cur*R, R);      // behind the first weight step: needed only after the pair's last dot
+    pair_pre epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), R > 1 ? MI_ROW_B(p_cur) : MI_ROW_A(p_cur));      // behind the first weight step: needed only after the pair's last dot
     MI_FENCE;
 
     // ---- (3) prologue: build the quantized activation image in LDS ----
@@ -456,11 +464,11 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
                         if (++nh == 8) { glu_flush8((const float (&)[8]) hg, (const float (&)[8]) hu, 8, p_cur, u_step, g, g_m, eid0, fin_on, lane); nh = 0; }
                     } else {
                         const float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
-                        if (lane == 0) finish_pair(g, p.rope, s0, s1, p_cur*R, pos0, idx0, epre, g_m, R);
+                        if (lane == 0) finish_pair(g, p.rope, s0, s1, MI_ROW_A(p_cur), MI_ROW_B(p_cur), pos0, idx0, epre, g_m, R);
                     }
                     it = 0; p_cur += u_step;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
-                    if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, p_cur*R, R);     // the next pair's epilogue operands
+                    if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), MI_ROW_B(p_cur));     // the next pair's epilogue operands
                 }
             }
         }
@@ -501,6 +509,8 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     }
     MI_STAMP(3); MI_STAMP_CYC(9);
 #undef MI_FETCH
+#undef MI_ROW_A
+#undef MI_ROW_B
 #undef MI_FENCE
 #undef MI_XOFF
 #undef MI_XLIVE

@@ -133,6 +133,12 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
     for (int i = 0; i < n_groups; i++) {
         a.g[i] = groups[i];
         a.x_off[i] = groups[i].x_off; a.gtype[i] = groups[i].type; a.gm[i] = groups[i].m; a.gW[i] = groups[i].W; a.gW2[i] = groups[i].W2;
+        if (groups[i].epi == EPI_ROPE && rope && (rope->p.mode & 2)) {
+            // NEOX rotation: a unit of this group is the partner rows i and i + n_dims/2 of one head (the caller checked n_dims == head size = 2^(h+1))
+            int h = 0; while ((2 << h) < rope->head_dim) h++;
+            if ((2 << h) != rope->head_dim || rope->p.n_dims != rope->head_dim || groups[i].m % rope->head_dim != 0) { fprintf(stderr, "mul_mat_vec_q_fused: NEOX rope needs n_dims == head size == a power of two\n"); abort(); }
+            a.gtype[i] |= (h + 1) << 16;
+        }
         a.geid[i] = groups[i].eid; a.kidx[i] = groups[i].st_mode == 1 ? groups[i].st_idx : nullptr;
         if (groups[i].row_stride > 0xFFFFFFFFull || groups[i].estride > 0xFFFFFFFFull) { fprintf(stderr, "mul_mat_vec_q_fused: row / expert stride beyond 4 GiB\n"); abort(); }
         a.grow_stride[i] = (uint32_t) groups[i].row_stride; a.gestride[i] = (uint32_t) groups[i].estride;

@@ -10,6 +10,7 @@ namespace mi355x {
 struct fused_rope {
     const int32_t * pos; const float * ff; int n_dims, head_dim, n_ctx_orig;
     float freq_scale, ext_factor, attn_factor, theta_scale, corr_lo, corr_hi;
+    int neox;       // 0: NORM pairs (2i, 2i+1); 1: NEOX pairs (i, i + n_dims/2)
 };
 
 static __device__ __forceinline__ void rope_pair(const fused_rope & r, int pos, int row_in_head, float & x0, float & x1) {
@@ -43,6 +44,7 @@ static inline fused_rope make_fused_rope(const mmvq_rope & rope) {
     const float start = floorf(rope_corr_dim_h(rope.p.n_dims, rope.p.n_ctx_orig, rope.p.beta_fast, rope.p.freq_base));
     const float end   = ceilf (rope_corr_dim_h(rope.p.n_dims, rope.p.n_ctx_orig, rope.p.beta_slow, rope.p.freq_base));
     r.corr_lo = fmaxf(0.0f, start); r.corr_hi = fminf((float)(rope.p.n_dims - 1), end);
+    r.neox = (rope.p.mode & 2) ? 1 : 0;
     return r;
 }
 

@@ -43,6 +43,35 @@ def test_synthetic_llama_matches_oracle(ftype):
         m.free()
 
 
+@pytest.mark.parametrize("model", ["tiny", "tiny-hd128"])
+def test_neox_rope_folded_into_the_qkv_launch(model):
+    """NEOX rotary embedding (rotation partners i and i + head/2, Qwen / gpt-oss style) on wq / wk: from round 2 the grouped norm+QKV launch
+    does it in its epilogue (a wave's row pair becomes the two partners) instead of two ROPE launches after it; with fusion off it is the
+    stand-alone ROPE kernel. Both against the oracle and against each other."""
+    be = backend()
+    outs = {}
+    for fusion in (1, 0):
+        be.set_option("graphs", 1); be.set_option("fusion", fusion)
+        m = ls.SynthLlama(be, model, "Q4_K_M", n_ctx=64, seed=8, rope_type=2)
+        m.cfg["rope_type"] = 2
+        try:
+            if fusion:
+                rc = RefLlama(m.cfg, read_weights(m), 64, "cpu")
+                be.reset_counters()
+            res = []
+            for toks in [[5, 9, 200, 17, 3], [7], [8], [300], [2], [11]]:
+                got = m.decode(toks)
+                if fusion:
+                    exp_c = rc.decode(np.stack([m.embedding(t) for t in toks]))
+                    assert orc.nmse(exp_c, got) <= 5e-4, (toks, orc.nmse(exp_c, got))
+                res.append(got)
+            outs[fusion] = res
+        finally:
+            m.free()
+    for a_, b_ in zip(outs[1], outs[0]):
+        assert orc.nmse(b_, a_) <= 1e-6
+
+
 def test_stories15m_shaped_q8_0_matches_oracle():
     """BASELINE.json configs[0] (stories15M Q8_0, llama-bench pp64/tg32): the stand-in of SURVEY.md Appendix B — the synthetic model of that
     shape (288/768/6 layers/6 heads x 48) — through the same protocol: one 64-token prompt pass, then 32 single-token steps. Head size 48 has no
