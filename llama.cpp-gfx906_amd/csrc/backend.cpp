@@ -882,7 +882,7 @@ static void rec_flush(mi_backend_ctx * c) {
 
 static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin, float * norm_out) {
     bool mega_ok = true;      // the persistent kernel knows NORM rotations without a bias only
-    for (int q = 0; q < nc; q++) if (grp[q].epi == EPI_ROPE && (grp[q].res || (rope && (rope->p.mode & 2)))) mega_ok = false;
+    for (int q = 0; q < nc; q++) if ((grp[q].epi == EPI_ROPE && (grp[q].res || (rope && (rope->p.mode & 2)))) || grp[q].res2 || grp[q].res_eid) mega_ok = false;
     if (!c->rec_on || !mega_ok) {
         if (c->rec_on) rec_flush(c);
         mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
@@ -972,6 +972,18 @@ static mmv_chain match_mmv_chain(mi_backend_ctx * c, const struct ggml_cgraph * 
         if (other->type == GGML_TYPE_F32 && ggml_are_same_shape(other, n) && ggml_is_contiguous(other) && ggml_is_contiguous(nx) && ggml_are_same_shape(nx, n)) {
             ch.grp.dst = (float *) nx->data; ch.grp.epi = EPI_ADD; ch.grp.res = (const float *) other->data; ch.last = j;
             ch.out_ptr = nx->data; ch.out_bytes = ggml_nbytes(nx);
+            // ... -> ADD again (gpt-oss: wo.x + bias, then + the residual stream, src/llama-graph.cpp:1479-1481 + llama-model.cpp:17676)
+            const int j2 = next_real(g, j);
+            if (j2 > 0 && is_internal(c, nx)) {
+                struct ggml_tensor * n2 = g->nodes[j2];
+                if (n2->op == GGML_OP_ADD && (n2->src[0] == nx || n2->src[1] == nx) && n2->src[0] != n2->src[1] && n2->type == GGML_TYPE_F32) {
+                    const struct ggml_tensor * o2 = n2->src[0] == nx ? n2->src[1] : n2->src[0];
+                    if (o2->type == GGML_TYPE_F32 && ggml_are_same_shape(o2, n) && ggml_is_contiguous(o2) && ggml_is_contiguous(n2) && ggml_are_same_shape(n2, n)) {
+                        ch.grp.dst = (float *) n2->data; ch.grp.res2 = (const float *) o2->data; ch.last = j2;
+                        ch.out_ptr = n2->data; ch.out_bytes = ggml_nbytes(n2);
+                    }
+                }
+            }
             return ch;
         }
     }
@@ -1047,6 +1059,8 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
             ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, chains[q].out_ptr, chains[q].out_bytes);
             if (ok && chains[q].grp.res) ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, chains[q].grp.res, (size_t) chains[q].grp.m*4);
             if (ok && ch.grp.res)       ok = !ranges_overlap(chains[q].out_ptr, chains[q].out_bytes, ch.grp.res, (size_t) ch.grp.m*4);
+            if (ok && chains[q].grp.res2) ok = !ranges_overlap(ch.out_ptr, ch.out_bytes, chains[q].grp.res2, (size_t) chains[q].grp.m*4);
+            if (ok && ch.grp.res2)        ok = !ranges_overlap(chains[q].out_ptr, chains[q].out_bytes, ch.grp.res2, (size_t) ch.grp.m*4);
         }
         // ... nor what a ROPE that now runs after the launch still has to write (its own chain's buffer excepted: in-place rotation)
         for (int r = 0; r < n_def + (def_j >= 0 ? 1 : 0) && ok; r++) {
@@ -1377,17 +1391,28 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
             }
         }
     }
-    // a single one-token MUL_MAT_ID
+    // a single one-token MUL_MAT_ID, optionally followed by its ADD_ID bias (gpt-oss's ffn_down_exps.bias, src/llama-graph.cpp:979-983)
     if (ranges_overlap(up->data, ggml_nbytes(up), b->data, ggml_nbytes(b))) return 0;
+    struct ggml_tensor * out = up; const struct ggml_tensor * bias = nullptr; int consumed = 1;
+    {
+        const int jn = next_real(g, i);
+        struct ggml_tensor * ad = jn > 0 ? g->nodes[jn] : nullptr;
+        if (ad && ad->op == GGML_OP_ADD_ID && ad->src[0] == up && ad->src[2] == ids && ad->type == GGML_TYPE_F32 && is_internal(c, up) && ggml_are_same_shape(ad, up) &&
+            ad->nb[0] == 4 && ad->nb[1] == up->nb[1] && ad->src[1]->type == GGML_TYPE_F32 && ad->src[1]->ne[0] == M && ad->src[1]->nb[0] == 4 &&
+            ad->src[1]->nb[1] == (size_t) M*4 && ad->src[1]->ne[1] == as->ne[2] && !ranges_overlap(ad->data, ggml_nbytes(ad), b->data, ggml_nbytes(b))) {
+            out = ad; bias = ad->src[1]; consumed = jn - i + 1;
+        }
+    }
     for (int u = 0; u < n_used; u++) {
-        grp[u] = { (const char *) as->data, nullptr, as->nb[1], (int) M, (int) as->type, (float *) ((char *) up->data + (size_t) u*up->nb[1]), EPI_NONE,
-                   nullptr, nullptr, nullptr, 0, 0, (const int32_t *) ids->data + u, as->nb[2], b->ne[1] > 1 ? (int)((size_t) u*b->nb[1]/4) : 0 };
+        grp[u] = { (const char *) as->data, nullptr, as->nb[1], (int) M, (int) as->type, (float *) ((char *) out->data + (size_t) u*out->nb[1]), bias ? EPI_ADD : EPI_NONE,
+                   bias ? (const float *) bias->data : nullptr, nullptr, nullptr, 0, 0, (const int32_t *) ids->data + u, as->nb[2], b->ne[1] > 1 ? (int)((size_t) u*b->nb[1]/4) : 0 };
+        grp[u].res_eid = bias ? 1 : 0;
     }
     rec_flush(c);
     mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
     c->cnt.weight_bytes += (uint64_t) n_used*M*ggml_row_size(as->type, K);
-    return 1;
+    return consumed;
 }
 
 // MUL_MAT(F32 router weights, x) [-> ADD bias] [-> SOFT_MAX] -> ARGSORT desc, one token (src/llama-graph.cpp:838-883)

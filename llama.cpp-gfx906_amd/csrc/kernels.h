@@ -199,6 +199,9 @@ struct mmvq_group {
     // EPI_GLU variants of gpt-oss's expert FFN (src/llama-graph.cpp:927-968): per-expert biases added to the two products (ADD_ID,
     // row `eid[0]` of [m, n_expert] f32 tensors) and swiglu_oai(alpha, limit) instead of swiglu when glu_alpha != 0
     const float * b_gate; const float * b_up; float glu_alpha, glu_limit;
+    // EPI_ADD extras: res2 = a second addend, added after res (MUL_MAT -> ADD(bias) -> ADD(residual)); res_eid != 0: res is a [m, n_expert]
+    // table and the group adds row eid[0] of it (MUL_MAT_ID -> ADD_ID)
+    const float * res2; int res_eid;
 };
 // GLU launches only: the launch also writes its f32 output as the quantized image (act_q8 layout for n = 1) the next mat-vec reads;
 // counters: >= m/256 words, zero between launches (the kernel re-arms them). m % 256 == 0, one group, no expert stack.

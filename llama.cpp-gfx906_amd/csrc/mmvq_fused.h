@@ -160,19 +160,24 @@ static __device__ __forceinline__ float4v ld_f4_sc1(const float * p) {      // t
 }
 
 // operands of one row pair's epilogue, requested when the pair starts (all lanes load the same addresses: one line, broadcast)
-struct pair_pre { float r0, r1; long long i0, i1; float ff; };
+struct pair_pre { float r0, r1; long long i0, i1; float ff; float q0, q1; };
 
 // Branch-free: an absent operand is read from `dummy` (a readable device address, the group's weights) and ignored — loads inside
 // branches made the compiler wait for EVERY outstanding load (vmcnt(0)) where the branches join.
 template <bool GLU>
-static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, const fused_rope & rope, const char * dummy, int m, int row0, int row1) {
-    pair_pre e = { 0.0f, 0.0f, 0, 0, 1.0f };
+static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, const fused_rope & rope, const char * dummy, int m, int row0, int row1, int eid0) {
+    pair_pre e = { 0.0f, 0.0f, 0, 0, 1.0f, 0.0f, 0.0f };
     if (GLU) return e;
     const int ra = min(row0, m - 1), rb = min(row1, m - 1);
     // res: the residual of EPI_ADD, or the bias added before the rotation (EPI_ROPE: gpt-oss's wq / wk, src/llama-model.cpp:17636-17652)
     const bool has_res = g.res != nullptr && (g.epi == EPI_ADD || g.epi == EPI_ROPE), has_ff = g.epi == EPI_ROPE && rope.ff != nullptr, has_idx = g.st_mode == 2;
-    const float * rp = has_res ? g.res : (const float *) dummy;
+    // res_eid: res is a [m, n_expert] bias table and this group is expert eid0 (ADD_ID after a one-token MUL_MAT_ID: gpt-oss's ffn_down_exps.bias)
+    const float * rp = has_res ? g.res + (g.res_eid ? (size_t) eid0*m : 0) : (const float *) dummy;
     e.r0 = rp[has_res ? ra : 0]; e.r1 = rp[has_res ? rb : 0];
+    // res2: a second addend after the first (wo.x + bias, then + the residual stream: two ADD nodes in the graph)
+    const bool has_res2 = g.res2 != nullptr && g.epi == EPI_ADD;
+    const float * rq = has_res2 ? g.res2 : (const float *) dummy;
+    e.q0 = rq[has_res2 ? ra : 0]; e.q1 = rq[has_res2 ? rb : 0];
     const float * fp = has_ff ? rope.ff : (const float *) dummy;
     e.ff = fp[has_ff ? (rope.neox ? min(ra % rope.head_dim, (rope.n_dims >> 1) - 1) : (min(ra % rope.head_dim, rope.n_dims - 1) >> 1)) : 0];
     const int64_t * ip = has_idx ? g.st_idx : (const int64_t *) dummy;
@@ -207,6 +212,7 @@ static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const f
     if (g.epi == EPI_ADD) {
         s0 += e.r0;
         if (row1 < m) s1 += e.r1;
+        if (g.res2) { s0 += e.q0; if (row1 < m) s1 += e.q1; }
     } else if (g.epi == EPI_ROPE) {
         if (g.res) { s0 += e.r0; s1 += e.r1; }                          // bias first, then the rotation
         rope_pair_ff(rope, pos0, row0 % rope.head_dim, e.ff, s0, s1);   // m is a multiple of the head size on this path
@@ -368,7 +374,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     // the activation is there.
     MI_FETCH(0)
     MI_FENCE;
-    pair_pre epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), R > 1 ? MI_ROW_B(p_cur) : MI_ROW_A(p_cur));      // behind the first weight step: needed only after the pair's last dot
+    pair_pre epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), R > 1 ? MI_ROW_B(p_cur) : MI_ROW_A(p_cur), eid0);      // behind the first weight step: needed only after the pair's last dot
     MI_FENCE;
 
     // ---- (3) prologue: build the quantized activation image in LDS ----
@@ -468,7 +474,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
                     }
                     it = 0; p_cur += u_step;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
-                    if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), MI_ROW_B(p_cur));     // the next pair's epilogue operands
+                    if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), MI_ROW_B(p_cur), eid0);     // the next pair's epilogue operands
                 }
             }
         }
