@@ -883,6 +883,7 @@ static void rec_flush(mi_backend_ctx * c) {
 static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin, float * norm_out) {
     bool mega_ok = true;      // the persistent kernel knows NORM rotations without a bias only
     for (int q = 0; q < nc; q++) if ((grp[q].epi == EPI_ROPE && (grp[q].res || (rope && (rope->p.mode & 2)))) || grp[q].res2 || grp[q].res_eid) mega_ok = false;
+    for (int q = 1; q < nc; q++) if (act_kind_for(grp[q].type) != act_kind_for(grp[0].type)) mega_ok = false;
     if (!c->rec_on || !mega_ok) {
         if (c->rec_on) rec_flush(c);
         mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
@@ -1020,6 +1021,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i);
 static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm, const struct ggml_tensor * normw) {
     struct ggml_tensor * n = g->nodes[i];
     if (!fusable_mmv(n)) return -1;
+    bool mixed = false;     // groups of two activation formats in the launch
     int deferred[MMVQ_MAX_GROUPS]; int n_def = 0;      // ROPE nodes between the grouped mat-vecs that the epilogue cannot do (NEOX): run after the launch
     const struct ggml_tensor * b = n->src[1];
     const int kind = act_kind_for((int) n->src[0]->type);
@@ -1043,13 +1045,21 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
             if (!okr) break;
             def_j = j; j = j2; m = g->nodes[j];
         }
-        if (!fusable_mmv(m) || m->src[1] != b || act_kind_for((int) m->src[0]->type) != kind) break;
+        if (!fusable_mmv(m) || m->src[1] != b) break;
+        if (act_kind_for((int) m->src[0]->type) != kind) {
+            // another activation format (Mixtral: wq Q4_K, wk / wv Q8_0) joins only a launch in which every workgroup quantizes the activation
+            // itself: the norm prologue, or the plain quantizing one when no image of b is cached
+            const bool cached_b = c->aq.valid && c->aq.data == b->data;
+            if (!(norm || !cached_b) || !mul_mat_vec_q_fused_can_group_mixed(chains[0].grp.type, (int) m->src[0]->type) ||
+                !mul_mat_vec_q_fused_prologue_supported(n->src[0]->ne[0], kind) || !mul_mat_vec_q_fused_prologue_supported(n->src[0]->ne[0], act_kind_for((int) m->src[0]->type))) break;
+            mixed = true;
+        }
         mmv_chain ch = match_mmv_chain(c, g, j);
         if (ch.grp.epi == EPI_GLU) break;   // the dual (GLU) kernel runs alone
         {   // at most two distinct weight types per launch, and only pairs that have a kernel
             int t2 = -1; bool ok_t = true;
             for (int q = 0; q < nc; q++) if (chains[q].grp.type != chains[0].grp.type) t2 = chains[q].grp.type;
-            if (ch.grp.type != chains[0].grp.type) { if (t2 >= 0 && t2 != ch.grp.type) ok_t = false; else ok_t = mul_mat_vec_q_fused_can_group(chains[0].grp.type, ch.grp.type); }
+            if (ch.grp.type != chains[0].grp.type) { if (t2 >= 0 && t2 != ch.grp.type) ok_t = false; else ok_t = mul_mat_vec_q_fused_can_group(chains[0].grp.type, ch.grp.type) || mul_mat_vec_q_fused_can_group_mixed(chains[0].grp.type, ch.grp.type); }
             if (!ok_t) break;
         }
         if (ch.has_rope && chains[0].has_rope && memcmp(&ch.rope, &chains[0].rope, sizeof(ch.rope)) != 0) break;   // one rope descriptor per launch

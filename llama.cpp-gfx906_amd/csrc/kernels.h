@@ -220,7 +220,8 @@ struct mmvq_input {
 };
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind);        // PRO_QUANT / PRO_NORM limits (k % 256, or k % 32 with Q8_0 activations)
-bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);   // may these two weight types share one grouped launch
+bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);
+bool mul_mat_vec_q_fused_can_group_mixed(int type_a, int type_b);   // pairs of different activation formats (only when the launch quantizes the activation itself)   // may these two weight types share one grouped launch
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                          const mmvq_fin * fin = nullptr);
 bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);

@@ -378,7 +378,10 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     MI_FENCE;
 
     // ---- (3) prologue: build the quantized activation image in LDS ----
-    int8_t * l_qs = (int8_t *) smem; float * l_d = (float *) (smem + sel.off_d); int16_t * l_bs = (int16_t *) (smem + sel.off_bs);
+    // the image this workgroup BUILDS (PRO_QUANT / PRO_NORM) is laid out for its own group's activation format — a launch may mix K-quant
+    // groups (Q8_K image) with Q8_0 groups (Mixtral's wq Q4_K + wk / wv Q8_0); a copied image (PRO_Q8) has the one layout the host gave
+    const int off_bs_l = PRO == PRO_Q8 ? sel.off_bs : sel.off_d + ((((sel.k >> (ACT == T_Q8_0 ? 5 : 8))*4) + 255) & ~255);
+    int8_t * l_qs = (int8_t *) smem; float * l_d = (float *) (smem + sel.off_d); int16_t * l_bs = (int16_t *) (smem + off_bs_l);
     if (PRO == PRO_Q8) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
@@ -388,7 +391,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     } else {
         float scale = 1.0f;
         if (PRO == PRO_NORM) {
-            float * red = (float *) (smem + sel.off_bs + (((sel.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15));   // FWT floats after the image
+            float * red = (float *) (smem + off_bs_l + (((sel.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15));   // FWT floats after the image
             float ss = 0.0f;
 #pragma unroll
             for (int i = 0; i < NA; i++) if (wave + FWT*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
@@ -488,7 +491,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
         // the one whose add came last (by the returned value) loads the chunk (sc1), quantizes it and stores the image piece.
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
-        int * fin_list = (int *) (smem + sel.off_bs + (((sel.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15) + 64);      // [0] = count, [1..] = chunks (after the RMS scratch)
+        int * fin_list = (int *) (smem + off_bs_l + (((sel.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15) + 64);      // [0] = count, [1..] = chunks (after the RMS scratch)
         const int RW = FWT*fin_rpw, ra = sel.wg_in_group*RW, rb = min(ra + RW, g_m);
         if (threadIdx.x == 0) {
             int n = 0;
@@ -619,6 +622,7 @@ void launch_fused_q4_0(const fused_launch & L, hipStream_t stream);
 void launch_fused_mxfp4(const fused_launch & L, hipStream_t stream);
 void launch_fused_q4_K_q5_K(const fused_launch & L, hipStream_t stream);
 void launch_fused_q4_K_q6_K(const fused_launch & L, hipStream_t stream);
+void launch_fused_q8_0_q4_K(const fused_launch & L, hipStream_t stream);
 void launch_fused_q5_K_q6_K(const fused_launch & L, hipStream_t stream);
 
 } // namespace mi355x

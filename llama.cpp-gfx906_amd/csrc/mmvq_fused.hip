@@ -164,7 +164,15 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         a.rope = make_fused_rope(*rope);
         a.pos = rope->pos;
     }
-    const size_t lds = bytes + 64 + 64;     // + FW floats for the RMS reduction + the finaliser's chunk list
+    size_t img_max = bytes;                   // groups of another activation format build a different image (PRO_QUANT / PRO_NORM only)
+    for (int i = 0; i < n_groups; i++) {
+        const int kd = act_kind_for(groups[i].type);
+        if (kd != in.act_kind) {
+            if (in.mode == PRO_Q8) { fprintf(stderr, "mul_mat_vec_q_fused: groups of two activation formats cannot share a copied image\n"); abort(); }
+            img_max = std::max(img_max, act_image_bytes(k, kd));
+        }
+    }
+    const size_t lds = img_max + 64 + 64;     // + FW floats for the RMS reduction + the finaliser's chunk list
     int ta = groups[0].type, tb = groups[0].type;
     for (int i = 1; i < n_groups; i++) if (groups[i].type != ta) tb = groups[i].type;
     if (tb < ta) { const int t = ta; ta = tb; tb = t; }
@@ -192,8 +200,9 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
     for (int i = 0; i < n_groups; i++) {
         const int nwg_i = a.block_end[i] - (i ? a.block_end[i - 1] : 0);
         const int64_t pairs = (groups[i].m + 1)/2, per_wave = (pairs + (int64_t) nwg_i*FW - 1)/((int64_t) nwg_i*FW);
-        const int64_t nblk = k/(in.act_kind == T_Q8_0 ? 32 : 256);
-        const int64_t it = in.act_kind == T_Q8_0 ? (nblk + 63)/64 : (nblk + 7)/8;      // <= the steps per row pair of every type
+        const int kd = act_kind_for(groups[i].type);
+        const int64_t nblk = k/(kd == T_Q8_0 ? 32 : 256);
+        const int64_t it = kd == T_Q8_0 ? (nblk + 63)/64 : (nblk + 7)/8;      // <= the steps per row pair of every type
         if (per_wave*it > max_steps) max_steps = per_wave*it;
     }
     const bool deep = depth_env ? depth_env > 2 : max_steps >= 16;
@@ -218,6 +227,7 @@ static void fused_launch_kernel(const fused_launch & L, hipStream_t stream) {
         if (ta == T_Q4_K && tb == T_Q5_K) { launch_fused_q4_K_q5_K(L, stream); return; }
         if (ta == T_Q4_K && tb == T_Q6_K) { launch_fused_q4_K_q6_K(L, stream); return; }
         if (ta == T_Q5_K && tb == T_Q6_K) { launch_fused_q5_K_q6_K(L, stream); return; }
+        if (ta == T_Q8_0 && tb == T_Q4_K && L.mode != PRO_Q8) { launch_fused_q8_0_q4_K(L, stream); return; }
     }
     fprintf(stderr, "mul_mat_vec_q_fused: type pair (%d, %d) has no kernel (check mul_mat_vec_q_fused_can_group)\n", ta, tb);
     abort();
@@ -244,6 +254,11 @@ bool mul_mat_vec_q_fused_can_group(int type_a, int type_b) {
     if (type_a == type_b) return true;
     const int lo = type_a < type_b ? type_a : type_b, hi = type_a < type_b ? type_b : type_a;
     return (lo == T_Q4_K && (hi == T_Q5_K || hi == T_Q6_K)) || (lo == T_Q5_K && hi == T_Q6_K);
+}
+// ... and which pairs of DIFFERENT activation formats may, when every workgroup quantizes the activation itself (PRO_QUANT / PRO_NORM)
+bool mul_mat_vec_q_fused_can_group_mixed(int type_a, int type_b) {
+    const int lo = type_a < type_b ? type_a : type_b, hi = type_a < type_b ? type_b : type_a;
+    return lo == T_Q8_0 && hi == T_Q4_K;
 }
 
 } // namespace mi355x
