@@ -1426,7 +1426,8 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
 }
 
 // MUL_MAT(F32 router weights, x) [-> ADD bias] [-> SOFT_MAX] -> ARGSORT desc, one token (src/llama-graph.cpp:838-883)
-static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+// norm / normw != NULL: x (= lg->src[1]) is MUL(RMS_NORM(norm->src[0]), normw), not computed yet: the router kernel computes it and writes it
+static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm = nullptr, const struct ggml_tensor * normw = nullptr) {
     struct ggml_tensor * lg = g->nodes[i];
     const struct ggml_tensor * w = lg->src[0]; const struct ggml_tensor * x = lg->src[1];
     if (w->type != GGML_TYPE_F32 || x->type != GGML_TYPE_F32 || lg->type != GGML_TYPE_F32) return 0;
@@ -1454,7 +1455,13 @@ static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i
     }
     if (nd->op != GGML_OP_ARGSORT || nd->src[0] != cur || nd->op_params[0] != GGML_SORT_ORDER_DESC || nd->type != GGML_TYPE_I32 ||
         !ggml_is_contiguous(nd) || ggml_nelements(nd) != E) return 0;
-    moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws);
+    if (norm) {
+        if (!moe_route_norm_supported(K, E, c->moe_ws) || ((uintptr_t) normw->data % 16) || ((uintptr_t) norm->src[0]->data % 16) || ((uintptr_t) x->data % 16)) return 0;
+        moe_route((const float *) w->data, w->nb[1], (const float *) norm->src[0]->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws,
+                  (const float *) normw->data, op_f32(norm, 0), (float *) x->data);
+    } else {
+        moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws);
+    }
     c->cnt.kernels_launched++;
     return j - i + 1;
 }
@@ -1724,6 +1731,14 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                             is_row_vec_f32(s0) && !(mul->flags & GGML_TENSOR_FLAG_OUTPUT)) {
                             const int l = try_fused_mmv(c, g, jn, node, w);
                             if (l >= 0) { consumed = l - i + 1; fresh_aq = c->aq_fresh; c->aq_fresh = false; break; }
+                        }
+                        // MoE: the router's F32 mat-mul reads the product first (build_moe_ffn, src/llama-graph.cpp:838): the norm runs inside the
+                        // router kernel, which also writes the product for the expert mat-vecs that follow
+                        if (mm && mm->op == GGML_OP_MUL_MAT && mm->src[1] == mul && mm->src[0]->type == GGML_TYPE_F32 && node->ne[1] == 1 && w->ne[0] == node->ne[0] &&
+                            ggml_nelements(w) == w->ne[0] && is_row_vec_f32(s0) && is_row_vec_f32(mul) && s0->data != mul->data) {
+                            rec_flush(c);
+                            const int f = try_fused_moe_route(c, g, jn, node, w);
+                            if (f) { consumed = jn + f - i; break; }
                         }
                         rec_flush(c);
                         if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&

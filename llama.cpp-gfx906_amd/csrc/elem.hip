@@ -593,7 +593,10 @@ void soft_max(const tensor_desc & src, const tensor_desc * mask, const float * s
 
 // ---- MoE router, one token (decode): logits = W_r . x (+ bias) -> [soft_max] -> argsort descending, one workgroup
 // (src/llama-graph.cpp:838-883: build_lora_mm(gate_inp), ggml_add(gate_inp_b), ggml_soft_max, ggml_top_k = argsort + view)
-struct moe_route_args { const float * w; size_t w_nb1; const float * x; const float * bias; int k, n_expert, softmax; float * logits; float * probs; int32_t * sorted; };
+struct moe_route_args { const float * w; size_t w_nb1; const float * x; const float * bias; int k, n_expert, softmax; float * logits; float * probs; int32_t * sorted;
+                        // norm_w != NULL (the wide kernel only): x is the RAW residual stream and the router's input is y = (x * rsqrt(mean(x^2) + eps)) * norm_w
+                        // (build_norm's RMS_NORM -> MUL folded in); workgroup 0 also writes y to y_out, where the expert mat-vecs read it
+                        const float * norm_w; float eps; float * y_out; };
 __global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
     __shared__ float v[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 16 waves: the rows of 32 experts are 2 per wave
@@ -642,18 +645,47 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e0 = blockIdx.x*MR_EPW + wave;
+    float scale = 1.0f;
+    if (p.norm_w) {        // every workgroup normalises the whole vector for itself (k floats from L2: 11-16 KB)
+        __shared__ float ssw[4];
+        float ss = 0.0f;
+        for (int i0 = threadIdx.x*4; i0 < p.k; i0 += 4*1024) {      // four loads in flight per thread (k = 4096: one trip)
+            float4v a[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[u] = *(const float4v *) (p.x + min(i0 + u*1024, p.k - 4));
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (i0 + u*1024 < p.k) ss += (a[u].x*a[u].x + a[u].y*a[u].y) + (a[u].z*a[u].z + a[u].w*a[u].w);
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) ssw[wave] = ss;
+        __syncthreads();
+        ss = (ssw[0] + ssw[1]) + (ssw[2] + ssw[3]);
+        scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
+        if (blockIdx.x == 0 && p.y_out) {
+            for (int i = threadIdx.x*4; i < p.k; i += 1024) {
+                const float4v a = *(const float4v *) (p.x + i), nw = *(const float4v *) (p.norm_w + i);
+                *(float4v *) (p.y_out + i) = float4v{ (a.x*scale)*nw.x, (a.y*scale)*nw.y, (a.z*scale)*nw.z, (a.w*scale)*nw.w };
+            }
+        }
+    }
+    auto xin = [&](int i) -> float4v {
+        const float4v a = *(const float4v *) (p.x + i);
+        if (!p.norm_w) return a;
+        const float4v nw = *(const float4v *) (p.norm_w + i);
+        return float4v{ (a.x*scale)*nw.x, (a.y*scale)*nw.y, (a.z*scale)*nw.z, (a.w*scale)*nw.w };
+    };
     if (wave < MR_EPW && e0 < p.n_expert) {
         const char * row = (const char *) p.w + (size_t) e0*p.w_nb1;
         float acc = 0.0f, acc2 = 0.0f;
         int i = lane*4;
         for (; i + 256 < p.k; i += 512) {
-            const float4v a = *(const float4v *) (row + (size_t) i*4), b = *(const float4v *) (p.x + i);
-            const float4v a2 = *(const float4v *) (row + (size_t)(i + 256)*4), b2 = *(const float4v *) (p.x + i + 256);
+            const float4v a = *(const float4v *) (row + (size_t) i*4), b = xin(i);
+            const float4v a2 = *(const float4v *) (row + (size_t)(i + 256)*4), b2 = xin(i + 256);
             acc  += (a.x*b.x + a.y*b.y) + (a.z*b.z + a.w*b.w);
             acc2 += (a2.x*b2.x + a2.y*b2.y) + (a2.z*b2.z + a2.w*b2.w);
         }
         if (i < p.k) {
-            const float4v a = *(const float4v *) (row + (size_t) i*4), b = *(const float4v *) (p.x + i);
+            const float4v a = *(const float4v *) (row + (size_t) i*4), b = xin(i);
             acc += (a.x*b.x + a.y*b.y) + (a.z*b.z + a.w*b.w);
         }
         acc += acc2;                        // the same summation order as k_moe_route: identical logits
@@ -688,10 +720,15 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         p.sorted[rank] = e;
     }
 }
-void moe_route(const float * w, size_t w_nb1, const float * x, const float * bias, int64_t k, int64_t n_expert, bool softmax,
-               float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws) {
-    moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted };
+bool moe_route_norm_supported(int64_t k, int64_t n_expert, const float * ws) {
     static const bool wide_on = !getenv("GGML_MI355X_MOE_ROUTE_WIDE") || atoi(getenv("GGML_MI355X_MOE_ROUTE_WIDE")) != 0;
+    return ws && wide_on && n_expert >= 4 && n_expert <= 256 && k % 4 == 0;
+}
+void moe_route(const float * w, size_t w_nb1, const float * x, const float * bias, int64_t k, int64_t n_expert, bool softmax,
+               float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws, const float * norm_w, float eps, float * y_out) {
+    moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted, norm_w, eps, y_out };
+    static const bool wide_on = !getenv("GGML_MI355X_MOE_ROUTE_WIDE") || atoi(getenv("GGML_MI355X_MOE_ROUTE_WIDE")) != 0;
+    if (norm_w && !moe_route_norm_supported(k, n_expert, ws)) { fprintf(stderr, "moe_route: the norm is folded into the multi-workgroup kernel only\n"); abort(); }
     if (ws && wide_on && n_expert >= 4 && n_expert <= 256) hipLaunchKernelGGL(k_moe_route_wide, dim3((unsigned)((n_expert + MR_EPW - 1)/MR_EPW)), dim3(256), 0, stream, a, ws);
     else hipLaunchKernelGGL(k_moe_route, dim3(1), dim3(1024), 0, stream, a);
 }
