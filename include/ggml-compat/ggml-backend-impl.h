@@ -1,5 +1,6 @@
-// ggml-compat/ggml-backend-impl.h — the five plugin vtables a ggml backend
-// fills in (SURVEY.md §8b "Vtables to restate"). [UPSTREAM-KNOWLEDGE]: the real
+// ggml-compat/ggml-backend-impl.h — restatement of upstream ggml's backend plugin interface (ggml/src/ggml-backend-impl.h; The ggml
+// authors, MIT License — see the attribution in ggml.h beside this file): the five vtables a ggml backend
+// fills in (SURVEY.md §8b "Vtables to restate"). Field order and the field comments are upstream's. [UPSTREAM-KNOWLEDGE]: the real
 // ggml/src/ggml-backend-impl.h is absent from the reference tree; field order is
 // ABI and MUST be verified against a real checkout before claiming drop-in
 // (a one-field mismatch is a crash, not a wrong number). Everything that depends

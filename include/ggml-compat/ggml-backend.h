@@ -1,5 +1,5 @@
-// ggml-compat/ggml-backend.h — clean-room restatement of the ggml-backend
-// public API surface that libllama / llama-bench / test-backend-ops consume
+// ggml-compat/ggml-backend.h — restatement of upstream ggml's backend API (ggml/include/ggml-backend.h; The ggml authors, MIT License —
+// see the attribution in ggml.h beside this file): the surface that libllama / llama-bench / test-backend-ops consume
 // (SURVEY.md §8b table "In-tree evidence of the surface"). Each group cites the
 // reference call sites that rely on it. The real header is absent from the
 // reference tree (.gitmodules:1-3); names and signatures are

@@ -1,5 +1,12 @@
-// ggml-compat/ggml.h — clean-room restatement of the slice of ggml's public
-// header that the MI355X backend's hot path touches.
+// ggml-compat/ggml.h — restatement of the slice of upstream ggml's public header (ggml/include/ggml.h) that the MI355X backend's hot
+// path touches.
+//
+// ATTRIBUTION: the declarations below restate the public interface of ggml (https://github.com/ggml-org/ggml, the tensor library of
+// llama.cpp; Copyright (c) 2023-2025 The ggml authors, MIT License). Struct field order, enum values, function names and signatures — and
+// several field comments — are upstream ggml's, as an ABI restatement requires; they are reproduced here from knowledge of that interface at
+// the sync point named below, because the reference tree carries no copy of it. MIT License notice: "Permission is hereby granted, free of
+// charge, to any person obtaining a copy of this software and associated documentation files, to deal in the Software without restriction
+// ... The above copyright notice and this permission notice shall be included in all copies or substantial portions of the Software."
 //
 // WHY THIS FILE EXISTS: the reference tree's `ggml/` is an empty, un-vendored
 // submodule (/root/reference/.gitmodules:1-3), so the real ggml.h is absent.

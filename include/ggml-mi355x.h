@@ -6,7 +6,7 @@
 // Plain C: pointers and sizes only.
 //
 // Build-time ABI note: the vtable/tensor layouts come from include/ggml-compat/*.h
-// (clean-room, [UPSTREAM-KNOWLEDGE]) because the reference's ggml/ submodule is empty
+// (a restatement of upstream ggml's interface — The ggml authors, MIT License, attributed there) because the reference's ggml/ submodule is empty
 // (/root/reference/.gitmodules:1-3). Against a real ggml checkout, build with its
 // headers instead — the symbols below do not change.
 #pragma once

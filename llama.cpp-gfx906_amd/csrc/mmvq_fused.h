@@ -160,29 +160,47 @@ static __device__ __forceinline__ float4v ld_f4_sc1(const float * p) {      // t
 }
 
 // operands of one row pair's epilogue, requested when the pair starts (all lanes load the same addresses: one line, broadcast)
+// EXT (template): the extended epilogue — a bias before the rotation and NEOX rotation pairs (EPI_ROPE), a second addend and per-expert
+// bias rows (EPI_ADD): gpt-oss's graphs. Compiled only into the instantiations a launch with such a group takes (fused_launch.ext): carried
+// in every kernel it cost the Llama-3-8B decode 2.7 % (528 -> 514 tok/s: code size and scalar registers of launches that last 4-8 us)
 struct pair_pre { float r0, r1; long long i0, i1; float ff; float q0, q1; };
 
-// Branch-free: an absent operand is read from `dummy` (a readable device address, the group's weights) and ignored — loads inside
-// branches made the compiler wait for EVERY outstanding load (vmcnt(0)) where the branches join.
-template <bool GLU>
+// The addresses are workgroup... wave-uniform (the rows of a unit are), so these are SCALAR loads (s_load, issued here by inline asm, waited
+// for in pair_wait just before the pair's finish): round 2 first had them as vector loads — seven 4-byte loads per row pair, most of
+// them of an absent operand (read from `dummy`, a readable address, and ignored: loads inside branches made the compiler wait for every
+// outstanding load where the branches join) — and two more for the second addend cost the Llama-3-8B decode 3.5 % (530 -> 511 tok/s).
+// The scalar cache is invalidated at kernel start; nothing read here is written inside the launch.
+template <bool GLU, bool EXT>
 static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, const fused_rope & rope, const char * dummy, int m, int row0, int row1, int eid0) {
     pair_pre e = { 0.0f, 0.0f, 0, 0, 1.0f, 0.0f, 0.0f };
     if (GLU) return e;
-    const int ra = min(row0, m - 1), rb = min(row1, m - 1);
+    const int ra = __builtin_amdgcn_readfirstlane(min(row0, m - 1)), rb = __builtin_amdgcn_readfirstlane(min(row1, m - 1));   // wave-uniform by construction
     // res: the residual of EPI_ADD, or the bias added before the rotation (EPI_ROPE: gpt-oss's wq / wk, src/llama-model.cpp:17636-17652)
-    const bool has_res = g.res != nullptr && (g.epi == EPI_ADD || g.epi == EPI_ROPE), has_ff = g.epi == EPI_ROPE && rope.ff != nullptr, has_idx = g.st_mode == 2;
+    const bool has_res = g.res != nullptr && (g.epi == EPI_ADD || (EXT && g.epi == EPI_ROPE)), has_ff = g.epi == EPI_ROPE && rope.ff != nullptr, has_idx = g.st_mode == 2;
     // res_eid: res is a [m, n_expert] bias table and this group is expert eid0 (ADD_ID after a one-token MUL_MAT_ID: gpt-oss's ffn_down_exps.bias)
-    const float * rp = has_res ? g.res + (g.res_eid ? (size_t) eid0*m : 0) : (const float *) dummy;
-    e.r0 = rp[has_res ? ra : 0]; e.r1 = rp[has_res ? rb : 0];
+    const float * rp = has_res ? g.res + (EXT && g.res_eid ? (size_t) eid0*m : 0) : (const float *) dummy;
     // res2: a second addend after the first (wo.x + bias, then + the residual stream: two ADD nodes in the graph)
-    const bool has_res2 = g.res2 != nullptr && g.epi == EPI_ADD;
+    const bool has_res2 = EXT && g.res2 != nullptr && g.epi == EPI_ADD;
     const float * rq = has_res2 ? g.res2 : (const float *) dummy;
-    e.q0 = rq[has_res2 ? ra : 0]; e.q1 = rq[has_res2 ? rb : 0];
     const float * fp = has_ff ? rope.ff : (const float *) dummy;
-    e.ff = fp[has_ff ? (rope.neox ? min(ra % rope.head_dim, (rope.n_dims >> 1) - 1) : (min(ra % rope.head_dim, rope.n_dims - 1) >> 1)) : 0];
     const int64_t * ip = has_idx ? g.st_idx : (const int64_t *) dummy;
-    e.i0 = ip[has_idx ? ra : 0]; e.i1 = ip[has_idx ? rb : 0];
+    const float * a_r0 = rp + (has_res ? ra : 0), * a_r1 = rp + (has_res ? rb : 0), * a_q0 = rq + (has_res2 ? ra : 0), * a_q1 = rq + (has_res2 ? rb : 0);
+    const float * a_ff = fp + (has_ff ? (rope.neox ? min(ra % rope.head_dim, (rope.n_dims >> 1) - 1) : (min(ra % rope.head_dim, rope.n_dims - 1) >> 1)) : 0);
+    auto uni = [](const int64_t * q) -> const int64_t * {       // (the compiler kept these two addresses in VGPRs)
+        const unsigned long long a = (unsigned long long) q;
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+        return (const int64_t *) (((unsigned long long) hi << 32) | lo);
+    };
+    const int64_t * a_i0 = uni(ip + (has_idx ? ra : 0)), * a_i1 = uni(ip + (has_idx ? rb : 0));
+    asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %8, 0x0\n\ts_load_dword %2, %9, 0x0\n\ts_load_dword %3, %10, 0x0\n\t"
+                 "s_load_dword %4, %11, 0x0\n\ts_load_dwordx2 %5, %12, 0x0\n\ts_load_dwordx2 %6, %13, 0x0"
+                 : "=&s"(e.r0), "=&s"(e.r1), "=&s"(e.q0), "=&s"(e.q1), "=&s"(e.ff), "=&s"(e.i0), "=&s"(e.i1)
+                 : "s"(a_r0), "s"(a_r1), "s"(a_q0), "s"(a_q1), "s"(a_ff), "s"(a_i0), "s"(a_i1));      // no memory clobber: it would fence the weight stream's scheduling
     return e;
+}
+// the scalar loads of pair_prefetch have landed (ties the registers to the wait so that no use can move above it)
+static __device__ __forceinline__ void pair_wait(pair_pre & e) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e.r0), "+s"(e.r1), "+s"(e.q0), "+s"(e.q1), "+s"(e.ff), "+s"(e.i0), "+s"(e.i1));
 }
 
 // rope on one rotation pair with the frequency factor already fetched: NORM (2i, 2i+1) or NEOX (i, i + n_dims/2), row_in_head = the
@@ -206,15 +224,16 @@ static __device__ __forceinline__ void rope_pair_ff(const fused_rope & r, int po
 }
 
 // what lane 0 does with the two finished rows of a pair (inlined: a call would spill the in-flight prefetch registers)
+template <bool EXT>
 static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const fused_rope & rope, float s0, float s1, int row0, int row1, int pos0, long long idx0,
                                                    const pair_pre & e, const int g_m, const int rows) {
     const int m = rows > 1 ? g_m : row0 + 1;      // rows == 1: the unit has no second row
     if (g.epi == EPI_ADD) {
         s0 += e.r0;
         if (row1 < m) s1 += e.r1;
-        if (g.res2) { s0 += e.q0; if (row1 < m) s1 += e.q1; }
+        if (EXT && g.res2) { s0 += e.q0; if (row1 < m) s1 += e.q1; }
     } else if (g.epi == EPI_ROPE) {
-        if (g.res) { s0 += e.r0; s1 += e.r1; }                          // bias first, then the rotation
+        if (EXT && g.res) { s0 += e.r0; s1 += e.r1; }                          // bias first, then the rotation
         rope_pair_ff(rope, pos0, row0 % rope.head_dim, e.ff, s0, s1);   // m is a multiple of the head size on this path
     }
     g.dst[row0] = s0;
@@ -282,7 +301,7 @@ static __device__ __forceinline__ void glu_flush8(const float (&hg)[8], const fl
 //   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*256*waves)
 //   D    : ring depth (2; 4 for the one-row GLU units and for long single-tensor streams)
 //   FWT  : waves per workgroup
-template <int TYPE, bool GLU, int PRO, int NA, int D, int FWT>
+template <int TYPE, bool GLU, int PRO, int NA, int D, int FWT, bool EXT>
 static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, const fused_sel & sel, char * smem, int lane, int wave) {
     typedef mmvq_t<TYPE> T;
     // rows per unit of work: a pair for single-tensor groups; ONE row (of gate and of up) for the dual GLU stream, so that n_ff = 14336
@@ -341,7 +360,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     const int n_mine = fin_on ? max(0, min(fin_rpw, P - u_base)) : (u_base < P ? (P - 1 - u_base)/u_step + 1 : 0);
     int p_cur = u_base;
     // the two rows of unit pp (single-tensor groups): adjacent, or the NEOX rotation partners i and i + half of one head
-    const int nhl = GLU ? 0 : sel.neox_hl;
+    const int nhl = (GLU || !EXT) ? 0 : sel.neox_hl;
 #define MI_ROW_A(pp_) (nhl ? ((((pp_) >> (nhl - 1)) << nhl) + ((pp_) & ((1 << (nhl - 1)) - 1))) : (pp_)*R)
 #define MI_ROW_B(pp_) (MI_ROW_A(pp_) + (nhl ? (1 << (nhl - 1)) : 1))
     // an expert of a stack (MUL_MAT_ID, one token): the index is a device value, workgroup-uniform
@@ -374,7 +393,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     // the activation is there.
     MI_FETCH(0)
     MI_FENCE;
-    pair_pre epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), R > 1 ? MI_ROW_B(p_cur) : MI_ROW_A(p_cur), eid0);      // behind the first weight step: needed only after the pair's last dot
+    pair_pre epre = pair_prefetch<GLU, EXT>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), R > 1 ? MI_ROW_B(p_cur) : MI_ROW_A(p_cur), eid0);      // behind the first weight step: needed only after the pair's last dot
     MI_FENCE;
 
     // ---- (3) prologue: build the quantized activation image in LDS ----
@@ -473,11 +492,12 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
                         if (++nh == 8) { glu_flush8((const float (&)[8]) hg, (const float (&)[8]) hu, 8, p_cur, u_step, g, g_m, eid0, fin_on, lane); nh = 0; }
                     } else {
                         const float s0 = wave_sum(acc[0]), s1 = R > 1 ? wave_sum(acc[1]) : 0.0f;
-                        if (lane == 0) finish_pair(g, p.rope, s0, s1, MI_ROW_A(p_cur), MI_ROW_B(p_cur), pos0, idx0, epre, g_m, R);
+                        pair_wait(epre);
+                        if (lane == 0) finish_pair<EXT>(g, p.rope, s0, s1, MI_ROW_A(p_cur), MI_ROW_B(p_cur), pos0, idx0, epre, g_m, R);
                     }
                     it = 0; p_cur += u_step;
                     acc[0] = acc[1] = 0.0f; acu[0] = acu[1] = 0.0f;
-                    if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), MI_ROW_B(p_cur), eid0);     // the next pair's epilogue operands
+                    if (!GLU && s + d + 1 < total) epre = pair_prefetch<GLU, EXT>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), MI_ROW_B(p_cur), eid0);     // the next pair's epilogue operands
                 }
             }
         }
@@ -530,18 +550,20 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
 // FWT = waves per workgroup: 8, or 16 for launches with more row pairs than 8 waves x CUs but no more than 16 x CUs (norm + QKV:
 // 3072 pairs) — ONE 1024-thread workgroup per CU shares one prologue (two 8-wave workgroups on a CU ran the second one's prologue
 // ~2x slower), every wave owns a single pair, and the prologue has one 256-chunk per wave instead of two
-template <int TA, int TB, bool GLU, int PRO, int NA, int D, int FWT = 8>
+template <int TA, int TB, bool GLU, int PRO, int NA, int D, int FWT = 8, bool EXT = false>
 __global__ void __launch_bounds__(FWT*64, FWT == 8 ? 2 : 1) k_mmvq_fused(const fused_mmvq_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // the wave index as a SCALAR: everything derived from it (the units a wave owns, its trip count, row offsets, the epilogue's addresses)
+    // then lives in SGPRs and its branches are scalar branches
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const fused_sel sel = load_header((int) blockIdx.x);
     // 16 waves: every wave owns ONE unit of k <= 4096; a format whose wave covers 16 blocks per step (Q6_K) finishes it in one step, and a
     // second register set would only hold a dead fetch (the Q4_K + Q6_K norm+QKV kernel spilled 3 dwords at its 128-VGPR limit, and the
     // reloads queued behind the weight stream: its Q6_K workgroups left the prologue 3.3 us late, tools/stamp_timeline.py)
     constexpr int DA = (FWT == 16 && mmvq_t<TA>::QK == 256 && mmvq_t<TA>::LPB <= 4) ? 1 : D;
     constexpr int DB = (FWT == 16 && mmvq_t<TB>::QK == 256 && mmvq_t<TB>::LPB <= 4) ? 1 : D;
-    if (TA == TB || sel.type == TA) fused_body<TA, GLU, PRO, NA, DA, FWT>(p, sel, smem, lane, wave);
-    else                            fused_body<TB, GLU, PRO, NA, DB, FWT>(p, sel, smem, lane, wave);
+    if (TA == TB || sel.type == TA) fused_body<TA, GLU, PRO, NA, DA, FWT, EXT>(p, sel, smem, lane, wave);
+    else                            fused_body<TB, GLU, PRO, NA, DB, FWT, EXT>(p, sel, smem, lane, wave);
 }
 
 // Timing hook: when the host set an event pair (option "profile"), the launch carries it as the DISPATCH's own start / stop events
@@ -549,19 +571,23 @@ __global__ void __launch_bounds__(FWT*64, FWT == 8 ? 2 : 1) k_mmvq_fused(const f
 // kernel trace reports — not "launch call to completion" as a pair of hipEventRecord around the launch measures
 extern hipEvent_t mi355x_fused_ev0, mi355x_fused_ev1;
 extern const char * mi355x_fused_last_kernel;       // the instantiation the last launch used, spelled as rocprofv3's kernel trace spells it
-template <int TA, int TB, bool GLU, int PRO, int NA, int D, int FWT = 8> static const char * fused_kname() {
+template <int TA, int TB, bool GLU, int PRO, int NA, int D, int FWT = 8, bool EXT = false> static const char * fused_kname() {
     static char name[96] = "";
-    if (!name[0]) snprintf(name, sizeof(name), "k_mmvq_fused<%d, %d, %s, %d, %d, %d, %d>", TA, TB, GLU ? "true" : "false", PRO, NA, D, FWT);
+    if (!name[0]) snprintf(name, sizeof(name), "k_mmvq_fused<%d, %d, %s, %d, %d, %d, %d, %s>", TA, TB, GLU ? "true" : "false", PRO, NA, D, FWT, EXT ? "true" : "false");
     return name;
 }
 #define MI_UNP(...) __VA_ARGS__
+// the single-tensor instantiations exist twice: with and without the extended epilogue
+#define MI_FLX(TARGS6_, FW_, grid_, block_, lds_, stream_, a_) do { \
+    if (L.ext) MI_FL((MI_UNP TARGS6_, FW_, true), grid_, block_, lds_, stream_, a_); \
+    else       MI_FL((MI_UNP TARGS6_, FW_, false), grid_, block_, lds_, stream_, a_); } while (0)
 #define MI_FL(TARGS_, grid_, block_, lds_, stream_, a_) do { \
     mi355x_fused_last_kernel = fused_kname<MI_UNP TARGS_>(); \
     if (mi355x_fused_ev0) { hipExtLaunchKernelGGL((k_mmvq_fused<MI_UNP TARGS_>), grid_, block_, lds_, stream_, mi355x_fused_ev0, mi355x_fused_ev1, 0, a_); mi355x_fused_ev0 = nullptr; mi355x_fused_ev1 = nullptr; } \
     else hipLaunchKernelGGL((k_mmvq_fused<MI_UNP TARGS_>), grid_, block_, lds_, stream_, a_); } while (0)
 
 // a grouped launch, prepared on the host
-struct fused_launch { fused_mmvq_args a; int blocks; size_t lds; int ta, tb; bool glu; int mode, na; bool deep; int64_t k; uint64_t wbytes; int fw; };
+struct fused_launch { fused_mmvq_args a; int blocks; size_t lds; int ta, tb; bool glu; int mode, na; bool deep; int64_t k; uint64_t wbytes; int fw; bool ext; };
 
 // the launcher of one {TA, TB} kernel family: picks the instantiation for L's prologue / activation size class / ring depth
 #define MI_DEFINE_FUSED_LAUNCHER(NAME_, TA_, TB_, HAS_GLU_) \
@@ -572,7 +598,7 @@ void NAME_(const fused_launch & L, hipStream_t stream) { \
     const int mode = L.mode, na = L.na; \
     const bool deep = L.deep; \
     constexpr int FW = 8; \
-    if (L.fw == 16) { MI_FL((TA_, TB_, false, PRO_NORM, 1, 2, 16), grid, dim3(1024), lds, stream, a); return; } \
+    if (L.fw == 16) { MI_FLX((TA_, TB_, false, PRO_NORM, 1, 2), 16, grid, dim3(1024), lds, stream, a); return; } \
     if (HAS_GLU_ && L.glu) {     /* one-row units: 4 steps = the bytes 2 steps of pairs held */ \
         if (mode == PRO_Q8) { \
             if (na == 1)      MI_FL((TA_, TB_, HAS_GLU_, PRO_Q8, 1, 4), grid, dim3(FW*64), lds, stream, a); \
@@ -589,28 +615,28 @@ void NAME_(const fused_launch & L, hipStream_t stream) { \
     } \
     if (deep) { \
         if (mode == PRO_Q8) { \
-            if (na == 1)      MI_FL((TA_, TB_, false, PRO_Q8, 1, 4), grid, dim3(FW*64), lds, stream, a); \
-            else if (na == 2) MI_FL((TA_, TB_, false, PRO_Q8, 2, 4), grid, dim3(FW*64), lds, stream, a); \
-            else              MI_FL((TA_, TB_, false, PRO_Q8, 4, 4), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 1)      MI_FLX((TA_, TB_, false, PRO_Q8, 1, 4), 8, grid, dim3(FW*64), lds, stream, a); \
+            else if (na == 2) MI_FLX((TA_, TB_, false, PRO_Q8, 2, 4), 8, grid, dim3(FW*64), lds, stream, a); \
+            else              MI_FLX((TA_, TB_, false, PRO_Q8, 4, 4), 8, grid, dim3(FW*64), lds, stream, a); \
         } else if (mode == PRO_NORM) { \
-            if (na == 2) MI_FL((TA_, TB_, false, PRO_NORM, 2, 4), grid, dim3(FW*64), lds, stream, a); \
-            else         MI_FL((TA_, TB_, false, PRO_NORM, 8, 4), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 2) MI_FLX((TA_, TB_, false, PRO_NORM, 2, 4), 8, grid, dim3(FW*64), lds, stream, a); \
+            else         MI_FLX((TA_, TB_, false, PRO_NORM, 8, 4), 8, grid, dim3(FW*64), lds, stream, a); \
         } else { \
-            if (na == 2) MI_FL((TA_, TB_, false, PRO_QUANT, 2, 4), grid, dim3(FW*64), lds, stream, a); \
-            else         MI_FL((TA_, TB_, false, PRO_QUANT, 8, 4), grid, dim3(FW*64), lds, stream, a); \
+            if (na == 2) MI_FLX((TA_, TB_, false, PRO_QUANT, 2, 4), 8, grid, dim3(FW*64), lds, stream, a); \
+            else         MI_FLX((TA_, TB_, false, PRO_QUANT, 8, 4), 8, grid, dim3(FW*64), lds, stream, a); \
         } \
         return; \
     } \
     if (mode == PRO_Q8) { \
-        if (na == 1)      MI_FL((TA_, TB_, false, PRO_Q8, 1, 2), grid, dim3(FW*64), lds, stream, a); \
-        else if (na == 2) MI_FL((TA_, TB_, false, PRO_Q8, 2, 2), grid, dim3(FW*64), lds, stream, a); \
-        else              MI_FL((TA_, TB_, false, PRO_Q8, 4, 2), grid, dim3(FW*64), lds, stream, a); \
+        if (na == 1)      MI_FLX((TA_, TB_, false, PRO_Q8, 1, 2), 8, grid, dim3(FW*64), lds, stream, a); \
+        else if (na == 2) MI_FLX((TA_, TB_, false, PRO_Q8, 2, 2), 8, grid, dim3(FW*64), lds, stream, a); \
+        else              MI_FLX((TA_, TB_, false, PRO_Q8, 4, 2), 8, grid, dim3(FW*64), lds, stream, a); \
     } else if (mode == PRO_NORM) { \
-        if (na == 2) MI_FL((TA_, TB_, false, PRO_NORM, 2, 2), grid, dim3(FW*64), lds, stream, a); \
-        else         MI_FL((TA_, TB_, false, PRO_NORM, 8, 2), grid, dim3(FW*64), lds, stream, a); \
+        if (na == 2) MI_FLX((TA_, TB_, false, PRO_NORM, 2, 2), 8, grid, dim3(FW*64), lds, stream, a); \
+        else         MI_FLX((TA_, TB_, false, PRO_NORM, 8, 2), 8, grid, dim3(FW*64), lds, stream, a); \
     } else { \
-        if (na == 2) MI_FL((TA_, TB_, false, PRO_QUANT, 2, 2), grid, dim3(FW*64), lds, stream, a); \
-        else         MI_FL((TA_, TB_, false, PRO_QUANT, 8, 2), grid, dim3(FW*64), lds, stream, a); \
+        if (na == 2) MI_FLX((TA_, TB_, false, PRO_QUANT, 2, 2), 8, grid, dim3(FW*64), lds, stream, a); \
+        else         MI_FLX((TA_, TB_, false, PRO_QUANT, 8, 2), 8, grid, dim3(FW*64), lds, stream, a); \
     } \
 }
 

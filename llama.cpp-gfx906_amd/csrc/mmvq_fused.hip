@@ -206,6 +206,9 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         if (per_wave*it > max_steps) max_steps = per_wave*it;
     }
     const bool deep = depth_env ? depth_env > 2 : max_steps >= 16;
+    L.ext = false;      // does any group need the extended epilogue
+    for (int i = 0; i < n_groups; i++)
+        if ((groups[i].epi == EPI_ROPE && (groups[i].res || (rope && (rope->p.mode & 2)))) || groups[i].res2 || groups[i].res_eid) L.ext = true;
     L.blocks = blocks; L.lds = lds; L.ta = ta; L.tb = tb; L.glu = glu; L.mode = mode; L.na = na; L.deep = deep; L.k = k;
     for (int i = 0; i < n_groups; i++) L.wbytes += (uint64_t) groups[i].m*groups[i].row_stride*(groups[i].epi == EPI_GLU ? 2 : 1);
     return L;
