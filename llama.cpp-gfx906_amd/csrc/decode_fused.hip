@@ -199,6 +199,17 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     const float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
     const char * kbase = p.k + (size_t) hk*p.k_nb2 + sub*16 + (size_t) kv_lo*p.k_nb1;
     const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 + (size_t) kv_lo*(p.mask_f16 ? 2 : 4) : nullptr;
+    // transposed V: the first 128 cells' worth of every lane's V rows is requested NOW, next to q and K — the soft_max in between does
+    // not need them and the loads do not need the soft_max (one memory round trip less on the chain for n_kv <= 128: tg128)
+    constexpr int NGP = VT ? HD/16 : 1;
+    int4v vpre[NGP];
+    if (VT) {
+        const int l16p = lane & 15, rwp = lane >> 4;
+        const char * vb0 = p.v + (size_t) hk*p.v_nb2 + (size_t)(wave*4 + rwp)*p.v_nb1 + (size_t) kv_lo*2;
+        const int c0 = min(l16p, max((kv_n >> 3) - 1, 0));
+#pragma unroll
+        for (int g = 0; g < NGP; g++) vpre[g] = ld_b128(vb0 + (size_t)(g*16)*p.v_nb1 + (size_t) c0*16);
+    }
     float mx = (p.sinks && !split) ? p.sinks[h] : -INFINITY;
     for (int j0 = wave*CPW + cw; j0 < kv_n; j0 += 4*CPW*U) {
         int4v kreg[U]; float mreg[U];
@@ -284,7 +295,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     for (int c = l16; c < nchunk; c += 16) {
         int4v vreg[NG];
 #pragma unroll
-        for (int g = 0; g < NG; g++) vreg[g] = ld_b128(vbase + (size_t)(g*16)*p.v_nb1 + (size_t) c*16);
+        for (int g = 0; g < NG; g++) vreg[g] = c == l16 ? vpre[g] : ld_b128(vbase + (size_t)(g*16)*p.v_nb1 + (size_t) c*16);
         const float4v p0 = *(const float4v *) (s + c*8), p1 = *(const float4v *) (s + c*8 + 4);
 #pragma unroll
         for (int g = 0; g < NG; g++) acc[g] += dot8_f16_f32(vreg[g], p0, p1);
