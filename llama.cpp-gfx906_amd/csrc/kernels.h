@@ -223,14 +223,13 @@ struct mmvq_input {
 };
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind);        // PRO_QUANT / PRO_NORM limits (k % 256, or k % 32 with Q8_0 activations)
-bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);
-bool mul_mat_vec_q_fused_can_group_mixed(int type_a, int type_b);   // pairs of different activation formats (only when the launch quantizes the activation itself)   // may these two weight types share one grouped launch
+bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);         // may these two weight types share one grouped launch
+bool mul_mat_vec_q_fused_can_group_mixed(int type_a, int type_b);   // pairs of different activation formats (only when the launch quantizes the activation itself)
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                          const mmvq_fin * fin = nullptr);
-bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);
-int  mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end);   // workgroups per group (one workgroup per CU in all)      // may a GLU launch with m output rows carry an mmvq_fin
-// Launches that fit a position of the per-layer chain (decode_fused.hip: k_mmvq_chain) are held back until the chain is complete
-// or broken. EVERY other use of the stream must call flush first; `pending` tells how many launches (and weight bytes) are held.
+bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);   // may a GLU launch with m output rows carry an mmvq_fin
+int  mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end);   // workgroups per group (one workgroup per CU in all)
+// (round 1's chained launch held launches back; nothing is held back any more: flush is a no-op kept for its call sites)
 void mul_mat_vec_q_fused_flush(hipStream_t stream);
 // called right before / after every kernel this module puts on the stream (type of the first group, weight bytes, launches merged, k)
 typedef void (*mmvq_launch_hook)(void * ctx, int type, uint64_t weight_bytes, int n_merged, int64_t k);
