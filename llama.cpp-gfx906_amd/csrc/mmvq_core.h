@@ -182,62 +182,53 @@ template <> struct mmvq_t<T_Q6_K> {
     }
 };
 #else
-// lane slot j: half n = j>>2 (128 elements each), l0 = 8*(j&3): the lane owns l = l0..l0+7 of that half, i.e.
-// elements 128n + {0,32,64,96} + l (quants.py:554-572): ql[64n+l] lo/hi nibble, ql[64n+32+l] lo/hi nibble,
-// qh[32n+l] 2-bit fields. 24 bytes of quants per lane.
+// -DMI_Q6K_LPB8 (round 2, measured and NOT the default: correct, but a pure Q6_K model decodes 4.5 % slower with it — 418 vs 438 tok/s — and
+// Q4_K_M the same: the slow start of Q6_K launches is not the number of memory requests per byte either).
+// Eight lanes per block, each load instruction CONTIGUOUS within the block (the four-lane split above touches the block in 32-byte
+// pieces: 4x the memory requests per byte of a Q4_K load): lane j loads ql[16j .. 16j+15] (the block's 128 ql bytes = one run) and
+// qh[32n + 16(m&1) ..+15], n = j>>2, m = j&3. Its 16 ql bytes are, for m < 2: l = 16m + t -> elements 128n + l (low nibbles, qh bits 0-1)
+// and 128n + 64 + l (high nibbles, qh bits 4-5); for m >= 2: l = 16(m-2) + t -> elements 128n + 32 + l (low, bits 2-3) and 128n + 96 + l
+// (high, bits 6-7) (quants.py:554-572). Each 16-element group is exactly one scale and one Q8_K bsum.
 template <> struct mmvq_t<T_Q6_K> {
     static constexpr int LPB = 8, BLOCK_BYTES = 210, QK = 256, ACT = T_Q8_K;
-    struct afrag { int2v a[4]; int s[4]; float d8; };   // s[i] = sum of the 8 int8 of a[i] (for the -32 offset)
-    struct wfrag { int2v qla, qlb, qh; int2v sc; uint32_t d; };
+    struct afrag { int4v lo, hi; int s_lo, s_hi; float d8; };
+    struct wfrag { int4v ql, qh; int2v sc; uint32_t d; };
     static __device__ __forceinline__ afrag load_a(const act_view & a, int64_t ib, int slot) {
-        const int n = slot >> 2, l0 = 8*(slot & 3);
+        const int n = slot >> 2, m = slot & 3;
+        const int g = 8*n + 2*(m >> 1) + (m & 1);         // 16-element group of the low-nibble elements; the high-nibble ones are group g + 4
         afrag f;
-        const int8_t * p = a.qs + ib*256 + 128*n + l0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            f.a[i] = lds_or_global_b64(p + 32*i);
-            f.s[i] = dot4(0x01010101, f.a[i].x, dot4(0x01010101, f.a[i].y, 0));
-        }
+        const int8_t * p = a.qs + ib*256 + 16*g;
+        f.lo = lds_or_global_b128(p); f.hi = lds_or_global_b128(p + 64);
+        f.s_lo = a.bs[ib*16 + g]; f.s_hi = a.bs[ib*16 + g + 4];
         f.d8 = a.d[ib];
         return f;
     }
     static __device__ __forceinline__ wfrag load_w(const char * row, int64_t ib, int slot) {
-        const int n = slot >> 2, l0 = 8*(slot & 3);
+        const int n = slot >> 2, m = slot & 3;
         const char * b = row + ib*BLOCK_BYTES;   // only 2-byte aligned: unaligned-mode global loads
         wfrag w;
-#ifndef MI_Q6K_ALIGNED_LOADS     // tried (round 2): dword-aligned 16-byte loads + v_alignbyte for the 2-byte-aligned fragments — slower (ffn_down Q6_K 14.8 -> 16.4 us)
-        w.qla = ld_b64(b + 64*n + l0);
-        w.qlb = ld_b64(b + 64*n + 32 + l0);
-        w.qh  = ld_b64(b + 128 + 32*n + l0);
-        w.sc  = ld_b64(b + 192 + 8*n);           // scales[8n .. 8n+7]
-#else
-        w.qla = ld_b64_a2(b + 64*n + l0);
-        w.qlb = ld_b64_a2(b + 64*n + 32 + l0);
-        w.qh  = ld_b64_a2(b + 128 + 32*n + l0);
-        w.sc  = ld_b64_a2(b + 192 + 8*n);        // scales[8n .. 8n+7]
-#endif
-        w.d   = ld_u16(b + 208);
+        w.ql = ld_b128(b + 16*slot);
+        w.qh = ld_b128(b + 128 + 32*n + 16*(m & 1));
+        w.sc = ld_b64(b + 192 + 8*n);            // scales[8n .. 8n+7]
+        w.d  = ld_u16(b + 208);
         return w;
     }
     static __device__ __forceinline__ float dot(const wfrag & w, const afrag & a, int slot) {
-        const int is = (slot & 3) >> 1;          // l0/16
-        // the four scales this lane needs are bytes is, is+2, is+4, is+6 of sc
-        const uint32_t sx = (uint32_t) w.sc.x >> (8*is), sy = (uint32_t) w.sc.y >> (8*is);
-        const int sc0 = (int8_t)(sx & 0xFF), sc1 = (int8_t)((sx >> 16) & 0xFF), sc2 = (int8_t)(sy & 0xFF), sc3 = (int8_t)((sy >> 16) & 0xFF);
-        int acc[4];
-#define MI_Q6(c, A0, A1, A2, A3) { \
-        const uint32_t qa = (uint32_t) w.qla.c, qb = (uint32_t) w.qlb.c, qh = (uint32_t) w.qh.c; \
-        const int v0 = (int)((qa & 0x0F0F0F0F)        | ((qh << 4) & 0x30303030)); \
-        const int v1 = (int)((qb & 0x0F0F0F0F)        | ((qh << 2) & 0x30303030)); \
-        const int v2 = (int)(((qa >> 4) & 0x0F0F0F0F) | ( qh       & 0x30303030)); \
-        const int v3 = (int)(((qb >> 4) & 0x0F0F0F0F) | ((qh >> 2) & 0x30303030)); \
-        A0 = dot4(v0, a.a[0].c, A0); A1 = dot4(v1, a.a[1].c, A1); A2 = dot4(v2, a.a[2].c, A2); A3 = dot4(v3, a.a[3].c, A3); }
-        acc[0] = acc[1] = acc[2] = acc[3] = 0;
-        MI_Q6(x, acc[0], acc[1], acc[2], acc[3])
-        MI_Q6(y, acc[0], acc[1], acc[2], acc[3])
-#undef MI_Q6
+        const int m = slot & 3;
+        const int idx = 2*(m >> 1) + (m & 1);    // scale bytes idx (low-nibble group) and idx + 4 (high-nibble group) of sc
+        const uint32_t sw_lo = (uint32_t) w.sc.x >> (8*idx), sw_hi = (uint32_t) w.sc.y >> (8*idx);
+        const int sc_lo = (int8_t)(sw_lo & 0xFF), sc_hi = (int8_t)(sw_hi & 0xFF);
+        const int sh = 2*(m >> 1);
+        int acc_lo = 0, acc_hi = 0;
+#define MI_Q6C(c) { \
+        const uint32_t ql = (uint32_t) w.ql.c, qh = (uint32_t) w.qh.c; \
+        const int v_lo = (int)((ql & 0x0F0F0F0Fu)        | (((qh >> sh) & 0x03030303u) << 4)); \
+        const int v_hi = (int)(((ql >> 4) & 0x0F0F0F0Fu) | (((qh >> (sh + 4)) & 0x03030303u) << 4)); \
+        acc_lo = dot4(v_lo, a.lo.c, acc_lo); acc_hi = dot4(v_hi, a.hi.c, acc_hi); }
+        MI_Q6C(x) MI_Q6C(y) MI_Q6C(z) MI_Q6C(w)
+#undef MI_Q6C
         // sum (q-32)*a = sum q*a - 32*sum a
-        const int isum = sc0*(acc[0] - 32*a.s[0]) + sc1*(acc[1] - 32*a.s[1]) + sc2*(acc[2] - 32*a.s[2]) + sc3*(acc[3] - 32*a.s[3]);
+        const int isum = sc_lo*(acc_lo - 32*a.s_lo) + sc_hi*(acc_hi - 32*a.s_hi);
         return (f16_bits_to_f32((uint16_t) w.d)*a.d8)*(float) isum;
     }
 };
