@@ -645,6 +645,20 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
     __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e0 = blockIdx.x*MR_EPW + wave;
+    // the expert's row of router weights (the HBM part of this kernel) is requested first, whole (k <= 4096: 16 x 16 bytes per lane), before the
+    // norm below and before any x is needed: the dot loop used to wait for two loads per trip, 6-8 dependent round trips (4.5 us of a 9 us kernel)
+    constexpr int RT = 8;
+    const bool pre = p.k <= RT*512;
+    const bool mine = wave < MR_EPW && e0 < p.n_expert;
+    float4v ra[RT], rb[RT];
+    if (pre && mine) {
+        const char * row = (const char *) p.w + (size_t) e0*p.w_nb1;
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            ra[t] = *(const float4v *) (row + (size_t) min(lane*4 + 512*t, p.k - 4)*4);
+            rb[t] = *(const float4v *) (row + (size_t) min(lane*4 + 512*t + 256, p.k - 4)*4);
+        }
+    }
     float scale = 1.0f;
     if (p.norm_w) {        // every workgroup normalises the whole vector for itself (k floats from L2: 11-16 KB)
         __shared__ float ssw[4];
@@ -674,9 +688,21 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         const float4v nw = *(const float4v *) (p.norm_w + i);
         return float4v{ (a.x*scale)*nw.x, (a.y*scale)*nw.y, (a.z*scale)*nw.z, (a.w*scale)*nw.w };
     };
-    if (wave < MR_EPW && e0 < p.n_expert) {
+    if (mine) {
         const char * row = (const char *) p.w + (size_t) e0*p.w_nb1;
         float acc = 0.0f, acc2 = 0.0f;
+        if (pre) {
+            // the same terms in the same order as the loop below: acc takes i = lane*4 + 512t (< k), acc2 takes i + 256 (< k)
+            float4v xa[RT], xb[RT];
+#pragma unroll
+            for (int t = 0; t < RT; t++) { xa[t] = xin(min(lane*4 + 512*t, p.k - 4)); xb[t] = xin(min(lane*4 + 512*t + 256, p.k - 4)); }
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                const int i = lane*4 + 512*t;
+                if (i < p.k)       acc  += (ra[t].x*xa[t].x + ra[t].y*xa[t].y) + (ra[t].z*xa[t].z + ra[t].w*xa[t].w);
+                if (i + 256 < p.k) acc2 += (rb[t].x*xb[t].x + rb[t].y*xb[t].y) + (rb[t].z*xb[t].z + rb[t].w*xb[t].w);
+            }
+        } else {
         int i = lane*4;
         for (; i + 256 < p.k; i += 512) {
             const float4v a = *(const float4v *) (row + (size_t) i*4), b = xin(i);
@@ -687,6 +713,7 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         if (i < p.k) {
             const float4v a = *(const float4v *) (row + (size_t) i*4), b = xin(i);
             acc += (a.x*b.x + a.y*b.y) + (a.z*b.z + a.w*b.w);
+        }
         }
         acc += acc2;                        // the same summation order as k_moe_route: identical logits
         acc = wave_sum(acc);
