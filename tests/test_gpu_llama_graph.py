@@ -416,3 +416,22 @@ def test_two_backends_from_two_threads():
     assert not errs, errs
     for i in (0, 1):
         assert np.array_equal(single[i], multi[i])
+
+
+@pytest.mark.parametrize("env", ["GGML_MI355X_ATTN_IN_WO", "GGML_MI355X_MEGA"])
+def test_opt_in_decode_paths_stay_correct(env):
+    """The two decode arrangements that measured slower and are off by default — the attention inside the wo launch (PRO_ATTN) and the
+    persistent whole-token kernel — read their switch once per process: the oracle comparisons of this file again, in a child process with
+    the switch on (has their timings)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("MI_NESTED_PYTEST"):
+        pytest.skip("already the child run")
+    child_env = dict(os.environ, MI_NESTED_PYTEST="1")
+    child_env[env] = "1"
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
+                        "test_synthetic_llama_matches_oracle or test_graph_replay_is_bitwise_neutral or test_kv_clear_restarts_sequence or test_flash_attention_graph"],
+                       env=child_env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
