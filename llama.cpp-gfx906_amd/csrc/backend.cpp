@@ -263,6 +263,9 @@ struct mi_backend_ctx {
     float * moe_ws = nullptr;                                   // logits + arrival counter of the multi-workgroup router kernel (moe_route)
     // producer-side activation quantization (mmvq_fin): the image a GLU launch writes for the mat-vec that follows + its arrival counters
     void * fin_img = nullptr; unsigned * fin_cnt = nullptr;
+    // the rotation table of the token being decoded ((cos, sin) per pair index; mmvq_rope::table): filled by one small launch when a graph's
+    // first rotated mat-vec launch comes up (and again if a launch asks for other rope parameters), read by every such launch after it
+    float * rope_tab = nullptr; mmvq_rope rope_tab_key = {}; bool rope_tab_valid = false;
     static constexpr size_t FIN_IMG_BYTES = 64*1024; static constexpr int FIN_COUNTERS = 256;
     float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
@@ -368,6 +371,7 @@ static void be_free(ggml_backend_t backend) {
     if (c->mega_err) (void) hipHostFree(c->mega_err);
     if (c->fin_img) (void) hipFree(c->fin_img);
     if (c->fin_cnt) (void) hipFree(c->fin_cnt);
+    if (c->rope_tab) (void) hipFree(c->rope_tab);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     delete backend;
@@ -1172,6 +1176,16 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
             }
         }
     }
+    mmvq_rope rope_l;
+    if (rope) {
+        if (!c->rope_tab || rope->p.n_dims/2 > 512) return -1;
+        if (!c->rope_tab_valid || memcmp(&c->rope_tab_key, rope, sizeof(*rope)) != 0) {
+            mul_mat_vec_q_fused_rope_table(*rope, c->rope_tab, c->stream);
+            c->cnt.kernels_launched++;
+            c->rope_tab_key = *rope; c->rope_tab_valid = true;
+        }
+        rope_l = *rope; rope_l.table = c->rope_tab; rope = &rope_l;
+    }
     emit_mmv(c, grp, nc, K, in, rope, fin_t ? &fin : nullptr, in.mode == PRO_NORM && normw ? (float *) norm_mul_data : nullptr);
     if (fin_t) {
         c->aq = { fin_t->data, grp[0].m, 1, 1, fin_t->nb[1], 0, fin.kind, fin_q, true, (size_t) grp[0].m*4, 0 };
@@ -1849,6 +1863,7 @@ done:
 }
 
 static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
+    c->rope_tab_valid = false;      // every pass over a graph (eager or under capture) fills the token's rotation table itself
     // the grouped mat-vec module keeps its launch hooks per host thread: (re)install this backend's for the thread that computes
     mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
     c->aq.valid = false;
@@ -1950,6 +1965,7 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
     set_device(c->device);
     c->cnt.graphs_computed++;
 
+    if (!c->rope_tab) { if (hipMalloc((void **) &c->rope_tab, 4096) != hipSuccess) { (void) hipGetLastError(); c->rope_tab = nullptr; } }
     if (!c->moe_ws) {
         if (hipMalloc((void **) &c->moe_ws, 1088) == hipSuccess) { MI_CHECK_G(hipMemsetAsync(c->moe_ws, 0, 1088, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }

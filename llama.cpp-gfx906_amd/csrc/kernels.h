@@ -209,7 +209,10 @@ struct mmvq_group {
 // GLU launches only: the launch also writes its f32 output as the quantized image (act_q8 layout for n = 1) the next mat-vec reads;
 // counters: >= m/256 words, zero between launches (the kernel re-arms them). m % 256 == 0, one group, no expert stack.
 struct mmvq_fin { int kind; int pad; int8_t * qs; float * d; int16_t * bs; unsigned * counters; };
-struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; };   // EPI_ROPE (NORM pairs)
+// EPI_ROPE. table: n_dims/2 x (cos, sin) for the token at pos[0], filled by mul_mat_vec_q_fused_rope_table on the same stream before the launch
+// (one tiny launch per token and rope configuration instead of powf / cosf / sinf per row pair inside every norm+QKV launch)
+struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim; rope_params p; const float * table; };
+void mul_mat_vec_q_fused_rope_table(const mmvq_rope & rope, float * table, hipStream_t stream);
 
 // where the activation vector comes from
 enum mmvq_prologue { PRO_Q8 = 0, PRO_QUANT = 1, PRO_NORM = 2, PRO_ATTN = 3 };

@@ -164,61 +164,53 @@ static __device__ __forceinline__ float4v ld_f4_sc1(const float * p) {      // t
 // EXT (template): the extended epilogue — a bias before the rotation and NEOX rotation pairs (EPI_ROPE), a second addend and per-expert
 // bias rows (EPI_ADD): gpt-oss's graphs. Compiled only into the instantiations a launch with such a group takes (fused_launch.ext): carried
 // in every kernel it cost the Llama-3-8B decode 2.7 % (528 -> 514 tok/s: code size and scalar registers of launches that last 4-8 us)
-struct pair_pre { float r0, r1; long long i0, i1; float ff; float q0, q1; };
+struct pair_pre { float r0, r1; long long i0, i1; long long rcs; float q0, q1; };      // rcs: the pair's rotation, (cos, sin)*mscale as two f32 (split only after pair_wait)
 
 // The addresses are workgroup... wave-uniform (the rows of a unit are), so these are SCALAR loads (s_load, issued here by inline asm, waited
 // for in pair_wait just before the pair's finish): round 2 first had them as vector loads — seven 4-byte loads per row pair, most of
 // them of an absent operand (read from `dummy`, a readable address, and ignored: loads inside branches made the compiler wait for every
 // outstanding load where the branches join) — and two more for the second addend cost the Llama-3-8B decode 3.5 % (530 -> 511 tok/s).
 // The scalar cache is invalidated at kernel start; nothing read here is written inside the launch.
+// a wave-uniform address into scalar registers (the compiler keeps some of these in VGPRs, depending on the instantiation)
+template <typename P> static __device__ __forceinline__ P mi_uni(P q) {
+    const unsigned long long a = (unsigned long long) q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+    return (P) (((unsigned long long) hi << 32) | lo);
+}
 template <bool GLU, bool EXT>
 static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, const fused_rope & rope, const char * dummy, int m, int row0, int row1, int eid0) {
-    pair_pre e = { 0.0f, 0.0f, 0, 0, 1.0f, 0.0f, 0.0f };
+    pair_pre e = { 0.0f, 0.0f, 0, 0, 0, 0.0f, 0.0f };
     if (GLU) return e;
     const int ra = __builtin_amdgcn_readfirstlane(min(row0, m - 1)), rb = __builtin_amdgcn_readfirstlane(min(row1, m - 1));   // wave-uniform by construction
     // res: the residual of EPI_ADD, or the bias added before the rotation (EPI_ROPE: gpt-oss's wq / wk, src/llama-model.cpp:17636-17652)
-    const bool has_res = g.res != nullptr && (g.epi == EPI_ADD || (EXT && g.epi == EPI_ROPE)), has_ff = g.epi == EPI_ROPE && rope.ff != nullptr, has_idx = g.st_mode == 2;
+    const bool has_res = g.res != nullptr && (g.epi == EPI_ADD || (EXT && g.epi == EPI_ROPE)), has_rot = g.epi == EPI_ROPE, has_idx = g.st_mode == 2;
     // res_eid: res is a [m, n_expert] bias table and this group is expert eid0 (ADD_ID after a one-token MUL_MAT_ID: gpt-oss's ffn_down_exps.bias)
     const float * rp = has_res ? g.res + (EXT && g.res_eid ? (size_t) eid0*m : 0) : (const float *) dummy;
     // res2: a second addend after the first (wo.x + bias, then + the residual stream: two ADD nodes in the graph)
     const bool has_res2 = EXT && g.res2 != nullptr && g.epi == EPI_ADD;
     const float * rq = has_res2 ? g.res2 : (const float *) dummy;
-    const float * fp = has_ff ? rope.ff : (const float *) dummy;
+    const float * fp = has_rot ? rope.tab : (const float *) dummy;       // the pair's (cos, sin): 8 bytes at tab + 2*ip
     const int64_t * ip = has_idx ? g.st_idx : (const int64_t *) dummy;
     const float * a_r0 = rp + (has_res ? ra : 0), * a_r1 = rp + (has_res ? rb : 0), * a_q0 = rq + (has_res2 ? ra : 0), * a_q1 = rq + (has_res2 ? rb : 0);
-    const float * a_ff = fp + (has_ff ? (rope.neox ? min(ra % rope.head_dim, (rope.n_dims >> 1) - 1) : (min(ra % rope.head_dim, rope.n_dims - 1) >> 1)) : 0);
-    auto uni = [](const int64_t * q) -> const int64_t * {       // (the compiler kept these two addresses in VGPRs)
-        const unsigned long long a = (unsigned long long) q;
-        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned) a), hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
-        return (const int64_t *) (((unsigned long long) hi << 32) | lo);
-    };
-    const int64_t * a_i0 = uni(ip + (has_idx ? ra : 0)), * a_i1 = uni(ip + (has_idx ? rb : 0));
+    const float * a_ff = fp + (has_rot ? 2*(rope.neox ? min(ra % rope.head_dim, (rope.n_dims >> 1) - 1) : (min(ra % rope.head_dim, rope.n_dims - 1) >> 1)) : 0);
+    const int64_t * a_i0 = ip + (has_idx ? ra : 0), * a_i1 = ip + (has_idx ? rb : 0);
     asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %8, 0x0\n\ts_load_dword %2, %9, 0x0\n\ts_load_dword %3, %10, 0x0\n\t"
-                 "s_load_dword %4, %11, 0x0\n\ts_load_dwordx2 %5, %12, 0x0\n\ts_load_dwordx2 %6, %13, 0x0"
-                 : "=&s"(e.r0), "=&s"(e.r1), "=&s"(e.q0), "=&s"(e.q1), "=&s"(e.ff), "=&s"(e.i0), "=&s"(e.i1)
-                 : "s"(a_r0), "s"(a_r1), "s"(a_q0), "s"(a_q1), "s"(a_ff), "s"(a_i0), "s"(a_i1));      // no memory clobber: it would fence the weight stream's scheduling
+                 "s_load_dwordx2 %4, %11, 0x0\n\ts_load_dwordx2 %5, %12, 0x0\n\ts_load_dwordx2 %6, %13, 0x0"
+                 : "=&s"(e.r0), "=&s"(e.r1), "=&s"(e.q0), "=&s"(e.q1), "=&s"(e.rcs), "=&s"(e.i0), "=&s"(e.i1)
+                 : "s"(mi_uni(a_r0)), "s"(mi_uni(a_r1)), "s"(mi_uni(a_q0)), "s"(mi_uni(a_q1)), "s"(mi_uni(a_ff)), "s"(mi_uni(a_i0)), "s"(mi_uni(a_i1)));      // no memory clobber: it would fence the weight stream's scheduling
     return e;
 }
 // the scalar loads of pair_prefetch have landed (ties the registers to the wait so that no use can move above it)
 static __device__ __forceinline__ void pair_wait(pair_pre & e) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e.r0), "+s"(e.r1), "+s"(e.q0), "+s"(e.q1), "+s"(e.ff), "+s"(e.i0), "+s"(e.i1));
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(e.r0), "+s"(e.r1), "+s"(e.q0), "+s"(e.q1), "+s"(e.rcs), "+s"(e.i0), "+s"(e.i1));
 }
 
-// rope on one rotation pair with the frequency factor already fetched: NORM (2i, 2i+1) or NEOX (i, i + n_dims/2), row_in_head = the
-// first of the two — same formulas as rope_pair / elem.hip k_rope
-static __device__ __forceinline__ void rope_pair_ff(const fused_rope & r, int pos, int row_in_head, float ff, float & x0, float & x1) {
+// rope on one rotation pair — NORM (2i, 2i+1) or NEOX (i, i + n_dims/2), row_in_head = the first of the two — with the pair's (cos, sin)*mscale
+// from the token's rotation table (k_rope_table: the formulas of rope_pair / elem.hip k_rope, evaluated once per token instead of once per
+// row pair inside every launch, where the one live lane of the finish cost as many issue cycles as 64)
+static __device__ __forceinline__ void rope_pair_cs(const fused_rope & r, int row_in_head, long long rcs, float & x0, float & x1) {
     if (row_in_head >= r.n_dims) return;
-    const int ip = r.neox ? row_in_head : row_in_head >> 1;
-    const float theta_base = (float) pos*powf(r.theta_scale, (float) ip);
-    const float theta_extrap = theta_base/(r.ff ? ff : 1.0f);
-    float theta_interp = r.freq_scale*theta_extrap, theta = theta_interp, mscale = r.attn_factor;
-    if (r.ext_factor != 0.0f) {
-        const float y = ((float) ip - r.corr_lo)/fmaxf(0.001f, r.corr_hi - r.corr_lo);
-        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y)))*r.ext_factor;
-        theta = theta_interp*(1.0f - ramp_mix) + theta_extrap*ramp_mix;
-        mscale *= 1.0f + 0.1f*logf(1.0f/r.freq_scale);
-    }
-    const float c = cosf(theta)*mscale, s = sinf(theta)*mscale;
+    const float c = __builtin_bit_cast(float, (int)(rcs & 0xFFFFFFFFll)), s = __builtin_bit_cast(float, (int)((unsigned long long) rcs >> 32));
     const float a = x0, b = x1;
     x0 = a*c - b*s;
     x1 = a*s + b*c;
@@ -235,7 +227,7 @@ static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const f
         if (EXT && g.res2) { s0 += e.q0; if (row1 < m) s1 += e.q1; }
     } else if (g.epi == EPI_ROPE) {
         if (EXT && g.res) { s0 += e.r0; s1 += e.r1; }                          // bias first, then the rotation
-        rope_pair_ff(rope, pos0, row0 % rope.head_dim, e.ff, s0, s1);   // m is a multiple of the head size on this path
+        rope_pair_cs(rope, row0 % rope.head_dim, e.rcs, s0, s1);   // m is a multiple of the head size on this path
     }
     g.dst[row0] = s0;
     if (row1 < m) g.dst[row1] = s1;

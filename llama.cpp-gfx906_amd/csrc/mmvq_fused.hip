@@ -97,6 +97,29 @@ int mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, i
     return share_groups(groups, n_groups, fw, device_cu_count(), block_end);
 }
 
+// ---- the rotation table of one token: tab[2*ip] = cos(theta_ip)*mscale, tab[2*ip + 1] = sin(theta_ip)*mscale, ip < n_dims/2, for the position
+//      pos[0] — elem.hip's k_rope / rope_pair formulas (YaRN ramp, frequency factors), one lane per pair index ----
+__global__ void __launch_bounds__(256) k_rope_table(const fused_rope r, float * tab) {
+    const int ip = blockIdx.x*256 + threadIdx.x;
+    if (ip >= (r.n_dims >> 1)) return;
+    const int pos = r.pos[0];
+    const float theta_base = (float) pos*powf(r.theta_scale, (float) ip);
+    const float theta_extrap = theta_base/(r.ff ? r.ff[ip] : 1.0f);
+    float theta_interp = r.freq_scale*theta_extrap, theta = theta_interp, mscale = r.attn_factor;
+    if (r.ext_factor != 0.0f) {
+        const float y = ((float) ip - r.corr_lo)/fmaxf(0.001f, r.corr_hi - r.corr_lo);
+        const float ramp_mix = (1.0f - fminf(1.0f, fmaxf(0.0f, y)))*r.ext_factor;
+        theta = theta_interp*(1.0f - ramp_mix) + theta_extrap*ramp_mix;
+        mscale *= 1.0f + 0.1f*logf(1.0f/r.freq_scale);
+    }
+    tab[2*ip] = cosf(theta)*mscale; tab[2*ip + 1] = sinf(theta)*mscale;
+}
+void mul_mat_vec_q_fused_rope_table(const mmvq_rope & rope, float * table, hipStream_t stream) {
+    const fused_rope r = make_fused_rope(rope);
+    const int np = rope.p.n_dims/2;
+    hipLaunchKernelGGL(k_rope_table, dim3((unsigned)((np + 255)/256)), dim3(256), 0, stream, r, table);
+}
+
 bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in) {
     // chunks are 256 rows; a workgroup's contiguous run (8 waves x rows per wave, one workgroup per CU) may touch at most 7 of them
     const int64_t rpw = (m + (int64_t) device_cu_count()*8 - 1)/((int64_t) device_cu_count()*8);
@@ -167,6 +190,7 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
     if (rope) {
         a.rope = make_fused_rope(*rope);
         a.pos = rope->pos;
+        if (!rope->table) { fprintf(stderr, "mul_mat_vec_q_fused: a launch with a rotation needs the token's table (mul_mat_vec_q_fused_rope_table)\n"); abort(); }
     }
     size_t img_max = bytes;                   // groups of another activation format build a different image (PRO_QUANT / PRO_NORM only)
     for (int i = 0; i < n_groups; i++) {

@@ -11,6 +11,7 @@ struct fused_rope {
     const int32_t * pos; const float * ff; int n_dims, head_dim, n_ctx_orig;
     float freq_scale, ext_factor, attn_factor, theta_scale, corr_lo, corr_hi;
     int neox;       // 0: NORM pairs (2i, 2i+1); 1: NEOX pairs (i, i + n_dims/2)
+    const float * tab;   // (cos, sin)*mscale per pair index for the token at pos[0] (k_rope_table), or NULL
 };
 
 static __device__ __forceinline__ void rope_pair(const fused_rope & r, int pos, int row_in_head, float & x0, float & x1) {
@@ -45,6 +46,7 @@ static inline fused_rope make_fused_rope(const mmvq_rope & rope) {
     const float end   = ceilf (rope_corr_dim_h(rope.p.n_dims, rope.p.n_ctx_orig, rope.p.beta_slow, rope.p.freq_base));
     r.corr_lo = fmaxf(0.0f, start); r.corr_hi = fminf((float)(rope.p.n_dims - 1), end);
     r.neox = (rope.p.mode & 2) ? 1 : 0;
+    r.tab = rope.table;
     return r;
 }
 
