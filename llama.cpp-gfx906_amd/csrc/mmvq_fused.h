@@ -171,6 +171,10 @@ struct pair_pre { float r0, r1; long long i0, i1; long long rcs; float q0, q1; }
 // them of an absent operand (read from `dummy`, a readable address, and ignored: loads inside branches made the compiler wait for every
 // outstanding load where the branches join) — and two more for the second addend cost the Llama-3-8B decode 3.5 % (530 -> 511 tok/s).
 // The scalar cache is invalidated at kernel start; nothing read here is written inside the launch.
+// row % head_dim without the integer-division sequence when the head size is a power of two (it is: 64 / 128)
+static __device__ __forceinline__ int mi_row_in_head(const fused_rope & r, int row) {
+    return (r.head_dim & (r.head_dim - 1)) == 0 ? (row & (r.head_dim - 1)) : row % r.head_dim;
+}
 // a wave-uniform address into scalar registers (the compiler keeps some of these in VGPRs, depending on the instantiation)
 template <typename P> static __device__ __forceinline__ P mi_uni(P q) {
     const unsigned long long a = (unsigned long long) q;
@@ -192,7 +196,8 @@ static __device__ __forceinline__ pair_pre pair_prefetch(const mmvq_group & g, c
     const float * fp = has_rot ? rope.tab : (const float *) dummy;       // the pair's (cos, sin): 8 bytes at tab + 2*ip
     const int64_t * ip = has_idx ? g.st_idx : (const int64_t *) dummy;
     const float * a_r0 = rp + (has_res ? ra : 0), * a_r1 = rp + (has_res ? rb : 0), * a_q0 = rq + (has_res2 ? ra : 0), * a_q1 = rq + (has_res2 ? rb : 0);
-    const float * a_ff = fp + (has_rot ? 2*(rope.neox ? min(ra % rope.head_dim, (rope.n_dims >> 1) - 1) : (min(ra % rope.head_dim, rope.n_dims - 1) >> 1)) : 0);
+    const int rih = mi_row_in_head(rope, ra);
+    const float * a_ff = fp + (has_rot ? 2*(rope.neox ? min(rih, (rope.n_dims >> 1) - 1) : (min(rih, rope.n_dims - 1) >> 1)) : 0);
     const int64_t * a_i0 = ip + (has_idx ? ra : 0), * a_i1 = ip + (has_idx ? rb : 0);
     asm volatile("s_load_dword %0, %7, 0x0\n\ts_load_dword %1, %8, 0x0\n\ts_load_dword %2, %9, 0x0\n\ts_load_dword %3, %10, 0x0\n\t"
                  "s_load_dwordx2 %4, %11, 0x0\n\ts_load_dwordx2 %5, %12, 0x0\n\ts_load_dwordx2 %6, %13, 0x0"
@@ -227,7 +232,7 @@ static __device__ __forceinline__ void finish_pair(const mmvq_group & g, const f
         if (EXT && g.res2) { s0 += e.q0; if (row1 < m) s1 += e.q1; }
     } else if (g.epi == EPI_ROPE) {
         if (EXT && g.res) { s0 += e.r0; s1 += e.r1; }                          // bias first, then the rotation
-        rope_pair_cs(rope, row0 % rope.head_dim, e.rcs, s0, s1);   // m is a multiple of the head size on this path
+        rope_pair_cs(rope, mi_row_in_head(rope, row0), e.rcs, s0, s1);   // m is a multiple of the head size on this path
     }
     g.dst[row0] = s0;
     if (row1 < m) g.dst[row1] = s1;
