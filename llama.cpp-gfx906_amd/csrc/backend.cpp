@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <unordered_map>
@@ -1939,10 +1940,17 @@ static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph *
 }
 
 static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggml_cgraph * g);
+static double g_host_ns = 0.0; static long g_host_calls = 0;     // GGML_MI355X_HOST_TIMING=1: host time spent inside graph_compute
 static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgraph * g) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     try {
+        static const bool timing = getenv("GGML_MI355X_HOST_TIMING") != nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         const enum ggml_status st = be_graph_compute_impl(backend, g);
+        if (timing) {
+            g_host_ns += std::chrono::duration<double, std::nano>(std::chrono::steady_clock::now() - t0).count();
+            if (++g_host_calls % 256 == 0) fprintf(stderr, "ggml-mi355x: graph_compute host time %.1f us per call over %ld calls\n", g_host_ns/g_host_calls/1e3, g_host_calls);
+        }
         // a kernel launch that failed (bad configuration, out of resources) shows up as the runtime's last error
         const hipError_t le = hipGetLastError();
         if (st == GGML_STATUS_SUCCESS && le != hipSuccess) { MI_LOG("graph_compute: %s (%s)\n", hipGetErrorName(le), hipGetErrorString(le)); return GGML_STATUS_FAILED; }
@@ -1990,7 +1998,11 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         const size_t pb = (size_t) 8*128*32*130*4;
         if (hipMalloc((void **) &c->attn_part, pb) == hipSuccess) c->attn_part_bytes = pb; else (void) hipGetLastError();
     }
+    static const bool timing2 = getenv("GGML_MI355X_HOST_TIMING") != nullptr;
+    static double t_need = 0, t_look = 0, t_launch = 0; static long n_rep = 0;
+    const auto ta = std::chrono::steady_clock::now();
     const size_t need = graph_scratch_need(g);
+    const auto tb = std::chrono::steady_clock::now();
     if (need > c->scratch_size) {
         MI_CHECK_G(hipStreamSynchronize(c->stream));
         if (c->scratch) MI_CHECK_G(hipFree(c->scratch));
@@ -2008,8 +2020,15 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
     if (try_graph) {
         graph_entry & e = graph_lookup(c, g);
         if (e.exec) {
+            const auto tc = std::chrono::steady_clock::now();
             MI_CHECK_G(hipGraphLaunch(e.exec, c->stream));
             c->cnt.graph_replays++;
+            if (timing2) {
+                const auto td = std::chrono::steady_clock::now();
+                t_need += std::chrono::duration<double, std::micro>(tb - ta).count(); t_look += std::chrono::duration<double, std::micro>(tc - tb).count();
+                t_launch += std::chrono::duration<double, std::micro>(td - tc).count();
+                if (++n_rep % 128 == 0) fprintf(stderr, "ggml-mi355x: replay host us: scratch-need %.1f lookup %.1f launch %.1f (n_nodes %d, %zu cached)\n", t_need/n_rep, t_look/n_rep, t_launch/n_rep, g->n_nodes, c->graphs.size());
+            }
             return GGML_STATUS_SUCCESS;
         }
         if (e.seen >= 2) {
