@@ -635,19 +635,21 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
         __syncthreads();
         int * fin_list = (int *) (smem + off_bs_l + (((sel.k >> (ACT == T_Q8_0 ? 5 : 4))*2 + 15) & ~15) + 64);      // [0] = count, [1..] = chunks (after the RMS scratch)
         const int RW = FWT*fin_rpw, ra = sel.wg_in_group*RW, rb = min(ra + RW, g_m);
-        if (threadIdx.x == 0) {
-            int n = 0;
-            if (ra < g_m) {
-                for (int c = ra >> 8; c <= (rb - 1) >> 8; c++) {
-                    const int expect = min((c << 8) + 255, g_m - 1)/RW - (c << 8)/RW + 1;
-                    const unsigned old = __hip_atomic_fetch_add(p.fin.counters + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    if ((int) old == expect - 1) {
-                        __hip_atomic_store(p.fin.counters + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
-                        fin_list[1 + n++] = c;
-                    }
-                }
+        if (wave == 0) {
+            // one lane per chunk this workgroup's rows touch (at most 7: mul_mat_vec_q_fused_fin_supported): the counter round trips run side by
+            // side instead of one after the other in a single thread's loop (a workgroup whose run of rows spans two chunks paid two of them)
+            const int c = (ra >> 8) + lane;
+            const bool mine = ra < g_m && lane < 8 && c <= ((rb - 1) >> 8);
+            bool last = false;
+            if (mine) {
+                const int expect = min((c << 8) + 255, g_m - 1)/RW - (c << 8)/RW + 1;
+                const unsigned old = __hip_atomic_fetch_add(p.fin.counters + c, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = (int) old == expect - 1;
+                if (last) __hip_atomic_store(p.fin.counters + c, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // re-armed for the next launch
             }
-            fin_list[0] = n;
+            const unsigned long long m = __ballot(last);
+            if (last) fin_list[1 + __popcll(m & ((1ull << lane) - 1))] = c;
+            if (lane == 0) fin_list[0] = __popcll(m);
         }
         __syncthreads();
         const int nfin = fin_list[0];
