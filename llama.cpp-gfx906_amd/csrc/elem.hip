@@ -717,19 +717,21 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         }
         acc += acc2;                        // the same summation order as k_moe_route: identical logits
         acc = wave_sum(acc);
-        if (lane == 0) { if (p.bias) acc += p.bias[e0]; ws[e0] = acc; if (p.logits) p.logits[e0] = acc; }
+        // the logit leaves with a write-through (agent-scope) store and the wave drains it before the workgroup takes its ticket; the last
+        // workgroup reads the logits with agent-scope loads. (A __threadfence() pair here wrote back and invalidated the whole L2 twice per launch.)
+        if (lane == 0) { if (p.bias) acc += p.bias[e0]; __hip_atomic_store(ws + e0, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p.logits) p.logits[e0] = acc; }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (threadIdx.x == 0) {
-        __threadfence();                                                     // release: this workgroup's logits before its ticket
-        const int t = atomicAdd((int *) (ws + 256), 1);
-        is_last = t == (int) gridDim.x - 1;
-        if (is_last) { __threadfence(); *(int *) (ws + 256) = 0; }          // acquire; re-arm for the next launch
+        const unsigned t = __hip_atomic_fetch_add((unsigned *) (ws + 256), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        is_last = t == gridDim.x - 1;
+        if (is_last) __hip_atomic_store((unsigned *) (ws + 256), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // re-arm for the next launch
     }
     __syncthreads();
     if (!is_last) return;
     const int e = threadIdx.x;
-    if (e < p.n_expert) v[e] = __builtin_nontemporal_load(ws + e);
+    if (e < p.n_expert) v[e] = __hip_atomic_load(ws + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
     if (p.softmax) {
         float mx = -INFINITY, sum = 0.0f;
