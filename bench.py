@@ -116,6 +116,11 @@ def cpu_baseline(model_cfg, ftype, budget_s=20.0):
 
 
 def main():
+    # the one JSON line is the ONLY thing on stdout: libraries that write to file descriptor 1 (gloo's "[Gloo] Rank 0 is connected ..." during
+    # the rendezvous, the HIP runtime) are sent to stderr, and the result is written to the saved descriptor at the end
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=128)
@@ -373,7 +378,8 @@ def main():
             "roofline": result.get("roofline"), "cpu_baseline": result.get("cpu_baseline"),
         }
         out.update(result.get("extra", {}))
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     be.free()
     if world > 1:
         dist.destroy_process_group()
