@@ -22,7 +22,10 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include "gguf_file.h"
+
 #include <map>
+#include <memory>
 #include <string>
 #include <thread>
 #include <tuple>
@@ -189,13 +192,40 @@ struct mi_llama {
     ggml_backend_buffer_t hbuf = nullptr;
     uint8_t * hbase = nullptr; size_t hsize = 0; int hslot = 0;   // 4-slot ring: a slot is reused only 4 decodes later
     std::vector<float> logits;
+    // a model read from a GGUF file (mi_llama_create_from_gguf): the mapping stays open for the input layer's rows
+    std::unique_ptr<mi355x::gguf_file> gf;
+    const uint8_t * tok_embd = nullptr; int tok_embd_type = 0; size_t tok_embd_row = 0;   // token_embd.weight in the mapping (host side: see gguf_tools.cpp)
+    std::vector<float> embd_tmp;
 };
 
 namespace {
 
 const int KV_PAD = 32;   // get_padding without flash attention (src/llama-kv-cache-unified.cpp:2407-2410)
 
+// With a GGUF file the tensor must be in it with the expected shape (llama_model_loader::check_tensor_dims, src/llama-model-loader.cpp:797-830:
+// "missing tensor" / "has wrong shape" are load errors) and takes the file's type; only types the backend's mat-mul supports are accepted.
+enum ggml_type file_type(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t ne1, int64_t ne2, const char * name, bool f32_only) {
+    if (!m->gf) return type;
+    const char * lookup = name;
+    if (strcmp(name, "output.weight") == 0 && !m->gf->find(name)) lookup = "token_embd.weight";   // tied embeddings (TENSOR_DUPLICATED, src/llama-model.cpp:2209-2212)
+    const mi355x::gguf_tensor_info * ti = m->gf->find(lookup);
+    if (!ti) throw std::runtime_error(std::string("missing tensor '") + name + "'");
+    if (ti->ne[0] != ne0 || ti->ne[1] != ne1 || ti->ne[2] != ne2 || ti->ne[3] != 1) {
+        char b[256];
+        snprintf(b, sizeof(b), "tensor '%s' has wrong shape; expected %lld, %lld, %lld, got %lld, %lld, %lld, %lld", name, (long long) ne0, (long long) ne1,
+                 (long long) ne2, (long long) ti->ne[0], (long long) ti->ne[1], (long long) ti->ne[2], (long long) ti->ne[3]);
+        throw std::runtime_error(b);
+    }
+    const enum ggml_type ft = (enum ggml_type) ti->type;
+    const bool ok = f32_only ? ft == GGML_TYPE_F32
+                             : (ft == GGML_TYPE_Q4_0 || ft == GGML_TYPE_Q8_0 || ft == GGML_TYPE_Q4_K || ft == GGML_TYPE_Q5_K || ft == GGML_TYPE_Q6_K ||
+                                ft == GGML_TYPE_MXFP4 || ft == GGML_TYPE_F16 || ft == GGML_TYPE_F32);
+    if (!ok) throw std::runtime_error(std::string("tensor '") + name + "' has type " + std::to_string((int) ti->type) + ", which this path does not run");
+    return ft;
+}
+
 ggml_tensor * new_weight(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t ne1, const char * name) {
+    type = file_type(m, type, ne0, ne1, 1, name, type == GGML_TYPE_F32);
     ggml_tensor * t = ggml_new_tensor_2d(m->wctx, type, ne0, ne1);
     ggml_set_name(t, name);
     if (ne1 > 1) m->weight_bytes += ggml_nbytes(t);
@@ -203,12 +233,14 @@ ggml_tensor * new_weight(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t
 }
 
 ggml_tensor * new_experts(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t ne1, int64_t ne2, const char * name) {
+    type = file_type(m, type, ne0, ne1, ne2, name, false);
     ggml_tensor * t = ggml_new_tensor_3d(m->wctx, type, ne0, ne1, ne2);
     ggml_set_name(t, name);
     m->expert_bytes += ggml_nbytes(t);
     return t;
 }
 ggml_tensor * new_f32(mi_llama * m, int64_t ne0, int64_t ne1, const char * name) {   // biases, sinks, router: not part of the byte model
+    (void) file_type(m, GGML_TYPE_F32, ne0, ne1, 1, name, true);
     ggml_tensor * t = ggml_new_tensor_2d(m->wctx, GGML_TYPE_F32, ne0, ne1);
     ggml_set_name(t, name);
     return t;
@@ -436,15 +468,68 @@ void synth_embedding(float * dst, int n_embd, int32_t token, uint64_t seed) {
 
 extern "C" {
 
-GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct mi_llama_hparams * hp_in, uint64_t seed) {
+} // extern "C"
+
+namespace {
+
+// Weights from the file into the device tensors through a ring of pinned staging buffers with one event each, as the loader does
+// (src/llama-model-loader.cpp:930-1010: 4 x 1 MiB; 4 x 4 MiB here — a chunk is one PCIe transfer and one event, and the mapping is pageable
+// memory the copy engine cannot read directly): wait for the slot's event, memcpy file -> slot, tensor_set_async, record the event.
+void upload_from_file(mi_llama * m) {
+    const size_t CHUNK = 4u << 20; const int NBUF = 4;
+    ggml_backend_dev_t dev = ggml_backend_get_device(m->backend);
+    ggml_backend_buffer_type_t hbt = ggml_backend_dev_host_buffer_type(dev);
+    ggml_backend_buffer_t ring = hbt ? ggml_backend_buft_alloc_buffer(hbt, CHUNK*NBUF) : nullptr;
+    std::vector<ggml_backend_event_t> ev;
+    if (ring) for (int i = 0; i < NBUF; i++) { ggml_backend_event_t e = ggml_backend_event_new(dev); if (!e) break; ev.push_back(e); }
+    const bool async = ring && (int) ev.size() == NBUF;
+    uint8_t * rbase = async ? (uint8_t *) ggml_backend_buffer_get_base(ring) : nullptr;
+    int slot = 0;
+    for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
+        const mi355x::gguf_tensor_info * ti = m->gf->find(t->name);
+        if (!ti && strcmp(t->name, "output.weight") == 0) ti = m->gf->find("token_embd.weight");
+        const size_t nb = ggml_nbytes(t);
+        const uint8_t * src = m->gf->tensor_data(*ti, nb);
+        if (!async) { ggml_backend_tensor_set(t, src, 0, nb); continue; }       // the loader's fallback: a synchronous copy per tensor (:1075)
+        for (size_t off = 0; off < nb; off += CHUNK) {
+            const size_t n = std::min(CHUNK, nb - off);
+            ggml_backend_event_synchronize(ev[slot]);
+            memcpy(rbase + slot*CHUNK, src + off, n);
+            ggml_backend_tensor_set_async(m->backend, t, rbase + slot*CHUNK, off, n);
+            ggml_backend_event_record(ev[slot], m->backend);
+            slot = (slot + 1) % NBUF;
+        }
+    }
+    for (ggml_backend_event_t e : ev) { ggml_backend_event_synchronize(e); ggml_backend_event_free(e); }
+    if (ring) ggml_backend_buffer_free(ring);
+}
+
+mi_llama * create_body(mi_llama * m);
+
+mi_llama * create_impl(ggml_backend_t backend, const mi_llama_hparams * hp_in, uint64_t seed, std::unique_ptr<mi355x::gguf_file> gf) {
     mi_llama * m = new mi_llama;
-    m->hp = *hp_in; m->backend = backend; m->seed = seed;
+    m->hp = *hp_in; m->backend = backend; m->seed = seed; m->gf = std::move(gf);
+    try {
+        return create_body(m);
+    } catch (...) {      // a tensor the file lacks or holds with another shape: release what was declared so far, the caller reports the message
+        if (m->wbuf) ggml_backend_buffer_free(m->wbuf);
+        if (m->kvbuf) ggml_backend_buffer_free(m->kvbuf);
+        if (m->wctx) ggml_free(m->wctx);
+        if (m->kvctx) ggml_free(m->kvctx);
+        delete m;
+        throw;
+    }
+}
+
+mi_llama * create_body(mi_llama * m) {
+    ggml_backend_t backend = m->backend; const uint64_t seed = m->seed;
+    const mi_llama_hparams * hp_in = &m->hp;
     m->n_past.assign(std::max(1, hp_in->n_seq_max), 0);
     const mi_llama_hparams & hp = m->hp;
     const int64_t n_embd = hp.n_embd, hd = hp.n_embd_head, n_ff = hp.n_ff;
     const int64_t n_embd_k_gqa = hd*hp.n_head_kv, n_embd_v_gqa = hd*hp.n_head_kv;
     const int kv_size = hp.n_ctx;
-    if (kv_size % (hp.flash_attn ? 256 : KV_PAD) != 0) { fprintf(stderr, "mi_llama: n_ctx must be a multiple of %d\n", hp.flash_attn ? 256 : KV_PAD); delete m; return nullptr; }
+    if (kv_size % (hp.flash_attn ? 256 : KV_PAD) != 0) { fprintf(stderr, "mi_llama: n_ctx must be a multiple of %d\n", hp.flash_attn ? 256 : KV_PAD); throw std::runtime_error("n_ctx is not a multiple of the KV padding"); }
     if (hp.n_swa > 0) {    // llama_kv_cache_unified_iswa (src/llama-kv-cache-unified-iswa.cpp:46-60): size_swa = min(size_base, PAD(n_swa*n_seq + n_ubatch, n_pad)); one stream per sequence here
         const int pad = hp.flash_attn ? 256 : KV_PAD;
         m->swa_size = std::min(kv_size, (int) GGML_PAD(hp.n_swa + std::max(1, hp.n_ubatch), pad));
@@ -501,13 +586,14 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
     }
     m->wbuf = ggml_backend_alloc_ctx_tensors(m->wctx, backend);
     m->kvbuf = ggml_backend_alloc_ctx_tensors(m->kvctx, backend);
-    if (!m->wbuf || !m->kvbuf) { fprintf(stderr, "mi_llama: weight/KV allocation failed\n"); delete m; return nullptr; }
+    if (!m->wbuf || !m->kvbuf) { fprintf(stderr, "mi_llama: weight/KV allocation failed\n"); throw std::runtime_error("weight / KV allocation failed"); }
     ggml_backend_buffer_set_usage(m->wbuf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);   // src/llama-model.cpp:5633
     ggml_backend_buffer_clear(m->kvbuf, 0);                                      // src/llama-kv-cache-unified.cpp:175-182
 
     std::vector<uint8_t> tmp;
     uint64_t s = seed*7919 + 13;
-    for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
+    if (m->gf) upload_from_file(m);
+    else for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
         if (t == m->rope_freqs) {
             std::vector<float> ff(t->ne[0]);
             for (size_t i = 0; i < ff.size(); i++) ff[i] = i < ff.size()/2 ? 1.0f : 8.0f;   // llama-3.1-like long/short factors
@@ -534,6 +620,88 @@ GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct 
     if (!m->hbase) m->hbase = (uint8_t *) malloc(m->hsize);
     m->logits.resize(hp.has_output ? hp.n_vocab : hp.n_embd);
     return m;
+}
+
+} // namespace
+
+extern "C" {
+
+GGML_API struct mi_llama * mi_llama_create(ggml_backend_t backend, const struct mi_llama_hparams * hp_in, uint64_t seed) {
+    try { return create_impl(backend, hp_in, seed, nullptr); } catch (const std::exception & e) { fprintf(stderr, "mi_llama_create: %s\n", e.what()); return nullptr; }
+}
+
+// A model from a GGUF file: hyper-parameters from its metadata as llama_model::load_hparams reads them (src/llama-model.cpp:420-560 for the
+// general keys, :574-600 LLM_ARCH_LLAMA, :1838-1850 LLM_ARCH_OPENAI_MOE), tensor types and bytes from the file. What the context decides
+// stays a parameter: n_ctx, n_seq_max, flash_attn, n_ubatch, and the layer range of a -sm layer rank (layer_end < 0: all layers).
+// hp_out (optional) receives the hyper-parameters. On any error: NULL with the message in err (the loader's "error loading model: ...").
+GGML_API struct mi_llama * mi_llama_create_from_gguf(ggml_backend_t backend, const char * path, int n_ctx, int n_seq_max, int flash_attn, int n_ubatch,
+                                                      int layer_begin, int layer_end, struct mi_llama_hparams * hp_out, char * err, int err_cap) {
+    try {
+        std::unique_ptr<mi355x::gguf_file> gf(new mi355x::gguf_file);
+        gf->open(path);
+        const std::string arch = gf->get_str("general.architecture");
+        if (arch != "llama" && arch != "gpt-oss") throw std::runtime_error("unknown model architecture: '" + arch + "' (this path builds llama and gpt-oss graphs)");
+        auto key = [&](const char * k) { return arch + "." + k; };
+        auto opt_u = [&](const char * k, uint64_t def) { return gf->has(key(k)) ? gf->get_u64(key(k)) : def; };
+        auto opt_f = [&](const char * k, double def) { return gf->has(key(k)) ? gf->get_f64(key(k)) : def; };
+        mi_llama_hparams hp; memset(&hp, 0, sizeof(hp));
+        hp.arch    = arch == "gpt-oss";
+        hp.n_embd  = (int32_t) gf->get_u64(key("embedding_length"));
+        hp.n_layer = (int32_t) gf->get_u64(key("block_count"));
+        hp.n_head  = (int32_t) gf->get_f64_at(key("attention.head_count"), 0);
+        hp.n_head_kv = gf->has(key("attention.head_count_kv")) ? (int32_t) gf->get_f64_at(key("attention.head_count_kv"), 0) : hp.n_head;
+        for (int il = 1; il < hp.n_layer; il++) {     // per-layer arrays are accepted when every layer agrees (get_key_or_arr)
+            if ((int32_t) gf->get_f64_at(key("attention.head_count"), il) != hp.n_head ||
+                (gf->has(key("attention.head_count_kv")) && (int32_t) gf->get_f64_at(key("attention.head_count_kv"), il) != hp.n_head_kv))
+                throw std::runtime_error("per-layer head counts differ: not supported");
+        }
+        hp.n_expert      = (int32_t) opt_u("expert_count", 0);
+        hp.n_expert_used = (int32_t) opt_u("expert_used_count", 0);
+        hp.n_ff = hp.n_expert > 0 && gf->has(key("expert_feed_forward_length")) ? (int32_t) gf->get_u64(key("expert_feed_forward_length"))
+                                                                                  : (int32_t) gf->get_f64_at(key("feed_forward_length"), 0);
+        if (hp.n_head <= 0 || hp.n_embd <= 0 || hp.n_layer <= 0 || hp.n_head_kv <= 0 || hp.n_head % hp.n_head_kv) throw std::runtime_error("invalid head / layer counts");
+        hp.n_embd_head = (int32_t) opt_u("attention.key_length", (uint64_t) hp.n_embd/hp.n_head);
+        if (opt_u("attention.value_length", (uint64_t) hp.n_embd_head) != (uint64_t) hp.n_embd_head) throw std::runtime_error("key and value head sizes differ: not supported");
+        if (opt_u("rope.dimension_count", (uint64_t) hp.n_embd_head) != (uint64_t) hp.n_embd_head) throw std::runtime_error("partial rotary dimension: not supported");
+        hp.f_norm_rms_eps  = (float) gf->get_f64(key("attention.layer_norm_rms_epsilon"));
+        hp.rope_freq_base  = (float) opt_f("rope.freq_base", 10000.0);
+        const double factor = opt_f("rope.scaling.factor", 0.0);
+        hp.rope_freq_scale = factor == 0.0 ? 1.0f : 1.0f/(float) factor;                       // src/llama-model.cpp:497-505
+        const uint64_t n_ctx_train = opt_u("context_length", 0);
+        hp.n_ctx_orig = (int32_t) opt_u("rope.scaling.original_context_length", n_ctx_train);
+        hp.rope_type = hp.arch == 1 ? 2 : 0;                                                   // llama_model_rope_type: NORM for llama, NEOX for gpt-oss
+        hp.ftype = gf->has("general.file_type") ? (int32_t) gf->get_u64("general.file_type") : 0;
+        if (hp.arch == 1) {                                                                    // :1838-1850
+            hp.n_swa = (int32_t) opt_u("attention.sliding_window", 0);
+            hp.swa_pattern = hp.n_swa > 0 ? 2 : 0;
+        }
+        const mi355x::gguf_tensor_info * te = gf->find("token_embd.weight");
+        if (!te) throw std::runtime_error("missing tensor 'token_embd.weight'");
+        if (te->ne[0] != hp.n_embd) throw std::runtime_error("tensor 'token_embd.weight' has wrong shape");
+        hp.n_vocab = (int32_t) te->ne[1];
+        hp.has_rope_freqs = gf->find("rope_freqs.weight") != nullptr;
+        hp.is_70b = 0;                                                                          // only steers the synthetic type choice
+        const int pad = flash_attn ? 256 : KV_PAD;
+        hp.n_ctx = (int32_t) GGML_PAD(std::max(1, n_ctx), pad);
+        hp.n_seq_max = std::max(1, n_seq_max); hp.flash_attn = flash_attn != 0; hp.n_ubatch = n_ubatch > 0 ? n_ubatch : 512;
+        hp.layer_begin = std::max(0, layer_begin); hp.layer_end = layer_end < 0 ? hp.n_layer : std::min(layer_end, hp.n_layer);
+        hp.has_output = hp.layer_end == hp.n_layer;
+
+        // the input layer's rows stay on the host
+        const size_t row = ggml_row_size((enum ggml_type) te->type, te->ne[0]);
+        const uint8_t * tdata = gf->tensor_data(*te, row*(size_t) te->ne[1]);
+        std::vector<float> probe((size_t) hp.n_embd);
+        if (!mi355x::dequant_row_host((int) te->type, tdata, probe.data(), hp.n_embd)) throw std::runtime_error("token_embd.weight: no host decoder for type " + std::to_string((int) te->type));
+        const int tt = (int) te->type;
+        mi_llama * m = create_impl(backend, &hp, 0, std::move(gf));
+        if (!m) throw std::runtime_error("weight / KV allocation failed");
+        m->tok_embd = tdata; m->tok_embd_type = tt; m->tok_embd_row = row;
+        if (hp_out) *hp_out = m->hp;
+        return m;
+    } catch (const std::exception & e) {
+        if (err && err_cap > 0) snprintf(err, (size_t) err_cap, "error loading model: %s", e.what());
+        return nullptr;
+    }
 }
 
 GGML_API void mi_llama_free(struct mi_llama * m) {
@@ -615,7 +783,13 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
         ggml_backend_tensor_set_async(m->backend, g.inp_embd, dev_act_in, 0, ggml_nbytes(g.inp_embd));   // device-to-device
     } else {
         float * e = (float *) stage((size_t) n_embd*n_tokens*4);
-        for (int i = 0; i < n_tokens; i++) synth_embedding(e + (size_t) i*n_embd, (int) n_embd, tokens ? tokens[i] : i, m->seed);
+        for (int i = 0; i < n_tokens; i++) {
+            const int32_t tk = tokens ? tokens[i] : i;
+            if (m->tok_embd) {     // GET_ROWS(token_embd, tokens) on the host (build_inp_embd, src/llama-graph.cpp:1059-1075)
+                if (tk < 0 || tk >= hp.n_vocab) return -1;                                      // llama_decode: "invalid token" (src/llama-batch.cpp:60-75)
+                mi355x::dequant_row_host(m->tok_embd_type, m->tok_embd + (size_t) tk*m->tok_embd_row, e + (size_t) i*n_embd, n_embd);
+            } else synth_embedding(e + (size_t) i*n_embd, (int) n_embd, tk, m->seed);
+        }
         ggml_backend_tensor_set_async(m->backend, g.inp_embd, e, 0, ggml_nbytes(g.inp_embd));
     }
     {
@@ -700,6 +874,10 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
 
 // the synthetic embedding row the harness feeds for `token` (so that tests can rebuild the same input)
 GGML_API void mi_llama_synth_embedding(const struct mi_llama * m, int32_t token, float * out) {
+    if (m->tok_embd) {
+        if (token >= 0 && token < m->hp.n_vocab) mi355x::dequant_row_host(m->tok_embd_type, m->tok_embd + (size_t) token*m->tok_embd_row, out, m->hp.n_embd);
+        return;
+    }
     synth_embedding(out, m->hp.n_embd, token, m->seed);
 }
 

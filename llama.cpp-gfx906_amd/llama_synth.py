@@ -95,6 +95,9 @@ def harness():
         L.mi_llama_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.mi_llama_synth_embedding.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
         L.mi_llama_graph_nodes.restype = C.c_int; L.mi_llama_graph_nodes.argtypes = [C.c_void_p, C.c_int]
+        L.mi_llama_create_from_gguf.restype = C.c_void_p
+        L.mi_llama_create_from_gguf.argtypes = [C.c_void_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(hparams), C.c_char_p, C.c_int]
+        L.mi_gguf_describe.restype = C.c_longlong; L.mi_gguf_describe.argtypes = [C.c_char_p, C.c_char_p, C.c_longlong]
         _hz = L
     return _hz
 
@@ -177,3 +180,37 @@ class SynthLlama:
         if self.m:
             self.L.mi_llama_free(self.m)
             self.m = None
+
+
+class GgufLlama(SynthLlama):
+    """a model read from a GGUF file (csrc/harness: gguf_file.h + mi_llama_create_from_gguf): hyper-parameters, tensor types and weights come
+    from the file, the embedding rows from its token_embd; the rest of the handle (decode, tensor, embedding ...) is SynthLlama's"""
+
+    def __init__(self, backend: gg.Backend, path, n_ctx=128, n_seq_max=1, flash_attn=False, n_ubatch=512, layer_begin=0, layer_end=-1):
+        self.backend = backend
+        self.L = harness()
+        hp = hparams()
+        err = C.create_string_buffer(512)
+        self.m = self.L.mi_llama_create_from_gguf(backend.be, str(path).encode(), n_ctx, n_seq_max, int(flash_attn), n_ubatch, layer_begin, layer_end,
+                                                  C.byref(hp), err, len(err))
+        if not self.m:
+            raise RuntimeError(err.value.decode() or "mi_llama_create_from_gguf failed")
+        self.hp = hp
+        self.cfg = {k: getattr(hp, k) for k, _ in hparams._fields_}
+        self.has_output = bool(hp.has_output)
+        self.n_result = self.L.mi_llama_n_result(self.m)
+
+
+def gguf_describe(path):
+    """what the C++ reader sees in a GGUF file, as a dict (metadata, tensor placement, a hash of each tensor's bytes); no GPU needed"""
+    import json
+    L = harness()
+    cap = 1 << 20
+    while True:
+        buf = C.create_string_buffer(cap)
+        n = L.mi_gguf_describe(str(path).encode(), buf, cap)
+        if n < 0:
+            raise RuntimeError(buf.value.decode())
+        if n < cap:
+            return json.loads(buf.value.decode())
+        cap = n + 1
