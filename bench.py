@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--ftype", default="Q4_K_M")
+    ap.add_argument("--gguf", default=None, help="run the same protocol on a model read from this GGUF file (llama / gpt-oss architectures) instead of the "
+                    "synthetic weights of --model / --ftype")
     ap.add_argument("--pp", type=int, default=512, help="prompt length for the extra pp measurement (0 = skip)")
     ap.add_argument("--fa", type=int, default=0, help="1 = llama-bench -fa 1: FLASH_ATTN_EXT, V cache not transposed, n_kv padded to 256")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -173,7 +175,23 @@ def main():
     gg, ls, lsp = pkg.ggml, pkg.llama_synth, pkg.layer_split
 
     be = gg.Backend(dev_index)
-    cfg = ls.MODELS[args.model]
+    if args.gguf:     # hyper-parameters from the file's metadata (csrc/harness/gguf_file.h); the model label follows the file
+        d = ls.gguf_describe(args.gguf)
+        kvs = {e["key"]: e["value"] for e in d["kv"]}
+        arch = kvs["general.architecture"]
+        emb = next(t for t in d["tensors"] if t["name"] == "token_embd.weight")
+        cfg = dict(n_layer=int(kvs[arch + ".block_count"]), n_vocab=int(emb["ne"][1]))
+        args.model, args.ftype = os.path.basename(args.gguf), f"ftype{kvs.get('general.file_type', '?')}"
+
+        def new_model(n_ctx, **kw):
+            kw.pop("has_output", None)
+            return ls.GgufLlama(be, args.gguf, n_ctx=n_ctx, n_seq_max=kw.get("n_seq_max", 1), flash_attn=kw.get("flash_attn", False),
+                                layer_begin=kw.get("layer_begin", 0), layer_end=kw.get("layer_end", -1))
+    else:
+        cfg = ls.MODELS[args.model]
+
+        def new_model(n_ctx, **kw):
+            return ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, **kw)
     K, W = args.steps, args.warmup
     ranges = lsp.layer_ranges(cfg["n_layer"], world)
     lb, le, has_out = ranges[rank]
@@ -181,8 +199,8 @@ def main():
     steps_per_seq = (max(K, W) + n_seq - 1) // n_seq + 1
     n_ctx = max(32, (steps_per_seq + 31) // 32 * 32) if world > 1 else max(128, (K + 31) // 32 * 32)
     t0 = time.time()
-    m = ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, layer_begin=lb, layer_end=le, has_output=has_out, n_seq_max=n_seq,
-                      flash_attn=bool(args.fa))
+    m = new_model(n_ctx, layer_begin=lb, layer_end=le, has_output=has_out, n_seq_max=n_seq, flash_attn=bool(args.fa))
+    cfg = m.cfg
     log(f"[rank {rank}] layers [{lb},{le}) output={has_out} weights {m.weight_bytes/1e9:.3f} GB, model ready in {time.time()-t0:.1f}s")
     rng = np.random.default_rng(1)   # llama-bench: std::rand() % n_vocab, default seed (tools/llama-bench/llama-bench.cpp:1798)
     tokens = rng.integers(0, cfg["n_vocab"], size=max(K, W) + 8).astype(np.int32)
@@ -268,7 +286,7 @@ def main():
         m.free()
 
         if args.pp > 0:
-            mp = ls.SynthLlama(be, args.model, args.ftype, n_ctx=args.pp, seed=1, flash_attn=bool(args.fa))
+            mp = new_model(args.pp, flash_attn=bool(args.fa))
             ptoks = rng.integers(0, cfg["n_vocab"], size=args.pp).astype(np.int32)
             mp.decode(ptoks); mp.kv_clear()                       # warm-up prompt pass (llama-bench.cpp:1949-1971)
             reps = []
@@ -371,7 +389,7 @@ def main():
             "metric": "llama-bench tg128 tok/s, Llama-3-8B Q4_K_M" if (args.model, args.ftype) == ("llama3-8b", "Q4_K_M") else f"llama-bench tg tok/s, {args.model} {args.ftype}",
             "value": round(result["value"], 2), "unit": "tok/s", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "int8 dot (4-6 bit weights x Q8 activations), f32 accumulate", "data": "synthetic",
+            "dtype": "int8 dot (4-6 bit weights x Q8 activations), f32 accumulate", "data": f"gguf file {args.model}" if args.gguf else "synthetic",
             "config": {"workload": f"{args.model} {args.ftype}, llama-bench tg{K} protocol (BASELINE.json configs[1]): 1 token/step, sync per token, "
                                    f"f16 KV cache, {'flash-attn' if args.fa else 'no flash-attn'}, n_ctx={n_ctx}",
                        "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs, {world} sequences in flight, {'RCCL' if transport == 'nccl' else 'gloo (host memory)'} p2p hand-off"},

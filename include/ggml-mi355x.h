@@ -70,7 +70,13 @@ struct ggml_backend_mi355x_counters {
     uint64_t weight_bytes;         // algorithmic weight bytes streamed by mmvq/mmq launches
     uint64_t act_quant_launches;
     uint64_t act_quant_reused;     // MUL_MATs that reused the previous node's quantized activations
+    uint64_t split_mul_mats;       // MUL_MATs on row-split weights (one launch per device that holds rows)
 };
+// Row-split weights (-sm row). Replaces ggml_backend_cuda_split_buffer_type, which the host finds through the registry proc
+// "ggml_backend_split_buffer_type" (src/llama-model.cpp:368-387; typedef ggml_backend_split_buffer_type_t, ggml-backend.h): main_device is
+// the index of the device whose backend runs the graph, tensor_split the per-device proportions (llama_model_params.tensor_split; all zero =
+// equal shares). NULL when a device that would hold rows has no peer mapping to the main device.
+GGML_BACKEND_API ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device, const float * tensor_split);
 GGML_BACKEND_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
 GGML_BACKEND_API void   ggml_backend_mi355x_get_counters(ggml_backend_t backend, struct ggml_backend_mi355x_counters * out);
 GGML_BACKEND_API void   ggml_backend_mi355x_reset_counters(ggml_backend_t backend);

@@ -266,8 +266,7 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
     const int mk = !mask ? 0 : (mask_f16 ? 2 : 1);
 #define MI_APF2(HD_, VT_, MK_, KS_) do { \
         constexpr size_t lds_ = (size_t) 2*KS_*(32*(HD_*2 + APF_KLD) + HD_*(64 + 8)); \
-        static const bool once_ = [] { MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_attn_prefill<HD_, VT_, MK_, KS_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds_)); return true; }(); \
-        (void) once_; \
+        MI_LDS_LIMIT_OR_DIE(lds_, k_attn_prefill<HD_, VT_, MK_, KS_>); \
         hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, MK_, KS_>), grid, dim3(64*APF_NW), lds_, stream, a, hpw); } while (0)
 #define MI_APF1(HD_, VT_, MK_) do { if (ksp == 2) MI_APF2(HD_, VT_, MK_, 2); else MI_APF2(HD_, VT_, MK_, 1); } while (0)
 #define MI_APF(HD_, VT_) do { if (mk == 0) MI_APF1(HD_, VT_, 0); else if (mk == 1) MI_APF1(HD_, VT_, 1); else MI_APF1(HD_, VT_, 2); } while (0)

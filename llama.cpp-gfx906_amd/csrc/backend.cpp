@@ -199,6 +199,125 @@ static const struct ggml_backend_buffer_type_i mi_buft_iface = {
 };
 
 // ---------------------------------------------------------------------------------------------
+// row-split buffer type (-sm row; the host binds it through the "ggml_backend_split_buffer_type" proc, src/llama-model.cpp:368-387):
+// a weight matrix's ROWS are spread over the devices in the proportions of tensor_split; every device holds its slice in its own HBM.
+// A MUL_MAT on such a weight runs one launch per device, each on its own stream: the devices read the (small) activations straight from the
+// main device's memory and write their rows of the result straight into the main device's dst — both through the peer mappings over xGMI, no
+// staging copies and no collective (the result is a concatenation of row ranges, not a sum). Only 2-D quantized weights of MUL_MAT can live here
+// (supports_op refuses everything else, so the host's weight_buft_supported probe, src/llama-model.cpp:152-286, sends norms, biases and
+// expert stacks to the device's ordinary buffer type).
+// ---------------------------------------------------------------------------------------------
+struct mi_split_buft_ctx {
+    int main_device = 0;                                   // index into G().devices
+    float cum[GGML_MI355X_MAX_DEVICES + 1] = {};           // cum[i] = fraction of the rows before device i; cum[n_devices] = 1
+    std::string name;
+    struct ggml_backend_buffer_type buft;
+};
+struct mi_split_tensor {                                   // tensor->extra of a tensor in a split buffer
+    void *  data[GGML_MI355X_MAX_DEVICES] = {};            // the slice in device i's memory (NULL: no rows there)
+    int64_t row_lo[GGML_MI355X_MAX_DEVICES + 1] = {};      // device i holds rows [row_lo[i], row_lo[i+1])
+};
+struct mi_split_buffer_ctx {
+    mi_split_buft_ctx * bt;
+    std::vector<mi_split_tensor *> tensors;
+};
+static const int64_t MI_SPLIT_ROW_ROUND = 64;              // slice boundaries at multiples of this many rows (the MFMA tile height of the prefill kernel)
+
+static void split_rows(const mi_split_buft_ctx * bt, int64_t nrows, int64_t * row_lo) {
+    const int n = G().n_devices;
+    for (int i = 0; i <= n; i++) {
+        int64_t r = i == n ? nrows : (int64_t)(nrows*(double) bt->cum[i]);
+        if (i > 0 && i < n) r -= r % MI_SPLIT_ROW_ROUND;
+        row_lo[i] = i == 0 ? 0 : std::max(r, row_lo[i - 1]);
+    }
+}
+static void split_buf_free(ggml_backend_buffer_t buffer) {
+    mi_split_buffer_ctx * c = (mi_split_buffer_ctx *) buffer->context;
+    for (mi_split_tensor * e : c->tensors) {
+        for (int i = 0; i < G().n_devices; i++) if (e->data[i]) { set_device(G().devices[i].id); MI_CHECK(hipFree(e->data[i])); }
+        delete e;
+    }
+    delete c;
+}
+static void * split_buf_get_base(ggml_backend_buffer_t) { return (void *) 0x1000; }     // never dereferenced: the slices hang off tensor->extra
+static enum ggml_status split_buf_init_tensor(ggml_backend_buffer_t buffer, struct ggml_tensor * tensor) {
+    mi_split_buffer_ctx * c = (mi_split_buffer_ctx *) buffer->context;
+    if (tensor->view_src != NULL || !ggml_is_contiguous(tensor) || tensor->ne[2] != 1 || tensor->ne[3] != 1) return GGML_STATUS_FAILED;   // whole 2-D matrices only
+    mi_split_tensor * e = new mi_split_tensor;
+    split_rows(c->bt, tensor->ne[1], e->row_lo);
+    for (int i = 0; i < G().n_devices; i++) {
+        const int64_t rows = e->row_lo[i + 1] - e->row_lo[i];
+        if (rows == 0) continue;
+        const size_t bytes = (size_t) rows*tensor->nb[1];
+        set_device(G().devices[i].id);
+        if (hipMalloc(&e->data[i], bytes + MI_TENSOR_PAD) != hipSuccess) {
+            (void) hipGetLastError();
+            for (int j = 0; j < i; j++) if (e->data[j]) { set_device(G().devices[j].id); (void) hipFree(e->data[j]); }
+            delete e;
+            return GGML_STATUS_ALLOC_FAILED;
+        }
+        MI_CHECK(hipMemset((char *) e->data[i] + bytes, 0, MI_TENSOR_PAD));       // wave-wide loads may run past the last block
+    }
+    c->tensors.push_back(e);
+    tensor->extra = e;
+    return GGML_STATUS_SUCCESS;
+}
+static void split_buf_set_tensor(ggml_backend_buffer_t, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor) && "split tensors are written whole");
+    const mi_split_tensor * e = (const mi_split_tensor *) tensor->extra;
+    for (int i = 0; i < G().n_devices; i++) {
+        if (!e->data[i]) continue;
+        set_device(G().devices[i].id);
+        MI_CHECK(hipMemcpyAsync(e->data[i], (const char *) data + e->row_lo[i]*tensor->nb[1], (size_t)(e->row_lo[i + 1] - e->row_lo[i])*tensor->nb[1], hipMemcpyHostToDevice, hipStreamPerThread));
+    }
+    for (int i = 0; i < G().n_devices; i++) if (e->data[i]) { set_device(G().devices[i].id); MI_CHECK(hipStreamSynchronize(hipStreamPerThread)); }
+}
+static void split_buf_get_tensor(ggml_backend_buffer_t, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
+    GGML_ASSERT(offset == 0 && size == ggml_nbytes(tensor) && "split tensors are read whole");
+    const mi_split_tensor * e = (const mi_split_tensor *) tensor->extra;
+    for (int i = 0; i < G().n_devices; i++) {
+        if (!e->data[i]) continue;
+        set_device(G().devices[i].id);
+        MI_CHECK(hipMemcpyAsync((char *) data + e->row_lo[i]*tensor->nb[1], e->data[i], (size_t)(e->row_lo[i + 1] - e->row_lo[i])*tensor->nb[1], hipMemcpyDeviceToHost, hipStreamPerThread));
+    }
+    for (int i = 0; i < G().n_devices; i++) if (e->data[i]) { set_device(G().devices[i].id); MI_CHECK(hipStreamSynchronize(hipStreamPerThread)); }
+}
+static void split_buf_clear(ggml_backend_buffer_t, uint8_t) {}
+static const struct ggml_backend_buffer_i mi_split_buffer_iface = {
+    /* .free_buffer   = */ split_buf_free,
+    /* .get_base      = */ split_buf_get_base,
+    /* .init_tensor   = */ split_buf_init_tensor,
+    /* .memset_tensor = */ NULL,
+    /* .set_tensor    = */ split_buf_set_tensor,
+    /* .get_tensor    = */ split_buf_get_tensor,
+    /* .cpy_tensor    = */ NULL,
+    /* .clear         = */ split_buf_clear,
+    /* .reset         = */ NULL,
+};
+static const char * split_buft_get_name(ggml_backend_buffer_type_t buft) { return ((mi_split_buft_ctx *) buft->context)->name.c_str(); }
+static ggml_backend_buffer_t split_buft_alloc_buffer(ggml_backend_buffer_type_t buft, size_t size) {
+    // the slices are allocated per tensor in init_tensor: the address range handed to the host's allocator is only bookkeeping
+    return ggml_backend_buffer_init(buft, mi_split_buffer_iface, new mi_split_buffer_ctx{ (mi_split_buft_ctx *) buft->context, {} }, size);
+}
+static size_t split_buft_get_alloc_size(ggml_backend_buffer_type_t buft, const struct ggml_tensor * tensor) {
+    int64_t row_lo[GGML_MI355X_MAX_DEVICES + 1];
+    split_rows((const mi_split_buft_ctx *) buft->context, tensor->ne[1], row_lo);
+    size_t total = 0;
+    for (int i = 0; i < G().n_devices; i++) if (row_lo[i + 1] > row_lo[i]) total += (size_t)(row_lo[i + 1] - row_lo[i])*tensor->nb[1] + MI_TENSOR_PAD;
+    return total;
+}
+static const struct ggml_backend_buffer_type_i mi_split_buft_iface = {
+    /* .get_name       = */ split_buft_get_name,
+    /* .alloc_buffer   = */ split_buft_alloc_buffer,
+    /* .get_alignment  = */ buft_get_alignment,
+    /* .get_max_size   = */ NULL,
+    /* .get_alloc_size = */ split_buft_get_alloc_size,
+    /* .is_host        = */ buft_is_host_no,
+};
+static bool buft_is_split(ggml_backend_buffer_type_t buft) { return buft && buft->iface.get_name == split_buft_get_name; }
+static bool tensor_is_split(const struct ggml_tensor * t) { return t && t->buffer && buft_is_split(t->buffer->buft); }
+
+// ---------------------------------------------------------------------------------------------
 // pinned host buffer type (src/llama-model-loader.cpp:951-959 uses it for the 4 x 1 MiB upload ring)
 // ---------------------------------------------------------------------------------------------
 static void host_buf_free(ggml_backend_buffer_t buffer) { MI_CHECK(hipHostFree(buffer->context)); }
@@ -255,7 +374,8 @@ struct graph_entry {
 static constexpr int MI_MAX_GRAPHS = 24;
 
 struct mi_backend_ctx {
-    int device;
+    int device;                    // HIP device id
+    int dev_index = 0;             // index into G().devices
     std::string name;
     hipStream_t stream = nullptr;
 
@@ -314,6 +434,12 @@ struct mi_backend_ctx {
     bool prof_suspend = false;       //   ... and eager passes (before a graph's capture) are not recorded
     std::vector<prof_rec> prof;
     std::vector<hipEvent_t> ev_pool;
+
+    // row-split mat-muls: a stream, a completion event and (for the many-token kernel) a scratch area per peer device, made on first use
+    struct split_peer { hipStream_t stream = nullptr; hipEvent_t done = nullptr; void * scratch = nullptr; size_t scratch_size = 0; };
+    split_peer peers[GGML_MI355X_MAX_DEVICES];
+    hipEvent_t split_ready = nullptr;
+    bool split_graph = false;        // the graph being run reads row-split weights: eager execution (several devices' streams take part)
 };
 
 static hipEvent_t prof_event(mi_backend_ctx * c) {
@@ -373,6 +499,16 @@ static void be_free(ggml_backend_t backend) {
     if (c->fin_img) (void) hipFree(c->fin_img);
     if (c->fin_cnt) (void) hipFree(c->fin_cnt);
     if (c->rope_tab) (void) hipFree(c->rope_tab);
+    for (int i = 0; i < G().n_devices; i++) {
+        mi_backend_ctx::split_peer & pr = c->peers[i];
+        if (!pr.stream) continue;
+        set_device(G().devices[i].id);
+        (void) hipStreamSynchronize(pr.stream);
+        if (pr.scratch) (void) hipFree(pr.scratch);
+        (void) hipEventDestroy(pr.done); (void) hipStreamDestroy(pr.stream);
+    }
+    set_device(c->device);
+    if (c->split_ready) (void) hipEventDestroy(c->split_ready);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     delete backend;
@@ -444,6 +580,11 @@ static float op_f32(const struct ggml_tensor * t, int i) { float f; memcpy(&f, &
 static bool mi_supports_op(const struct ggml_tensor * op) {
     const struct ggml_tensor * s0 = op->src[0];
     const struct ggml_tensor * s1 = op->src[1];
+    // row-split weights: MUL_MAT's 2-D quantized src0 only
+    for (int j = 0; j < GGML_MAX_SRC; j++) {
+        if (!tensor_is_split(op->src[j])) continue;
+        if (op->op != GGML_OP_MUL_MAT || j != 0 || !ggml_is_quantized(s0->type) || s0->ne[2] != 1 || s0->ne[3] != 1 || s1->ne[2] != 1 || s1->ne[3] != 1) return false;
+    }
     switch (op->op) {
         case GGML_OP_NONE: case GGML_OP_RESHAPE: case GGML_OP_VIEW: case GGML_OP_PERMUTE: case GGML_OP_TRANSPOSE:
             return true;
@@ -630,6 +771,54 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml
     }
     mul_mat_dense(p, c->stream);
     c->cnt.kernels_launched++;
+}
+
+// MUL_MAT on a row-split weight: the main device quantizes the activations once (few tokens) and runs its own slice; every other device that holds
+// rows runs the same kernel on its slice on its own stream, reading the activations from and writing its rows of dst into the main device's
+// memory through the peer mapping. Order: peers start after everything the main stream has queued so far (split_ready), the main stream
+// continues after every peer's launch has finished (peer.done) — so dst is complete, and the scratch the peers read is not reused early.
+static void op_mul_mat_split(mi_backend_ctx * c, struct ggml_tensor * dst) {
+    const struct ggml_tensor * a = dst->src[0];
+    const struct ggml_tensor * b = dst->src[1];
+    const mi_split_tensor * e = (const mi_split_tensor *) a->extra;
+    const int kind = act_kind_for((int) a->type);
+    const int64_t K = a->ne[0], N = b->ne[1];
+    const bool few = N <= MMVQ_MAX_N;
+    act_q8 q = {};
+    if (few) q = get_act(c, b->data, K, N, 1, b->nb[1], 0, kind);
+    else c->aq.valid = false;
+    if (!c->split_ready) MI_CHECK_G(hipEventCreateWithFlags(&c->split_ready, hipEventDisableTiming));
+    MI_CHECK_G(hipEventRecord(c->split_ready, c->stream));
+    const size_t need = c->scratch_size;
+    bool waited[GGML_MI355X_MAX_DEVICES] = {};
+    for (int i = 0; i < G().n_devices; i++) {
+        const int64_t rows = e->row_lo[i + 1] - e->row_lo[i];
+        if (rows == 0) continue;
+        float * d = (float *) dst->data + e->row_lo[i];
+        const bool local = i == c->dev_index;
+        hipStream_t st = c->stream; void * scr = c->scratch;
+        if (!local) {
+            mi_backend_ctx::split_peer & pr = c->peers[i];
+            set_device(G().devices[i].id);
+            if (!pr.stream) { MI_CHECK_G(hipStreamCreateWithFlags(&pr.stream, hipStreamNonBlocking)); MI_CHECK_G(hipEventCreateWithFlags(&pr.done, hipEventDisableTiming)); }
+            if (!few && pr.scratch_size < need) {
+                MI_CHECK_G(hipStreamSynchronize(pr.stream));
+                if (pr.scratch) MI_CHECK_G(hipFree(pr.scratch));
+                pr.scratch = nullptr; pr.scratch_size = 0;
+                MI_CHECK_G(hipMalloc(&pr.scratch, need)); pr.scratch_size = need;
+            }
+            MI_CHECK_G(hipStreamWaitEvent(pr.stream, c->split_ready, 0));
+            st = pr.stream; scr = pr.scratch;
+        }
+        if (few) mul_mat_vec_q((int) a->type, e->data[i], a->nb[1], rows, K, q, N, d, dst->nb[1], st);
+        else     mul_mat_q((int) a->type, e->data[i], a->nb[1], rows, K, (const float *) b->data, b->nb[1], N, scr, false, d, dst->nb[1], nullptr, 0, st);
+        c->cnt.kernels_launched++; c->cnt.weight_bytes += (uint64_t) rows*a->nb[1];
+        if (few) c->cnt.mmvq_launches++; else c->cnt.mmq_launches++;
+        if (!local) { MI_CHECK_G(hipEventRecord(c->peers[i].done, st)); waited[i] = true; }
+    }
+    set_device(c->device);
+    for (int i = 0; i < G().n_devices; i++) if (waited[i]) MI_CHECK_G(hipStreamWaitEvent(c->stream, c->peers[i].done, 0));
+    c->cnt.split_mul_mats++;
 }
 
 static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
@@ -924,7 +1113,7 @@ static bool is_row_vec_f32(const struct ggml_tensor * t) {   // [ne0, 1, 1, 1] c
 static bool fusable_mmv(const struct ggml_tensor * n) {       // quantized weights x one f32 column
     if (n->op != GGML_OP_MUL_MAT) return false;
     const struct ggml_tensor * a = n->src[0]; const struct ggml_tensor * b = n->src[1];
-    if (!ggml_is_quantized(a->type) || !mul_mat_vec_q_supported((int) a->type)) return false;
+    if (!ggml_is_quantized(a->type) || !mul_mat_vec_q_supported((int) a->type) || tensor_is_split(a)) return false;
     if (a->ne[2] != 1 || a->ne[3] != 1 || !is_row_vec_f32(b)) return false;
     if (a->nb[0] != ggml_type_size(a->type)) return false;
     return mul_mat_vec_q_fused_supported(a->ne[0], act_kind_for((int) a->type)) && a->ne[1] < (1 << 30);
@@ -1204,7 +1393,7 @@ static const struct ggml_tensor * prefill_mm_consumer(mi_backend_ctx * c, const 
     const int j = next_real(g, last);
     if (!on || j < 0 || j == g->n_nodes - 1) return nullptr;      // (a view that ends at the consumer: the eval-callback case — its src1 must exist as f32)
     const struct ggml_tensor * n = g->nodes[j];
-    if (n->op != GGML_OP_MUL_MAT || n->src[1] != t || !ggml_is_quantized(n->src[0]->type) || t->type != GGML_TYPE_F32 || t->ne[1] <= MMVQ_MAX_N || t->ne[2] != 1 || t->ne[3] != 1 ||
+    if (n->op != GGML_OP_MUL_MAT || n->src[1] != t || !ggml_is_quantized(n->src[0]->type) || tensor_is_split(n->src[0]) || t->type != GGML_TYPE_F32 || t->ne[1] <= MMVQ_MAX_N || t->ne[2] != 1 || t->ne[3] != 1 ||
         n->src[0]->ne[2] != 1 || n->src[0]->ne[3] != 1 || t->nb[0] != 4 || t->ne[0] % 64 != 0 || !is_internal(c, t)) return nullptr;
     return n;
 }
@@ -1511,7 +1700,7 @@ static int try_fused_prefill_glu(mi_backend_ctx * c, struct ggml_cgraph * g, int
         b->nb[0] != 4 || !mul_mat_q_glu_supported(a->ne[1], b->ne[1]) || !is_internal(c, n)) return 0;
     const int j = next_real(g, i); if (j < 0) return 0;
     struct ggml_tensor * nx = g->nodes[j];
-    if (nx->op != GGML_OP_MUL_MAT || nx->src[1] != b || nx->src[0]->type != a->type || !ggml_are_same_shape(nx->src[0], a) || nx->src[0]->nb[1] != a->nb[1] ||
+    if (nx->op != GGML_OP_MUL_MAT || nx->src[1] != b || tensor_is_split(nx->src[0]) || nx->src[0]->type != a->type || !ggml_are_same_shape(nx->src[0], a) || nx->src[0]->nb[1] != a->nb[1] ||
         !is_internal(c, nx)) return 0;
     const int j2 = next_real(g, j); if (j2 < 0) return 0;
     struct ggml_tensor * gl = g->nodes[j2];
@@ -1554,7 +1743,7 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
         struct ggml_tensor * n = g->nodes[at];
         if (n->op != GGML_OP_MUL_MAT) break;
         const struct ggml_tensor * a = n->src[0];
-        if (n->src[1] != b || !ggml_is_quantized(a->type) || b->type != GGML_TYPE_F32 || b->ne[1] <= MMVQ_MAX_N || b->ne[2] != 1 || b->ne[3] != 1 ||
+        if (n->src[1] != b || !ggml_is_quantized(a->type) || tensor_is_split(a) || b->type != GGML_TYPE_F32 || b->ne[1] <= MMVQ_MAX_N || b->ne[2] != 1 || b->ne[3] != 1 ||
             a->ne[2] != 1 || a->ne[3] != 1 || b->nb[0] != 4 || a->ne[0] != g->nodes[i]->src[0]->ne[0] || n->nb[0] != 4) break;
         ch[nc] = { at, -1, at };
         const int j = next_real(g, at);
@@ -1706,7 +1895,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     bool fresh_aq = false;   // this step produced the cached quantized activations itself
     if (c->use_fusion) {
         int f = 0;
-        if (node->op == GGML_OP_MUL_MAT) {
+        if (node->op == GGML_OP_MUL_MAT && !tensor_is_split(s0)) {
             const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0;
             if (!f) f = try_fused_attn(c, g, i);       // (one token: recorded; many tokens: flushes, then launches)
             if (!f) { rec_flush(c); f = try_fused_moe_route(c, g, i); }
@@ -1726,7 +1915,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     // RMS_NORM may still be absorbed into the next grouped launch's prologue
     if (node->op != GGML_OP_RMS_NORM) rec_flush(c);
     switch (node->op) {
-        case GGML_OP_MUL_MAT:    op_mul_mat(c, node); break;
+        case GGML_OP_MUL_MAT:    if (tensor_is_split(s0)) op_mul_mat_split(c, node); else op_mul_mat(c, node); break;
         case GGML_OP_MUL_MAT_ID: op_mul_mat_id(c, node); break;
         case GGML_OP_FLASH_ATTN_EXT: {
             const struct ggml_tensor * q = s0; const struct ggml_tensor * k = node->src[1]; const struct ggml_tensor * v = node->src[2];
@@ -1870,7 +2059,7 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
     c->aq.valid = false;
     c->uses.clear();
     c->rec.clear();
-    c->rec_on = c->use_mega && c->use_fusion && !c->profiling && c->mega_err != nullptr;
+    c->rec_on = c->use_mega && c->use_fusion && !c->profiling && c->mega_err != nullptr && !c->split_graph;
     if (c->use_fusion) {
         for (int i = 0; i < g->n_nodes; i++) {
             for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[i]->src[s]) c->uses[g->nodes[i]->src[s]]++;
@@ -2015,6 +2204,12 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
 
     // hipGraph path: launch-bound decode graphs (~10^3 tiny kernels per token) are captured the second time their
     // signature is seen, then replayed while the signature is unchanged.
+    c->split_graph = false;
+    for (int i = 0; i < g->n_nodes && !c->split_graph; i++) c->split_graph = g->nodes[i]->op == GGML_OP_MUL_MAT && tensor_is_split(g->nodes[i]->src[0]);
+    if (c->split_graph) {     // several devices' streams take part: eager execution, no capture (the fusion matchers leave split weights to op_mul_mat_split)
+        run_nodes(c, g);
+        return GGML_STATUS_SUCCESS;
+    }
     const bool try_graph = c->use_graphs && (!c->profiling || c->prof_in_graph) && g->n_nodes >= 8;
     c->prof_suspend = try_graph && c->prof_in_graph;     // only what is captured gets recorded in that mode
     if (try_graph) {
@@ -2114,13 +2309,14 @@ static void dev_get_props(ggml_backend_dev_t dev, struct ggml_backend_dev_props 
     props->caps.events = true;
 }
 static ggml_backend_t dev_init_backend(ggml_backend_dev_t dev, const char *) {
-    return ggml_backend_mi355x_init(((mi_device *) dev->context)->id);
+    return ggml_backend_mi355x_init((int)((mi_device *) dev->context - G().devices));
 }
 static ggml_backend_buffer_type_t dev_get_buffer_type(ggml_backend_dev_t dev) { return &((mi_device *) dev->context)->buft; }
 static ggml_backend_buffer_type_t dev_get_host_buffer_type(ggml_backend_dev_t) { return ggml_backend_mi355x_host_buffer_type(); }
 static bool dev_supports_op(ggml_backend_dev_t, const struct ggml_tensor * op) { return mi_supports_op(op); }
 static bool dev_supports_buft(ggml_backend_dev_t dev, ggml_backend_buffer_type_t buft) {
     if (buft->iface.get_name == host_buft_get_name) return false;   // kernels read device memory only
+    if (buft_is_split(buft)) return ((mi_split_buft_ctx *) buft->context)->main_device == (int)((mi_device *) dev->context - G().devices);
     if (buft->iface.get_name != buft_get_name) return false;
     return ((mi_device *) buft->context)->id == ((mi_device *) dev->context)->id;
 }
@@ -2169,6 +2365,7 @@ static struct ggml_backend_feature * mi_get_features(ggml_backend_reg_t) {
 
 static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (strcmp(name, "ggml_backend_get_features") == 0)        return (void *) mi_get_features;
+    if (strcmp(name, "ggml_backend_split_buffer_type") == 0)   return (void *) ggml_backend_mi355x_split_buffer_type;
     if (strcmp(name, "ggml_backend_mi355x_get_stream") == 0)   return (void *) ggml_backend_mi355x_get_stream;
     if (strcmp(name, "ggml_backend_mi355x_get_counters") == 0) return (void *) ggml_backend_mi355x_get_counters;
     if (strcmp(name, "ggml_backend_mi355x_reset_counters") == 0) return (void *) ggml_backend_mi355x_reset_counters;
@@ -2191,7 +2388,11 @@ static mi_globals & G() {
         if (hipGetDeviceCount(&n) != hipSuccess) { (void) hipGetLastError(); n = 0; }
         g.reg = { GGML_BACKEND_API_VERSION, mi_reg_iface, NULL };
         g.host_buft = { mi_host_buft_iface, NULL, NULL };
-        for (int i = 0; i < n && g.n_devices < GGML_MI355X_MAX_DEVICES; i++) {
+        // GGML_MI355X_VIRTUAL_DEVICES=v lists every GPU v times (same HIP device, separate backend / stream / buffer type each): lets the
+        // multi-device paths (layer split in one process, row split) be exercised on a one-GPU box
+        const int virt = getenv("GGML_MI355X_VIRTUAL_DEVICES") ? std::max(1, atoi(getenv("GGML_MI355X_VIRTUAL_DEVICES"))) : 1;
+        for (int iv = 0; iv < n*virt && g.n_devices < GGML_MI355X_MAX_DEVICES; iv++) {
+            const int i = iv/virt;
             hipDeviceProp_t prop;
             if (hipGetDeviceProperties(&prop, i) != hipSuccess) { (void) hipGetLastError(); continue; }
             if (!arch_is_gfx950(prop)) {
@@ -2211,7 +2412,7 @@ static mi_globals & G() {
         // peer access for the layer-split hand-off over xGMI
         for (int i = 0; i < g.n_devices; i++) {
             for (int j = 0; j < g.n_devices; j++) {
-                if (i == j) continue;
+                if (g.devices[i].id == g.devices[j].id) continue;
                 int can = 0;
                 if (hipDeviceCanAccessPeer(&can, g.devices[i].id, g.devices[j].id) == hipSuccess && can) {
                     (void) hipSetDevice(g.devices[i].id);
@@ -2273,6 +2474,7 @@ ggml_backend_t ggml_backend_mi355x_init(int device) {
     set_device(d.id);
     mi_backend_ctx * c = new mi_backend_ctx;
     c->device = d.id;
+    c->dev_index = device;
     c->name = d.name;
     MI_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->use_graphs = atoi(e) != 0;
@@ -2280,6 +2482,36 @@ ggml_backend_t ggml_backend_mi355x_init(int device) {
     if (const char * e = getenv("GGML_MI355X_MEGA")) c->use_mega = atoi(e) != 0;
     ggml_backend_t backend = new ggml_backend{ mi_guid(), mi_backend_iface, &d.dev, c };
     return backend;
+}
+
+ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device, const float * tensor_split) {
+    static std::mutex mu;
+    static std::vector<mi_split_buft_ctx *> made;          // buffer types live as long as the process (the host keeps the pointer in its buft lists)
+    const int n = G().n_devices;
+    if (main_device < 0 || main_device >= n) return NULL;
+    float share[GGML_MI355X_MAX_DEVICES]; double sum = 0;
+    for (int i = 0; i < n; i++) { share[i] = tensor_split && tensor_split[i] > 0 ? tensor_split[i] : 0.0f; sum += share[i]; }
+    if (sum == 0) { for (int i = 0; i < n; i++) share[i] = 1.0f; sum = n; }       // all zero: equal shares
+    mi_split_buft_ctx want; want.main_device = main_device;
+    double acc = 0;
+    for (int i = 0; i < n; i++) { want.cum[i] = (float)(acc/sum); acc += share[i]; }
+    want.cum[n] = 1.0f;
+    for (int i = 0; i < n; i++) {                           // every device that holds rows must be mapped into the main device's address space and back
+        if (share[i] == 0 || G().devices[i].id == G().devices[main_device].id) continue;
+        int ab = 0, ba = 0;
+        if (hipDeviceCanAccessPeer(&ab, G().devices[i].id, G().devices[main_device].id) != hipSuccess || hipDeviceCanAccessPeer(&ba, G().devices[main_device].id, G().devices[i].id) != hipSuccess || !ab || !ba) {
+            (void) hipGetLastError();
+            MI_LOG("row split: no peer mapping between %s and %s\n", G().devices[i].name.c_str(), G().devices[main_device].name.c_str());
+            return NULL;
+        }
+    }
+    std::lock_guard<std::mutex> lock(mu);
+    for (mi_split_buft_ctx * m : made) if (m->main_device == main_device && memcmp(m->cum, want.cum, sizeof(want.cum)) == 0) return &m->buft;
+    mi_split_buft_ctx * m = new mi_split_buft_ctx(want);
+    m->name = std::string(GGML_MI355X_NAME) + "_Split";
+    m->buft = { mi_split_buft_iface, &G().devices[main_device].dev, m };
+    made.push_back(m);
+    return &m->buft;
 }
 
 bool ggml_backend_is_mi355x(ggml_backend_t backend) { return backend != NULL && ggml_guid_matches(backend->guid, mi_guid()); }

@@ -5,11 +5,23 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_fp16.h>
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #define MI_WAVE 64
 
 #define MI_HIP_CHECK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { \
     fprintf(stderr, "HIP error %s at %s:%d: %s\n", hipGetErrorName(e_), __FILE__, __LINE__, hipGetErrorString(e_)); abort(); } } while (0)
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel: a process that drives several GPUs (a layer split or a row split held in
+// one process) must raise a kernel's dynamic-LDS limit once per device, not once per process. Returns false (and clears the error) on failure.
+#define MI_LDS_LIMIT(bytes, ...) ([&]() -> bool { static std::atomic<uint32_t> done_{ 0 }; int d_ = 0; (void) hipGetDevice(&d_); \
+    if (done_.load(std::memory_order_acquire) >> (d_ & 31) & 1) return true; \
+    if (hipFuncSetAttribute((const void *) (__VA_ARGS__), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(bytes)) != hipSuccess) { (void) hipGetLastError(); return false; } \
+    done_.fetch_or(1u << (d_ & 31), std::memory_order_release); return true; }())
+#define MI_LDS_LIMIT_OR_DIE(bytes, ...) do { if (!MI_LDS_LIMIT(bytes, __VA_ARGS__)) { fprintf(stderr, "hipFuncSetAttribute failed at %s:%d\n", __FILE__, __LINE__); abort(); } } while (0)
 
 namespace mi355x {
 

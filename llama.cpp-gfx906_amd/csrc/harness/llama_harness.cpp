@@ -54,6 +54,8 @@ struct mi_llama_hparams {
     int32_t n_swa, swa_pattern;       // > 0: sliding-window attention on the layers il % swa_pattern < swa_pattern - 1 (llama_hparams::set_swa_pattern,
                                       // src/llama-hparams.cpp:5-13; gpt-oss: 128 / 2), which get their own, smaller cache (llama_kv_cache_unified_iswa)
     int32_t n_ubatch;                 // most tokens per decode call; sizes the window cache: min(n_ctx, PAD(n_swa + n_ubatch)) (src/llama-kv-cache-unified-iswa.cpp:46-60)
+    int32_t row_split;                // -sm row over this many devices (0 / 1 = off): the 2-D weight matrices go to the backend's split buffer type, equal shares
+                                      // (make_gpu_buft_list, src/llama-model.cpp:368-387); everything else, the KV cache and the graph stay on `backend`'s device
 };
 
 struct mi_llama;
@@ -175,6 +177,9 @@ struct mi_llama {
     mi_llama_hparams hp;
     ggml_backend_t backend;
     ggml_context * wctx = nullptr;
+    ggml_context * wsplit = nullptr;                    // row-split weights (hp.row_split > 1) and their buffer
+    ggml_backend_buffer_t wsplit_buf = nullptr;
+    ggml_backend_buffer_type_t split_buft = nullptr;
     ggml_backend_buffer_t wbuf = nullptr;
     ggml_context * kvctx = nullptr;
     ggml_backend_buffer_t kvbuf = nullptr;
@@ -224,9 +229,17 @@ enum ggml_type file_type(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t
     return ft;
 }
 
+// every weight tensor: the ordinary context, then the row-split one
+template <typename F> void for_each_weight(mi_llama * m, F f) {
+    for (ggml_context * ctx : { m->wctx, m->wsplit }) {
+        if (!ctx) continue;
+        for (ggml_tensor * t = ggml_get_first_tensor(ctx); t; t = ggml_get_next_tensor(ctx, t)) f(t);
+    }
+}
+
 ggml_tensor * new_weight(mi_llama * m, enum ggml_type type, int64_t ne0, int64_t ne1, const char * name) {
     type = file_type(m, type, ne0, ne1, 1, name, type == GGML_TYPE_F32);
-    ggml_tensor * t = ggml_new_tensor_2d(m->wctx, type, ne0, ne1);
+    ggml_tensor * t = ggml_new_tensor_2d(m->split_buft && ne1 > 1 && ggml_is_quantized(type) ? m->wsplit : m->wctx, type, ne0, ne1);
     ggml_set_name(t, name);
     if (ne1 > 1) m->weight_bytes += ggml_nbytes(t);
     return t;
@@ -485,12 +498,13 @@ void upload_from_file(mi_llama * m) {
     const bool async = ring && (int) ev.size() == NBUF;
     uint8_t * rbase = async ? (uint8_t *) ggml_backend_buffer_get_base(ring) : nullptr;
     int slot = 0;
-    for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
+    for_each_weight(m, [&](ggml_tensor * t) {
         const mi355x::gguf_tensor_info * ti = m->gf->find(t->name);
         if (!ti && strcmp(t->name, "output.weight") == 0) ti = m->gf->find("token_embd.weight");
         const size_t nb = ggml_nbytes(t);
         const uint8_t * src = m->gf->tensor_data(*ti, nb);
-        if (!async) { ggml_backend_tensor_set(t, src, 0, nb); continue; }       // the loader's fallback: a synchronous copy per tensor (:1075)
+        // the loader's fallback: a synchronous copy per tensor (:1075); row-split tensors are written whole (their buffer spreads the rows)
+        if (!async || t->buffer == m->wsplit_buf) { ggml_backend_tensor_set(t, src, 0, nb); return; }
         for (size_t off = 0; off < nb; off += CHUNK) {
             const size_t n = std::min(CHUNK, nb - off);
             ggml_backend_event_synchronize(ev[slot]);
@@ -499,7 +513,7 @@ void upload_from_file(mi_llama * m) {
             ggml_backend_event_record(ev[slot], m->backend);
             slot = (slot + 1) % NBUF;
         }
-    }
+    });
     for (ggml_backend_event_t e : ev) { ggml_backend_event_synchronize(e); ggml_backend_event_free(e); }
     if (ring) ggml_backend_buffer_free(ring);
 }
@@ -514,6 +528,8 @@ mi_llama * create_impl(ggml_backend_t backend, const mi_llama_hparams * hp_in, u
     } catch (...) {      // a tensor the file lacks or holds with another shape: release what was declared so far, the caller reports the message
         if (m->wbuf) ggml_backend_buffer_free(m->wbuf);
         if (m->kvbuf) ggml_backend_buffer_free(m->kvbuf);
+        if (m->wsplit_buf) ggml_backend_buffer_free(m->wsplit_buf);
+        if (m->wsplit) ggml_free(m->wsplit);
         if (m->wctx) ggml_free(m->wctx);
         if (m->kvctx) ggml_free(m->kvctx);
         delete m;
@@ -538,6 +554,19 @@ mi_llama * create_body(mi_llama * m) {
 
     m->wctx = ggml_init({ 0, NULL, true });
     m->kvctx = ggml_init({ 0, NULL, true });
+    if (hp.row_split > 1) {     // make_gpu_buft_list (src/llama-model.cpp:368-387): the split buffer type through the registry's proc, if the backend has one
+        ggml_backend_dev_t dev = ggml_backend_get_device(backend);
+        ggml_backend_reg_t reg = ggml_backend_dev_backend_reg(dev);
+        auto fn = (ggml_backend_split_buffer_type_t) ggml_backend_reg_get_proc_address(reg, "ggml_backend_split_buffer_type");
+        size_t idx = 0, ndev = ggml_backend_reg_dev_count(reg);
+        while (idx < ndev && ggml_backend_reg_dev_get(reg, idx) != dev) idx++;
+        if (!fn || idx == ndev || (size_t) hp.row_split > ndev) throw std::runtime_error("row split over " + std::to_string(hp.row_split) + " devices: the backend has " + std::to_string(ndev));
+        float ts[128] = {};
+        for (int i = 0; i < hp.row_split; i++) ts[i] = 1.0f;
+        m->split_buft = fn((int) idx, ts);
+        if (!m->split_buft) throw std::runtime_error("the backend refused the row split (no peer mapping between the devices)");
+        m->wsplit = ggml_init({ 0, NULL, true });
+    }
     char name[64];
     for (int il = hp.layer_begin; il < hp.layer_end; il++) {
         const layer_types t = types_for_layer(hp, il);
@@ -585,6 +614,11 @@ mi_llama * create_body(mi_llama * m) {
         m->output = new_weight(m, output_type(hp), n_embd, hp.n_vocab, "output.weight");
     }
     m->wbuf = ggml_backend_alloc_ctx_tensors(m->wctx, backend);
+    if (m->wsplit) {
+        m->wsplit_buf = ggml_backend_alloc_ctx_tensors_from_buft(m->wsplit, m->split_buft);
+        if (!m->wsplit_buf) throw std::runtime_error("row-split weight allocation failed");
+        ggml_backend_buffer_set_usage(m->wsplit_buf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);
+    }
     m->kvbuf = ggml_backend_alloc_ctx_tensors(m->kvctx, backend);
     if (!m->wbuf || !m->kvbuf) { fprintf(stderr, "mi_llama: weight/KV allocation failed\n"); throw std::runtime_error("weight / KV allocation failed"); }
     ggml_backend_buffer_set_usage(m->wbuf, GGML_BACKEND_BUFFER_USAGE_WEIGHTS);   // src/llama-model.cpp:5633
@@ -593,18 +627,18 @@ mi_llama * create_body(mi_llama * m) {
     std::vector<uint8_t> tmp;
     uint64_t s = seed*7919 + 13;
     if (m->gf) upload_from_file(m);
-    else for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
+    else for_each_weight(m, [&](ggml_tensor * t) {
         if (t == m->rope_freqs) {
             std::vector<float> ff(t->ne[0]);
             for (size_t i = 0; i < ff.size(); i++) ff[i] = i < ff.size()/2 ? 1.0f : 8.0f;   // llama-3.1-like long/short factors
             ggml_backend_tensor_set(t, ff.data(), 0, ggml_nbytes(t));
-            continue;
+            return;
         }
         // seeded by the tensor's NAME: a rank that holds only some layers (-sm layer) generates the same bytes for them as a whole model does
         uint64_t h = 1469598103934665603ull;
         for (const char * c = ggml_get_name(t); *c; c++) h = (h ^ (uint8_t) *c)*1099511628211ull;
         upload_random(m, t, 1.0f/sqrtf((float) t->ne[0]), s ^ h, tmp);
-    }
+    });
 
     // pinned staging for per-step inputs
     ggml_backend_buffer_type_t hbt = ggml_backend_dev_host_buffer_type(ggml_backend_get_device(backend));
@@ -710,7 +744,9 @@ GGML_API void mi_llama_free(struct mi_llama * m) {
     for (auto & kv : m->graphs) free_graph(kv.second);
     if (m->hbuf) ggml_backend_buffer_free(m->hbuf); else free(m->hbase);
     if (m->wbuf) ggml_backend_buffer_free(m->wbuf);
+    if (m->wsplit_buf) ggml_backend_buffer_free(m->wsplit_buf);
     if (m->kvbuf) ggml_backend_buffer_free(m->kvbuf);
+    if (m->wsplit) ggml_free(m->wsplit);
     ggml_free(m->wctx); ggml_free(m->kvctx);
     delete m;
 }
@@ -725,10 +761,9 @@ GGML_API int      mi_llama_n_result(const struct mi_llama * m) { return (int) m-
 
 // tensor access for graph-level parity tests
 GGML_API struct ggml_tensor * mi_llama_get_tensor(struct mi_llama * m, const char * name) {
-    for (ggml_tensor * t = ggml_get_first_tensor(m->wctx); t; t = ggml_get_next_tensor(m->wctx, t)) {
-        if (strcmp(t->name, name) == 0) return t;
-    }
-    return nullptr;
+    ggml_tensor * found = nullptr;
+    for_each_weight(m, [&](ggml_tensor * t) { if (!found && strcmp(t->name, name) == 0) found = t; });
+    return found;
 }
 
 // One llama_decode() of n_tokens tokens of sequence 0 (src/llama-context.cpp:946-1254 restricted to one ubatch):

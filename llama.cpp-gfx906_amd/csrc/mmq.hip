@@ -592,18 +592,10 @@ constexpr size_t MQ_LDS_BYTES_DUAL = 2*(size_t)(2*MQ_BM + 256)*MQ_LD;
 // 108 KB of dynamic LDS: more than the 64 KB a kernel gets without asking
 template <int T_>
 static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
-    static const bool once = [] {
-        MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq<T_, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
-        return true;
-    }();
-    (void) once;
+    MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_256, k_mmq<T_, 256>);
     static const bool w16 = !getenv("GGML_MI355X_MMQ16") || atoi(getenv("GGML_MI355X_MMQ16")) != 0;
     if (w16 && !a.moe && a.ne12 == 1 && a.r2 == 1 && a.r3 == 1) {
-        static const bool once16 = [] {
-            MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq16<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
-            return true;
-        }();
-        (void) once16;
+        MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_256, k_mmq16<T_>);
         hipLaunchKernelGGL((k_mmq16<T_>), grid, dim3(1024), MQ_LDS_BYTES_256, stream, a);
         return;
     }
@@ -707,18 +699,10 @@ __global__ void __launch_bounds__(256) k_combine_seg(const combine_seg_args p) {
 
 template <int T_, int T2_>
 static void launch_mmq_multi(dim3 grid, const mmq_args & a, hipStream_t stream) {
-    static const bool once = [] {
-        MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq<T_, 256, false, T2_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
-        return true;
-    }();
-    (void) once;
+    MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_256, k_mmq<T_, 256, false, T2_>);
     static const bool w16 = !getenv("GGML_MI355X_MMQ16") || atoi(getenv("GGML_MI355X_MMQ16")) != 0;
     if (w16) {
-        static const bool once16 = [] {
-            MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq16<T_, T2_>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_256));
-            return true;
-        }();
-        (void) once16;
+        MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_256, k_mmq16<T_, T2_>);
         hipLaunchKernelGGL((k_mmq16<T_, T2_>), grid, dim3(1024), MQ_LDS_BYTES_256, stream, a);
         return;
     }
@@ -796,11 +780,7 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
 // gate / up + SwiGLU of build_ffn (src/llama-graph.cpp:632-774) for many tokens: dst[n][m] = silu(Wg.x) * (Wu.x)
 template <int T_>
 static void launch_mmq_dual(dim3 grid, const mmq_args & a, hipStream_t stream) {
-    static const bool once = [] {
-        MI_HIP_CHECK(hipFuncSetAttribute((const void *) k_mmq<T_, 256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int) MQ_LDS_BYTES_DUAL));
-        return true;
-    }();
-    (void) once;
+    MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_DUAL, k_mmq<T_, 256, true>);
     hipLaunchKernelGGL((k_mmq<T_, 256, true>), grid, dim3(512), MQ_LDS_BYTES_DUAL, stream, a);
 }
 bool mul_mat_q_glu_supported(int64_t m, int64_t n) { return n >= 256 && ((m + MQ_BM - 1)/MQ_BM)*((n + 255)/256) >= 160; }

@@ -222,11 +222,7 @@ static bool launch_mmvq_cols(const mmvq_args & a, int act_kind, hipStream_t stre
         int dev = 0; hipDeviceProp_t prop;
         n_cu = hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess ? prop.multiProcessorCount : 256;
     }
-    static size_t lds_set = 0;
-    if (lds > lds_set) {
-        if (hipFuncSetAttribute((const void *) k_mmvq_cols<TYPE, NCOLS>, hipFuncAttributeMaxDynamicSharedMemorySize, 152*1024) != hipSuccess) { (void) hipGetLastError(); return false; }
-        lds_set = 152*1024;
-    }
+    if (!MI_LDS_LIMIT(152*1024, k_mmvq_cols<TYPE, NCOLS>)) return false;
     const int64_t pairs = (a.m + 1)/2;
     const int blocks = (int) std::min<int64_t>(n_cu, (pairs + 7)/8);
     hipLaunchKernelGGL((k_mmvq_cols<TYPE, NCOLS>), dim3((unsigned) blocks), dim3(512), lds, stream, a);

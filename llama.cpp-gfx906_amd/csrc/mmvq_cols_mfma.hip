@@ -305,11 +305,7 @@ __global__ void __launch_bounds__(512, 1) k_mmvq_cols_mfma(const colmf_args p) {
 
 template <int TYPE>
 static bool launch_cols_mfma(colmf_args & a, size_t lds, hipStream_t stream) {
-    static bool attr = false;
-    if (!attr) {
-        if (hipFuncSetAttribute((const void *) k_mmvq_cols_mfma<TYPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 156*1024) != hipSuccess) { (void) hipGetLastError(); return false; }
-        attr = true;
-    }
+    if (!MI_LDS_LIMIT(156*1024, k_mmvq_cols_mfma<TYPE>)) return false;
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0; hipDeviceProp_t prop;

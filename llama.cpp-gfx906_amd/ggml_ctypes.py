@@ -65,7 +65,7 @@ class ggml_init_params(C.Structure):
 class mi355x_counters(C.Structure):
     _fields_ = [(n, C.c_uint64) for n in (
         "graphs_computed", "nodes_computed", "kernels_launched", "graph_replays", "graph_captures", "mmvq_launches",
-        "mmq_launches", "weight_bytes", "act_quant_launches", "act_quant_reused")]
+        "mmq_launches", "weight_bytes", "act_quant_launches", "act_quant_reused", "split_mul_mats")]
 
 
 class mi355x_prof_entry(C.Structure):
@@ -91,7 +91,7 @@ MI355X_EXPORTS = [
     "ggml_backend_mi355x_get_device_count", "ggml_backend_mi355x_get_device_description", "ggml_backend_mi355x_get_device_memory",
     "ggml_backend_mi355x_buffer_type", "ggml_backend_mi355x_host_buffer_type", "ggml_backend_mi355x_get_stream",
     "ggml_backend_mi355x_get_counters", "ggml_backend_mi355x_reset_counters", "ggml_backend_mi355x_set_option",
-    "ggml_backend_mi355x_get_profile",
+    "ggml_backend_mi355x_get_profile", "ggml_backend_mi355x_split_buffer_type",
 ]
 
 

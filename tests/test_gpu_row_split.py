@@ -1,0 +1,135 @@
+"""Row-split weights (-sm row; VERDICT r1 "missing" 1): the split buffer type the host binds through the registry proc
+"ggml_backend_split_buffer_type" (src/llama-model.cpp:368-387) and MUL_MAT on it. A one-GPU box has one device, so the checks run in a
+child process with GGML_MI355X_VIRTUAL_DEVICES=2: the registry then lists the GPU twice (separate backend, stream and buffer type each) and
+the two "devices" take part exactly as two GPUs would — slices in separate allocations, one launch per device on its own stream, the
+event fork / join — except that the peer reads and writes stay on the card. What is compared: split vs unsplit results of the same weights
+(bit-identical for <= 8 tokens, where a row's arithmetic does not depend on the launch shape), the oracle, a whole model, the probes."""
+import os
+import subprocess
+import sys
+from pathlib import Path
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def test_row_split_in_a_two_device_process():
+    env = dict(os.environ, GGML_MI355X_VIRTUAL_DEVICES="2", PYTHONPATH=f"{ROOT}:{ROOT / 'oracle'}:{ROOT / 'tests'}")
+    r = subprocess.run([sys.executable, str(Path(__file__).resolve()), "worker"], env=env, capture_output=True, text=True, timeout=900)
+    sys.stdout.write(r.stdout[-4000:]); sys.stderr.write(r.stderr[-4000:])
+    assert r.returncode == 0 and "ROW SPLIT OK" in r.stdout
+
+
+def worker():
+    import ctypes as C
+
+    import numpy as np
+
+    import oracle as orc
+    import ref_llama
+    from gpu_util import QTYPES, gg, pkg
+    ls = pkg.llama_synth
+    L = gg.base()
+    be = gg.Backend(0)
+    assert L.ggml_backend_reg_dev_count(be.reg) == 2
+    fn = C.CFUNCTYPE(C.c_void_p, C.c_int, C.POINTER(C.c_float))(L.ggml_backend_reg_get_proc_address(be.reg, b"ggml_backend_split_buffer_type"))
+    L.ggml_backend_alloc_ctx_tensors_from_buft.restype = C.c_void_p
+    L.ggml_backend_alloc_ctx_tensors_from_buft.argtypes = [C.c_void_p, C.c_void_p]
+    L.ggml_backend_buft_name.restype = C.c_char_p; L.ggml_backend_buft_name.argtypes = [C.c_void_p]
+    L.ggml_backend_buft_get_alloc_size.restype = C.c_size_t; L.ggml_backend_buft_get_alloc_size.argtypes = [C.c_void_p, gg.tensor_p]
+    L.ggml_backend_dev_supports_buft.restype = C.c_bool; L.ggml_backend_dev_supports_buft.argtypes = [C.c_void_p, C.c_void_p]
+
+    def split_buft(shares):
+        ts = (C.c_float * 16)(*shares)
+        return fn(0, ts)
+
+    equal = split_buft([0.0] * 16)
+    assert equal and L.ggml_backend_buft_name(equal) == b"MI355X_Split"
+    assert split_buft([1.0, 1.0]) == equal and split_buft([3.0, 1.0]) != equal          # one buffer type per (main device, proportions)
+    assert L.ggml_backend_dev_supports_buft(be.dev, equal)
+    assert not L.ggml_backend_dev_supports_buft(L.ggml_backend_reg_dev_get(be.reg, 1), equal)   # the main device's backend runs the graph
+    assert not fn(5, (C.c_float * 16)())                                                   # no such device
+
+    def mul_mat(buft, qt, w, x, m, k, check_probe=False):
+        n = x.shape[0]
+        with gg.Context() as wc, gg.Context() as ctx:
+            a = wc.new_tensor(qt, [k, m], "a")
+            if buft:
+                buf = L.ggml_backend_alloc_ctx_tensors_from_buft(wc.ctx, buft)
+                assert buf
+                wc.buffers.append(buf)
+            else:
+                assert wc.alloc(be)
+            b = ctx.new_tensor(gg.F32, [k, n], "b")
+            guard0 = ctx.new_tensor(gg.F32, [1024], "g0")
+            out = L.ggml_mul_mat(ctx.ctx, a, b)
+            guard1 = ctx.new_tensor(gg.F32, [1024], "g1")
+            assert be.supports_op(out)
+            if check_probe and buft:       # what the host's weight_buft_supported probe asks (src/llama-model.cpp:152-286): only MUL_MAT's src0 may be split
+                assert not be.supports_op(L.ggml_transpose(ctx.ctx, a)) and not be.supports_op(L.ggml_mul_mat(ctx.ctx, b, a))
+                assert L.ggml_backend_buft_get_alloc_size(buft, a) >= L.ggml_nbytes(a)
+            assert ctx.alloc(be)
+            pat = np.full((1, 1024), 7.5, np.float32)
+            gg.tensor_set(guard0, pat); gg.tensor_set(guard1, pat)
+            gg.tensor_set(a, w); gg.tensor_set(b, x)
+            assert np.array_equal(gg.tensor_get(a)[0, 0], w)                               # scatter over the devices and gather back
+            be.compute(gg.graph_of(ctx, out))
+            res = gg.tensor_get(out)[0, 0].copy()
+            assert np.array_equal(gg.tensor_get(guard0)[0, 0, 0], pat[0]) and np.array_equal(gg.tensor_get(guard1)[0, 0, 0], pat[0])
+            return res
+
+    rng = np.random.default_rng(4)
+    n_split = 0
+    for tname in ("q4_K", "q6_K", "q5_K", "q8_0", "q4_0", "mxfp4"):
+        qt = QTYPES[tname]
+        for (m, k) in ((300, 1024), (64, 256), (4096, 4096)):
+            w = orc.random_blocks(rng, qt, (m,), k, scale=1.0/np.sqrt(k))
+            for n in (1, 3, 8, 40) if m < 4096 else (1, 512):
+                x = rng.standard_normal((n, k)).astype(np.float32)
+                ref = mul_mat(None, qt, w, x, m, k)
+                be.reset_counters()
+                for shares in ([0.0] * 16, [3.0, 1.0], [0.0, 1.0], [1.0, 0.0]):
+                    got = mul_mat(split_buft(shares), qt, w, x, m, k, check_probe=(n == 1))
+                    if n <= 8:
+                        assert np.array_equal(got, ref), (tname, m, k, n, shares)
+                    else:
+                        assert orc.nmse(ref, got) <= 1e-6, (tname, m, k, n, shares, orc.nmse(ref, got))
+                n_split += 4
+                assert orc.nmse(orc.mul_mat_2d(w, qt, x, "exact"), got) <= 5e-4
+                assert be.counters()["split_mul_mats"] == 4
+    print("op level:", n_split, "split mat-muls match the unsplit ones")
+
+    # ---- a whole model: every 2-D weight matrix split over the two devices, the rest (norms, KV cache, graph) on the main one
+    for ftype in ("Q4_K_M", "Q8_0"):
+        outs = {}
+        for rs in (0, 2):
+            m = ls.SynthLlama(be, "tiny", ftype, n_ctx=64, seed=3, row_split=rs)
+            try:
+                if rs:
+                    rc = ref_llama.RefLlama(m.cfg, ref_llama.read_weights(m, gg), 64, "cpu")
+                res = []
+                tight = True            # until a > 8-token prompt pass has gone through the bf16 matrix-core kernels (their K / V rows stay in the cache)
+                be.reset_counters()
+                for toks in [[5, 9, 200, 17, 3, 44, 101], [7], [8], [300], list(range(40, 60)), [2]]:
+                    got = m.decode(toks)
+                    res.append(got)
+                    if rs:
+                        exp = rc.decode(np.stack([m.embedding(t) for t in toks]))
+                        tight = tight and len(toks) <= 8
+                        assert orc.nmse(exp, got) <= (5e-4 if tight else 2e-3), (ftype, toks, orc.nmse(exp, got))
+                cnt = be.counters()
+                assert cnt["split_mul_mats"] == (6*(2*7 + 1) if rs else 0), cnt["split_mul_mats"]
+                if rs:
+                    assert cnt["graph_replays"] == 0
+                outs[rs] = res
+            finally:
+                m.free()
+        for a_, b_ in zip(outs[0], outs[2]):
+            assert orc.nmse(a_, b_) <= 1e-4, (ftype, orc.nmse(a_, b_))
+    print("ROW SPLIT OK")
+
+
+if __name__ == "__main__" and len(sys.argv) > 1 and sys.argv[1] == "worker":
+    worker()
