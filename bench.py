@@ -127,6 +127,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--ftype", default="Q4_K_M")
+    ap.add_argument("--row-split", type=int, default=0, help="-sm row inside ONE process: spread the weight matrices' rows over this many devices of the "
+                    "registry (csrc/backend.cpp: the split buffer type); on a one-GPU box set GGML_MI355X_VIRTUAL_DEVICES to list the GPU several times")
     ap.add_argument("--gguf", default=None, help="run the same protocol on a model read from this GGUF file (llama / gpt-oss architectures) instead of the "
                     "synthetic weights of --model / --ftype")
     ap.add_argument("--pp", type=int, default=512, help="prompt length for the extra pp measurement (0 = skip)")
@@ -191,7 +193,7 @@ def main():
         cfg = ls.MODELS[args.model]
 
         def new_model(n_ctx, **kw):
-            return ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, **kw)
+            return ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, row_split=args.row_split, **kw)
     K, W = args.steps, args.warmup
     ranges = lsp.layer_ranges(cfg["n_layer"], world)
     lb, le, has_out = ranges[rank]
@@ -236,7 +238,7 @@ def main():
         be.set_option("graphs", 1)
 
         roof = None
-        if not args.no_profile:
+        if not args.no_profile and args.row_split <= 1:      # (the per-device launches of a row split are not bracketed: that mode reports throughput only)
             # dominant kernel, timed live with HIP events on the backend stream. Option "profile" = 1: eager launches, each grouped mat-vec
             # dispatch carrying its own start/stop event pair (hipExtLaunchKernelGGL), i.e. kernel start -> kernel end by the packet's
             # timestamps, the same interval rocprofv3's kernel trace reports (round 1 recorded an event either side of the launch call,
@@ -392,7 +394,7 @@ def main():
             "dtype": "int8 dot (4-6 bit weights x Q8 activations), f32 accumulate", "data": f"gguf file {args.model}" if args.gguf else "synthetic",
             "config": {"workload": f"{args.model} {args.ftype}, llama-bench tg{K} protocol (BASELINE.json configs[1]): 1 token/step, sync per token, "
                                    f"f16 KV cache, {'flash-attn' if args.fa else 'no flash-attn'}, n_ctx={n_ctx}",
-                       "parallelism": "single GPU" if world == 1 else f"layer split over {world} GPUs, {world} sequences in flight, {'RCCL' if transport == 'nccl' else 'gloo (host memory)'} p2p hand-off"},
+                       "parallelism": (f"rows of the weight matrices split over {args.row_split} devices in one process" if args.row_split > 1 else "single GPU") if world == 1 else f"layer split over {world} GPUs, {world} sequences in flight, {'RCCL' if transport == 'nccl' else 'gloo (host memory)'} p2p hand-off"},
             "roofline": result.get("roofline"), "cpu_baseline": result.get("cpu_baseline"),
         }
         out.update(result.get("extra", {}))
