@@ -716,6 +716,7 @@ static act_q8 get_act(mi_backend_ctx * c, const void * x, int64_t k, int64_t n_i
     return q;
 }
 
+static bool mmq_i8_on() { static const bool on = getenv("GGML_MI355X_MMQ_I8") && atoi(getenv("GGML_MI355X_MMQ_I8")) != 0; return on; }
 static constexpr int ACT_KIND_BF16 = -16;   // aq.kind of the dense bf16 copy the MFMA prefill kernel reads
 
 // out/res: the prefill residual fusion (try_fused_prefill_add) writes W.x + res into `out` instead of W.x into dst
@@ -736,6 +737,10 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml
                     const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
                     mul_mat_vec_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
                     c->cnt.mmvq_launches++;
+                } else if (!out && mmq_i8_on() && mul_mat_q_i8_supported((int) a->type, M, K, N) && act_q8_bytes(kind, K, N) <= c->scratch_size) {
+                    const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
+                    mul_mat_q_i8((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
+                    c->cnt.mmq_launches++;
                 } else {
                     // the scratch holds the bf16 copy of the activations; wq/wk/wv and gate/up read the same ones: convert once
                     const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == bp && c->aq.k == K && c->aq.n_inner == N &&

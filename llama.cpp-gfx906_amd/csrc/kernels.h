@@ -59,6 +59,10 @@ void mul_mat_vec_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_
 // x: f32 rows of k floats at x + i*x_row_stride; scratch: mul_mat_q_scratch_bytes(k, n, m) bytes (the bf16 copy of x + the split-K planes)
 // (scratch_ready: it already holds the copy of exactly this x — the caller's cache — so the conversion pass is skipped)
 // res != NULL: dst = W.x + res (f32 rows of m floats at res + i*res_row_stride; may be dst itself) — the residual ADD of build_attn / build_ffn
+// Q4_K x Q8_K activations on the int8 matrix cores (mmq_i8.hip), n > 8 tokens: opt-in (GGML_MI355X_MMQ_I8=1) while it is being measured
+bool mul_mat_q_i8_supported(int type_a, int64_t m, int64_t k, int64_t n);
+bool mul_mat_q_i8(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k, const act_q8 & act, int64_t n,
+                  float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m);
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes,
