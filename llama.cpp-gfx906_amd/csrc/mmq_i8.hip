@@ -28,6 +28,7 @@ struct mmq_i8_args {
     const int8_t * qs; const float * d; const int16_t * bs;     // Q8_K image of the n tokens
     float * dst; size_t ldd;                  // dst[token*ldd + row]
     int m, k, n;
+    int dbg;                                   // GGML_MI355X_MMQ_I8_DBG (ablations, wrong results): 1 = no global loads after the first block, 2 = no compute
 };
 
 constexpr int I8_TOK = 64;                    // tokens per workgroup
@@ -279,8 +280,10 @@ static __device__ __forceinline__ int pkmul(int a, uint32_t b2) {
     return __builtin_bit_cast(int, (u16x2)(__builtin_bit_cast(u16x2, a)*__builtin_bit_cast(u16x2, b2)));
 }
 
-__global__ void __launch_bounds__(256, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
-    constexpr int ROWS = 128, I8_BUF = i8_buf_bytes(ROWS), NT = 2;
+// NW = 4: a wave owns 32 rows x 64 tokens (2 waves per SIMD); NW = 8: 32 rows x 32 tokens, waves 2i / 2i + 1 share a row group (4 waves per SIMD at <= 128 registers)
+template <int NW>
+__global__ void __launch_bounds__(NW*64, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
+    constexpr int ROWS = 128, I8_BUF = i8_buf_bytes(ROWS), NT = NW == 4 ? 2 : 1, NTH = NW*64;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kh = lane >> 5;
@@ -290,34 +293,36 @@ __global__ void __launch_bounds__(256, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
     const int rblk = (slot/ntok)*8 + xcd;
     if (rblk*ROWS >= p.m) return;
     const int tok0 = (slot % ntok)*I8_TOK;
-    const int row0 = rblk*ROWS + wave*32;
+    const int rgrp = NW == 4 ? wave : wave >> 1, tw = NW == 4 ? 0 : (wave & 1)*32;
+    const int row0 = rblk*ROWS + rgrp*32;
     const bool active = row0 < p.m;
 
+    constexpr int AST = 1024/NTH;                                 // activation chunks per thread
     const int s_chunk = tid & 15, s_tok = tid >> 4;
-    int4v stage[4];
+    int4v stage[AST];
     float stage_d = 0.0f;
-    constexpr int WCH = ROWS*9, WST = (WCH + 255)/256;
+    constexpr int WCH = ROWS*9, WST = (WCH + NTH - 1)/NTH;
     int4v wstage[WST];
     // per-thread source pointers, advanced by one 256-block per step (the address arithmetic of the copy is otherwise a fifth of the loop's instructions)
-    const int8_t * sp[4]; const float * sdp = p.d + (size_t) min(tok0 + (tid & (I8_TOK - 1)), p.n - 1)*nb; const uint8_t * wp[WST];
+    const int8_t * sp[AST]; const float * sdp = p.d + (size_t) min(tok0 + (tid & (I8_TOK - 1)), p.n - 1)*nb; const uint8_t * wp[WST];
 #pragma unroll
-    for (int i = 0; i < 4; i++) sp[i] = p.qs + (size_t) min(tok0 + s_tok + 16*i, p.n - 1)*p.k + s_chunk*16;
+    for (int i = 0; i < AST; i++) sp[i] = p.qs + (size_t) min(tok0 + s_tok + (NTH/16)*i, p.n - 1)*p.k + s_chunk*16;
 #pragma unroll
-    for (int i = 0; i < WST; i++) { const int ch = min(tid + 256*i, WCH - 1); wp[i] = p.W + (size_t) min(rblk*ROWS + ch/9, p.m - 1)*p.w_stride + (ch % 9)*16; }
+    for (int i = 0; i < WST; i++) { const int ch = min(tid + NTH*i, WCH - 1); wp[i] = p.W + (size_t) min(rblk*ROWS + ch/9, p.m - 1)*p.w_stride + (ch % 9)*16; }
     auto stage_load = [&](int) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { stage[i] = *(const int4v *) sp[i]; sp[i] += 256; }
+        for (int i = 0; i < AST; i++) { stage[i] = *(const int4v *) sp[i]; sp[i] += 256; }
         if (tid < I8_TOK) { stage_d = *sdp; sdp++; }
 #pragma unroll
-        for (int i = 0; i < WST; i++) { if (tid + 256*i < WCH) wstage[i] = ld_b128(wp[i]); wp[i] += 144; }
+        for (int i = 0; i < WST; i++) { if (tid + NTH*i < WCH) wstage[i] = ld_b128(wp[i]); wp[i] += 144; }
     };
     auto stage_store = [&](int buf) {
         char * b = smem + buf*I8_BUF;
 #pragma unroll
-        for (int i = 0; i < 4; i++) *(int4v *) (b + (s_tok + 16*i)*I8_PITCH + s_chunk*16) = stage[i];
+        for (int i = 0; i < AST; i++) *(int4v *) (b + (s_tok + (NTH/16)*i)*I8_PITCH + s_chunk*16) = stage[i];
         if (tid < I8_TOK) *(float *) (b + I8_TOK*I8_PITCH + tid*4) = stage_d;
 #pragma unroll
-        for (int i = 0; i < WST; i++) { const int ch = tid + 256*i; if (ch < WCH) *(int4v *) (b + I8_ACT + ch*16) = wstage[i]; }
+        for (int i = 0; i < WST; i++) { const int ch = tid + NTH*i; if (ch < WCH) *(int4v *) (b + I8_ACT + ch*16) = wstage[i]; }
     };
 
     f32x16 accf[NT];
@@ -336,9 +341,9 @@ __global__ void __launch_bounds__(256, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
     for (int kb = 0; kb < nb; kb++) {
         const int buf = kb & 1;
         const char * lb = smem + buf*I8_BUF;
-        if (kb + 1 < nb) stage_load(kb + 1);
-        if (active) {
-            const char * wl = lb + I8_ACT + (wave*32 + col)*144;
+        if (kb + 1 < nb && !(p.dbg & 1)) stage_load(kb + 1);
+        if (active && !(p.dbg & 2)) {
+            const char * wl = lb + I8_ACT + (rgrp*32 + col)*144;
             const int4v hd = *(const int4v *) wl;
             const uint32_t dd = (uint32_t) hd.x, s0 = (uint32_t) hd.y, s1 = (uint32_t) hd.z, s2 = (uint32_t) hd.w;
             const uint32_t scp[2] = { s0 & 0x3F3F3F3Fu, (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u) };
@@ -371,7 +376,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
                     const int4v blo = { pkmul(nib.x, lo2), pkmul(nib.y, lo2), pkmul(nib.z, lo2), pkmul(nib.w, lo2) };
 #pragma unroll
                     for (int t = 0; t < NT; t++) {
-                        const int4v aop = *(const int4v *) (lb + (t*32 + col)*I8_PITCH + sub*32 + kh*16);
+                        const int4v aop = *(const int4v *) (lb + (tw + t*32 + col)*I8_PITCH + sub*32 + kh*16);
                         ahi[t] = mfma_i8(aop, bhi, sub == 0 ? zero : ahi[t]);
                         alo[t] = mfma_i8(aop, blo, sub == 0 ? zero : alo[t]);
                     }
@@ -384,7 +389,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
             for (int t = 0; t < NT; t++) {
 #pragma unroll
                 for (int q4 = 0; q4 < 4; q4++) {
-                    const float4v v = *(const float4v *) (dl + t*32 + q4*8 + kh*4);
+                    const float4v v = *(const float4v *) (dl + tw + t*32 + q4*8 + kh*4);
                     const float da[4] = { v.x, v.y, v.z, v.w };
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
@@ -397,7 +402,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
                 const int blk = (kb & ~1) + kh;
 #pragma unroll
                 for (int t = 0; t < NT; t++) {
-                    const int tok = min(tok0 + t*32 + col, p.n - 1);
+                    const int tok = min(tok0 + tw + t*32 + col, p.n - 1);
                     f16x8 ab;
                     if (blk < nb) {
                         const float dtok = p.d[(size_t) tok*nb + blk];
@@ -427,7 +432,7 @@ __global__ void __launch_bounds__(256, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) {
-            const int tok = tok0 + t*32 + (r >> 2)*8 + kh*4 + (r & 3);
+            const int tok = tok0 + tw + t*32 + (r >> 2)*8 + kh*4 + (r & 3);
             if (tok < p.n) p.dst[(size_t) tok*p.ldd + row0 + col] = accf[t][r];
         }
 }
@@ -443,6 +448,8 @@ bool mul_mat_q_i8(int type_a, const void * W, size_t w_row_stride, int64_t m, in
     mmq_i8_args a;
     a.W = (const uint8_t *) W; a.w_stride = w_row_stride; a.qs = act.qs; a.d = act.d; a.bs = act.bsums;
     a.dst = dst; a.ldd = dst_col_stride_bytes/4; a.m = (int) m; a.k = (int) k; a.n = (int) n;
+    static const int dbg = getenv("GGML_MI355X_MMQ_I8_DBG") ? atoi(getenv("GGML_MI355X_MMQ_I8_DBG")) : 0;
+    a.dbg = dbg;
     static const int nt = getenv("GGML_MI355X_MMQ_I8_NT") ? atoi(getenv("GGML_MI355X_MMQ_I8_NT")) : 1;
     const int rows = nt == 2 ? 256 : 128;
     const int64_t ntok = (n + I8_TOK - 1)/I8_TOK, nrow = (m + rows - 1)/rows;
@@ -450,8 +457,9 @@ bool mul_mat_q_i8(int type_a, const void * W, size_t w_row_stride, int64_t m, in
     static const int variant = getenv("GGML_MI355X_MMQ_I8_VARIANT") ? atoi(getenv("GGML_MI355X_MMQ_I8_VARIANT")) : 1;     // 1 = split scale, 0 = multiply-add per result
     if (variant == 1) {
         const dim3 gs((unsigned)((((m + 127)/128 + 7)/8)*8*ntok));
-        MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K);
-        hipLaunchKernelGGL(k_mmq_i8s_q4_K, gs, dim3(256), 2*i8_buf_bytes(128), stream, a);
+        static const int nw = getenv("GGML_MI355X_MMQ_I8_WAVES") ? atoi(getenv("GGML_MI355X_MMQ_I8_WAVES")) : 8;
+        if (nw == 4) { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<4>); hipLaunchKernelGGL(k_mmq_i8s_q4_K<4>, gs, dim3(256), 2*i8_buf_bytes(128), stream, a); }
+        else         { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<8>); hipLaunchKernelGGL(k_mmq_i8s_q4_K<8>, gs, dim3(512), 2*i8_buf_bytes(128), stream, a); }
         return true;
     }
     if (nt == 2) { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(256), k_mmq_i8_q4_K<2>); hipLaunchKernelGGL(k_mmq_i8_q4_K<2>, grid, dim3(256), 2*i8_buf_bytes(256), stream, a); }
