@@ -135,3 +135,20 @@ def test_layer_split_of_a_file_model(golden_dir):
             assert np.array_equal(got, whole.decode(toks))
     finally:
         whole.free(); a.free(); b.free()
+
+
+def test_bench_runs_on_a_gguf_file(golden_dir):
+    """bench.py --gguf FILE: the llama-bench protocol on a model read from a file; one JSON line that names the file as its data"""
+    import json
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parent.parent
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gguf", str(golden_dir / NAME), "--steps", "16", "--warmup", "4", "--pp", "32", "--no-cpu-baseline"],
+                       capture_output=True, text=True, timeout=600, env=dict(os.environ))
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["data"] == f"gguf file {NAME}" and d["value"] > 0 and d["steps"] == 16 and d["roofline"]["frac"] > 0
