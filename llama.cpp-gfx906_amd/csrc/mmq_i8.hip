@@ -281,9 +281,12 @@ static __device__ __forceinline__ int pkmul(int a, uint32_t b2) {
 }
 
 // NW = 4: a wave owns 32 rows x 64 tokens (2 waves per SIMD); NW = 8: 32 rows x 32 tokens, waves 2i / 2i + 1 share a row group (4 waves per SIMD at <= 128 registers)
-template <int NW>
-__global__ void __launch_bounds__(NW*64, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
-    constexpr int ROWS = 128, I8_BUF = i8_buf_bytes(ROWS), NT = NW == 4 ? 2 : 1, NTH = NW*64;
+// TOK = 128 (NW = 4): a wave owns 32 rows x 128 tokens — the operand arithmetic of a weight fragment is shared by four token tiles (8 matrix instructions per
+// 18 vector ones); 12 accumulator sets = 192 registers, so one wave per SIMD
+template <int NW, int TOK>
+__global__ void __launch_bounds__(NW*64, TOK == 128 ? 1 : 2) k_mmq_i8s_q4_K(const mmq_i8_args p) {
+    constexpr int ROWS = 128, ACT = TOK*I8_PITCH + TOK*4, I8_BUF = ACT + ROWS*144, NT = NW == 4 ? TOK/32 : 1, NTH = NW*64;
+    constexpr int I8_TOK = TOK, I8_ACT = ACT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int col = lane & 31, kh = lane >> 5;
@@ -297,7 +300,7 @@ __global__ void __launch_bounds__(NW*64, 2) k_mmq_i8s_q4_K(const mmq_i8_args p) 
     const int row0 = rblk*ROWS + rgrp*32;
     const bool active = row0 < p.m;
 
-    constexpr int AST = 1024/NTH;                                 // activation chunks per thread
+    constexpr int AST = TOK*16/NTH;                                 // activation chunks per thread
     const int s_chunk = tid & 15, s_tok = tid >> 4;
     int4v stage[AST];
     float stage_d = 0.0f;
@@ -457,9 +460,15 @@ bool mul_mat_q_i8(int type_a, const void * W, size_t w_row_stride, int64_t m, in
     static const int variant = getenv("GGML_MI355X_MMQ_I8_VARIANT") ? atoi(getenv("GGML_MI355X_MMQ_I8_VARIANT")) : 1;     // 1 = split scale, 0 = multiply-add per result
     if (variant == 1) {
         const dim3 gs((unsigned)((((m + 127)/128 + 7)/8)*8*ntok));
-        static const int nw = getenv("GGML_MI355X_MMQ_I8_WAVES") ? atoi(getenv("GGML_MI355X_MMQ_I8_WAVES")) : 8;
-        if (nw == 4) { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<4>); hipLaunchKernelGGL(k_mmq_i8s_q4_K<4>, gs, dim3(256), 2*i8_buf_bytes(128), stream, a); }
-        else         { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<8>); hipLaunchKernelGGL(k_mmq_i8s_q4_K<8>, gs, dim3(512), 2*i8_buf_bytes(128), stream, a); }
+        static const int nw = getenv("GGML_MI355X_MMQ_I8_WAVES") ? atoi(getenv("GGML_MI355X_MMQ_I8_WAVES")) : 8;      // 8 | 4 | 1 (= 4 waves, 128-token tiles)
+        if (nw == 1) {
+            const int64_t ntok128 = (n + 127)/128;
+            const dim3 g1((unsigned)((((m + 127)/128 + 7)/8)*8*ntok128));
+            constexpr int lds = 2*(128*I8_PITCH + 128*4 + 128*144);
+            MI_LDS_LIMIT_OR_DIE(lds, k_mmq_i8s_q4_K<4, 128>); hipLaunchKernelGGL((k_mmq_i8s_q4_K<4, 128>), g1, dim3(256), lds, stream, a);
+        }
+        else if (nw == 4) { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<4, 64>); hipLaunchKernelGGL((k_mmq_i8s_q4_K<4, 64>), gs, dim3(256), 2*i8_buf_bytes(128), stream, a); }
+        else              { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<8, 64>); hipLaunchKernelGGL((k_mmq_i8s_q4_K<8, 64>), gs, dim3(512), 2*i8_buf_bytes(128), stream, a); }
         return true;
     }
     if (nt == 2) { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(256), k_mmq_i8_q4_K<2>); hipLaunchKernelGGL(k_mmq_i8_q4_K<2>, grid, dim3(256), 2*i8_buf_bytes(256), stream, a); }
