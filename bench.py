@@ -110,7 +110,8 @@ def cpu_baseline(model_cfg, ftype, budget_s=20.0):
     t1 = time.perf_counter(); matvec(w, c["n_vocab"], c["n_embd"], orc.Q6_K); t_head = time.perf_counter() - t1
     t_tok = t_layer * c["n_layer"] + t_head
     return {"value": round(1.0 / t_tok, 3), "unit": "tok/s", "cores": cores, "kind": "port",
-            "sample": f"oracle/ggml_oracle.c (Q8_K activation quantize + integer vec_dot, OpenMP): {n_sample_layers} distinct "
+            "sample": f"oracle/ggml_oracle.c (Q8_K activation quantize + integer vec_dot — AVX2 forms of the Q4_K / Q6_K dots, bit-identical to the "
+                      f"scalar restatement — OpenMP): {n_sample_layers} distinct "
                       f"Llama-3-8B Q4_K_M layers x {reps} reps + one full lm_head mat-vec, extrapolated to {c['n_layer']} layers; "
                       f"mat-vec work only (attention/norm/rope excluded)"}
 

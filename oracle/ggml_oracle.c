@@ -523,8 +523,100 @@ static float vec_dot_q6_K_q8_K(int64_t n, const block_q6_K * x, const block_q8_K
     return sumf;
 }
 
+// ---- AVX2 forms of the two K-quant dots a Q4_K_M model spends its time in (bench.py's cpu_baseline: the scalar loops above run at ~0.3 GB/s of
+// weights per core, an order of magnitude under what a vectorised CPU backend streams). Same arithmetic as the scalar restatement, lane for lane:
+// the eight int32 lanes aux32[l] (elements with index = l mod 8) and the eight float lanes sums[l] are kept as they are, so the result is
+// BIT-IDENTICAL to the scalar function (tests/test_oracle_golden.py checks that) — only the 32 int16 products of a sub-block are formed at once.
+#if defined(__x86_64__)
+#include <immintrin.h>
+static int g_simd = -1;   // -1: ask the CPU once; 0: scalar; 1: AVX2
+void orc_set_simd(int on) { g_simd = on ? (__builtin_cpu_supports("avx2") ? 1 : 0) : 0; }
+static inline int use_avx2(void) { if (g_simd < 0) g_simd = __builtin_cpu_supports("avx2") ? 1 : 0; return g_simd; }
+
+// lane l of the result = sum over g of (int16)(q8[8g + l] * a[8g + l]) for the 32 (n16 = 2) or the first / second 16 (n16 = 1) elements
+__attribute__((target("avx2"))) static inline void lane_sums32(__m256i a8, __m256i q8, __m256i * first16, __m256i * second16) {
+    const __m256i a_lo = _mm256_cvtepi8_epi16(_mm256_castsi256_si128(a8)), a_hi = _mm256_cvtepi8_epi16(_mm256_extracti128_si256(a8, 1));
+    const __m256i q_lo = _mm256_cvtepi8_epi16(_mm256_castsi256_si128(q8)), q_hi = _mm256_cvtepi8_epi16(_mm256_extracti128_si256(q8, 1));
+    const __m256i p_lo = _mm256_mullo_epi16(a_lo, q_lo), p_hi = _mm256_mullo_epi16(a_hi, q_hi);       // elements 0..15, 16..31 (each product fits int16)
+    *first16  = _mm256_add_epi32(_mm256_cvtepi16_epi32(_mm256_castsi256_si128(p_lo)), _mm256_cvtepi16_epi32(_mm256_extracti128_si256(p_lo, 1)));
+    *second16 = _mm256_add_epi32(_mm256_cvtepi16_epi32(_mm256_castsi256_si128(p_hi)), _mm256_cvtepi16_epi32(_mm256_extracti128_si256(p_hi, 1)));
+}
+
+__attribute__((target("avx2"))) static float vec_dot_q4_K_q8_K_avx2(int64_t n, const block_q4_K * x, const block_q8_K * y) {
+    const int64_t nb = n / QK_K;
+    float sums[8] = {0};
+    float sumf = 0;
+    const __m256i m4 = _mm256_set1_epi8(0xF);
+    for (int64_t i = 0; i < nb; ++i) {
+        uint8_t scales[8], mins[8];
+        for (int j = 0; j < 8; j++) get_scale_min_k4(j, x[i].scales, &scales[j], &mins[j]);
+        int sumi = 0;
+        for (int j = 0; j < QK_K/16; ++j) sumi += y[i].bsums[j] * mins[j/2];
+        __m256i acc = _mm256_setzero_si256();
+        for (int j = 0; j < QK_K/64; ++j) {
+            const __m256i q4 = _mm256_loadu_si256((const __m256i *) (x[i].qs + 32*j));
+            const __m256i lo = _mm256_and_si256(q4, m4), hi = _mm256_and_si256(_mm256_srli_epi16(q4, 4), m4);
+            __m256i f, s2;
+            lane_sums32(lo, _mm256_loadu_si256((const __m256i *) (y[i].qs + 64*j)), &f, &s2);
+            acc = _mm256_add_epi32(acc, _mm256_mullo_epi32(_mm256_set1_epi32(scales[2*j]), _mm256_add_epi32(f, s2)));
+            lane_sums32(hi, _mm256_loadu_si256((const __m256i *) (y[i].qs + 64*j + 32)), &f, &s2);
+            acc = _mm256_add_epi32(acc, _mm256_mullo_epi32(_mm256_set1_epi32(scales[2*j + 1]), _mm256_add_epi32(f, s2)));
+        }
+        int32_t aux32[8];
+        _mm256_storeu_si256((__m256i *) aux32, acc);
+        const float d = fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+        const float dmin = fp16_to_fp32(x[i].dmin) * y[i].d;
+        sumf -= dmin * sumi;
+    }
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
+    return sumf;
+}
+
+__attribute__((target("avx2"))) static float vec_dot_q6_K_q8_K_avx2(int64_t n, const block_q6_K * x, const block_q8_K * y) {
+    const int64_t nb = n / QK_K;
+    float sums[8] = {0};
+    const __m256i m4 = _mm256_set1_epi8(0xF), m2 = _mm256_set1_epi8(3), off = _mm256_set1_epi8(32);
+    for (int64_t i = 0; i < nb; ++i) {
+        __m256i acc = _mm256_setzero_si256();
+        for (int h = 0; h < 2; h++) {                       // 128 elements: ql 64 bytes, qh 32 bytes, 8 scales
+            const __m256i ql0 = _mm256_loadu_si256((const __m256i *) (x[i].ql + 64*h)), ql1 = _mm256_loadu_si256((const __m256i *) (x[i].ql + 64*h + 32));
+            const __m256i qh = _mm256_loadu_si256((const __m256i *) (x[i].qh + 32*h));
+            __m256i a[4];
+            a[0] = _mm256_or_si256(_mm256_and_si256(ql0, m4), _mm256_slli_epi16(_mm256_and_si256(qh, m2), 4));
+            a[1] = _mm256_or_si256(_mm256_and_si256(ql1, m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(qh, 2), m2), 4));
+            a[2] = _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(ql0, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(qh, 4), m2), 4));
+            a[3] = _mm256_or_si256(_mm256_and_si256(_mm256_srli_epi16(ql1, 4), m4), _mm256_slli_epi16(_mm256_and_si256(_mm256_srli_epi16(qh, 6), m2), 4));
+            for (int v = 0; v < 4; v++) {
+                __m256i f, s2;
+                lane_sums32(_mm256_sub_epi8(a[v], off), _mm256_loadu_si256((const __m256i *) (y[i].qs + 128*h + 32*v)), &f, &s2);
+                const int is = 8*h + 2*v;
+                acc = _mm256_add_epi32(acc, _mm256_mullo_epi32(_mm256_set1_epi32(x[i].scales[is]), f));
+                acc = _mm256_add_epi32(acc, _mm256_mullo_epi32(_mm256_set1_epi32(x[i].scales[is + 1]), s2));
+            }
+        }
+        int32_t aux32[8];
+        _mm256_storeu_si256((__m256i *) aux32, acc);
+        const float d = fp16_to_fp32(x[i].d) * y[i].d;
+        for (int l = 0; l < 8; ++l) sums[l] += d * aux32[l];
+    }
+    float sumf = 0;
+    for (int l = 0; l < 8; ++l) sumf += sums[l];
+    return sumf;
+}
+#else
+void orc_set_simd(int on) { (void) on; }
+static inline int use_avx2(void) { return 0; }
+#endif
+
 // vec_dot(n, &s, x (weight row, type), y (row already in vec_dot_type)) — tests/test-quantize-fns.cpp:93
 float orc_vec_dot(int type, int64_t n, const void * x, const void * y) {
+#if defined(__x86_64__)
+    if (use_avx2()) {
+        if (type == T_Q4_K) return vec_dot_q4_K_q8_K_avx2(n, (const block_q4_K *) x, (const block_q8_K *) y);
+        if (type == T_Q6_K) return vec_dot_q6_K_q8_K_avx2(n, (const block_q6_K *) x, (const block_q8_K *) y);
+    }
+#endif
     switch (type) {
         case T_Q4_0:  return vec_dot_q4_0_q8_0 (n, (const block_q4_0  *) x, (const block_q8_0 *) y);
         case T_Q8_0:  return vec_dot_q8_0_q8_0 (n, (const block_q8_0  *) x, (const block_q8_0 *) y);

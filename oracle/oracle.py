@@ -79,6 +79,7 @@ def lib(path: Path | None = None):
     L.orc_vec_dot.restype = ctypes.c_float; L.orc_vec_dot.argtypes = [c_int, c_i64, c_vp, c_vp]
     L.orc_mul_mat.restype = c_int; L.orc_mul_mat.argtypes = [c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64, c_int]
     L.orc_mul_mat_q.restype = c_int; L.orc_mul_mat_q.argtypes = [c_int, c_vp, c_vp, c_vp, c_i64, c_i64, c_i64]
+    L.orc_set_simd.restype = None; L.orc_set_simd.argtypes = [c_int]
     if path is None:
         _lib = L
     return L
@@ -114,6 +115,11 @@ def quantize(x: np.ndarray, qtype: int) -> np.ndarray:
     rc = lib().orc_quantize_row(qtype, _ptr(x), _ptr(out), x.size)
     assert rc == 0, f"quantize: no reference quantizer for type {qtype}"
     return out
+
+
+def set_simd(on: bool):
+    """the AVX2 forms of the Q4_K / Q6_K dots on (default where the CPU has AVX2) or off; both give bit-identical results"""
+    lib().orc_set_simd(int(on))
 
 
 def vec_dot_type(qtype: int) -> int:

@@ -85,3 +85,27 @@ def test_q8_K_round_trip_and_bsums():
     rec = (qs * d[:, :, None]).reshape(4, 512)
     amax = np.abs(x.reshape(4, 2, 256)).max(-1, keepdims=True)
     assert np.all(np.abs(rec.reshape(4, 2, 256) - x.reshape(4, 2, 256)) <= amax / 127 * 0.5001 + 1e-12)
+
+
+@pytest.mark.parametrize("tname", ["q4_K", "q6_K"])
+def test_avx2_dot_is_bit_identical_to_the_scalar_restatement(tname):
+    """oracle/ggml_oracle.c carries AVX2 forms of the two dots bench.py's cpu_baseline spends its time in; they keep the scalar code's eight integer and
+    eight float lanes, so every result must be the same bits (random valid blocks, edge blocks with all-ones / all-zero bytes, several row lengths)"""
+    import numpy as np
+    import oracle as orc
+    qt = {"q4_K": orc.Q4_K, "q6_K": orc.Q6_K}[tname]
+    rng = np.random.default_rng(11)
+    for k in (256, 1024, 4096):
+        w = orc.random_blocks(rng, qt, (64,), k, scale=1.0/np.sqrt(k))
+        w[0, :] = 0xFF; w[1, :] = 0x00; w[2, :] = 0xAA
+        w[0, -2:] = np.array([1.0], np.float16).view(np.uint8); w[2, -2:] = np.array([0.5], np.float16).view(np.uint8)      # (Q6_K: d is last; keep it finite)
+        if tname == "q4_K":
+            blocks = w.reshape(64, -1, 144); blocks[0:3, :, 0:4] = np.array([1.0, 0.5], np.float16).view(np.uint8)
+        x = (rng.standard_normal((5, k))*rng.uniform(0.01, 30.0)).astype(np.float32)
+        x[4, :] = 0
+        try:
+            orc.set_simd(False); ref = orc.mul_mat_2d(w, qt, x, "cpu")
+            orc.set_simd(True);  got = orc.mul_mat_2d(w, qt, x, "cpu")
+        finally:
+            orc.set_simd(True)
+        assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (tname, k)
