@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--ftype", default="Q4_K_M")
+    ap.add_argument("--ctk", default="f16", choices=["f16", "q8_0", "q4_0"], help="llama-bench -ctk: K cache type (no flash attention: V stays f16)")
     ap.add_argument("--row-split", type=int, default=0, help="-sm row inside ONE process: spread the weight matrices' rows over this many devices of the "
                     "registry (csrc/backend.cpp: the split buffer type); on a one-GPU box set GGML_MI355X_VIRTUAL_DEVICES to list the GPU several times")
     ap.add_argument("--gguf", default=None, help="run the same protocol on a model read from this GGUF file (llama / gpt-oss architectures) instead of the "
@@ -194,7 +195,7 @@ def main():
         cfg = ls.MODELS[args.model]
 
         def new_model(n_ctx, **kw):
-            return ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, row_split=args.row_split, **kw)
+            return ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, row_split=args.row_split, type_k={"f16": 0, "q8_0": 8, "q4_0": 2}[args.ctk], **kw)
     K, W = args.steps, args.warmup
     ranges = lsp.layer_ranges(cfg["n_layer"], world)
     lb, le, has_out = ranges[rank]
@@ -394,7 +395,7 @@ def main():
             "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 dot (4-6 bit weights x Q8 activations), f32 accumulate", "data": f"gguf file {args.model}" if args.gguf else "synthetic",
             "config": {"workload": f"{args.model} {args.ftype}, llama-bench tg{K} protocol (BASELINE.json configs[1]): 1 token/step, sync per token, "
-                                   f"f16 KV cache, {'flash-attn' if args.fa else 'no flash-attn'}, n_ctx={n_ctx}",
+                                   f"{'f16 KV cache' if args.ctk == 'f16' else args.ctk + ' K / f16 V cache'}, {'flash-attn' if args.fa else 'no flash-attn'}, n_ctx={n_ctx}",
                        "parallelism": (f"rows of the weight matrices split over {args.row_split} devices in one process" if args.row_split > 1 else "single GPU") if world == 1 else f"layer split over {world} GPUs, {world} sequences in flight, {'RCCL' if transport == 'nccl' else 'gloo (host memory)'} p2p hand-off"},
             "roofline": result.get("roofline"), "cpu_baseline": result.get("cpu_baseline"),
         }

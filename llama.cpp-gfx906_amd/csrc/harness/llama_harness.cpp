@@ -54,6 +54,8 @@ struct mi_llama_hparams {
     int32_t n_swa, swa_pattern;       // > 0: sliding-window attention on the layers il % swa_pattern < swa_pattern - 1 (llama_hparams::set_swa_pattern,
                                       // src/llama-hparams.cpp:5-13; gpt-oss: 128 / 2), which get their own, smaller cache (llama_kv_cache_unified_iswa)
     int32_t n_ubatch;                 // most tokens per decode call; sizes the window cache: min(n_ctx, PAD(n_swa + n_ubatch)) (src/llama-kv-cache-unified-iswa.cpp:46-60)
+    int32_t type_k;                   // K cache type: 0 = F16 (default), GGML_TYPE_Q8_0 / Q4_0 = llama-bench -ctk (cpy_k: SET_ROWS quantizes the row; get_k: a quantized
+                                      // src0 of the K.q mat-mul; src/llama-kv-cache-unified.cpp:114-132). V stays F16: a quantized V cache needs flash attention
     int32_t row_split;                // -sm row over this many devices (0 / 1 = off): the 2-D weight matrices go to the backend's split buffer type, equal shares
                                       // (make_gpu_buft_list, src/llama-model.cpp:368-387); everything else, the KV cache and the graph stay on `backend`'s device
 };
@@ -395,8 +397,9 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
             }
         }
         // get_k / get_v (:1056-1106), v_trans layout
+        const enum ggml_type tk = L.k_cache[seq]->type;
         ggml_tensor * k = ggml_view_4d(ctx0, L.k_cache[seq], hd, n_head_kv, n_kv_l, 1,
-                ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_k_gqa*kv_size), 0);
+                ggml_row_size(tk, hd), ggml_row_size(tk, n_embd_k_gqa), ggml_row_size(tk, n_embd_k_gqa*kv_size), 0);
         ggml_tensor * v = hp.flash_attn
             ? ggml_view_4d(ctx0, L.v_cache[seq], hd, n_head_kv, n_kv_l, 1,      // !v_trans (:1087-1096)
                 ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa*kv_size), 0)
@@ -603,7 +606,7 @@ mi_llama * create_body(mi_llama * m) {
         // KV cache on the layer's device, F16 (src/llama-kv-cache-unified.cpp:114-132)
         L.swa = hp.n_swa > 0 && (hp.swa_pattern <= 0 || il % hp.swa_pattern < hp.swa_pattern - 1);     // llama_hparams::set_swa_pattern
         for (int sq = 0; sq < std::max(1, hp.n_seq_max); sq++) {
-            L.k_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_k_gqa, L.swa ? m->swa_size : kv_size));
+            L.k_cache.push_back(ggml_new_tensor_2d(m->kvctx, hp.type_k ? (enum ggml_type) hp.type_k : GGML_TYPE_F16, n_embd_k_gqa, L.swa ? m->swa_size : kv_size));
             L.v_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_v_gqa, L.swa ? m->swa_size : kv_size));
         }
         m->layers.push_back(L);

@@ -46,6 +46,11 @@ class RefLlama:
         hd, hkv = cfg["n_embd_head"], cfg["n_head_kv"]
         self.k = np.zeros((cfg["n_layer"], kv_size, hkv, hd), np.float16)
         self.v = np.zeros((cfg["n_layer"], kv_size, hkv, hd), np.float16)
+        # a quantized K cache (cfg["type_k"], -ctk q8_0 / q4_0): rows are quantized on the way in by the reference row quantizer (SET_ROWS) and K.q
+        # becomes a quantized mat-mul (src0 = the cache), evaluated per head over the head's blocks of the row
+        self.tk = cfg.get("type_k", 0)
+        if self.tk:
+            self.kq = np.zeros((cfg["n_layer"], kv_size, orc.row_size(self.tk, hkv*hd)), np.uint8)
         self.n_past = 0
         self.selected = []      # expert choices, so that a test can tell a routing flip from an arithmetic error
 
@@ -98,6 +103,8 @@ class RefLlama:
             q = ref.rope(q, pos, hd, rmode, c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
             k = ref.rope(k, pos, hd, rmode, c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
             self.k[il, pos] = k.astype(np.float16)
+            if self.tk:
+                self.kq[il, pos] = orc.quantize(k.reshape(n_tok, hkv*hd), self.tk)
             self.v[il, pos] = v.astype(np.float16)
             n_kv = self.n_past + n_tok
             K = self.k[il, :n_kv].astype(np.float32); V = self.v[il, :n_kv].astype(np.float32)
@@ -108,7 +115,11 @@ class RefLlama:
                 # the probabilities, are rounded to f16 before the dot; sums in f32. Mode "cpu16" restates that too (used where the CPU path as
                 # a whole is the yardstick: the perplexity delta); "cpu" and "exact" keep q and p in f32, as this backend's decode kernel does.
                 qh = q[:, hh, :].astype(np.float16).astype(np.float64) if self.f16_attn else q[:, hh, :].astype(np.float64)
-                s = (qh @ K[:, kvh, :].T.astype(np.float64)).astype(np.float32)   # kq (f32 result)
+                if self.tk:
+                    hb = orc.row_size(self.tk, hd)
+                    s = orc.mul_mat_2d(np.ascontiguousarray(self.kq[il, :n_kv, kvh*hb:(kvh + 1)*hb]), self.tk, q[:, hh, :], self.mode).astype(np.float32)
+                else:
+                    s = (qh @ K[:, kvh, :].T.astype(np.float64)).astype(np.float32)   # kq (f32 result)
                 s = s.astype(np.float64) / np.sqrt(hd)
                 causal = np.arange(n_kv)[None, :] <= pos[:, None]
                 n_swa, pat = c.get("n_swa", 0), c.get("swa_pattern", 0)

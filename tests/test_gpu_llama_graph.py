@@ -435,3 +435,37 @@ def test_opt_in_decode_paths_stay_correct(env):
                        env=child_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+@pytest.mark.parametrize("type_k,model", [(8, "tiny"), (2, "tiny"), (8, "tiny-hd128")])
+def test_quantized_k_cache(type_k, model):
+    """llama-bench -ctk q8_0 / q4_0 without flash attention: SET_ROWS quantizes each K row into the cache (bit-exact row quantizers) and K.q is a
+    quantized mat-mul whose src0 is a strided, permuted view of the cache (src/llama-kv-cache-unified.cpp:114-132,1056-1075); V stays F16. The oracle
+    keeps the same quantized cache (oracle/ref_llama.py). Prompt pass, decode steps and a second prompt chunk; fusion on vs off must agree."""
+    be = backend()
+    outs = {}
+    for fusion in (1, 0):
+        be.set_option("graphs", 1); be.set_option("fusion", fusion)
+        m = ls.SynthLlama(be, model, "Q4_K_M", n_ctx=64, seed=5, type_k=type_k)
+        try:
+            assert m.tensor("blk.0.attn_k.weight")                   # (the cache itself is not a weight tensor: nothing to fetch by name)
+            if fusion:
+                W = read_weights(m)
+                rc = RefLlama(m.cfg, W, 64, "cpu"); re_ = RefLlama(m.cfg, W, 64, "exact")
+            res = []
+            tight = True
+            for toks in [[5, 9, 200, 17, 3, 44, 101], [7], [8], [300], list(range(50, 62)), [2], [11]]:
+                got = m.decode(toks)
+                assert np.isfinite(got).all()
+                if fusion:
+                    emb = np.stack([m.embedding(t) for t in toks])
+                    exp_c = rc.decode(emb); exp_e = re_.decode(emb)
+                    tight = tight and len(toks) <= 8
+                    assert orc.nmse(exp_c, got) <= (5e-4 if tight else 2e-3), (toks, orc.nmse(exp_c, got))
+                    assert orc.nmse(exp_e, got) <= 2e-3, (toks, orc.nmse(exp_e, got))
+                res.append(got)
+            outs[fusion] = res
+        finally:
+            m.free()
+    for a_, b_ in zip(outs[1], outs[0]):
+        assert orc.nmse(b_, a_) <= 1e-5
