@@ -685,7 +685,7 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             if (kind < 0) continue;
             const struct ggml_tensor * b = n->src[1];
             const int64_t rows = n->op == GGML_OP_MUL_MAT ? b->ne[1] : b->ne[1]*b->ne[2];
-            size_t s = act_q8_bytes(kind, b->ne[0], rows);
+            size_t s = act_q8_bytes(kind, b->ne[0], n->op == GGML_OP_MUL_MAT && rows <= MMVQ_MAX_N ? rows*b->ne[2] : rows);    // (few columns: all batches quantized at once)
             if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows, n->src[0]->ne[1]) + mul_mat_q_x_bytes(b->ne[0], rows);   // + room for a producer's copy above its own
             if (n->op == GGML_OP_MUL_MAT_ID) {
                 const struct ggml_tensor * ids = n->src[2];
@@ -727,6 +727,16 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml
         const int kind = act_kind_for((int) a->type);
         const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
         const int64_t r2 = b->ne[2]/a->ne[2], r3 = b->ne[3]/a->ne[3];
+        // few columns x several batches (the K.q product over a quantized K cache: one batch per head): ONE launch, blockIdx.y = batch
+        if (N <= MMVQ_MAX_N && b->ne[2] > 1 && b->ne[3] == 1 && a->ne[3] == 1 && act_q8_bytes(kind, K, N*b->ne[2]) <= c->scratch_size) {
+            const act_q8 q = get_act(c, b->data, K, N, b->ne[2], b->nb[1], b->nb[2], kind);
+            prof_begin(c, (int) a->type, M, K, N, (uint64_t) a->ne[2]*M*ggml_row_size(a->type, K));
+            mul_mat_vec_q_batched((int) a->type, a->data, a->nb[1], a->nb[2], (int) r2, M, K, q, N, b->ne[2], (float *) dst->data, dst->nb[1], dst->nb[2], c->stream);
+            prof_end(c);
+            c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
+            c->cnt.weight_bytes += (uint64_t) a->ne[2]*M*ggml_row_size(a->type, K);
+            return;
+        }
         for (int64_t i13 = 0; i13 < b->ne[3]; i13++) {
             for (int64_t i12 = 0; i12 < b->ne[2]; i12++) {
                 const char * bp = (const char *) b->data + i12*b->nb[2] + i13*b->nb[3];

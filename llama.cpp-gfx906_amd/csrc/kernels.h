@@ -45,6 +45,9 @@ bool mul_mat_vec_q_supported(int type_a);
 void mul_mat_vec_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                    const act_q8 & act, int64_t n, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
 
+void mul_mat_vec_q_batched(int type_a, const void * W, size_t w_row_stride, size_t w_batch_stride, int r2, int64_t m, int64_t k,
+                           const act_q8 & act, int64_t n, int64_t n_batch, float * dst, size_t dst_col_stride_bytes, size_t dst_batch_stride_bytes, hipStream_t stream);
+
 // 2 <= n <= 8 columns of Q4_K / Q5_K / Q6_K on the int8 matrix cores; false = not taken (the caller runs its own kernel)
 bool mul_mat_vec_q_cols_mfma(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                              const act_q8 & act, int64_t n, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);

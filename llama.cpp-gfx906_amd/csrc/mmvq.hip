@@ -34,6 +34,9 @@ struct mmvq_args {
     float * dst; size_t dst_col_stride;                              // bytes
     // MUL_MAT_ID form (ids != nullptr): blockIdx.y = pair p = t*n_used + u
     const char * ids; size_t ids_nb0, ids_nb1; int n_used; int n_b; size_t dst_nb1, dst_nb2;
+    // batched form (n_batch > 1, ids == nullptr): blockIdx.y = batch b of src1 / dst; weights of batch b / r2 (ggml's broadcast); the activation image holds
+    // the batches one after the other (n columns each); dst += b*dst_nb2
+    int n_batch, r2; size_t w_batch_stride;
 };
 
 template <int TYPE, int NCOLS, int R, bool LDS_ACT, bool IDS>
@@ -62,6 +65,12 @@ __global__ void __launch_bounds__(256) k_mmvq(const mmvq_args p) {
         const int64_t arow = (int64_t) t*p.n_b + (u % p.n_b);
         a_qs += arow*p.k; a_d += arow*(p.k/ND); a_bs += arow*(p.k/NBS);
         dst = (float *) ((char *) dst + (size_t) t*p.dst_nb2 + (size_t) u*p.dst_nb1);
+    } else if (p.n_batch > 1) {
+        const int bt = blockIdx.y;
+        W += (size_t)(bt / p.r2)*p.w_batch_stride;
+        const int64_t arow = (int64_t) bt*NCOLS;
+        a_qs += arow*p.k; a_d += arow*(p.k/ND); a_bs += arow*(p.k/NBS);
+        dst = (float *) ((char *) dst + (size_t) bt*p.dst_nb2);
     }
 
     act_view av[NCOLS];
@@ -253,7 +262,7 @@ static void launch_mmvq_n(const mmvq_args & a, int act_kind, int64_t n_pairs, hi
     // measured (tools/op_perf.py, m = 4096, k = 14336): faster for the 32-element block formats (Q8_0 n = 8: 57.7 -> 30.4 us, Q4_0 35.9 ->
     // 27.4) but not for the K-quants, whose n dot chains per block are VALU-bound either way (Q4_K n = 8: 29.5 -> 35.5 us with 2 waves
     // per SIMD; 16 waves per workgroup spill) — those keep the simple kernel until the int8 MFMA kernel exists
-    if (NCOLS > 1 && !IDS && (TYPE == T_Q8_0 || TYPE == T_Q4_0)) {
+    if (NCOLS > 1 && !IDS && a.n_batch <= 1 && (TYPE == T_Q8_0 || TYPE == T_Q4_0)) {
         static int use_cols = -1;
         if (use_cols < 0) { const char * e = getenv("GGML_MI355X_MMVQ_COLS"); use_cols = e ? atoi(e) : 1; }
         if (use_cols && launch_mmvq_cols<TYPE, (NCOLS > 1 ? NCOLS : 2)>(a, act_kind, stream)) return;
@@ -299,6 +308,18 @@ void mul_mat_vec_q(int type_a, const void * W, size_t w_row_stride, int64_t m, i
     a.a_qs = act.qs; a.a_d = act.d; a.a_bs = act.bsums;
     a.dst = dst; a.dst_col_stride = dst_col_stride_bytes;
     launch_mmvq<false>(type_a, a, act.kind, n, 1, stream);
+}
+
+// the same for n_batch batches in one launch: batch b reads the weights at W + (b / r2)*w_batch_stride, columns [b*n, (b+1)*n) of the image, writes dst + b*dst_batch_stride
+void mul_mat_vec_q_batched(int type_a, const void * W, size_t w_row_stride, size_t w_batch_stride, int r2, int64_t m, int64_t k,
+                           const act_q8 & act, int64_t n, int64_t n_batch, float * dst, size_t dst_col_stride_bytes, size_t dst_batch_stride_bytes, hipStream_t stream) {
+    if (m == 0 || n == 0 || n_batch == 0) return;
+    mmvq_args a = {};
+    a.W = (const char *) W; a.w_row_stride = w_row_stride; a.m = m; a.k = k;
+    a.a_qs = act.qs; a.a_d = act.d; a.a_bs = act.bsums;
+    a.dst = dst; a.dst_col_stride = dst_col_stride_bytes;
+    a.n_batch = (int) n_batch; a.r2 = r2; a.w_batch_stride = w_batch_stride; a.dst_nb2 = dst_batch_stride_bytes;
+    launch_mmvq<false>(type_a, a, act.kind, n, n_batch, stream);
 }
 
 void mul_mat_vec_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
