@@ -439,6 +439,7 @@ struct mi_backend_ctx {
     struct split_peer { hipStream_t stream = nullptr; hipEvent_t done = nullptr; void * scratch = nullptr; size_t scratch_size = 0; };
     split_peer peers[GGML_MI355X_MAX_DEVICES];
     hipEvent_t split_ready = nullptr;
+    hipEvent_t cpy_ev = nullptr;     // cpy_tensor_async to another backend: the destination stream waits on it
     bool split_graph = false;        // the graph being run reads row-split weights: eager execution (several devices' streams take part)
 };
 
@@ -509,6 +510,7 @@ static void be_free(ggml_backend_t backend) {
     }
     set_device(c->device);
     if (c->split_ready) (void) hipEventDestroy(c->split_ready);
+    if (c->cpy_ev) (void) hipEventDestroy(c->cpy_ev);
     if (c->stream) (void) hipStreamDestroy(c->stream);
     delete c;
     delete backend;
@@ -544,13 +546,12 @@ static bool be_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backe
         } else {
             MI_CHECK(hipMemcpyPeerAsync(dst->data, cd->device, src->data, cs->device, ggml_nbytes(dst), cs->stream));
         }
-        // make the destination stream wait for the copy
-        hipEvent_t ev;
-        MI_CHECK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-        MI_CHECK(hipEventRecord(ev, cs->stream));
+        // make the destination stream wait for the copy: one event per source backend, re-recorded per copy (a wait captures the record that precedes it,
+        // so re-recording for the next copy does not disturb a wait already queued)
+        if (!cs->cpy_ev) MI_CHECK(hipEventCreateWithFlags(&cs->cpy_ev, hipEventDisableTiming));
+        MI_CHECK(hipEventRecord(cs->cpy_ev, cs->stream));
         set_device(cd->device);
-        MI_CHECK(hipStreamWaitEvent(cd->stream, ev, 0));
-        MI_CHECK(hipEventDestroy(ev));
+        MI_CHECK(hipStreamWaitEvent(cd->stream, cs->cpy_ev, 0));
     } else {
         set_device(cs->device);
         MI_CHECK(hipMemcpyAsync(dst->data, src->data, ggml_nbytes(dst), hipMemcpyDeviceToDevice, cs->stream));
