@@ -660,6 +660,39 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         }
     }
     float scale = 1.0f;
+    // k <= 4096 with the norm folded in: a wave's 64 lanes cover the whole vector at exactly the positions its dot needs (lane*4 + 512t and + 256), so the wave
+    // takes x ONCE, sums the squares over its own lanes (no LDS, no barrier, no second trip to L2 for the dot) and normalises what it holds
+    const bool wave_norm = p.norm_w && pre;
+    float4v xa[RT], xb[RT];
+    if (wave_norm) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int t = 0; t < RT; t++) { xa[t] = *(const float4v *) (p.x + min(lane*4 + 512*t, p.k - 4)); xb[t] = *(const float4v *) (p.x + min(lane*4 + 512*t + 256, p.k - 4)); }
+        float4v na[RT], nb[RT];
+#pragma unroll
+        for (int t = 0; t < RT; t++) { na[t] = *(const float4v *) (p.norm_w + min(lane*4 + 512*t, p.k - 4)); nb[t] = *(const float4v *) (p.norm_w + min(lane*4 + 512*t + 256, p.k - 4)); }
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            const int i = lane*4 + 512*t;
+            if (i < p.k)       ss += (xa[t].x*xa[t].x + xa[t].y*xa[t].y) + (xa[t].z*xa[t].z + xa[t].w*xa[t].w);
+            if (i + 256 < p.k) ss += (xb[t].x*xb[t].x + xb[t].y*xb[t].y) + (xb[t].z*xb[t].z + xb[t].w*xb[t].w);
+        }
+        ss = wave_sum(ss);
+        scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
+#pragma unroll
+        for (int t = 0; t < RT; t++) {
+            xa[t] = float4v{ (xa[t].x*scale)*na[t].x, (xa[t].y*scale)*na[t].y, (xa[t].z*scale)*na[t].z, (xa[t].w*scale)*na[t].w };
+            xb[t] = float4v{ (xb[t].x*scale)*nb[t].x, (xb[t].y*scale)*nb[t].y, (xb[t].z*scale)*nb[t].z, (xb[t].w*scale)*nb[t].w };
+        }
+        if (blockIdx.x == 0 && wave == 0 && p.y_out) {
+#pragma unroll
+            for (int t = 0; t < RT; t++) {
+                const int i = lane*4 + 512*t;
+                if (i < p.k)       *(float4v *) (p.y_out + i) = xa[t];
+                if (i + 256 < p.k) *(float4v *) (p.y_out + i + 256) = xb[t];
+            }
+        }
+    } else
     if (p.norm_w) {        // every workgroup normalises the whole vector for itself (k floats from L2: 11-16 KB)
         __shared__ float ssw[4];
         float ss = 0.0f;
@@ -693,9 +726,10 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         float acc = 0.0f, acc2 = 0.0f;
         if (pre) {
             // the same terms in the same order as the loop below: acc takes i = lane*4 + 512t (< k), acc2 takes i + 256 (< k)
-            float4v xa[RT], xb[RT];
+            if (!wave_norm) {
 #pragma unroll
-            for (int t = 0; t < RT; t++) { xa[t] = xin(min(lane*4 + 512*t, p.k - 4)); xb[t] = xin(min(lane*4 + 512*t + 256, p.k - 4)); }
+                for (int t = 0; t < RT; t++) { xa[t] = xin(min(lane*4 + 512*t, p.k - 4)); xb[t] = xin(min(lane*4 + 512*t + 256, p.k - 4)); }
+            }
 #pragma unroll
             for (int t = 0; t < RT; t++) {
                 const int i = lane*4 + 512*t;
