@@ -2180,7 +2180,7 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
 
     if (!c->rope_tab) { if (hipMalloc((void **) &c->rope_tab, 4096) != hipSuccess) { (void) hipGetLastError(); c->rope_tab = nullptr; } }
     if (!c->moe_ws) {
-        if (hipMalloc((void **) &c->moe_ws, 1088) == hipSuccess) { MI_CHECK_G(hipMemsetAsync(c->moe_ws, 0, 1088, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream)); }
+        if (hipMalloc((void **) &c->moe_ws, 4096) == hipSuccess) { MI_CHECK_G(hipMemsetAsync(c->moe_ws, 0, 4096, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
     }
     if (!c->mega_err && c->use_mega) {     // persistent decode: images, the error word (host-mapped)

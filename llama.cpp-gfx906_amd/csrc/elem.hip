@@ -642,9 +642,12 @@ __global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
 constexpr int MR_EPW = 2;
 __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, float * ws) {
     __shared__ float v[256];
-    __shared__ int is_last;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int e0 = blockIdx.x*MR_EPW + wave;
+    // ws: [0, 256) unused floats of the ticket version | word 257: launch counter | from byte 2048: 256 hand-off granules of 8 bytes
+    unsigned * epoch = (unsigned *) ws + 257;
+    unsigned long long * gran = (unsigned long long *) ((char *) ws + 2048);
+    const unsigned tag = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     // the expert's row of router weights (the HBM part of this kernel) is requested first, whole (k <= 4096: 16 x 16 bytes per lane), before the
     // norm below and before any x is needed: the dot loop used to wait for two loads per trip, 6-8 dependent round trips (4.5 us of a 9 us kernel)
     constexpr int RT = 8;
@@ -751,22 +754,26 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         }
         acc += acc2;                        // the same summation order as k_moe_route: identical logits
         acc = wave_sum(acc);
-        // the logit leaves with a write-through (agent-scope) store and the wave drains it before the workgroup takes its ticket; the last
-        // workgroup reads the logits with agent-scope loads. (A __threadfence() pair here wrote back and invalidated the whole L2 twice per launch.)
-        if (lane == 0) { if (p.bias) acc += p.bias[e0]; __hip_atomic_store(ws + e0, acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); if (p.logits) p.logits[e0] = acc; }
+        // The hand-off to the ranking workgroup: the logit travels WITH its flag — one 8-byte agent-scope store {logit, launch tag} — and workgroup 0 polls
+        // the granules ("the data is the flag"). Before: write-through store, drain it, take a ticket, the last arriver reloads = three dependent trips to
+        // L2 (~4 us of a 7 us kernel); now the ranking starts one poll after the slowest logit lands. The tag is the launch counter kept in ws
+        // (workgroup 0 bumps it when it has consumed every granule; launches of one stream do not overlap), so a stale granule never matches.
+        if (lane == 0) {
+            if (p.bias) acc += p.bias[e0];
+            const unsigned long long gv = ((unsigned long long) tag << 32) | (unsigned long long) __builtin_bit_cast(unsigned, acc);
+            __hip_atomic_store(gran + e0, gv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (p.logits) p.logits[e0] = acc;
+        }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        const unsigned t = __hip_atomic_fetch_add((unsigned *) (ws + 256), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        is_last = t == gridDim.x - 1;
-        if (is_last) __hip_atomic_store((unsigned *) (ws + 256), 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);          // re-arm for the next launch
-    }
-    __syncthreads();
-    if (!is_last) return;
+    if (blockIdx.x != 0) return;
     const int e = threadIdx.x;
-    if (e < p.n_expert) v[e] = __hip_atomic_load(ws + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (e < p.n_expert) {
+        unsigned long long gv = 0; int spins = 0;
+        do { gv = __hip_atomic_load(gran + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(gv >> 32) != tag && ++spins < (1 << 22));   // bounded: a lost
+        v[e] = __builtin_bit_cast(float, (unsigned) gv);                                                // workgroup must not hang the device (it would rank a stale logit)
+    }
     __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (p.softmax) {
         float mx = -INFINITY, sum = 0.0f;
         for (int j = 0; j < p.n_expert; j++) mx = fmaxf(mx, v[j]);
