@@ -469,3 +469,34 @@ def test_quantized_k_cache(type_k, model):
             m.free()
     for a_, b_ in zip(outs[1], outs[0]):
         assert orc.nmse(b_, a_) <= 1e-5
+
+
+def test_full_size_llama3_8b_execution_modes_agree():
+    """BASELINE.json configs[1] at its FULL size (32 layers, vocabulary 128256, 4.6 GB of Q4_K_M weights; the oracle cannot walk that in test time, so the
+    check is a size-independent property): the three ways the backend can run the same decode graph — fused launches replayed from a captured hipGraph (the
+    benchmarked path), fused launches issued eagerly, and node-by-node kernels — must give the same logits (the first two bit-identical, the third within the whole-graph
+    gate: other rounding points in the norm / quantize / bf16 fusions, amplified through 32 layers), over a prompt pass, decode steps across a KV-padding boundary, and a repeated run after kv_clear."""
+    be = backend()
+    toks = [[11, 7, 20000, 128000, 5, 99, 3000, 42, 17, 65000, 1, 2], [7], [8], [300]] + [[1000 + i] for i in range(24)]
+    outs = {}
+    for name, graphs, fusion in (("replay", 1, 1), ("eager", 0, 1), ("plain", 0, 0)):
+        be.set_option("graphs", graphs); be.set_option("fusion", fusion)
+        m = ls.SynthLlama(be, "llama3-8b", "Q4_K_M", n_ctx=64, seed=1)
+        try:
+            res = [m.decode(t) for t in toks]
+            if name == "replay":
+                m.kv_clear()
+                again = [m.decode(t) for t in toks]
+                for a_, b_ in zip(res, again):
+                    assert np.array_equal(a_, b_)                      # a second pass over the cached graphs: the same bits
+                assert be.counters()["graph_replays"] > 0
+            outs[name] = res
+        finally:
+            m.free()
+    be.set_option("graphs", 1); be.set_option("fusion", 1)
+    for a_, b_, c_ in zip(outs["replay"], outs["eager"], outs["plain"]):
+        assert np.isfinite(a_).all() and a_.shape == (128256,)
+        assert np.array_equal(a_, b_)
+        # node-by-node kernels round differently (separate norm / quantize / bf16 conversion passes): a last-bit difference re-quantized through 32 layers
+        # and the KV rows it leaves behind comes out at 1e-4 of the logit variance here (2-layer models: 1e-6) — the gate is the whole-graph gate of the op tests
+        assert orc.nmse(c_, a_) <= 2e-3, orc.nmse(c_, a_)
