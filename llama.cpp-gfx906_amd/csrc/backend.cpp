@@ -1438,11 +1438,13 @@ static int try_fused_kv_store(mi_backend_ctx * c, struct ggml_cgraph * g, int i)
 static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     struct ggml_tensor * kq = g->nodes[i];
     const struct ggml_tensor * k = kq->src[0]; const struct ggml_tensor * q = kq->src[1];
-    if (k->type != GGML_TYPE_F16 || q->type != GGML_TYPE_F32 || k->ne[3] != 1 || q->ne[3] != 1) return 0;
+    const bool kq8 = k->type == GGML_TYPE_Q8_0;       // -ctk q8_0: the decode kernel reads the blocks itself (<= 8 tokens); prompts keep the generic ops
+    if ((k->type != GGML_TYPE_F16 && !kq8) || q->type != GGML_TYPE_F32 || k->ne[3] != 1 || q->ne[3] != 1) return 0;
     const int64_t hd = k->ne[0], n_kv = k->ne[1], n_head_kv = k->ne[2], T = q->ne[1], n_head = q->ne[2];
     const bool prefill = T > 8;      // many tokens: the matrix-core kernel with online softmax (attn_prefill.hip)
+    if (kq8 && (prefill || k->nb[0] != 34 || k->nb[2] != (size_t) hd/32*34 || k->nb[1] % 2 || (uintptr_t) k->data % 2)) return 0;
     if (n_head % n_head_kv != 0 || !(prefill ? attn_prefill_supported(hd, n_kv) : (attn_decode_supported(hd, n_kv) || (c->attn_part && attn_decode_supported_split(hd, n_kv) && attn_decode_part_bytes(hd, n_kv, n_head, T) <= c->attn_part_bytes)))) return 0;
-    if (k->nb[0] != 2 || q->nb[0] != 4 || k->nb[1] % 16 || k->nb[2] % 16 || (uintptr_t) k->data % 16 || q->nb[1] % 16 || q->nb[2] % 16 || (uintptr_t) q->data % 16) return 0;
+    if ((!kq8 && (k->nb[0] != 2 || k->nb[1] % 16 || k->nb[2] % 16 || (uintptr_t) k->data % 16)) || q->nb[0] != 4 || q->nb[1] % 16 || q->nb[2] % 16 || (uintptr_t) q->data % 16) return 0;
     const int j1 = next_real(g, i); if (j1 < 0) return 0;
     struct ggml_tensor * sm = g->nodes[j1];
     if (sm->op != GGML_OP_SOFT_MAX || sm->src[0] != kq || op_f32(sm, 1) != 0.0f || !is_internal(c, kq)) return 0;
@@ -1481,6 +1483,15 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     }
     // the mat-vec that reads the result next (wo) computes the attention itself in its first n_head workgroups (PRO_ATTN): no launch of its
     // own, no launch boundary, and wo's weight stream starts while the heads are being computed. Short caches only (one workgroup per head).
+    if (kq8) {
+        rec_flush(c);
+        const bool use_part = c->attn_part && attn_decode_part_bytes(hd, n_kv, n_head, T) <= c->attn_part_bytes;
+        attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0,
+                    mask && mask->type == GGML_TYPE_F16, sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
+                    hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream, true, use_part ? c->attn_part : nullptr, use_part ? c->attn_part_bytes : 0, true);
+        c->cnt.kernels_launched++;
+        return j3 - i + 1;
+    }
     static const bool attn_in_wo = getenv("GGML_MI355X_ATTN_IN_WO") ? atoi(getenv("GGML_MI355X_ATTN_IN_WO")) != 0 : false;
     if (attn_in_wo && !c->rec_on && !c->profiling && T == 1 && c->fin_cnt && attn_decode_supported(hd, n_kv) && n_kv <= 256 && is_internal(c, ct) &&
         (!mask || mask->nb[0] == (mask->type == GGML_TYPE_F16 ? 2u : 4u))) {

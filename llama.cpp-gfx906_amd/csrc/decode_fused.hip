@@ -179,7 +179,8 @@ static __device__ __forceinline__ float dot8_f16_f32(const int4v kv, const float
 // 16-byte loads in batches of U before touching the data.
 // VT: V is the transposed cache [n_kv, hd] (rows over cells; the graph without flash attention). !VT: V rows are cells [hd, n_kv]
 // (FLASH_ATTN_EXT, src/llama-graph.cpp:1245-1265): v_nb1 is then the cell stride.
-template <int HD, bool VT = true>
+// KQ: the K cache is Q8_0 (-ctk q8_0): a head's row is HD/32 blocks of {f16 d, 32 int8}; a lane's 8 elements are 8 bytes of one block
+template <int HD, bool VT = true, bool KQ = false>
 __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float * s = (float *) smem;                          // [n_kv] scores -> probabilities
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     // ---- scores: s[j] = scale * K[j].q + mask[j] ----
     const float * qp = (const float *) (p.q + (size_t) t*p.q_nb1 + (size_t) h*p.q_nb2) + sub*8;
     const float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
-    const char * kbase = p.k + (size_t) hk*p.k_nb2 + sub*16 + (size_t) kv_lo*p.k_nb1;
+    const char * kbase = p.k + (size_t) hk*p.k_nb2 + (KQ ? (sub >> 2)*34 : sub*16) + (size_t) kv_lo*p.k_nb1;
     const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 + (size_t) kv_lo*(p.mask_f16 ? 2 : 4) : nullptr;
     // transposed V: the first 128 cells' worth of every lane's V rows is requested NOW, next to q and K — the soft_max in between does
     // not need them and the loads do not need the soft_max (one memory round trip less on the chain for n_kv <= 128: tg128)
@@ -216,6 +217,10 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int j = min(j0 + u*4*CPW, kv_n - 1);
+            if (KQ) {     // .x, .y: the lane's 8 quants; .z: the block's scale (blocks are 34 bytes: 2-byte aligned loads)
+                const int2v qq = ld_b64(kbase + (size_t) j*p.k_nb1 + 2 + (sub & 3)*8);
+                kreg[u] = int4v{ qq.x, qq.y, (int) ld_u16(kbase + (size_t) j*p.k_nb1), 0 };
+            } else
             kreg[u] = *(const int4v *) (kbase + (size_t) j*p.k_nb1);
             mreg[u] = 0.0f;
             if (mrow) mreg[u] = p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (mrow + (size_t) j*2)) : *(const float *) (mrow + (size_t) j*4);
@@ -223,7 +228,13 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int j = j0 + u*4*CPW;
-            float acc = dot8_f16_f32(kreg[u], q0, q1);
+            float acc;
+            if (KQ) {
+                const int a0 = kreg[u].x, a1 = kreg[u].y;
+                acc = ((float)(int8_t) a0*q0.x + (float)(int8_t)(a0 >> 8)*q0.y) + ((float)(int8_t)(a0 >> 16)*q0.z + (float)(a0 >> 24)*q0.w)
+                    + ((float)(int8_t) a1*q1.x + (float)(int8_t)(a1 >> 8)*q1.y) + ((float)(int8_t)(a1 >> 16)*q1.z + (float)(a1 >> 24)*q1.w);
+                acc *= f16_bits_to_f32((uint16_t) kreg[u].z);
+            } else acc = dot8_f16_f32(kreg[u], q0, q1);
             acc += dpp_f<0xB1>(acc); acc += dpp_f<0x4E>(acc); acc += dpp_f<0x141>(acc);   // sum over the LPC lanes of the row
             if (LPC == 16) acc += dpp_f<0x140>(acc);
             if (j < kv_n) {
@@ -340,7 +351,7 @@ size_t attn_decode_part_bytes(int64_t head_dim, int64_t n_kv, int64_t n_head, in
 void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                  const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans,
-                 float * part, size_t part_bytes) {
+                 float * part, size_t part_bytes, bool k_q8_0) {
     attn_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
                     (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale, 0, 1, nullptr };
     // long contexts: one workgroup per (head, token) walks every cell alone — 32 workgroups on 256 CUs. With a partial buffer the cells
@@ -359,6 +370,10 @@ void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, siz
         if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, false>), grid, dim3(256), lds, stream, a);
         else                 hipLaunchKernelGGL((k_attn_decode<64, false>),  grid, dim3(256), lds, stream, a);
     }
+    if (v_trans && k_q8_0) {
+        if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, true, true>), grid, dim3(256), lds, stream, a);
+        else                 hipLaunchKernelGGL((k_attn_decode<64, true, true>),  grid, dim3(256), lds, stream, a);
+    } else
     if (v_trans) {
         if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128>), grid, dim3(256), lds, stream, a);
         else                 hipLaunchKernelGGL((k_attn_decode<64>),  grid, dim3(256), lds, stream, a);

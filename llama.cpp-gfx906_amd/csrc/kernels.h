@@ -177,7 +177,7 @@ bool attn_decode_supported(int64_t head_dim, int64_t n_kv);
 void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                  const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans = true,
-                 float * part = nullptr, size_t part_bytes = 0);
+                 float * part = nullptr, size_t part_bytes = 0, bool k_q8_0 = false);     // k_q8_0: K rows are Q8_0 blocks (transposed-V form only)
 // long contexts (n_kv >= 384, or 256 with row-major V; a multiple of 32; GGML_MI355X_ATTN_SPLIT_MIN): with a partial buffer of attn_decode_part_bytes() the cells are split over up to 32 workgroups per
 // (head, token) and merged by a second small kernel; attn_decode_supported_split: shapes that only work with the buffer (scores beyond one LDS)
 size_t attn_decode_part_bytes(int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t T);

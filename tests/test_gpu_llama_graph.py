@@ -461,14 +461,16 @@ def test_quantized_k_cache(type_k, model):
                     emb = np.stack([m.embedding(t) for t in toks])
                     exp_c = rc.decode(emb); exp_e = re_.decode(emb)
                     tight = tight and len(toks) <= 8
-                    assert orc.nmse(exp_c, got) <= (5e-4 if tight else 2e-3), (toks, orc.nmse(exp_c, got))
+                    # Q8_0 with fusion on: the decode attention kernel reads the blocks itself and multiplies them with the UNquantized q (the generic path and
+                    # the CPU-style oracle quantize q to Q8_0 first): it sits between the two oracles, so both get the whole-graph gate
+                    assert orc.nmse(exp_c, got) <= (5e-4 if tight and type_k != 8 else 2e-3), (toks, orc.nmse(exp_c, got))
                     assert orc.nmse(exp_e, got) <= 2e-3, (toks, orc.nmse(exp_e, got))
                 res.append(got)
             outs[fusion] = res
         finally:
             m.free()
     for a_, b_ in zip(outs[1], outs[0]):
-        assert orc.nmse(b_, a_) <= 1e-5
+        assert orc.nmse(b_, a_) <= (2e-3 if type_k == 8 else 1e-5)
 
 
 def test_full_size_llama3_8b_execution_modes_agree():
