@@ -1307,10 +1307,13 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
                 if (base_of(ks)->data == chains[q].out_ptr && ks->data == chains[q].out_ptr) qk = q;
                 if (base_of(vs)->data == chains[q].out_ptr && vs->data == chains[q].out_ptr) qv = q;
             }
-            const bool ok = qk >= 0 && qv >= 0 && qk != qv && sk->type == GGML_TYPE_F16 && sv->type == GGML_TYPE_F16 &&
+            // a quantized K cache (-ctk q8_0 / q4_0): the row quantizer needs whole 32-element blocks, which no wave of this launch holds — K's SET_ROWS runs as
+            // its own launch right after this one (deferred), V's store is still taken into the launch
+            const bool k_quant = sk->type == GGML_TYPE_Q8_0 || sk->type == GGML_TYPE_Q4_0;
+            const bool ok = qk >= 0 && qv >= 0 && qk != qv && (sk->type == GGML_TYPE_F16 || (k_quant && n_def < MMVQ_MAX_GROUPS)) && sv->type == GGML_TYPE_F16 &&
                 ks->type == GGML_TYPE_F32 && vs->type == GGML_TYPE_F32 && ki->type == GGML_TYPE_I64 && vi->type == GGML_TYPE_I64 &&
                 ggml_is_contiguous(ki) && ggml_is_contiguous(vi) && ggml_is_contiguous(ks) && ggml_is_contiguous(vs) &&
-                ks->ne[1] == 1 && ks->ne[2] == 1 && ks->ne[3] == 1 && ks->ne[0] == chains[qk].grp.m && sk->nb[0] == 2 && sk->nb[1] % 2 == 0 &&
+                ks->ne[1] == 1 && ks->ne[2] == 1 && ks->ne[3] == 1 && ks->ne[0] == chains[qk].grp.m && (k_quant || (sk->nb[0] == 2 && sk->nb[1] % 2 == 0)) &&
                 vs->ne[2] == 1 && vs->ne[3] == 1 && qv >= 0 && (chains[qv].grp.epi == EPI_NONE || chains[qv].grp.epi == EPI_ADD) &&
                 // V: element scatter on the transposed cache's [1, N] view (v_trans), or — with flash attention — a row like K (:1154)
                 ((vs->ne[0] == 1 && vs->ne[1] == chains[qv].grp.m && sv->ne[0] == 1 && sv->nb[1] == 2 && ggml_nelements(vi) == chains[qv].grp.m) ||
@@ -1318,8 +1321,11 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
                 // the cache rows written must not be read by anything inside the launch (they are not: only weights and the activation are)
                 !ranges_overlap(sk->data, ggml_nbytes(sk), b->data, ggml_nbytes(b)) && !ranges_overlap(sv->data, ggml_nbytes(sv), b->data, ggml_nbytes(b));
             if (ok) {
-                chains[qk].grp.st16 = (uint16_t *) sk->data; chains[qk].grp.st_idx = (const int64_t *) ki->data;
-                chains[qk].grp.st_row_elems = (int64_t)(sk->nb[1]/2); chains[qk].grp.st_mode = 1;
+                if (k_quant) deferred[n_def++] = j1;
+                else {
+                    chains[qk].grp.st16 = (uint16_t *) sk->data; chains[qk].grp.st_idx = (const int64_t *) ki->data;
+                    chains[qk].grp.st_row_elems = (int64_t)(sk->nb[1]/2); chains[qk].grp.st_mode = 1;
+                }
                 chains[qv].grp.st16 = (uint16_t *) sv->data; chains[qv].grp.st_idx = (const int64_t *) vi->data;
                 if (vs->ne[0] == 1) { chains[qv].grp.st_row_elems = 0; chains[qv].grp.st_mode = 2; }
                 else                { chains[qv].grp.st_row_elems = (int64_t)(sv->nb[1]/2); chains[qv].grp.st_mode = 1; }
