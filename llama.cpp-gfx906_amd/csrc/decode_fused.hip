@@ -163,6 +163,7 @@ struct attn_args {
     // soft_max-weighted V sum (normalised within the range) + its max and denominator to part[(t*n_head + h)*nsplit + z][HD + 2];
     // k_attn_merge combines them (and adds the sink). nsplit = 1: the kernel finishes the row itself.
     int kv_chunk, nsplit; float * part;
+    int live_scan;      // row-major V, one workgroup per head: stop at the last unmasked cell
 };
 
 static __device__ __forceinline__ float dot8_f16_f32(const int4v kv, const float4v a, const float4v b) {
@@ -188,7 +189,25 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     const int h = blockIdx.x, t = blockIdx.y;
     const int hk = h/(p.n_head/p.n_head_kv);
     const bool split = p.nsplit > 1;
-    const int kv_lo = split ? (int) blockIdx.z*p.kv_chunk : 0, kv_n = split ? min(p.n_kv - kv_lo, p.kv_chunk) : p.n_kv;   // this workgroup's cells
+    const int kv_lo = split ? (int) blockIdx.z*p.kv_chunk : 0;
+    int kv_n = split ? min(p.n_kv - kv_lo, p.kv_chunk) : p.n_kv;   // this workgroup's cells
+    if (!VT && !split && p.live_scan && p.mask) {
+        // flash attention pads the cache view to 256 cells; everything behind the last unmasked cell is dead weight for K, the soft_max and V: find that cell
+        // first (one mask value per thread and trip) and walk only up to it (a multiple of 8 cells, at least 8)
+        __shared__ int live_w[4];
+        const char * mr = p.mask + (size_t) blockIdx.y*p.m_nb1;
+        int last = -1;
+        for (int j = threadIdx.x; j < kv_n; j += 256) {
+            const float mv = p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (mr + (size_t) j*2)) : *(const float *) (mr + (size_t) j*4);
+            if (mv != -INFINITY) last = j;
+        }
+        const float lw = wave_max((float) last);
+        if ((threadIdx.x & 63) == 0) live_w[threadIdx.x >> 6] = (int) lw;
+        __syncthreads();
+        const int lm = max(max(live_w[0], live_w[1]), max(live_w[2], live_w[3]));
+        kv_n = min(kv_n, max(8, (lm + 8) & ~7));
+        __syncthreads();
+    }
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     constexpr int LPC = HD/8;                            // lanes per K row (8 f16 = 16 B each)
     constexpr int CPW = 64/LPC;                          // K rows per wave step
@@ -358,7 +377,12 @@ void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, siz
     // are split into ranges of >= 256 (at most 32 ranges) that run side by side and a small second kernel merges them.
     static const bool split_on = !getenv("GGML_MI355X_ATTN_SPLIT") || atoi(getenv("GGML_MI355X_ATTN_SPLIT")) != 0;
     const size_t need = attn_decode_part_bytes(head_dim, n_kv, n_head, T);
-    if (part && need && need <= part_bytes && n_kv >= attn_split_min(v_trans) && (split_on || n_kv*4 > 48*1024)) {
+    // row-major V (flash attention) at exactly the padding size: most cells of a short context are masked padding — one workgroup per head that stops at the last
+    // live cell beats two ranges + a merge launch there (GGML_MI355X_ATTN_LIVE_SCAN=0: the split as before)
+    static const bool live_on = !getenv("GGML_MI355X_ATTN_LIVE_SCAN") || atoi(getenv("GGML_MI355X_ATTN_LIVE_SCAN")) != 0;
+    const bool live_scan = live_on && !v_trans && mask && n_kv == 256 && T == 1;
+    a.live_scan = live_scan ? 1 : 0;
+    if (!live_scan && part && need && need <= part_bytes && n_kv >= attn_split_min(v_trans) && (split_on || n_kv*4 > 48*1024)) {
         int64_t ns = (n_kv + 127)/128 < 32 ? (n_kv + 127)/128 : 32;       // ranges of >= 128 cells
         const int64_t chunk = ((n_kv + ns - 1)/ns + 31)/32*32;          // the KV cache pads n_kv to 32 (256 with flash attention)
         ns = (n_kv + chunk - 1)/chunk;
