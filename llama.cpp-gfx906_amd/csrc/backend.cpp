@@ -1373,7 +1373,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     // image of its output (mmvq_fin) — the f32 tensor is written as always, so any other reader still finds it
     mmvq_fin fin = {}; act_q8 fin_q = {}; const struct ggml_tensor * fin_t = nullptr;
     static const bool fin_env = !getenv("GGML_MI355X_FIN") || atoi(getenv("GGML_MI355X_FIN")) != 0;
-    if (fin_env && !c->rec_on && nc == 1 && grp[0].epi == EPI_GLU && !grp[0].eid && c->fin_img) {
+    if (fin_env && !c->rec_on && nc == 1 && grp[0].epi == EPI_GLU && !grp[0].eid && c->fin_img && !mul_mat_vec_q_stream_takes(grp, nc, K, in, rope)) {
         const int jn = next_real(g, last);
         const struct ggml_tensor * gl = g->nodes[last];
         const struct ggml_tensor * mm = jn > 0 ? g->nodes[jn] : nullptr;

@@ -250,6 +250,12 @@ bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);         // may these
 bool mul_mat_vec_q_fused_can_group_mixed(int type_a, int type_b);   // pairs of different activation formats (only when the launch quantizes the activation itself)
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                          const mmvq_fin * fin = nullptr);
+// the streamed form of the grouped launch (mmvq_stream.h: loader wave + LDS slot ring + one 256-weight unit per lane): K-quant weights in
+// contiguous rows, no expert stacks; mul_mat_vec_q_fused routes to it when mul_mat_vec_q_stream_takes says so (it never writes an mmvq_fin image)
+bool mul_mat_vec_q_stream_enabled(void);       // GGML_MI355X_STREAM (default 1)
+bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope);
+void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
+                          hipEvent_t e0, hipEvent_t e1, const char ** kernel_name);
 bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);   // may a GLU launch with m output rows carry an mmvq_fin
 int  mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end);   // workgroups per group (one workgroup per CU in all)
 // (round 1's chained launch held launches back; nothing is held back any more: flush is a no-op kept for its call sites)

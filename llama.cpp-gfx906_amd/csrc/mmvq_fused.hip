@@ -270,6 +270,16 @@ void mul_mat_vec_q_fused_flush(hipStream_t) { }
 
 void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                          const mmvq_fin * fin) {
+    if (mul_mat_vec_q_stream_takes(groups, n_groups, k, in, rope)) {      // the streamed kernel (mmvq_stream.h); callers do not pass it a `fin`
+        uint64_t wbytes = 0;
+        for (int i = 0; i < n_groups; i++) wbytes += (uint64_t) groups[i].m*groups[i].row_stride*(groups[i].epi == EPI_GLU ? 2 : 1);
+        if (g_hook.pre) g_hook.pre(g_hook.ctx, groups[0].type, wbytes, 1, k);
+        hipEvent_t e0 = mi355x_fused_ev0, e1 = mi355x_fused_ev1;
+        mi355x_fused_ev0 = nullptr; mi355x_fused_ev1 = nullptr;
+        mul_mat_vec_q_stream(groups, n_groups, k, in, rope, stream, e0, e1, &mi355x_fused_last_kernel);
+        if (g_hook.post) g_hook.post(g_hook.ctx, groups[0].type, wbytes, 1, k);
+        return;
+    }
     const fused_launch L = fused_prepare(groups, n_groups, k, in, rope, fin);
     if (g_hook.pre) g_hook.pre(g_hook.ctx, L.ta, L.wbytes, 1, L.k);
     fused_launch_kernel(L, stream);

@@ -1,0 +1,186 @@
+// mmvq_stream.hip — host side of the streamed mat-vec (device code and the design: mmvq_stream.h): decides whether a grouped launch can
+// take this path, deals the workgroups (one per CU) to the groups in proportion to their weight bytes, sizes the LDS carve and the slot
+// ring, and launches. Called by mul_mat_vec_q_fused (mmvq_fused.hip), which falls back to round 2's register-ring kernels when this
+// returns false (MUL_MAT_ID expert stacks, Q4_0 / Q8_0 / MXFP4 weights, rows longer than 16384 elements, strided rows).
+#include <hip/hip_ext.h>
+
+#include "mmvq_stream.h"
+
+#include <limits.h>
+#include <algorithm>
+
+namespace mi355x {
+
+template <int TA, int TB> static void st_launch_t(const st_args & a, int blocks, size_t lds, bool nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, const char ** kname) {
+    static char name_nt[64] = "", name_pl[64] = "";
+    if (!name_nt[0]) { snprintf(name_nt, sizeof(name_nt), "k_mmvq_stream<%d, %d, true>", TA, TB); snprintf(name_pl, sizeof(name_pl), "k_mmvq_stream<%d, %d, false>", TA, TB); }
+    *kname = nt ? name_nt : name_pl;
+    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, true>);
+    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, false>);
+    if (e0) {
+        if (nt) hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, true>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
+        else    hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, false>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
+    } else {
+        if (nt) hipLaunchKernelGGL((k_mmvq_stream<TA, TB, true>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
+        else    hipLaunchKernelGGL((k_mmvq_stream<TA, TB, false>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
+    }
+}
+
+static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : 0; }
+static int st_cu_count() {
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0; hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+        if (n_cu <= 0) n_cu = 256;
+    }
+    return n_cu;
+}
+
+#ifdef MI_STAMPS
+static unsigned long long * g_st_stamps = nullptr; static int g_st_slots = 0, g_st_next = 0;
+struct st_stamp_meta { int blocks, k, rows, type_a, type_b, mode, glu; long long bytes; };
+static st_stamp_meta g_st_meta[4096];
+extern "C" int mi355x_stream_stamps_enable(int n_slots) {
+    if (g_st_stamps) { (void) hipFree(g_st_stamps); g_st_stamps = nullptr; }
+    g_st_slots = n_slots > 4096 ? 4096 : n_slots; g_st_next = 0;
+    if (g_st_slots <= 0) return 0;
+    const size_t bytes = (size_t) g_st_slots*256*(ST_NC + 1)*8*8;
+    if (hipMalloc(&g_st_stamps, bytes) != hipSuccess) return -1;
+    (void) hipMemset(g_st_stamps, 0, bytes);
+    return 0;
+}
+extern "C" int mi355x_stream_stamps_used(void) { return g_st_next; }
+extern "C" int mi355x_stream_stamps_read(int slot, unsigned long long * out, int * meta, long long * bytes) {
+    if (!g_st_stamps || slot < 0 || slot >= g_st_slots) return -1;
+    const st_stamp_meta & m = g_st_meta[slot];
+    (void) hipMemcpy(out, g_st_stamps + (size_t) slot*256*(ST_NC + 1)*8, (size_t) 256*(ST_NC + 1)*8*8, hipMemcpyDeviceToHost);
+    meta[0] = m.blocks; meta[1] = m.k; meta[2] = m.rows; meta[3] = m.type_a; meta[4] = m.type_b; meta[5] = m.mode; meta[6] = m.glu;
+    *bytes = m.bytes;
+    return 0;
+}
+#endif
+
+bool mul_mat_vec_q_stream_enabled(void) {
+    static int on = -1;
+    if (on < 0) { const char * e = getenv("GGML_MI355X_STREAM"); on = e ? atoi(e) : 1; }
+    return on != 0;
+}
+
+// can (and does) this grouped launch go to the streamed kernel?
+bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope) {
+    if (!mul_mat_vec_q_stream_enabled() || n_groups < 1 || n_groups > MMVQ_MAX_GROUPS) return false;
+    if (k % 256 != 0 || k > 16384 || k < 256) return false;
+    if (in.mode != PRO_Q8 && in.mode != PRO_QUANT && in.mode != PRO_NORM) return false;
+    if (in.act_kind != T_Q8_K) return false;
+    if (in.mode == PRO_Q8) { if (((uintptr_t) in.act.qs % 16) || ((uintptr_t) in.act.bsums % 16) || !in.act.d) return false; }
+    else { if (((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
+    const int64_t nb = k/256;
+    int ta = -1, tb = -1;
+    for (int i = 0; i < n_groups; i++) {
+        const mmvq_group & g = groups[i];
+        const int ub = st_unit_bytes(g.type);
+        if (!ub) return false;
+        if (g.type != ta && g.type != tb) { if (ta < 0) ta = g.type; else if (tb < 0) tb = g.type; else return false; }
+        if (g.eid || g.x_off || g.b_gate || g.b_up || g.res_eid) return false;             // (MUL_MAT_ID stacks: the register-ring kernels)
+        if (g.row_stride != (size_t)(nb*ub) || ((uintptr_t) g.W % 16) || (g.W2 && ((uintptr_t) g.W2 % 16))) return false;
+        if (g.epi == EPI_GLU && (n_groups != 1 || !g.W2)) return false;
+        if (g.epi == EPI_ROPE) {
+            if (!rope || !rope->table || (g.m & 1)) return false;
+            if (rope->p.mode & 2) { const int hd = rope->head_dim; if (hd <= 0 || (hd & (hd - 1)) || rope->p.n_dims != hd || g.m % hd) return false; }
+            else if (rope->p.mode != 0) return false;
+        }
+        if (g.epi == EPI_ADD && !g.res) return false;
+        if (g.m < 1) return false;
+    }
+    return true;
+}
+
+void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
+                          hipEvent_t e0, hipEvent_t e1, const char ** kname) {
+    static int nt_env = -1, ring_env = -1;
+    if (nt_env < 0) { const char * e = getenv("GGML_MI355X_STREAM_NT"); nt_env = e ? atoi(e) : 1; const char * r = getenv("GGML_MI355X_STREAM_RING"); ring_env = r ? atoi(r) : 0; }
+    st_args a = {};
+    const int nb = (int)(k/256);
+    a.n_groups = n_groups; a.k = (int) k; a.nb = nb; a.mode = in.mode; a.eps = in.eps;
+    a.magic = (uint32_t)((0x100000000ull + nb - 1)/nb);
+    a.x = in.x; a.norm_w = in.norm_w;
+    if (in.mode == PRO_Q8) { a.a_qs = in.act.qs; a.a_d = in.act.d; a.a_bs = in.act.bsums; }
+    if (rope) a.rope = make_fused_rope(*rope);
+
+    // workgroups per group: in proportion to the weight bytes, at least one each, never more than the group has row units
+    const int budget = st_cu_count();
+    double bytes_total = 0; double gbytes[MMVQ_MAX_GROUPS];
+    int ta = groups[0].type, tb = groups[0].type;
+    for (int i = 0; i < n_groups; i++) {
+        gbytes[i] = (double) groups[i].m*nb*st_unit_bytes(groups[i].type)*(groups[i].epi == EPI_GLU ? 2 : 1);
+        bytes_total += gbytes[i];
+        if (groups[i].type != ta) tb = groups[i].type;
+    }
+    if (tb < ta) std::swap(ta, tb);
+    int blocks = 0, slot_max = 0; size_t fixed_max = 0; int nslots_max = 0;
+    for (int i = 0; i < MMVQ_MAX_GROUPS; i++) a.block_end[i] = INT_MAX;
+    int share[MMVQ_MAX_GROUPS], used = 0;
+    for (int i = 0; i < n_groups; i++) {
+        const mmvq_group & g = groups[i];
+        st_group & s = a.g[i];
+        s.W = g.W; s.W2 = g.W2; s.dst = g.dst; s.res = g.res; s.res2 = g.res2; s.st16 = g.st16; s.st_idx = g.st_idx; s.st_row_elems = g.st_row_elems;
+        s.m = g.m; s.type = g.type; s.epi = g.epi; s.st_mode = g.st_mode; s.glu_alpha = g.glu_alpha; s.glu_limit = g.glu_limit;
+        s.ralign = 1;
+        if (g.epi == EPI_ROPE) s.ralign = (rope->p.mode & 2) ? rope->head_dim : 2;
+        while (((int64_t) s.ralign*nb*st_unit_bytes(g.type)) % 16 != 0) s.ralign *= 2;      // a workgroup's rows start on a 16-byte boundary (LDS-DMA source)
+        const int nru = std::max(1, g.m/s.ralign);
+        int sh = (int)((double) budget*gbytes[i]/bytes_total);
+        sh = sh < 1 ? 1 : (sh > nru ? nru : sh);
+        share[i] = sh; used += sh;
+    }
+    // hand the workgroups rounding left over to the groups with the most bytes per workgroup
+    while (used < budget) {
+        int best = -1; double bw = 0;
+        for (int i = 0; i < n_groups; i++) { const int nru = std::max(1, groups[i].m/a.g[i].ralign); if (share[i] < nru && gbytes[i]/share[i] > bw) { bw = gbytes[i]/share[i]; best = i; } }
+        if (best < 0) break;
+        share[best]++; used++;
+    }
+    for (int i = 0; i < n_groups; i++) {
+        const mmvq_group & g = groups[i];
+        st_group & s = a.g[i];
+        const int nru = std::max(1, g.m/s.ralign), sh = share[i];
+        const int Rmax = ((nru + sh - 1)/sh)*s.ralign + (g.m - (g.m/s.ralign)*s.ralign);
+        const bool row16 = (nb & 15) == 0;
+        s.npart_max = (row16 ? Rmax*(nb >> 4) : Rmax*nb)*(g.epi == EPI_GLU ? 2 : 1);
+        const size_t fixed = ST_SYNC_WORDS*4 + (size_t) nb*ST_ACT_STRIDE + (size_t)((nb + 3) & ~3)*4 + 64 + (size_t) s.npart_max*4 + 16;
+        fixed_max = std::max(fixed_max, fixed);
+        const int pps = (64*st_unit_bytes(g.type) + 1023)/1024;
+        slot_max = std::max(slot_max, pps*1024);
+        nslots_max = std::max(nslots_max, (int)(((int64_t) Rmax*nb + 63)/64)*(g.epi == EPI_GLU ? 2 : 1));
+        blocks += sh;
+        a.block_end[i] = blocks;
+    }
+    int S = (int)((163840 - (int64_t) fixed_max)/slot_max);
+    if (S > nslots_max) S = nslots_max;
+    if (S > ST_MAX_RING) S = ST_MAX_RING;
+    if (ring_env > 0 && S > ring_env) S = ring_env;
+    if (S < (nslots_max < 2 ? nslots_max : 2)) { fprintf(stderr, "mul_mat_vec_q_stream: no room for a slot ring (k = %lld)\n", (long long) k); abort(); }
+    a.S = S;
+    const size_t lds = fixed_max + (size_t) S*slot_max;
+#ifdef MI_STAMPS
+    a.stamps = nullptr;
+    if (g_st_stamps && g_st_next < g_st_slots && blocks <= 256) {
+        st_stamp_meta & sm = g_st_meta[g_st_next];
+        sm.blocks = blocks; sm.k = (int) k; sm.rows = 0; for (int i = 0; i < n_groups; i++) sm.rows += groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1);
+        sm.type_a = ta; sm.type_b = tb; sm.mode = in.mode; sm.glu = groups[0].epi == EPI_GLU; sm.bytes = (long long) bytes_total;
+        a.stamps = g_st_stamps + (size_t) g_st_next*256*(ST_NC + 1)*8;
+        g_st_next++;
+    }
+#endif
+    const bool nt = nt_env != 0;
+    if (ta == T_Q4_K && tb == T_Q4_K) st_launch_t<T_Q4_K, T_Q4_K>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q5_K && tb == T_Q5_K) st_launch_t<T_Q5_K, T_Q5_K>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q6_K && tb == T_Q6_K) st_launch_t<T_Q6_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q4_K && tb == T_Q5_K) st_launch_t<T_Q4_K, T_Q5_K>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q4_K && tb == T_Q6_K) st_launch_t<T_Q4_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q5_K && tb == T_Q6_K) st_launch_t<T_Q5_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else { fprintf(stderr, "mul_mat_vec_q_stream: type pair (%d, %d) has no kernel\n", ta, tb); abort(); }
+}
+
+} // namespace mi355x

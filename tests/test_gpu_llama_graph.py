@@ -101,6 +101,31 @@ def test_stories15m_shaped_q8_0_matches_oracle():
         m.free()
 
 
+def test_llama3_8b_full_width_layers_match_oracle():
+    """BASELINE.json configs[1] shapes against the ORACLE (the reference's whole-graph test runs n_embd 3200 / n_ff 8640,
+    tests/test-backend-ops.cpp:4972-5096): two Llama-3-8B layers at full width (4096 / 14336, GQA 32:8, Q4_K_M with its Q6_K wv / ffn_down in
+    layer 0), a small vocabulary. The single-token steps run on the streamed mat-vec kernels (csrc/mmvq_stream.h) with every prologue and
+    epilogue of the decode graph: norm + QKV + RoPE + KV stores, quantize + wo + residual, norm + gate/up + SwiGLU, quantize + down + residual.
+    The first step has no history: nothing but the mat-vec arithmetic separates it from the CPU-style oracle, and the gate says so."""
+    be = backend()
+    be.set_option("graphs", 1); be.set_option("fusion", 1)
+    m = ls.SynthLlama(be, "llama3-8b", "Q4_K_M", n_ctx=32, seed=5, n_layer=2, n_vocab=512)
+    try:
+        W = read_weights(m)
+        rc = RefLlama(m.cfg, W, 32, "cpu"); re_ = RefLlama(m.cfg, W, 32, "exact")
+        be.reset_counters()
+        for i, (toks, gate) in enumerate((([3], 1e-9), ([7], 5e-4), ([9], 5e-4), ([11], 5e-4), ([3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8], 2e-3), ([2], 2e-3))):
+            emb = np.stack([m.embedding(t) for t in toks])
+            got = m.decode(toks)
+            exp_c = rc.decode(emb); exp_e = re_.decode(emb)
+            assert np.isfinite(got).all()
+            assert orc.nmse(exp_c, got) <= gate, (i, len(toks), orc.nmse(exp_c, got))
+            assert orc.nmse(exp_e, got) <= 2e-3, (i, len(toks), orc.nmse(exp_e, got))
+        assert be.counters()["mmvq_launches"] > 0
+    finally:
+        m.free()
+
+
 def test_llama3_70b_shaped_layers_match_oracle():
     """BASELINE.json configs[3] shapes on one GPU: two Llama-3-70B-shaped layers (k = 8192 / 28672, GQA 64:8, the Q5_K attn_v bump of
     src/llama-quant.cpp:305-310 in layer 0 and the Q6_K use_more_bits tensors in layer 1), Q4_K_M"""
