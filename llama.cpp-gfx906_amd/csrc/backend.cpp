@@ -16,7 +16,6 @@
 #include "ggml-impl.h"
 
 #include "kernels.h"
-#include "decode_mega.h"
 
 #include <hip/hip_runtime.h>
 
@@ -405,27 +404,26 @@ struct mi_backend_ctx {
 
     struct ggml_backend_mi355x_counters cnt = {};
 
-    // ---- persistent decode (decode_mega.hip): the single-token launches of a graph are recorded instead of launched; at the next op that
-    // is not one of them (or at the end of the graph) the recorded run becomes ONE launch if it has the shape the kernel serves,
-    // else its items go out one by one ----
+    // ---- chained decode (k_mmvq_chain, mmvq_stream.h): the grouped single-token mat-vec launches of a graph are recorded instead of launched;
+    // at the next op that is not one of them (or at the end of the graph) a recorded run of two or more becomes ONE persistent launch whose
+    // phases hand their vectors over inside the kernel (the loader wave streams the next phase's weights meanwhile); a run of one goes out as it is ----
     struct rec_item {
-        int kind;                                   // 0: grouped mat-vec, 1: attention
+        int kind;                                   // 0: grouped mat-vec, 1: attention (never held back: launched when it comes up)
         mmvq_group grp[MMVQ_MAX_GROUPS]; int nc; int64_t K; mmvq_input in; bool has_rope; mmvq_rope rope;
-        float * norm_out;                           // PRO_NORM: the RMS_NORM*w tensor (the launch path leaves it unwritten; the finaliser writes it)
         struct { const void * q; size_t q_nb1, q_nb2; const void * k; size_t k_nb1, k_nb2; const void * v; size_t v_nb1, v_nb2; const void * mask; size_t m_nb1;
                  bool mask_f16; const float * sinks; float * dst; size_t dst_nb1; int64_t hd, n_kv, n_head, n_head_kv, T; float scale; bool v_trans; } at;
     };
     std::vector<rec_item> rec;
-    // opt-in (GGML_MI355X_MEGA=1 / option "mega"): bit-identical to the launch path, but at the end of round 2 still slower than it
-    // (every hand-off hop costs ~2 us beside streaming CUs and a layer has nine of them)
-    bool use_mega = false, rec_on = false, capturing = false;
-    void * mega_gran = nullptr; unsigned * mega_epoch = nullptr;      // hand-off granules (decode_mega.h) and the launch counter their tags derive from
-    unsigned * mega_err = nullptr;                   // host-mapped word: a bounded wait inside the kernel gave up
-    void * mega_prog_dev = nullptr; void * mega_prog_host = nullptr; unsigned * mega_ws = nullptr;    // eager runs (captured graphs own theirs)
+    // opt-in (GGML_MI355X_CHAIN=1 / option "chain"): correct, and at the end of round 3 slower than one launch per group (505 vs 628 tok/s): a phase's
+    // hand-off + activation load + prologue (~7 us) is longer than the stream the LDS ring can hold ahead (117 KB = 4.7 us) — DESIGN.md section 4
+    bool use_chain = false, rec_on = false, capturing = false;
+    unsigned * chain_err = nullptr;                  // host-mapped word: a bounded wait inside the kernel gave up
+    void * chain_prog_dev = nullptr; void * chain_prog_host = nullptr; unsigned * chain_ws = nullptr;    // eager runs (captured graphs own theirs)
+    size_t chain_prog_used = 0, chain_ws_used = 0;   // eager: carved per graph pass (reset in run_nodes)
     struct pending_upload { void * dev; std::vector<char> host; };
-    std::vector<pending_upload> mega_uploads;        // program tables built during a capture: copied once the capture has ended
+    std::vector<pending_upload> chain_uploads;       // phase tables built during a capture: copied once the capture has ended
     graph_entry * cap_entry = nullptr; size_t cap_prog_used = 0, cap_ws_used = 0;
-    static constexpr size_t MEGA_IMG_BYTES = 64*1024; static constexpr int MEGA_MAX_PHASES = 1024;
+    static constexpr int CHAIN_MAX_PHASES = 192;     // per graph (a 32-layer token: 129 grouped launches)
 
     // "profile" option: every quantized mat-mul launch is bracketed by a hipEvent pair on this stream (eager mode)
     struct prof_rec { int type; int64_t m, k, n; uint64_t bytes; hipEvent_t e0, e1; const char * kernel = nullptr; };
@@ -491,12 +489,10 @@ static void be_free(ggml_backend_t backend) {
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
-    if (c->mega_gran) (void) hipFree(c->mega_gran);
-    if (c->mega_epoch) (void) hipFree(c->mega_epoch);
-    if (c->mega_prog_dev) (void) hipFree(c->mega_prog_dev);
-    if (c->mega_prog_host) (void) hipHostFree(c->mega_prog_host);
-    if (c->mega_ws) (void) hipFree(c->mega_ws);
-    if (c->mega_err) (void) hipHostFree(c->mega_err);
+    if (c->chain_prog_dev) (void) hipFree(c->chain_prog_dev);
+    if (c->chain_prog_host) (void) hipHostFree(c->chain_prog_host);
+    if (c->chain_ws) (void) hipFree(c->chain_ws);
+    if (c->chain_err) (void) hipHostFree(c->chain_err);
     if (c->fin_img) (void) hipFree(c->fin_img);
     if (c->fin_cnt) (void) hipFree(c->fin_cnt);
     if (c->rope_tab) (void) hipFree(c->rope_tab);
@@ -563,10 +559,10 @@ static void be_synchronize(ggml_backend_t backend) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     MI_CHECK(hipStreamSynchronize(c->stream));
-    if (c->mega_err && c->mega_err[0] != 0) {
-        // a bounded wait inside the persistent decode kernel gave up (a workgroup was not resident, e.g. the device was shared): the results of
+    if (c->chain_err && c->chain_err[0] != 0) {
+        // a bounded wait inside the chained decode kernel gave up (a workgroup was not resident, e.g. the device was shared): the results of
         // that graph are not valid. Hard internal error (GGML_ABORT), reported instead of hanging the device.
-        GGML_ABORT("MI355X backend: the persistent decode kernel timed out waiting for a hand-off (GGML_MI355X_MEGA=0 selects the launch-per-phase path)");
+        GGML_ABORT("MI355X backend: the chained decode kernel timed out waiting for a hand-off (GGML_MI355X_CHAIN=0 selects one launch per mat-vec group)");
     }
 }
 
@@ -864,15 +860,8 @@ static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// persistent decode: recorder and program builder (decode_mega.h)
+// chained decode: recorder (k_mmvq_chain, mmvq_stream.h)
 // ---------------------------------------------------------------------------------------------------------------
-static size_t mega_pad256(size_t x) { return (x + 255) & ~(size_t) 255; }
-static void mega_image_layout(int kind, int64_t k, int & off_d, int & off_bs, int & chunks16) {      // = act_q8_carve(…, n = 1)
-    const int64_t nd = kind == T_Q8_0 ? k/32 : k/256, nbs = kind == T_Q8_0 ? k/32 : k/16;
-    off_d = (int) mega_pad256((size_t) k); off_bs = (int)(mega_pad256((size_t) k) + mega_pad256((size_t) nd*4));
-    chunks16 = (int)((off_bs + ((nbs*2 + 15) & ~(int64_t) 15))/16);
-}
-
 static void launch_rec_item(mi_backend_ctx * c, const mi_backend_ctx::rec_item & it) {
     if (it.kind == 0) {
         mul_mat_vec_q_fused(it.grp, it.nc, it.K, it.in, it.has_rope ? &it.rope : nullptr, c->stream, nullptr);
@@ -884,224 +873,78 @@ static void launch_rec_item(mi_backend_ctx * c, const mi_backend_ctx::rec_item &
     c->cnt.kernels_launched++;
 }
 
-// the recorded run as a program of the persistent kernel; false: it does not have the shape the kernel serves.
-// Signalling words are kept as (phase index + 1) (+ 0x10000 for a phase's second counter) while building and patched by rec_flush.
-static bool build_mega_program(mi_backend_ctx * c, std::vector<mega_phase> & prog, size_t & lds_bytes) {
-    const auto & rec = c->rec;
-    const int n = (int) rec.size();
-    static const int min_items = getenv("GGML_MI355X_MEGA_DBG_NOLAST") ? 2 : 3;
-    if (n < min_items || n + 2 > mi_backend_ctx::MEGA_MAX_PHASES || !c->mega_gran) return false;
-    const int n_cu = mega_max_workgroups();
-    if (n_cu < 32) return false;
-    prog.clear(); lds_bytes = 1024;
-    auto as_ptr = [](size_t v) { return (unsigned *) v; };
-    // granule buffers (decode_mega.h): three for the residual stream (rotating), q / k / v, the GLU output, two sets of pieces
-    unsigned long long * gbase = (unsigned long long *) c->mega_gran;
-    unsigned long long * x_gran[3] = { gbase, gbase + 8192, gbase + 2*8192 };
-    unsigned long long * q_gran = gbase + 3*8192, * k_gran = gbase + 4*8192, * v_gran = gbase + 5*8192;
-    unsigned long long * act_gran = gbase + 6*8192;                               // 32768 rows
-    unsigned long long * pieces_a = act_gran + 32768, * pieces_b = pieces_a + 128*MEGA_PIECE_WORDS;
-    int xi = 0;
-    const void * gran_of_ptr[3] = { nullptr, nullptr, nullptr };                  // which f32 vector each residual-stream buffer holds
-    auto find_gran = [&](const void * p) -> unsigned long long * { for (int q = 0; q < 3; q++) if (gran_of_ptr[q] == p && p) return x_gran[q]; return nullptr; };
-    for (int j = 0; j < n; j++) {
-        const auto & it = rec[j];
-        mega_phase ph = {};
-        const int self = (int) prog.size();
-        for (int q = 0; q < 4; q++) ph.block_end[q] = INT_MAX;
-        ph.hint = as_ptr((size_t) self + 1);
-        if (it.kind == 0) {
-            if (it.nc > MEGA_MAX_GROUPS) return false;
-            int types[MMVQ_MAX_GROUPS];
-            for (int q = 0; q < it.nc; q++) {
-                const mmvq_group & g = it.grp[q];
-                types[q] = g.type;
-                if (g.eid || g.b_gate || g.b_up || g.glu_alpha != 0.0f || g.x_off != 0 || g.row_stride > 0xFFFFFFFFull) return false;
-                if (g.epi == EPI_GLU && it.nc != 1) return false;
-            }
-            if (!mega_supported_types(types, it.nc)) return false;
-            const int kind = it.in.act_kind;
-            if (kind != T_Q8_K || it.K % 256 != 0 || it.K > 32768) return false;
-            ph.kind = MEGA_MM; ph.n_groups = it.nc; ph.glu = it.grp[0].epi == EPI_GLU ? 1 : 0;
-            ph.n_active = mul_mat_vec_q_fused_share(it.grp, it.nc, 8, ph.block_end);
-            if (ph.n_active > n_cu) return false;
-            ph.k = (int) it.K; ph.act_kind = kind;
-            mega_image_layout(kind, it.K, ph.off_d, ph.off_bs, ph.act_chunks);
-            lds_bytes = std::max(lds_bytes, (size_t) ph.act_chunks*16 + 256);
-            for (int q = 0; q < it.nc; q++) {
-                const mmvq_group & g = it.grp[q];
-                ph.g[q] = { g.W, g.W2, g.dst, g.res, nullptr, nullptr, g.st16, g.st_idx, g.st_row_elems, (uint32_t) g.row_stride, g.m, g.type, g.epi, g.st_mode, 0 };
-                if (g.epi == EPI_ADD) ph.g[q].res_gran = find_gran(g.res);      // a vector an earlier phase of this launch produced, or a graph input (plain)
-            }
-            if (it.has_rope) { ph.rope = make_fused_rope(it.rope); ph.pos = it.rope.pos; }
-            // the RMS_NORM*w tensor itself is written (by workgroup 0, at the start of the phase) only when that cannot collide with what the phase
-            // writes: the graph allocator may have placed an output of the fused nodes (rope result, SwiGLU result) in the memory the norm
-            // tensor occupied until its last reader — the launch path never writes it, so it never noticed
-            float * norm_out = getenv("GGML_MI355X_MEGA_DBG_NONORMOUT") ? nullptr : it.norm_out;
-            for (int q = 0; q < it.nc && norm_out; q++) if (ranges_overlap(norm_out, (size_t) it.K*4, it.grp[q].dst, (size_t) it.grp[q].m*4)) norm_out = nullptr;
-            // where the input comes from
-            if (j == 0) {
-                if (it.in.mode == PRO_NORM) {
-                    if (it.K > 8192) return false;
-                    ph.in_mode = MIN_NORM_PLAIN; ph.x = it.in.x; ph.norm_w = it.in.norm_w; ph.eps = it.in.eps; ph.norm_out = norm_out;
-                } else if (it.in.mode == PRO_Q8) {
-                    ph.in_mode = MIN_IMAGE; ph.act = (const char *) it.in.act.qs;      // an image some earlier kernel made
-                    if ((const char *) it.in.act.d - (const char *) it.in.act.qs != ph.off_d || (const char *) it.in.act.bsums - (const char *) it.in.act.qs != ph.off_bs) return false;
-                } else return false;
-            } else {
-                mega_phase & pr = prog.back();             // the producer: patched to deliver what this consumer reads
-                const auto & pit = rec[j - 1];
-                const int pidx = (int) prog.size() - 1;
-                if (pit.kind == 1) {                       // attention -> pieces -> this mat-vec (wo)
-                    if (it.in.mode != PRO_QUANT || it.in.x != pit.at.dst || it.K != pit.at.hd*pit.at.n_head) return false;
-                    ph.in_mode = MIN_PIECES; ph.pieces = pieces_a; ph.n_pieces = (int)(it.K/256); ph.pieces_tag_phase = pidx;
-                    ph.wait = nullptr;      // no hint hop: the pieces are 10 KB, the consumers poll by the data
-                } else {
-                    const mmvq_group & pg = pit.grp[0];
-                    if (pit.nc != 1 || it.K != pg.m) return false;
-                    if (it.in.mode == PRO_NORM) {          // residual stream -> RMS_NORM * w -> quantize, in every consumer workgroup
-                        if (it.in.x != pg.dst || pg.epi == EPI_GLU || it.K > 8192) return false;
-                        pr.g[0].gran = x_gran[xi]; gran_of_ptr[xi] = pg.dst; xi = (xi + 1) % 3;
-                        ph.in_mode = MIN_NORM_GRAN; ph.x_gran = pr.g[0].gran; ph.in_tag_phase = pidx;
-                        ph.norm_w = it.in.norm_w; ph.eps = it.in.eps; ph.norm_out = norm_out;
-                        ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active;
-                    } else if (it.in.mode == PRO_QUANT && pg.epi == EPI_GLU && it.K <= 8192 && getenv("GGML_MI355X_MEGA_DBG_GATHER")) {      // (debugging aid)
-                        if (it.in.x != pg.dst) return false;
-                        pr.g[0].gran = act_gran;
-                        ph.in_mode = MIN_QUANT_GRAN; ph.x_gran = act_gran; ph.in_tag_phase = pidx;
-                        ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active;
-                    } else if (it.in.mode == PRO_QUANT && pg.epi == EPI_GLU) {      // gate/up/SwiGLU -> chunk owners quantize -> pieces -> down
-                        const int n_ch = pg.m/256;
-                        if (it.in.x != pg.dst || pg.m % 256 != 0 || n_ch > 128 || n_ch > ph.n_active || pg.m > 32768) return false;
-                        pr.g[0].gran = act_gran;
-                        ph.n_own = n_ch; ph.own_src = act_gran; ph.own_src_tag_phase = pidx; ph.own_wait = pr.hint; ph.own_wait_target = (unsigned) pr.n_active;
-                        ph.own_pieces = pieces_b; ph.hint2 = as_ptr((size_t) 0x10000 + self + 1);
-                        ph.in_mode = MIN_PIECES; ph.pieces = pieces_b; ph.n_pieces = n_ch; ph.pieces_tag_phase = self;
-                        ph.wait = ph.hint2; ph.wait_target = (unsigned) n_ch;
-                    } else return false;
-                }
-            }
-            prog.push_back(ph);
-        } else {
-            // attention: reads q / k / v granules of the previous phase (QKV) + the cache of older cells, publishes the pieces wo reads
-            if (j == 0 || rec[j - 1].kind != 0) return false;
-            static const bool no_attn = getenv("GGML_MI355X_MEGA_NOATTN") != nullptr;      // (debugging aid: runs with attention stay on the launch path)
-            if (no_attn) return false;
-            const auto & a = it.at;
-            const auto & pit = rec[j - 1];
-            if (a.T != 1 || a.hd != 128 || !a.v_trans || a.sinks || a.n_head % 2 != 0 || a.n_head % a.n_head_kv != 0 || a.n_kv % 8 != 0 || (a.n_head/2) > n_cu) return false;
-            const int64_t gqa = a.n_head/a.n_head_kv;
-            if (gqa != 1 && gqa % 2 != 0) return false;
-            if (a.hd*a.n_head > 8192 || a.hd*a.n_head_kv > 8192) return false;
-            if (a.k_nb1 % 16 || a.k_nb2 % 16 || a.v_nb1 % 16 || a.v_nb2 % 16 || ((uintptr_t) a.k % 16) || ((uintptr_t) a.v % 16)) return false;
-            const size_t lds = ((size_t) 2*((a.n_kv + 3) & ~(int64_t) 3) + 16 + 1024)*4;
-            if (lds > 60*1024) return false;
-            lds_bytes = std::max(lds_bytes, lds);
-            mega_phase & pr = prog.back();
-            // the QKV phase's groups: q = the rope output attention reads; k = the group that stores K rows; v = the one that scatters into the V cache
-            int qg = -1, kg = -1, vg = -1;
-            for (int q = 0; q < pit.nc; q++) {
-                if ((const void *) pit.grp[q].dst == a.q) qg = q;
-                else if (pit.grp[q].st_mode == 1) kg = q;
-                else if (pit.grp[q].st_mode == 2) vg = q;
-            }
-            if (qg < 0 || kg < 0 || vg < 0 || pit.grp[qg].m != a.hd*a.n_head || pit.grp[kg].m != a.hd*a.n_head_kv || pit.grp[vg].m != a.hd*a.n_head_kv) return false;
-            if (a.q_nb2 != (size_t) a.hd*4) return false;                      // q rows of head h at h*hd
-            // the cache rows K / V are written to must be the cache attention reads
-            pr.g[qg].gran = q_gran; pr.g[kg].gran = k_gran; pr.g[vg].gran = v_gran;
-            ph.kind = MEGA_ATTN; ph.n_active = (int)(a.n_head/2);
-            ph.wait = pr.hint; ph.wait_target = (unsigned) pr.n_active; ph.in_tag_phase = (int) prog.size() - 1;
-            ph.q_gran = q_gran; ph.k_gran = k_gran; ph.v_gran = v_gran;
-            ph.kc = (const char *) a.k; ph.k_nb1 = a.k_nb1; ph.k_nb2 = a.k_nb2; ph.vc = (const char *) a.v; ph.v_nb1 = a.v_nb1; ph.v_nb2 = a.v_nb2;
-            ph.cell_idx = pit.grp[kg].st_idx;
-            ph.mask = (const char *) a.mask; ph.mask_f16 = a.mask_f16 ? 1 : 0;
-            ph.attn_dst = a.dst; ph.scale = a.scale; ph.n_kv = (int) a.n_kv; ph.n_head = (int) a.n_head; ph.n_head_kv = (int) a.n_head_kv; ph.head_dim = (int) a.hd;
-            ph.own_pieces = pieces_a;
-            prog.push_back(ph);
-        }
-    }
-    prog.back().hint = nullptr;        // nobody waits for the last phase
-    return true;
-}
-
+// the recorded run: two or more grouped launches become one chained launch (phase j + 1 waits for phase j inside the kernel)
 static void rec_flush(mi_backend_ctx * c) {
     if (c->rec.empty()) return;
-    // (debugging aid) GGML_MI355X_MEGA_DBG_NOLAST: the last recorded launch stays a launch of its own
-    static const bool dbg_nolast = getenv("GGML_MI355X_MEGA_DBG_NOLAST") != nullptr;
-    if (dbg_nolast && c->rec.size() >= 3) {
-        const mi_backend_ctx::rec_item last = c->rec.back();
-        c->rec.pop_back();
-        rec_flush(c);
-        launch_rec_item(c, last);
-        return;
-    }
-    std::vector<mega_phase> prog; size_t lds = 0;
-    bool ok = c->use_mega && c->mega_err && build_mega_program(c, prog, lds);
-    static const bool dbg = getenv("GGML_MI355X_MEGA_DEBUG") != nullptr;
-    if (dbg) fprintf(stderr, "ggml-mi355x: recorded run of %d launches -> %s (%d phases, %zu B LDS)%s\n", (int) c->rec.size(), ok ? "persistent kernel" : "separate launches",
-                     (int) prog.size(), lds, c->capturing ? " [capture]" : "");
+    const int n = (int) c->rec.size();
+    static const bool dbg = getenv("GGML_MI355X_CHAIN_DEBUG") != nullptr;
+    bool ok = n >= 2 && c->chain_err != nullptr;
+    const size_t pb = mul_mat_vec_q_chain_phase_bytes();
+    const size_t prog_bytes = (size_t) n*pb, ws_words = (size_t) mul_mat_vec_q_chain_ws_words(n);
+    const size_t pcap = mi_backend_ctx::CHAIN_MAX_PHASES*pb, wcap = (size_t) mul_mat_vec_q_chain_ws_words(mi_backend_ctx::CHAIN_MAX_PHASES)*4;
     void * prog_dev = nullptr; unsigned * ws = nullptr;
-    const size_t prog_bytes = prog.size()*sizeof(mega_phase);
-    const size_t ws_words = prog.size()*MEGA_SIG_WORDS;
-    const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*MEGA_SIG_WORDS*4;
     if (ok) {
-        if (c->capturing) {       // a captured graph owns its tables and signal words: carved from buffers allocated before the capture began
+        if (c->capturing) {       // a captured graph owns its tables and counters: carved from buffers allocated before the capture began
             if (c->cap_entry->owned_dev.size() != 2 || c->cap_prog_used + prog_bytes > pcap || c->cap_ws_used + ws_words*4 > wcap) ok = false;
             else {
                 prog_dev = (char *) c->cap_entry->owned_dev[0] + c->cap_prog_used; ws = (unsigned *) ((char *) c->cap_entry->owned_dev[1] + c->cap_ws_used);
-                c->cap_prog_used += (prog_bytes + 255) & ~(size_t) 255; c->cap_ws_used += (ws_words*4 + 255) & ~(size_t) 255;
             }
         } else {
-            if (!c->mega_prog_dev) {
-                if (hipMalloc(&c->mega_prog_dev, pcap) != hipSuccess || hipHostMalloc(&c->mega_prog_host, pcap, hipHostMallocDefault) != hipSuccess ||
-                    hipMalloc((void **) &c->mega_ws, wcap) != hipSuccess) { (void) hipGetLastError(); ok = false; }
+            if (!c->chain_prog_dev) {
+                if (hipMalloc(&c->chain_prog_dev, pcap) != hipSuccess || hipHostMalloc(&c->chain_prog_host, pcap, hipHostMallocDefault) != hipSuccess ||
+                    hipMalloc((void **) &c->chain_ws, wcap) != hipSuccess) { (void) hipGetLastError(); ok = false; }
             }
-            prog_dev = c->mega_prog_dev; ws = c->mega_ws;
+            if (ok && (c->chain_prog_used + prog_bytes > pcap || c->chain_ws_used + ws_words*4 > wcap)) ok = false;
+            if (ok) { prog_dev = (char *) c->chain_prog_dev + c->chain_prog_used; ws = (unsigned *) ((char *) c->chain_ws + c->chain_ws_used); }
         }
     }
+    std::vector<char> host(ok ? prog_bytes : 0);
+    mmvq_chain_launch L = {};
+    if (ok) {
+        std::vector<mmvq_chain_item> items((size_t) n);
+        for (int j = 0; j < n; j++) {
+            const auto & it = c->rec[j];
+            mmvq_chain_item & ci = items[(size_t) j];
+            for (int q = 0; q < it.nc; q++) ci.grp[q] = it.grp[q];
+            ci.n_groups = it.nc; ci.k = it.K; ci.in = it.in; ci.has_rope = it.has_rope; ci.rope = it.rope;
+        }
+        ok = mul_mat_vec_q_chain_build(items.data(), n, host.data(), &L);
+    }
+    if (dbg) fprintf(stderr, "ggml-mi355x: recorded run of %d grouped launches -> %s%s\n", n, ok ? "one chained launch" : "separate launches", c->capturing ? " [capture]" : "");
     if (!ok) {
         for (const auto & it : c->rec) launch_rec_item(c, it);
         c->rec.clear();
         return;
     }
-    // patch the signalling indices into addresses: a phase's hint = its first counter, hint2 = its second
-    auto fix = [&](unsigned * p) -> unsigned * {
-        const size_t v = (size_t) p;
-        if (v == 0) return nullptr;
-        if (v >= 0x10000) return ws + (v - 0x10000 - 1)*MEGA_SIG_WORDS + 128;
-        return ws + (v - 1)*MEGA_SIG_WORDS;
-    };
-    for (auto & ph : prog) {
-        ph.wait = fix((unsigned *) ph.wait); ph.hint = fix(ph.hint); ph.hint2 = fix(ph.hint2); ph.own_wait = fix((unsigned *) ph.own_wait);
-    }
     if (c->capturing) {
-        mi_backend_ctx::pending_upload up; up.dev = prog_dev; up.host.assign((const char *) prog.data(), (const char *) prog.data() + prog_bytes);
-        c->mega_uploads.push_back(std::move(up));     // copied when the capture has ended (be_graph_compute), before the graph's first launch
+        mi_backend_ctx::pending_upload up; up.dev = prog_dev; up.host = std::move(host);
+        c->chain_uploads.push_back(std::move(up));     // copied when the capture has ended (be_graph_compute), before the graph's first launch
+        c->cap_prog_used += (prog_bytes + 255) & ~(size_t) 255; c->cap_ws_used += (ws_words*4 + 255) & ~(size_t) 255;
     } else {
-        MI_CHECK_G(hipStreamSynchronize(c->stream));    // the staging copy of the previous eager run may still be in flight
-        memcpy(c->mega_prog_host, prog.data(), prog_bytes);
-        MI_CHECK_G(hipMemcpyAsync(prog_dev, c->mega_prog_host, prog_bytes, hipMemcpyHostToDevice, c->stream));
+        // eager: the host table of this pass is carved from the pinned staging area at the same offset as the device table (the stream
+        // was synchronized before the pass reused the area: be_graph_compute)
+        memcpy((char *) c->chain_prog_host + c->chain_prog_used, host.data(), prog_bytes);
+        MI_CHECK_G(hipMemcpyAsync(prog_dev, (char *) c->chain_prog_host + c->chain_prog_used, prog_bytes, hipMemcpyHostToDevice, c->stream));
+        c->chain_prog_used += (prog_bytes + 255) & ~(size_t) 255; c->chain_ws_used += (ws_words*4 + 255) & ~(size_t) 255;
     }
     MI_CHECK_G(hipMemsetAsync(ws, 0, ws_words*4, c->stream));
     unsigned * err_dev = nullptr;
-    MI_CHECK_G(hipHostGetDevicePointer((void **) &err_dev, c->mega_err, 0));
-    mega_launch((const mega_phase *) prog_dev, (int) prog.size(), mega_max_workgroups(), c->mega_epoch, err_dev, lds, c->stream);
+    MI_CHECK_G(hipHostGetDevicePointer((void **) &err_dev, c->chain_err, 0));
+    mul_mat_vec_q_chain_launch(prog_dev, L, ws, err_dev, c->stream);
     c->cnt.kernels_launched += 2;
     c->rec.clear();
 }
 
 static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin, float * norm_out) {
-    bool mega_ok = true;      // the persistent kernel knows NORM rotations without a bias only
-    for (int q = 0; q < nc; q++) if ((grp[q].epi == EPI_ROPE && (grp[q].res || (rope && (rope->p.mode & 2)))) || grp[q].res2 || grp[q].res_eid) mega_ok = false;
-    for (int q = 1; q < nc; q++) if (act_kind_for(grp[q].type) != act_kind_for(grp[0].type)) mega_ok = false;
-    if (!c->rec_on || !mega_ok) {
+    // only what the streamed kernel takes can be a phase of a chain; anything else ends the recorded run and goes out by itself
+    if (!c->rec_on || fin || !mul_mat_vec_q_stream_takes(grp, nc, K, in, rope) || (int) c->rec.size() >= mi_backend_ctx::CHAIN_MAX_PHASES) {
         if (c->rec_on) rec_flush(c);
         mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
         c->cnt.kernels_launched++;
         return;
     }
     mi_backend_ctx::rec_item it = {};
-    it.kind = 0; it.nc = nc; it.K = K; it.in = in; it.has_rope = rope != nullptr; if (rope) it.rope = *rope; it.norm_out = norm_out;
+    it.kind = 0; it.nc = nc; it.K = K; it.in = in; it.has_rope = rope != nullptr; if (rope) it.rope = *rope;
     for (int q = 0; q < nc; q++) it.grp[q] = grp[q];
     c->rec.push_back(it);
 }
@@ -1392,6 +1235,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     if (rope) {
         if (!c->rope_tab || rope->p.n_dims/2 > 512) return -1;
         if (!c->rope_tab_valid || memcmp(&c->rope_tab_key, rope, sizeof(*rope)) != 0) {
+            rec_flush(c);      // recorded launches still to go out read the table as it is
             mul_mat_vec_q_fused_rope_table(*rope, c->rope_tab, c->stream);
             c->cnt.kernels_launched++;
             c->rope_tab_key = *rope; c->rope_tab_valid = true;
@@ -1503,7 +1347,7 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         (!mask || mask->nb[0] == (mask->type == GGML_TYPE_F16 ? 2u : 4u))) {
         const int jw = next_real(g, j3);
         struct ggml_tensor * wo = jw > 0 ? g->nodes[jw] : nullptr;
-        if (wo && fusable_mmv(wo) && wo->src[1] == ct && n_uses(c, ct) == 1 && n_head <= 64 && wo->src[0]->ne[1]/16 >= n_head && mega_max_workgroups() >= n_head) {
+        if (wo && fusable_mmv(wo) && wo->src[1] == ct && n_uses(c, ct) == 1 && n_head <= 64 && wo->src[0]->ne[1]/16 >= n_head && true) {
             mmvq_attn at = { (const char *) q->data, q->nb[2], (const char *) k->data, k->nb[1], k->nb[2], (const char *) v->data, v->nb[1], v->nb[2],
                              mask ? (const char *) mask->data : nullptr, mask && mask->type == GGML_TYPE_F16 ? 1 : 0, sm->src[2] ? (const float *) sm->src[2]->data : nullptr,
                              (int) n_kv, (int) n_head, (int) n_head_kv, (int) hd, op_f32(sm, 0), c->fin_cnt + mi_backend_ctx::FIN_COUNTERS };
@@ -1517,7 +1361,8 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         it.at = { q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0,
                   mask && mask->type == GGML_TYPE_F16, sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
                   hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), true };
-        if (c->rec_on) c->rec.push_back(it); else launch_rec_item(c, it);
+        rec_flush(c);
+        launch_rec_item(c, it);
     }
     return j3 - i + 1;
 }
@@ -2092,7 +1937,11 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
     c->aq.valid = false;
     c->uses.clear();
     c->rec.clear();
-    c->rec_on = c->use_mega && c->use_fusion && !c->profiling && c->mega_err != nullptr && !c->split_graph;
+    c->rec_on = c->use_chain && c->use_fusion && !c->profiling && c->chain_err != nullptr && !c->split_graph && mul_mat_vec_q_stream_enabled();
+    if (!c->capturing) {      // eager pass: its phase tables are staged through one pinned area, which the previous eager pass's copies may still be reading
+        if (c->chain_prog_used) MI_CHECK_G(hipStreamSynchronize(c->stream));
+        c->chain_prog_used = 0; c->chain_ws_used = 0;
+    }
     if (c->use_fusion) {
         for (int i = 0; i < g->n_nodes; i++) {
             for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[i]->src[s]) c->uses[g->nodes[i]->src[s]]++;
@@ -2183,7 +2032,7 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
             hipGraph_t graph = nullptr;
             (void) hipStreamEndCapture(c->stream, &graph);
             if (graph) (void) hipGraphDestroy(graph);
-            c->capturing = false; c->cap_entry = nullptr; c->mega_uploads.clear();
+            c->capturing = false; c->cap_entry = nullptr; c->chain_uploads.clear();
         }
         c->rec.clear(); c->rec_on = false; c->aq.valid = false;
         (void) hipGetLastError();
@@ -2200,15 +2049,9 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         if (hipMalloc((void **) &c->moe_ws, 4096) == hipSuccess) { MI_CHECK_G(hipMemsetAsync(c->moe_ws, 0, 4096, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
     }
-    if (!c->mega_err && c->use_mega) {     // persistent decode: images, the error word (host-mapped)
-        const size_t gran_bytes = ((size_t) 6*8192 + 32768 + 2*128*MEGA_PIECE_WORDS)*8;
-        bool ok = hipMalloc(&c->mega_gran, gran_bytes) == hipSuccess && hipMalloc((void **) &c->mega_epoch, 256) == hipSuccess;
-        ok = ok && hipHostMalloc((void **) &c->mega_err, 64, hipHostMallocMapped) == hipSuccess;
-        if (ok) {
-            c->mega_err[0] = 0;
-            MI_CHECK_G(hipMemsetAsync(c->mega_gran, 0, gran_bytes, c->stream)); MI_CHECK_G(hipMemsetAsync(c->mega_epoch, 0, 256, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream));
-        }
-        else { (void) hipGetLastError(); c->use_mega = false; }
+    if (!c->chain_err && c->use_chain) {     // chained decode: the error word (host-mapped)
+        if (hipHostMalloc((void **) &c->chain_err, 64, hipHostMallocMapped) == hipSuccess) c->chain_err[0] = 0;
+        else { (void) hipGetLastError(); c->chain_err = nullptr; c->use_chain = false; }
     }
     if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
         if (hipMalloc(&c->fin_img, mi_backend_ctx::FIN_IMG_BYTES) != hipSuccess) { (void) hipGetLastError(); c->fin_img = nullptr; }
@@ -2261,21 +2104,21 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         }
         if (e.seen >= 2) {
             hipGraph_t graph = nullptr;
-            if (c->use_mega && c->mega_err && e.owned_dev.empty()) {       // room for the persistent-decode programs of this graph (no allocation inside a capture)
+            if (c->use_chain && c->chain_err && e.owned_dev.empty()) {       // room for the chained launches' phase tables and counters of this graph (no allocation inside a capture)
                 void * pd = nullptr; void * wd = nullptr;
-                const size_t pcap = mi_backend_ctx::MEGA_MAX_PHASES*sizeof(mega_phase), wcap = (size_t) mi_backend_ctx::MEGA_MAX_PHASES*MEGA_SIG_WORDS*4;
+                const size_t pcap = mi_backend_ctx::CHAIN_MAX_PHASES*mul_mat_vec_q_chain_phase_bytes(), wcap = (size_t) mul_mat_vec_q_chain_ws_words(mi_backend_ctx::CHAIN_MAX_PHASES)*4;
                 if (hipMalloc(&pd, pcap) == hipSuccess && hipMalloc(&wd, wcap) == hipSuccess) { e.owned_dev.push_back(pd); e.owned_dev.push_back(wd); }
                 else { (void) hipGetLastError(); if (pd) (void) hipFree(pd); }
             }
             MI_CHECK_G(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             c->prof_suspend = false;
-            c->capturing = true; c->cap_entry = &e; c->mega_uploads.clear(); c->cap_prog_used = 0; c->cap_ws_used = 0;
+            c->capturing = true; c->cap_entry = &e; c->chain_uploads.clear(); c->cap_prog_used = 0; c->cap_ws_used = 0;
             run_nodes(c, g);
             c->capturing = false; c->cap_entry = nullptr;
             c->prof_suspend = c->prof_in_graph;
             MI_CHECK_G(hipStreamEndCapture(c->stream, &graph));
-            for (auto & up : c->mega_uploads) MI_CHECK_G(hipMemcpy(up.dev, up.host.data(), up.host.size(), hipMemcpyHostToDevice));     // the program tables the captured launches read
-            c->mega_uploads.clear();
+            for (auto & up : c->chain_uploads) MI_CHECK_G(hipMemcpy(up.dev, up.host.data(), up.host.size(), hipMemcpyHostToDevice));     // the phase tables the captured launches read
+            c->chain_uploads.clear();
             hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
             MI_CHECK_G(hipGraphDestroy(graph));
             if (err == hipSuccess) {
@@ -2512,7 +2355,7 @@ ggml_backend_t ggml_backend_mi355x_init(int device) {
     MI_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->use_fusion = atoi(e) != 0;
-    if (const char * e = getenv("GGML_MI355X_MEGA")) c->use_mega = atoi(e) != 0;
+    if (const char * e = getenv("GGML_MI355X_CHAIN")) c->use_chain = atoi(e) != 0;
     ggml_backend_t backend = new ggml_backend{ mi_guid(), mi_backend_iface, &d.dev, c };
     return backend;
 }
@@ -2576,8 +2419,8 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
         mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
         return 0;
     }
-    if (strcmp(key, "mega") == 0) {
-        c->use_mega = value != 0;
+    if (strcmp(key, "chain") == 0) {
+        c->use_chain = value != 0;
         MI_CHECK(hipStreamSynchronize(c->stream));
         drop_graphs(c);
         return 0;

@@ -256,6 +256,15 @@ bool mul_mat_vec_q_stream_enabled(void);       // GGML_MI355X_STREAM (default 1)
 bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope);
 void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                           hipEvent_t e0, hipEvent_t e1, const char ** kernel_name);
+// a CHAIN of grouped launches as one persistent launch (k_mmvq_chain, mmvq_stream.h): phase j + 1 reads what phase j wrote (or older data);
+// each item must be one mul_mat_vec_q_stream_takes says yes to. The phase table lives in device memory (prog_dev: n*phase_bytes, copied from
+// the host table _build fills), ws = n*ws_words counter words that are ZERO when the launch starts, err = a host-visible word (set if a wait gave up)
+struct mmvq_chain_item { mmvq_group grp[MMVQ_MAX_GROUPS]; int n_groups; int64_t k; mmvq_input in; bool has_rope; mmvq_rope rope; };
+struct mmvq_chain_launch { int n_phases, blocks; size_t lds; uint64_t weight_bytes; int cfg[4]; };
+size_t mul_mat_vec_q_chain_phase_bytes(void);
+int    mul_mat_vec_q_chain_ws_words(int n_phases);
+bool   mul_mat_vec_q_chain_build(const mmvq_chain_item * items, int n, void * prog_host, mmvq_chain_launch * out);
+void   mul_mat_vec_q_chain_launch(const void * prog_dev, const mmvq_chain_launch & L, unsigned * ws, unsigned * err_dev, hipStream_t stream);
 bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);   // may a GLU launch with m output rows carry an mmvq_fin
 int  mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end);   // workgroups per group (one workgroup per CU in all)
 // (round 1's chained launch held launches back; nothing is held back any more: flush is a no-op kept for its call sites)

@@ -56,6 +56,24 @@ struct st_args {
     st_group g[MMVQ_MAX_GROUPS];
     unsigned long long * stamps;              // diagnostic builds (-DMI_STAMPS): [workgroup][wave][8]
 };
+// ---- a CHAIN of such launches as ONE launch (k_mmvq_chain): consecutive mat-vecs of the decode graph (wo -> gate/up/SwiGLU -> down -> the next
+// layer's norm+QKV ...) as phases of a persistent kernel. Every workgroup walks the phases in order; its loader runs ahead into the next
+// phases' weights (they depend on nothing) while the consumers finish a phase, hand its rows over and wait for everybody else's:
+// the kernel boundary, the launch ramp, the first-byte latency and the prologue of each phase overlap the stream instead of stopping it.
+// Hand-off (MI355X guide, inter-workgroup visibility, the drained-sc1 form): a phase's outputs leave with write-through (sc1) stores, every
+// storing wave drains them, the workgroup arrives at the phase's counter (agent-scope atomic add); the next phase's consumers poll that
+// counter (sc1 load) and read activations / residuals with sc1 loads.
+struct st_phase {
+    st_args a;
+    int n_active;                             // workgroups that take part (= a.block_end[a.n_groups - 1])
+    int wait_idx, sig_idx;                    // words of the launch's counter array: wait until ws[wait_idx] >= wait_target before reading inputs; add 1 to ws[sig_idx] when this workgroup's rows are stored (-1: none)
+    unsigned wait_target;
+};
+constexpr int ST_WS_WORDS = 512;              // counter words per phase: 8 shards, 256 bytes apart (256 arrivals at ONE word take ~3 us; workgroup b arrives at shard b % 8)
+struct st_chain_cfg {                         // the LDS carve, the same in every phase (the loader is phases ahead of the consumers)
+    int nb_max, npart_max, slot_stride, S;
+};
+struct st_chain_dbg { unsigned long long * stamps; };      // diagnostic builds (-DMI_STAMPS): [phase][workgroup][wave][8]
 
 // LDS-DMA, 1 KiB per instruction: lane l's 16 bytes at gbase + OFF + 16*l -> LDS M0 + OFF + 16*l (the instruction's offset field advances
 // BOTH addresses). gbase and the LDS address are wave-uniform (scalar registers), voff = 16*lane: nothing per piece is vector work — a
@@ -111,10 +129,11 @@ static __device__ __forceinline__ void st_wait_ge(const uint32_t * w, uint32_t t
     asm volatile("" ::: "memory");      // nothing that reads what the word guards moves above the wait
 }
 // every consumer wave arrives once at counter w (its LDS writes drained first), then waits for all of them
-static __device__ __forceinline__ void st_consumers_meet(uint32_t * w, int lane) {
+// (the counters are cumulative: the n-th meeting at w, n = 0, 1, ..., waits for (n + 1)*ST_NC arrivals)
+static __device__ __forceinline__ void st_consumers_meet(uint32_t * w, int lane, int n) {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (lane == 0) st_flag_add(w, 1u);
-    st_wait_ge(w, ST_NC);
+    st_wait_ge(w, (uint32_t)(n + 1)*ST_NC);
 }
 
 // ---- per-format unit: UB bytes of packed weights = 256 weights; one lane consumes one unit ----
@@ -257,7 +276,7 @@ template <> struct st_unit<T_Q6_K> {
 };
 
 #ifdef MI_STAMPS
-#define ST_STAMP(i_) do { if (p.stamps && lane == 0) p.stamps[((size_t) blockIdx.x*(ST_NC + 1) + wave)*8 + (i_)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ST_STAMP(i_) do { if (stamps && lane == 0) __hip_atomic_store(&stamps[((size_t) blockIdx.x*(ST_NC + 1) + wave)*8 + (i_)], (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
 #define ST_STAMP(i_) do { } while (0)
 #endif
@@ -272,150 +291,227 @@ static __device__ __forceinline__ float st_row_sum(const float * part, int row, 
     return s;
 }
 
+// ---- loads / stores of bytes another workgroup of the SAME launch wrote or will read (CHAIN): sc1 = served by / written through to L2 and
+// beyond, never this CU's L1. Raw buffer instructions so that the compiler keeps counting them (aux 16 = sc1). ----
+typedef __attribute__((ext_vector_type(4))) unsigned int st_u4;
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void * base) {
+    return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, 0x7FFFFFFF, 0x00020000);
+}
+template <bool CHAIN> static __device__ __forceinline__ float4v st_ldx4(const float * base, int elem) {
+    if (CHAIN) { const st_u4 v = __builtin_amdgcn_raw_buffer_load_b128(st_rsrc(base), elem*4, 0, 16); return __builtin_bit_cast(float4v, v); }
+    return *(const float4v *) (base + elem);
+}
+template <bool CHAIN> static __device__ __forceinline__ float st_ldx1(const float * base, int elem) {
+    if (CHAIN) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(st_rsrc(base), elem*4, 0, 16));
+    return base[elem];
+}
+template <bool CHAIN> static __device__ __forceinline__ void st_stx1(float * base, int elem, float v) {
+    if (CHAIN) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), st_rsrc(base), elem*4, 0, 16);
+    else base[elem] = v;
+}
+
+// where a workgroup's LDS regions are
+struct st_lds {
+    uint32_t * sync; char * act; float * dd; float * red; float * part; uint32_t ring_a; int slot_stride, S;
+};
+// rows of workgroup wg of nwg in group g: [r0, r0 + R), dealt in multiples of ralign (which also keeps every workgroup's first byte 16-byte
+// aligned — Q6_K rows are 210 nb bytes); the rows past the last whole unit belong to the last workgroup
+static __device__ __forceinline__ void st_rows(const st_group & g, int wg, int nwg, int & r0, int & R) {
+    const int nru = g.m/g.ralign;
+    r0 = (int)((long long) wg*nru/nwg)*g.ralign;
+    R = (wg == nwg - 1 ? g.m : (int)((long long)(wg + 1)*nru/nwg)*g.ralign) - r0;
+}
+
+// ================= the loader's share of one phase: slots slot0 .. slot0 + nslots of the workgroup's slot sequence =================
+// In flight: at most ST_INFLIGHT pieces behind the slot being issued (a wave counts at most 63 outstanding loads; a slot is at most 14).
+// Which slots have LANDED follows from the piece count alone — after `s_waitcnt vmcnt(N)` all but the youngest N pieces are in LDS — and
+// the pieces a slot ends at are kept per slot (cum[]: phases of a chain have slots of different sizes).
+constexpr int ST_INFLIGHT = 36;
+// Everything here is wave-uniform and must stay in scalar registers and out of memory: the loader is the critical path of the whole kernel
+// (a version that kept a per-slot table — in LDS, then in an array the compiler moved to vector registers — and re-read the group's
+// pointers from the kernel arguments every slot lost a sixth of the stream rate). So: slots of ONE phase have one size, and which of them
+// have landed is arithmetic on the piece count; of the phase before, the same with its own size; anything older has landed for sure
+// because a phase that issued fewer than ST_INFLIGHT pieces is followed by a full drain.
+struct st_loader_state {
+    int landed, pieces;                       // slots published; pieces issued so far
+    int c_slot0, c_base, p_slot0, p_base, p_magic;      // the current / the previous phase: its first slot, the pieces issued before it; 65536 / pieces-per-slot (rounded up) of the previous one
+};
+template <int PPS>
+static __device__ __forceinline__ void st_loader_publish(const st_lds & L, st_loader_state & s, int issued_slots, int outstanding, int lane) {
+    const int done = s.pieces - outstanding;
+    int l;
+    if (done >= s.c_base) l = s.c_slot0 + (done - s.c_base)/PPS;
+    else if (done >= s.p_base) l = s.p_slot0 + (((done - s.p_base)*s.p_magic) >> 16);
+    else l = s.p_slot0;
+    l = min(l, issued_slots);
+    if (l > s.landed) { s.landed = l; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) l); }
+}
 template <int TYPE, bool NT>
-static __device__ __forceinline__ void st_body(const st_args & p, const st_group & g, const int wg, const int nwg, char * lds, const int lane, const int wave) {
+static __device__ __forceinline__ void st_loader_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, st_loader_state & ls, int lane) {
     typedef st_unit<TYPE> U;
-    constexpr int PPS = (64*U::UB + 1023)/1024, SLOT = PPS*1024;
-    constexpr int DEPTH = 63/PPS < 6 ? 63/PPS : 6;      // slots the loader keeps in flight (a wave counts at most 63 outstanding loads)
+    constexpr int PPS = (64*U::UB + 1023)/1024;
     const int nb = p.nb;
     const bool GLU = g.epi == EPI_GLU;
-    // rows of this workgroup: [r0, r0 + R), dealt in multiples of ralign
-    // (ralign also keeps every workgroup's first byte 16-byte aligned — Q6_K rows are 210 nb bytes; the rows past the last whole unit belong to the last workgroup)
-    const int nru = g.m/g.ralign;
-    const int r0 = (int)((long long) wg*nru/nwg)*g.ralign, R = (wg == nwg - 1 ? g.m : (int)((long long)(wg + 1)*nru/nwg)*g.ralign) - r0;
-    const int n1 = R*nb, ns1 = (n1 + 63) >> 6, nslots = GLU ? 2*ns1 : ns1;      // units / slots of one stream; slots of the workgroup
-    const int S = p.S;
+    int r0, R; st_rows(g, wg, nwg, r0, R);
+    const int n1 = R*nb, ns1 = (n1 + 63) >> 6, nslots = GLU ? 2*ns1 : ns1;
+    const int S = L.S;
+    const uint32_t voff = lane*16;
+    // a new phase: the one before becomes "previous"; if it was short, nothing of it (or of anything older) may stay unpublished
+    if (ls.pieces - ls.c_base < ST_INFLIGHT && ls.pieces > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (slot0 > ls.landed) { ls.landed = slot0; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) slot0); }
+    }
+    ls.p_slot0 = ls.c_slot0; ls.p_base = ls.c_base; ls.c_slot0 = slot0; ls.c_base = ls.pieces;
+    const long long row_off = (long long) r0*nb*U::UB;
+    const char * const w0 = g.W + row_off; const char * const w1 = GLU ? g.W2 + row_off : w0;
+    const long long lim_all = (long long) g.m*nb*U::UB - 16 - row_off;      // the tensor's last 16 bytes, relative to this workgroup's first
+    int ring_i = slot0 % S;
+    for (int i = 0; i < nslots; i++) {
+        const int gi = slot0 + i;                            // slot number in the workgroup's sequence
+        const int si = GLU ? (i >= ns1) : 0, il = i - si*ns1;
+        const char * gb = (si ? w1 : w0) + (long long) il*(64*U::UB);
+        if (gi >= S) {
+            // the ring slot must have been consumed; publish what is in flight first so that nobody waits for us meanwhile
+            if (st_poll_ld(&L.sync[16 + ring_i]) < (uint32_t)(gi - S + 1)) {
+                if (ls.landed < gi) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ls.landed = gi; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) gi); }
+                st_wait_ge(&L.sync[16 + ring_i], (uint32_t)(gi - S + 1));
+            }
+        }
+        const uint32_t dst = L.ring_a + (uint32_t) ring_i*L.slot_stride;
+        if (il == ns1 - 1) {       // the stream's last slot may reach past the end of the tensor
+            const long long lim = lim_all - (long long) il*(64*U::UB);
+            st_dma_slot_clamped<NT, PPS>(gb, voff, dst, (uint32_t)(lim < 0x7FFFFFFF ? lim : 0x7FFFFFFF));
+        } else st_dma_slot<NT, PPS>(gb, voff, dst);
+        ls.pieces += PPS;
+        if (++ring_i == S) ring_i = 0;
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ST_INFLIGHT) : "memory");
+        if (ls.pieces > ST_INFLIGHT) st_loader_publish<PPS>(L, ls, gi + 1, ST_INFLIGHT, lane);
+    }
+    ls.p_magic = (65536 + PPS - 1)/PPS;       // (for the phase after this one)
+}
+// after the last phase: everything lands
+static __device__ __forceinline__ void st_loader_drain(const st_lds & L, int nslots_total, st_loader_state & ls, int lane) {
+    // (the last phase's slot size is not known here: 27 / 14 / 0 outstanding pieces cover whole slots of every format well enough)
+    asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
+    { const int done = ls.pieces - 18; const int l = min(nslots_total, done >= ls.c_base ? ls.c_slot0 + (done - ls.c_base)/14 : ls.c_slot0);      // /14: never more than have landed
+      if (l > ls.landed) { ls.landed = l; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) l); } }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (nslots_total > ls.landed) { ls.landed = nslots_total; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) nslots_total); }
+}
+
+// ---- the activation image of a phase ----
+// PRO_Q8: a Q8_K image some earlier launch made (act_q8_carve layout), re-laid for the consumers
+template <bool FIRST>
+static __device__ __forceinline__ void st_prologue_q8(const st_args & p, const st_lds & L, int ctid) {
+    const int nb = p.nb, nq = p.k >> 4;
+    int4v areg[2], breg[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const int q = min(ctid + i*ST_NC*64, nq - 1); areg[i] = *(const int4v *) (p.a_qs + (size_t) q*16); }
+    const int ibl = min(ctid, nb - 1);
+    breg[0] = *(const int4v *) (p.a_bs + (size_t) ibl*16); breg[1] = *(const int4v *) (p.a_bs + (size_t) ibl*16 + 8);
+    const float dreg = p.a_d[ibl];
+    if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+        const int q = ctid + i*ST_NC*64;
+        if (q < nq) { const int ib = q >> 4, c = q & 15; *(int4v *) (L.act + (size_t) ib*ST_ACT_STRIDE + c*16) = areg[i]; }
+    }
+    if (ctid < nb) {
+        uint32_t h32[2] = { 0, 0 }, l32[2] = { 0, 0 }, h16[4] = { 0, 0, 0, 0 }, l16[4] = { 0, 0, 0, 0 };
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t wsum = (uint32_t)(j < 4 ? breg[0][j] : breg[1][j - 4]);
+            const int sa = (int)(int16_t)(wsum & 0xFFFF), sb = (int)(int16_t)(wsum >> 16);
+            int h, l;
+            st_hl(sa + sb, h, l); h32[j >> 2] |= (uint32_t)(h & 0xFF) << (8*(j & 3)); l32[j >> 2] |= (uint32_t)(l & 0xFF) << (8*(j & 3));
+            st_hl(sa, h, l); h16[j >> 1] |= (uint32_t)(h & 0xFF) << (8*((2*j) & 3)); l16[j >> 1] |= (uint32_t)(l & 0xFF) << (8*((2*j) & 3));
+            st_hl(sb, h, l); h16[j >> 1] |= (uint32_t)(h & 0xFF) << (8*((2*j + 1) & 3)); l16[j >> 1] |= (uint32_t)(l & 0xFF) << (8*((2*j + 1) & 3));
+        }
+        char * ab = L.act + (size_t) ctid*ST_ACT_STRIDE;
+        *(int4v *) (ab + 256) = int4v{ (int) h32[0], (int) h32[1], (int) l32[0], (int) l32[1] };
+        *(int4v *) (ab + 272) = int4v{ (int) h16[0], (int) h16[1], (int) h16[2], (int) h16[3] };
+        *(int4v *) (ab + 288) = int4v{ (int) l16[0], (int) l16[1], (int) l16[2], (int) l16[3] };
+        L.dd[ctid] = dreg;
+    }
+}
+// PRO_QUANT / PRO_NORM: x (f32) -> [RMS_NORM * w ->] Q8_K blocks, quant_core.h's arithmetic. Consumer wave w owns the 256-element chunks
+// w, w + 8, ...: NA of them, all quantized in straight-line code (a chunk past the end is a clamped duplicate that is not stored) so that
+// the dependent chains of the wave-wide maxima and sums interleave — chunk after chunk behind a branch each cost ~0.5 us per chunk
+template <int NA, bool CHAIN, bool FIRST>
+static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const st_lds & L, int seq, int & n_norm, int lane, int wave) {
+    const int nchunk = p.nb;
+    const bool norm = p.mode == PRO_NORM;
+    float4v xv[NA], wv[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int c = min(wave + ST_NC*i, nchunk - 1);
+        xv[i] = st_ldx4<CHAIN>(p.x, c*256 + lane*4);
+        wv[i] = norm ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
+    }
+    if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    float scale = 1.0f;
+    if (norm) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NA; i++) if (wave + ST_NC*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
+        ss = wave_sum(ss);
+        if (lane == 0) L.red[wave] = ss;      // (everybody has read the previous phase's sums: three meetings lie in between)
+        st_consumers_meet(&L.sync[4], lane, n_norm++);
+        const float * red = L.red;
+        ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+        scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
+    }
+    uint32_t q4[NA]; float d8[NA]; int bs16[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        float4v v = xv[i];
+        if (norm) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
+        q4[i] = quant_frag_q8_K(v, d8[i], bs16[i]);
+    }
+#pragma unroll
+    for (int i = 0; i < NA; i++) {
+        const int c = wave + ST_NC*i;
+        if (c < nchunk) {
+            char * ab = L.act + (size_t) c*ST_ACT_STRIDE;
+            *(uint32_t *) (ab + lane*4) = q4[i];
+            // the 16-element sum of quad q = lane >> 2 (valid in its four lanes); the 32-element sum j at lane 8j + 4 (row_shr:4 brings lane 8j's)
+            const int bs32 = bs16[i] + dpp_i<0x114>(bs16[i]);
+            int h, l;
+            st_hl(bs16[i], h, l);
+            if ((lane & 3) == 0) { ab[272 + (lane >> 2)] = (char) h; ab[288 + (lane >> 2)] = (char) l; }
+            st_hl(bs32, h, l);
+            if ((lane & 7) == 4) { ab[256 + (lane >> 3)] = (char) h; ab[264 + (lane >> 3)] = (char) l; }
+            if (lane == 0) L.dd[c] = d8[i];
+        }
+    }
+}
+
+// ================= the consumers' share of one phase =================
+//   seq: how many phases this workgroup has run before (its LDS counters are cumulative); FIRST: the launch's first phase — the activation
+//   loads are queued before the loader starts (the barrier every wave of the workgroup takes exactly once)
+template <int TYPE, bool CHAIN, bool FIRST>
+static __device__ __forceinline__ void st_consumer_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, int seq, int & n_norm,
+                                                         int lane, int wave, unsigned long long * stamps) {
+    typedef st_unit<TYPE> U;
+    const int nb = p.nb;
+    const bool GLU = g.epi == EPI_GLU;
+    int r0, R; st_rows(g, wg, nwg, r0, R);
+    const int n1 = R*nb, ns1 = (n1 + 63) >> 6, nslots = GLU ? 2*ns1 : ns1;
+    const int S = L.S;
     const bool row16 = (nb & 15) == 0;               // a DPP row of 16 lanes = 16 units of ONE weight row
     const int npr = row16 ? nb >> 4 : nb;            // partials per row
-    uint32_t * sync = (uint32_t *) lds;
-    char * act = lds + ST_SYNC_WORDS*4;
-    float * dd = (float *) (act + (size_t) nb*ST_ACT_STRIDE);
-    float * red = dd + ((nb + 3) & ~3);              // [ST_NC] sums of squares (PRO_NORM)
-    float * part = red + 16;
-    char * ring = (char *) (((size_t)(part + g.npart_max) + 15) & ~(size_t) 15);
-    ST_STAMP(0);
-    if (threadIdx.x < ST_SYNC_WORDS) sync[threadIdx.x] = 0;
+    uint32_t * sync = L.sync; char * act = L.act; float * dd = L.dd; float * part = L.part;
+    const int ctid = threadIdx.x;                    // consumer thread id (the consumers are waves 0 .. ST_NC - 1)
 
-    // ---- consumers: request the activation before any weight is requested (a CU returns loads in request order) ----
+    // ---- the activation image (FIRST: the loads are requested before any weight is — a CU returns loads in request order) ----
     const int mode = p.mode;
-    const int nchunk = nb;                            // 256-element chunks of the activation; consumer wave w owns chunks w, w + 8, ...
-    float4v xv[8], wv[8];
-    int4v areg[2], breg[2]; float dreg = 0.0f;
-    if (wave < ST_NC) {
-        if (mode == PRO_Q8) {
-            const int nq = p.k >> 4;
-#pragma unroll
-            for (int i = 0; i < 2; i++) { const int q = min((int) threadIdx.x + i*ST_NC*64, nq - 1); areg[i] = *(const int4v *) (p.a_qs + (size_t) q*16); }
-            const int ibl = min((int) threadIdx.x, nb - 1);
-            breg[0] = *(const int4v *) (p.a_bs + (size_t) ibl*16); breg[1] = *(const int4v *) (p.a_bs + (size_t) ibl*16 + 8);
-            dreg = p.a_d[ibl];
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const int c = wave + ST_NC*i;
-                if (c < nchunk) {      // wave-uniform
-                    xv[i] = *(const float4v *) (p.x + (size_t) c*256 + lane*4);
-                    if (mode == PRO_NORM) wv[i] = *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4);
-                }
-            }
-        }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-
-    if (wave == ST_NC) {
-        // ================= the loader =================
-        const uint32_t ring_a = st_lds_addr(ring);
-        const uint32_t voff = lane*16;
-        int landed = 0;
-        for (int i = 0; i < nslots; i++) {
-            const int si = GLU ? (i >= ns1) : 0, il = i - si*ns1;
-            const char * gb = (si ? g.W2 : g.W) + (long long) r0*nb*U::UB + (long long) il*64*U::UB;
-            if (i >= S) {
-                // the slot must have been consumed; publish what is in flight first so that nobody waits for us meanwhile
-                if (st_poll_ld(&sync[16 + i % S]) < (uint32_t)(i - S + 1)) {
-                    if (landed < i) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); landed = i; if (lane == 0) st_flag_st(&sync[0], (uint32_t) landed); }
-                    st_wait_ge(&sync[16 + i % S], (uint32_t)(i - S + 1));
-                }
-            }
-            if (il == ns1 - 1) {       // the stream's last slot may reach past the end of the tensor
-                const long long lim = (long long) g.m*nb*U::UB - 16 - ((long long) r0*nb*U::UB + (long long) il*64*U::UB);
-                st_dma_slot_clamped<NT, PPS>(gb, voff, ring_a + (uint32_t)(i % S)*SLOT, (uint32_t)(lim < 0x7FFFFFFF ? lim : 0x7FFFFFFF));
-            } else st_dma_slot<NT, PPS>(gb, voff, ring_a + (uint32_t)(i % S)*SLOT);
-            if (i >= DEPTH - 1) {      // all but the youngest DEPTH - 1 slots have landed
-                asm volatile("s_waitcnt vmcnt(%0)" :: "n"((DEPTH - 1)*PPS) : "memory");
-                if (landed < i - (DEPTH - 2)) { landed = i - (DEPTH - 2); if (lane == 0) st_flag_st(&sync[0], (uint32_t) landed); }
-            }
-        }
-#define MI_DRAIN(d_) if (DEPTH - 2 >= (d_)) { asm volatile("s_waitcnt vmcnt(%0)" :: "n"((d_)*PPS) : "memory"); \
-            if (nslots - (d_) > landed) { landed = nslots - (d_); if (lane == 0) st_flag_st(&sync[0], (uint32_t) landed); } }
-        MI_DRAIN(4) MI_DRAIN(3) MI_DRAIN(2) MI_DRAIN(1) MI_DRAIN(0)
-#undef MI_DRAIN
-        ST_STAMP(1);
-        return;
-    }
-
-    // ================= consumers =================
-    // ---- the activation image ----
+    if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
+    else if (nb <= 8)   st_prologue_f32<1, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
+    else if (nb <= 16)  st_prologue_f32<2, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
+    else if (nb <= 32)  st_prologue_f32<4, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
+    else                st_prologue_f32<8, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
     ST_STAMP(1);
-    if (mode == PRO_Q8) {
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-            const int q = threadIdx.x + i*ST_NC*64;
-            if (q < (p.k >> 4)) { const int ib = q >> 4, c = q & 15; *(int4v *) (act + (size_t) ib*ST_ACT_STRIDE + c*16) = areg[i]; }
-        }
-        if ((int) threadIdx.x < nb) {
-            const int ib = threadIdx.x;
-            uint32_t h32[2] = { 0, 0 }, l32[2] = { 0, 0 }, h16[4] = { 0, 0, 0, 0 }, l16[4] = { 0, 0, 0, 0 };
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const uint32_t wsum = (uint32_t)(j < 4 ? breg[0][j] : breg[1][j - 4]);
-                const int sa = (int)(int16_t)(wsum & 0xFFFF), sb = (int)(int16_t)(wsum >> 16);
-                int h, l;
-                st_hl(sa + sb, h, l); h32[j >> 2] |= (uint32_t)(h & 0xFF) << (8*(j & 3)); l32[j >> 2] |= (uint32_t)(l & 0xFF) << (8*(j & 3));
-                st_hl(sa, h, l); h16[j >> 1] |= (uint32_t)(h & 0xFF) << (8*((2*j) & 3)); l16[j >> 1] |= (uint32_t)(l & 0xFF) << (8*((2*j) & 3));
-                st_hl(sb, h, l); h16[j >> 1] |= (uint32_t)(h & 0xFF) << (8*((2*j + 1) & 3)); l16[j >> 1] |= (uint32_t)(l & 0xFF) << (8*((2*j + 1) & 3));
-            }
-            char * ab = act + (size_t) ib*ST_ACT_STRIDE;
-            *(int4v *) (ab + 256) = int4v{ (int) h32[0], (int) h32[1], (int) l32[0], (int) l32[1] };
-            *(int4v *) (ab + 272) = int4v{ (int) h16[0], (int) h16[1], (int) h16[2], (int) h16[3] };
-            *(int4v *) (ab + 288) = int4v{ (int) l16[0], (int) l16[1], (int) l16[2], (int) l16[3] };
-            dd[ib] = dreg;
-        }
-    } else {
-        float scale = 1.0f;
-        if (mode == PRO_NORM) {
-            float ss = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) if (wave + ST_NC*i < nchunk) ss += xv[i].x*xv[i].x + xv[i].y*xv[i].y + xv[i].z*xv[i].z + xv[i].w*xv[i].w;
-            ss = wave_sum(ss);
-            if (lane == 0) red[wave] = ss;
-            st_consumers_meet(&sync[4], lane);
-            ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-            scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
-        }
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const int c = wave + ST_NC*i;
-            if (c < nchunk) {
-                float4v v = xv[i];
-                if (mode == PRO_NORM) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
-                float d8; int bs16;
-                const uint32_t q4 = quant_frag_q8_K(v, d8, bs16);
-                char * ab = act + (size_t) c*ST_ACT_STRIDE;
-                *(uint32_t *) (ab + lane*4) = q4;
-                // the 16-element sum of quad q = lane >> 2 (valid in its four lanes); the 32-element sum j at lane 8j + 4 (row_shr:4 brings lane 8j's)
-                const int bs32 = bs16 + dpp_i<0x114>(bs16);
-                int h, l;
-                st_hl(bs16, h, l);
-                if ((lane & 3) == 0) { ab[272 + (lane >> 2)] = (char) h; ab[288 + (lane >> 2)] = (char) l; }
-                st_hl(bs32, h, l);
-                if ((lane & 7) == 4) { ab[256 + (lane >> 3)] = (char) h; ab[264 + (lane >> 3)] = (char) l; }
-                if (lane == 0) dd[c] = d8;
-            }
-        }
-    }
-    st_consumers_meet(&sync[2], lane);
+    st_consumers_meet(&sync[2], lane, seq);
     ST_STAMP(2);
 
     // ---- the epilogue's operands of this thread's first row / pair: requested now, needed after the last slot ----
@@ -423,7 +519,7 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
     const long long idx0 = g.st_mode == 1 ? g.st_idx[0] : 0;
     if (g.epi == EPI_ROPE) {
         const fused_rope & rp = p.rope;
-        const int pr = threadIdx.x, hd = rp.head_dim;
+        const int pr = ctid, hd = rp.head_dim;
         if (pr < (R >> 1)) {
             int ra, rb, ip;
             if (rp.neox) { const int hh = pr/(hd >> 1), i = pr - hh*(hd >> 1); ra = hh*hd + i; rb = ra + (hd >> 1); ip = i; }
@@ -432,17 +528,18 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
             if (ip < (rp.n_dims >> 1)) { e_c = rp.tab[2*ip]; e_s = rp.tab[2*ip + 1]; }
             if (g.st_mode == 2) { e_i0 = g.st_idx[r0 + ra]; e_i1 = g.st_idx[r0 + rb]; }
         }
-    } else if ((int) threadIdx.x < R) {
-        const int row = r0 + threadIdx.x;
-        if (g.epi == EPI_ADD) { e_r0 = g.res[row]; if (g.res2) e_q0 = g.res2[row]; }
+    } else if (ctid < R) {
+        const int row = r0 + ctid;
+        if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, row); if (g.res2) e_q0 = st_ldx1<CHAIN>(g.res2, row); }
         if (g.st_mode == 2) e_i0 = g.st_idx[row];
     }
 
     // ---- the stream ----
-    const uint32_t ring_a = st_lds_addr(ring);
     const uint32_t magic = p.magic;
     bool first = true;
+    int ring_i = (slot0 + wave) % S;
     for (int i = wave; i < nslots; i += ST_NC) {
+        const int gi = slot0 + i;
         const int si = GLU ? (i >= ns1) : 0, il = i - si*ns1;
         const int u = il*64 + lane;                              // unit inside the stream
         const bool live = u < n1;
@@ -450,13 +547,13 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
         const int ib = nb == 1 ? 0 : uc - (int) __umulhi((uint32_t) uc, magic)*nb;      // (the magic number of nb = 1 does not fit 32 bits)
         const char * ab = act + (size_t) ib*ST_ACT_STRIDE;
         const float d8 = dd[ib];
-        st_wait_ge(&sync[0], (uint32_t)(i + 1));
+        st_wait_ge(&sync[0], (uint32_t)(gi + 1));
         if (first) { ST_STAMP(3); first = false; }
-        const typename U::wfrag w = U::load(ring_a + (uint32_t)(i % S)*SLOT + (uint32_t)(live ? lane : 0)*U::UB);
-        if (nslots > S) {      // the slot is free as soon as its bytes are in registers
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            if (lane == 0) st_flag_st(&sync[16 + i % S], (uint32_t)(i + 1));
-        }
+        const typename U::wfrag w = U::load(L.ring_a + (uint32_t) ring_i*L.slot_stride + (uint32_t)(live ? lane : 0)*U::UB);
+        // the slot is free as soon as its bytes are in registers
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (lane == 0) st_flag_st(&sync[16 + ring_i], (uint32_t)(gi + 1));
+        ring_i += ST_NC; while (ring_i >= S) ring_i -= S;
         float res = U::dot(w, ab, d8);
         if (!live) res = 0.0f;
         if (row16) {
@@ -465,7 +562,7 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
         } else if (live) part[(size_t) si*n1 + u] = res;
     }
     ST_STAMP(4);
-    st_consumers_meet(&sync[3], lane);
+    st_consumers_meet(&sync[3], lane, 2*seq);
     ST_STAMP(5);
 
     // ---- rows: partials added in a fixed order, epilogue with a lane per row (or rotation pair) ----
@@ -473,12 +570,12 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
     if (g.epi == EPI_ROPE) {
         const fused_rope & rp = p.rope;
         const int hd = rp.head_dim, half = rp.n_dims >> 1;
-        for (int pr = threadIdx.x; pr < (R >> 1); pr += ST_NC*64) {
+        for (int pr = ctid; pr < (R >> 1); pr += ST_NC*64) {
             // the two rows of pair pr (local): NORM (2 pr, 2 pr + 1); NEOX: i and i + hd/2 inside one head (ralign = hd)
             int ra, rb, ip;
             if (rp.neox) { const int hh = pr/(hd >> 1), i = pr - hh*(hd >> 1); ra = hh*hd + i; rb = ra + (hd >> 1); ip = i; }
             else         { ra = 2*pr; rb = ra + 1; ip = ((r0 + ra) % hd) >> 1; }
-            if (pr != (int) threadIdx.x) {       // (not the prefetched pair: a workgroup with more than 1024 rotated rows)
+            if (pr != ctid) {       // (not the prefetched pair: a workgroup with more than 1024 rotated rows)
                 e_r0 = e_r1 = 0.0f; e_c = 1.0f; e_s = 0.0f;
                 if (g.res) { e_r0 = g.res[r0 + ra]; e_r1 = g.res[r0 + rb]; }
                 if (ip < half) { e_c = rp.tab[2*ip]; e_s = rp.tab[2*ip + 1]; }
@@ -487,16 +584,16 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
             float s0 = st_row_sum(part, ra, npr), s1 = st_row_sum(part, rb, npr);
             if (g.res) { s0 += e_r0; s1 += e_r1; }              // bias first, then the rotation
             if (ip < half) { const float a = s0, b = s1; s0 = a*e_c - b*e_s; s1 = a*e_s + b*e_c; }
-            g.dst[r0 + ra] = s0; g.dst[r0 + rb] = s1;
+            st_stx1<CHAIN>(g.dst, r0 + ra, s0); st_stx1<CHAIN>(g.dst, r0 + rb, s1);
             if (g.st_mode == 1) { uint16_t * q = g.st16 + idx0*g.st_row_elems; q[r0 + ra] = f32_to_f16_bits(s0); q[r0 + rb] = f32_to_f16_bits(s1); }
             else if (g.st_mode == 2) { g.st16[e_i0] = f32_to_f16_bits(s0); g.st16[e_i1] = f32_to_f16_bits(s1); }
         }
     } else {
-        for (int rr = threadIdx.x; rr < R; rr += ST_NC*64) {
+        for (int rr = ctid; rr < R; rr += ST_NC*64) {
             float s0 = st_row_sum(part, rr, npr);
             const int row = r0 + rr;
-            if (rr != (int) threadIdx.x) {
-                if (g.epi == EPI_ADD) { e_r0 = g.res[row]; e_q0 = g.res2 ? g.res2[row] : 0.0f; }
+            if (rr != ctid) {
+                if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, row); e_q0 = g.res2 ? st_ldx1<CHAIN>(g.res2, row) : 0.0f; }
                 if (g.st_mode == 2) e_i0 = g.st_idx[row];
             }
             if (GLU) {
@@ -511,7 +608,7 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
                 s0 += e_r0;
                 if (g.res2) s0 += e_q0;
             }
-            g.dst[row] = s0;
+            st_stx1<CHAIN>(g.dst, row, s0);
             if (g.st_mode == 1) g.st16[idx0*g.st_row_elems + row] = f32_to_f16_bits(s0);
             else if (g.st_mode == 2) g.st16[e_i0] = f32_to_f16_bits(s0);
         }
@@ -519,18 +616,133 @@ static __device__ __forceinline__ void st_body(const st_args & p, const st_group
     ST_STAMP(6);
 }
 
+// which group of the phase a workgroup belongs to
+static __device__ __forceinline__ int st_group_of(const st_args & p, int b, int & first, int & nwg) {
+    int gi = 0;
+#pragma unroll
+    for (int q = 0; q < MMVQ_MAX_GROUPS - 1; q++) if (b >= p.block_end[q]) gi = q + 1;
+    first = gi ? p.block_end[gi - 1] : 0; nwg = p.block_end[gi] - first;
+    return gi;
+}
+static __device__ __forceinline__ st_lds st_carve(char * lds, int nb_max, int npart_max, int slot_stride, int S) {
+    st_lds L;
+    L.sync = (uint32_t *) lds;
+    L.act = lds + 2*ST_SYNC_WORDS*4;
+    L.dd = (float *) (L.act + (size_t) nb_max*ST_ACT_STRIDE);
+    L.red = L.dd + ((nb_max + 3) & ~3);              // [2][ST_NC] sums of squares (PRO_NORM)
+    L.part = L.red + 16;
+    L.ring_a = st_lds_addr((char *) (((size_t)(L.part + npart_max) + 15) & ~(size_t) 15));
+    L.slot_stride = slot_stride; L.S = S;
+    return L;
+}
+
+static __device__ __forceinline__ int st_phase_slots(const st_args & a, const st_group & g, int wg, int nwg) {
+    int r0, R; st_rows(g, wg, nwg, r0, R);
+    const int ns1 = (R*a.nb + 63) >> 6;
+    return g.epi == EPI_GLU ? 2*ns1 : ns1;
+}
+
+// ---- one grouped launch ----
 template <int TA, int TB, bool NT>
 __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.x;
-    int gi = 0;
-#pragma unroll
-    for (int q = 0; q < MMVQ_MAX_GROUPS - 1; q++) if (b >= p.block_end[q]) gi = q + 1;
-    const int first = gi ? p.block_end[gi - 1] : 0, nwg = p.block_end[gi] - first;
+    int first, nwg;
+    const int gi = st_group_of(p, (int) blockIdx.x, first, nwg);
     const st_group & g = p.g[gi];
-    if (TA == TB || g.type == TA) st_body<TA, NT>(p, g, b - first, nwg, lds, lane, wave);
-    else                          st_body<TB, NT>(p, g, b - first, nwg, lds, lane, wave);
+    const int wg = (int) blockIdx.x - first;
+    const bool is_a = TA == TB || g.type == TA;
+    const st_lds L = st_carve(lds, p.nb, g.npart_max, ((64*(is_a ? st_unit<TA>::UB : st_unit<TB>::UB) + 1023)/1024)*1024, p.S);
+    unsigned long long * stamps = p.stamps;
+    ST_STAMP(0);
+    if (threadIdx.x < ST_SYNC_WORDS) L.sync[threadIdx.x] = 0;
+    if (wave == ST_NC) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0 };
+        if (is_a) st_loader_phase<TA, NT>(p, g, wg, nwg, L, 0, ls, lane);
+        else      st_loader_phase<TB, NT>(p, g, wg, nwg, L, 0, ls, lane);
+        st_loader_drain(L, st_phase_slots(p, g, wg, nwg), ls, lane);
+        ST_STAMP(1);
+        return;
+    }
+    int n_norm = 0;
+    if (is_a) st_consumer_phase<TA, false, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
+    else      st_consumer_phase<TB, false, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
+}
+
+// ---- a chain of grouped launches as one launch ----
+template <bool NT>
+__global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_chain(const st_phase * __restrict__ prog, const int n_phases, unsigned * ws, unsigned * err, const st_chain_cfg cfg, const st_chain_dbg dbg) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int b = blockIdx.x;
+    const st_lds L = st_carve(lds, cfg.nb_max, cfg.npart_max, cfg.slot_stride, cfg.S);
+    unsigned long long * stamps = dbg.stamps; (void) stamps;
+    ST_STAMP(0);
+    if (threadIdx.x < ST_SYNC_WORDS) L.sync[threadIdx.x] = 0;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();            // (the chain's first phase queues its activation loads behind this barrier: one barrier per wave, and the loader must not wait for consumers)
+    int slot0 = 0;
+    if (wave == ST_NC) {
+        st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0 };
+        for (int ph = 0; ph < n_phases; ph++) {
+            const st_phase & P = prog[ph];
+            if (b >= P.n_active) continue;
+            int first, nwg;
+            const int gi = st_group_of(P.a, b, first, nwg);
+            const st_group & g = P.a.g[gi];
+            const int wg = b - first;
+            if (g.type == T_Q4_K)      st_loader_phase<T_Q4_K, NT>(P.a, g, wg, nwg, L, slot0, ls, lane);
+            else if (g.type == T_Q5_K) st_loader_phase<T_Q5_K, NT>(P.a, g, wg, nwg, L, slot0, ls, lane);
+            else                       st_loader_phase<T_Q6_K, NT>(P.a, g, wg, nwg, L, slot0, ls, lane);
+            slot0 += st_phase_slots(P.a, g, wg, nwg);
+#ifdef MI_STAMPS
+            if (dbg.stamps) { stamps = dbg.stamps + (size_t) ph*256*(ST_NC + 1)*8; ST_STAMP(1); }      // this phase's slots are all issued
+#endif
+        }
+        st_loader_drain(L, slot0, ls, lane);
+        return;
+    }
+    int seq = 0, n_norm = 0;
+    for (int ph = 0; ph < n_phases; ph++) {
+        const st_phase & P = prog[ph];
+        if (b >= P.n_active) continue;
+        int first, nwg;
+        const int gi = st_group_of(P.a, b, first, nwg);
+        const st_group & g = P.a.g[gi];
+        const int wg = b - first;
+#ifdef MI_STAMPS
+        if (dbg.stamps) stamps = dbg.stamps + (size_t) ph*256*(ST_NC + 1)*8;
+        if (ph > 0) ST_STAMP(0);
+#endif
+        // ---- the inputs of this phase exist once every workgroup of the phase that makes them has arrived ----
+        if (P.wait_idx >= 0) {
+            if (wave == 0) {
+                bool ok = false;
+                const unsigned * wp = ws + (size_t) P.wait_idx*ST_WS_WORDS + (lane & 7)*64;
+                for (int spin = 0; spin < (1 << 22); spin++) {
+                    unsigned v = lane < 8 ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+                    v += dpp_i<0xB1>((int) v); v += dpp_i<0x4E>((int) v); v += dpp_i<0x141>((int) v);      // lanes 0..7 = half a DPP row
+                    if ((unsigned) __builtin_amdgcn_readfirstlane((int) v) >= P.wait_target) { ok = true; break; }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+                if (!ok && lane == 0) __hip_atomic_store(err, 0x57000000u | (unsigned) ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // gave up: the results are wrong, the host is told
+                asm volatile("" ::: "memory");
+                if (lane == 0) st_flag_st(&L.sync[5], (uint32_t)(seq + 1));
+            } else st_wait_ge(&L.sync[5], (uint32_t)(seq + 1));
+        }
+        if (g.type == T_Q4_K)      st_consumer_phase<T_Q4_K, true, false>(P.a, g, wg, nwg, L, slot0, seq, n_norm, lane, wave, stamps);
+        else if (g.type == T_Q5_K) st_consumer_phase<T_Q5_K, true, false>(P.a, g, wg, nwg, L, slot0, seq, n_norm, lane, wave, stamps);
+        else                       st_consumer_phase<T_Q6_K, true, false>(P.a, g, wg, nwg, L, slot0, seq, n_norm, lane, wave, stamps);
+        slot0 += st_phase_slots(P.a, g, wg, nwg);
+        // ---- this workgroup's rows are stored: drain, meet (which also frees the image and the partials for the next phase), arrive ----
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        st_consumers_meet(&L.sync[3], lane, 2*seq + 1);
+        ST_STAMP(7);
+        if (P.sig_idx >= 0 && threadIdx.x == 0) __hip_atomic_fetch_add(ws + (size_t) P.sig_idx*ST_WS_WORDS + (b & 7)*64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        seq++;
+    }
 }
 
 } // namespace mi355x

@@ -7,6 +7,7 @@
 #include "mmvq_stream.h"
 
 #include <limits.h>
+#include <string.h>
 #include <algorithm>
 
 namespace mi355x {
@@ -96,29 +97,29 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     return true;
 }
 
-void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
-                          hipEvent_t e0, hipEvent_t e1, const char ** kname) {
-    static int nt_env = -1, ring_env = -1;
-    if (nt_env < 0) { const char * e = getenv("GGML_MI355X_STREAM_NT"); nt_env = e ? atoi(e) : 1; const char * r = getenv("GGML_MI355X_STREAM_RING"); ring_env = r ? atoi(r) : 0; }
-    st_args a = {};
+// fills the phase descriptor of one grouped launch; returns the workgroups it uses. fixed: LDS bytes besides the ring; slot: bytes of a ring slot;
+// nslots: slots the busiest workgroup streams
+static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, st_args & a,
+                   size_t & fixed_max, int & slot_max, int & nslots_max, int & npart_max, int & ta, int & tb, double & bytes_total) {
+    a = st_args{};
     const int nb = (int)(k/256);
     a.n_groups = n_groups; a.k = (int) k; a.nb = nb; a.mode = in.mode; a.eps = in.eps;
-    a.magic = (uint32_t)((0x100000000ull + nb - 1)/nb);
+    a.magic = nb == 1 ? 0u : (uint32_t)((0x100000000ull + nb - 1)/nb);
     a.x = in.x; a.norm_w = in.norm_w;
     if (in.mode == PRO_Q8) { a.a_qs = in.act.qs; a.a_d = in.act.d; a.a_bs = in.act.bsums; }
     if (rope) a.rope = make_fused_rope(*rope);
 
     // workgroups per group: in proportion to the weight bytes, at least one each, never more than the group has row units
     const int budget = st_cu_count();
-    double bytes_total = 0; double gbytes[MMVQ_MAX_GROUPS];
-    int ta = groups[0].type, tb = groups[0].type;
+    bytes_total = 0; double gbytes[MMVQ_MAX_GROUPS];
+    ta = groups[0].type; tb = groups[0].type;
     for (int i = 0; i < n_groups; i++) {
         gbytes[i] = (double) groups[i].m*nb*st_unit_bytes(groups[i].type)*(groups[i].epi == EPI_GLU ? 2 : 1);
         bytes_total += gbytes[i];
         if (groups[i].type != ta) tb = groups[i].type;
     }
     if (tb < ta) std::swap(ta, tb);
-    int blocks = 0, slot_max = 0; size_t fixed_max = 0; int nslots_max = 0;
+    int blocks = 0; slot_max = 0; fixed_max = 0; nslots_max = 0; npart_max = 0;
     for (int i = 0; i < MMVQ_MAX_GROUPS; i++) a.block_end[i] = INT_MAX;
     int share[MMVQ_MAX_GROUPS], used = 0;
     for (int i = 0; i < n_groups; i++) {
@@ -148,7 +149,8 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
         const int Rmax = ((nru + sh - 1)/sh)*s.ralign + (g.m - (g.m/s.ralign)*s.ralign);
         const bool row16 = (nb & 15) == 0;
         s.npart_max = (row16 ? Rmax*(nb >> 4) : Rmax*nb)*(g.epi == EPI_GLU ? 2 : 1);
-        const size_t fixed = ST_SYNC_WORDS*4 + (size_t) nb*ST_ACT_STRIDE + (size_t)((nb + 3) & ~3)*4 + 64 + (size_t) s.npart_max*4 + 16;
+        npart_max = std::max(npart_max, s.npart_max);
+        const size_t fixed = 2*ST_SYNC_WORDS*4 + (size_t) nb*ST_ACT_STRIDE + (size_t)((nb + 3) & ~3)*4 + 64 + (size_t) s.npart_max*4 + 16;
         fixed_max = std::max(fixed_max, fixed);
         const int pps = (64*st_unit_bytes(g.type) + 1023)/1024;
         slot_max = std::max(slot_max, pps*1024);
@@ -156,6 +158,15 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
         blocks += sh;
         a.block_end[i] = blocks;
     }
+    return blocks;
+}
+
+void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
+                          hipEvent_t e0, hipEvent_t e1, const char ** kname) {
+    static int nt_env = -1, ring_env = -1;
+    if (nt_env < 0) { const char * e = getenv("GGML_MI355X_STREAM_NT"); nt_env = e ? atoi(e) : 1; const char * r = getenv("GGML_MI355X_STREAM_RING"); ring_env = r ? atoi(r) : 0; }
+    st_args a; size_t fixed_max; int slot_max, nslots_max, npart_max, ta, tb; double bytes_total;
+    const int blocks = st_fill(groups, n_groups, k, in, rope, a, fixed_max, slot_max, nslots_max, npart_max, ta, tb, bytes_total);
     int S = (int)((163840 - (int64_t) fixed_max)/slot_max);
     if (S > nslots_max) S = nslots_max;
     if (S > ST_MAX_RING) S = ST_MAX_RING;
@@ -181,6 +192,58 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
     else if (ta == T_Q4_K && tb == T_Q6_K) st_launch_t<T_Q4_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
     else if (ta == T_Q5_K && tb == T_Q6_K) st_launch_t<T_Q5_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
     else { fprintf(stderr, "mul_mat_vec_q_stream: type pair (%d, %d) has no kernel\n", ta, tb); abort(); }
+}
+
+// ---- chains (k_mmvq_chain) ----
+size_t mul_mat_vec_q_chain_phase_bytes(void) { return sizeof(st_phase); }
+int    mul_mat_vec_q_chain_ws_words(int n_phases) { return n_phases*ST_WS_WORDS; }
+
+// builds the phase table of `n` consecutive grouped launches (each one mul_mat_vec_q_stream_takes) into prog_host; false: they do not fit one launch
+bool mul_mat_vec_q_chain_build(const mmvq_chain_item * items, int n, void * prog_host, mmvq_chain_launch * out) {
+    st_phase * prog = (st_phase *) prog_host;
+    st_chain_cfg cfg = { 0, 0, 0, 0 };
+    int nslots_sum = 0, blocks_max = 0; uint64_t wbytes = 0;
+    for (int j = 0; j < n; j++) {
+        const mmvq_chain_item & it = items[j];
+        size_t fixed; int slot, nslots, npart, ta, tb; double bytes;
+        st_phase & P = prog[j];
+        const int blocks = st_fill(it.grp, it.n_groups, it.k, it.in, it.has_rope ? &it.rope : nullptr, P.a, fixed, slot, nslots, npart, ta, tb, bytes);
+        P.a.stamps = nullptr;
+        P.n_active = blocks;
+        P.wait_idx = j > 0 ? j - 1 : -1; P.wait_target = j > 0 ? (unsigned) prog[j - 1].n_active : 0;
+        P.sig_idx = j + 1 < n ? j : -1;
+        cfg.nb_max = std::max(cfg.nb_max, P.a.nb); cfg.npart_max = std::max(cfg.npart_max, npart); cfg.slot_stride = std::max(cfg.slot_stride, slot);
+        nslots_sum += nslots; blocks_max = std::max(blocks_max, blocks); wbytes += (uint64_t) bytes;
+    }
+    const size_t fixed = 2*ST_SYNC_WORDS*4 + (size_t) cfg.nb_max*ST_ACT_STRIDE + (size_t)((cfg.nb_max + 3) & ~3)*4 + 64 + (size_t) cfg.npart_max*4 + 16;
+    int S = (int)((163840 - (int64_t) fixed)/cfg.slot_stride);
+    if (S > nslots_sum) S = nslots_sum;
+    if (S > ST_MAX_RING) S = ST_MAX_RING;
+    if (S < (nslots_sum < 4 ? nslots_sum : 4)) return false;
+    cfg.S = S;
+    static_assert(sizeof(st_chain_cfg) == sizeof(out->cfg), "mmvq_chain_launch::cfg holds an st_chain_cfg");
+    memcpy(out->cfg, &cfg, sizeof(cfg));
+    out->n_phases = n; out->blocks = blocks_max; out->lds = fixed + (size_t) S*cfg.slot_stride; out->weight_bytes = wbytes;
+    return true;
+}
+
+void mul_mat_vec_q_chain_launch(const void * prog_dev, const mmvq_chain_launch & Lc, unsigned * ws, unsigned * err_dev, hipStream_t stream) {
+    static int nt_env = -1;
+    if (nt_env < 0) { const char * e = getenv("GGML_MI355X_STREAM_NT"); nt_env = e ? atoi(e) : 1; }
+    st_chain_cfg cfg; memcpy(&cfg, Lc.cfg, sizeof(cfg));
+    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_chain<true>);
+    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_chain<false>);
+    st_chain_dbg dbg = { nullptr };
+#ifdef MI_STAMPS
+    // each chained launch takes n_phases consecutive stamp slots (one per phase, [workgroup][wave][8] like the single launches)
+    if (g_st_stamps && g_st_next + Lc.n_phases <= g_st_slots && Lc.blocks <= 256) {
+        dbg.stamps = g_st_stamps + (size_t) g_st_next*256*(ST_NC + 1)*8;
+        for (int j = 0; j < Lc.n_phases; j++) { st_stamp_meta & sm = g_st_meta[g_st_next + j]; sm = st_stamp_meta{}; sm.blocks = Lc.blocks; sm.k = -1 - j; sm.mode = Lc.n_phases; }
+        g_st_next += Lc.n_phases;
+    }
+#endif
+    if (nt_env) hipLaunchKernelGGL((k_mmvq_chain<true>), dim3((unsigned) Lc.blocks), dim3(ST_THREADS), Lc.lds, stream, (const st_phase *) prog_dev, Lc.n_phases, ws, err_dev, cfg, dbg);
+    else        hipLaunchKernelGGL((k_mmvq_chain<false>), dim3((unsigned) Lc.blocks), dim3(ST_THREADS), Lc.lds, stream, (const st_phase *) prog_dev, Lc.n_phases, ws, err_dev, cfg, dbg);
 }
 
 } // namespace mi355x
