@@ -1071,7 +1071,7 @@ static const struct ggml_tensor * base_of(const struct ggml_tensor * t) {   // s
 //   that product is a mat-vec; if they all fit into this launch the norm is computed in the prologue (PRO_NORM).
 // Returns the index of the last node consumed (-1 = not fused).
 static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i);
-static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm, const struct ggml_tensor * normw, const mmvq_attn * attn = nullptr) {
+static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm, const struct ggml_tensor * normw) {
     struct ggml_tensor * n = g->nodes[i];
     if (!fusable_mmv(n)) return -1;
     bool mixed = false;     // groups of two activation formats in the launch
@@ -1196,11 +1196,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     bool view_ends_here = false;
     for (int q = 0; q < g->n_nodes; q++) if (g->nodes[q]->op == GGML_OP_MUL_MAT && g->nodes[q]->src[1] == b && q == g->n_nodes - 1) view_ends_here = true;
     const bool keep_norm = norm && (view_ends_here || strncmp(b->name, "result_norm", 11) == 0 || strncmp(b->name, "result_embd", 11) == 0);
-    if (attn) {
-        // the launch computes its own activation: the one-token attention whose output b is (try_fused_attn)
-        if (nc != 1 || mixed || !mul_mat_vec_q_fused_prologue_supported(K, kind) || K % 256 != 0 || grp[0].epi == EPI_GLU) return -1;
-        in.mode = PRO_ATTN; in.x = (const float *) b->data; in.attn = attn;
-    } else if (norm && !keep_norm && n_mm == n_uses(c, b) && mul_mat_vec_q_fused_prologue_supported(K, kind) && ((uintptr_t) normw->data % 16) == 0) {
+    if (norm && !keep_norm && n_mm == n_uses(c, b) && mul_mat_vec_q_fused_prologue_supported(K, kind) && ((uintptr_t) normw->data % 16) == 0) {
         in.mode = PRO_NORM; in.x = (const float *) norm->src[0]->data; in.norm_w = (const float *) normw->data; in.eps = op_f32(norm, 0);
     } else if (norm) {
         return -1;      // the caller runs the norm (+ quantization) as its own kernel, then comes back without `norm`
@@ -1331,8 +1327,6 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         c->cnt.kernels_launched++;
         return j3 - i + 1;
     }
-    // the mat-vec that reads the result next (wo) computes the attention itself in its first n_head workgroups (PRO_ATTN): no launch of its
-    // own, no launch boundary, and wo's weight stream starts while the heads are being computed. Short caches only (one workgroup per head).
     if (kq8) {
         rec_flush(c);
         const bool use_part = c->attn_part && attn_decode_part_bytes(hd, n_kv, n_head, T) <= c->attn_part_bytes;
@@ -1341,19 +1335,6 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                     hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream, true, use_part ? c->attn_part : nullptr, use_part ? c->attn_part_bytes : 0, true);
         c->cnt.kernels_launched++;
         return j3 - i + 1;
-    }
-    static const bool attn_in_wo = getenv("GGML_MI355X_ATTN_IN_WO") ? atoi(getenv("GGML_MI355X_ATTN_IN_WO")) != 0 : false;
-    if (attn_in_wo && !c->rec_on && !c->profiling && T == 1 && c->fin_cnt && attn_decode_supported(hd, n_kv) && n_kv <= 256 && is_internal(c, ct) &&
-        (!mask || mask->nb[0] == (mask->type == GGML_TYPE_F16 ? 2u : 4u))) {
-        const int jw = next_real(g, j3);
-        struct ggml_tensor * wo = jw > 0 ? g->nodes[jw] : nullptr;
-        if (wo && fusable_mmv(wo) && wo->src[1] == ct && n_uses(c, ct) == 1 && n_head <= 64 && wo->src[0]->ne[1]/16 >= n_head && true) {
-            mmvq_attn at = { (const char *) q->data, q->nb[2], (const char *) k->data, k->nb[1], k->nb[2], (const char *) v->data, v->nb[1], v->nb[2],
-                             mask ? (const char *) mask->data : nullptr, mask && mask->type == GGML_TYPE_F16 ? 1 : 0, sm->src[2] ? (const float *) sm->src[2]->data : nullptr,
-                             (int) n_kv, (int) n_head, (int) n_head_kv, (int) hd, op_f32(sm, 0), c->fin_cnt + mi_backend_ctx::FIN_COUNTERS };
-            const int l = try_fused_mmv(c, g, jw, nullptr, nullptr, &at);
-            if (l >= 0) { c->aq_fresh = false; return l - i + 1; }
-        }
     }
     {
         mi_backend_ctx::rec_item it = {};
@@ -2055,7 +2036,7 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
     }
     if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
         if (hipMalloc(&c->fin_img, mi_backend_ctx::FIN_IMG_BYTES) != hipSuccess) { (void) hipGetLastError(); c->fin_img = nullptr; }
-        if (c->fin_img && hipMalloc((void **) &c->fin_cnt, (mi_backend_ctx::FIN_COUNTERS + 8)*4) == hipSuccess) {      // + the two counters of the attention hand-off (PRO_ATTN)
+        if (c->fin_img && hipMalloc((void **) &c->fin_cnt, (mi_backend_ctx::FIN_COUNTERS + 8)*4) == hipSuccess) {
             MI_CHECK_G(hipMemsetAsync(c->fin_cnt, 0, (mi_backend_ctx::FIN_COUNTERS + 8)*4, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream));
         } else if (c->fin_img) { (void) hipGetLastError(); (void) hipFree(c->fin_img); c->fin_img = nullptr; c->fin_cnt = nullptr; }
     }

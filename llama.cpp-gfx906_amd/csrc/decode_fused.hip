@@ -216,7 +216,15 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
 
     // ---- scores: s[j] = scale * K[j].q + mask[j] ----
     const float * qp = (const float *) (p.q + (size_t) t*p.q_nb1 + (size_t) h*p.q_nb2) + sub*8;
-    const float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
+    float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
+    if (!KQ) {
+        // the no-flash-attention graph's K.q is MUL_MAT(F16 cache, F32 q): the CPU backend converts q to the F16 operand type first (vec_dot_type of
+        // F16, tests/test-quantize-fns.cpp:82-99) — followed here, so that the logits match the CPU reference and not just the exact product
+        // (round 3: 8192-position perplexity statistics put the f32-q kernel 1.4e-3 in ln PPL from the CPU arithmetic, all of it this rounding).
+        // FLASH_ATTN_EXT on the CPU converts q the same way (its K operand type), so both forms of the kernel do
+#define MI_R16(x_) x_ = f16_bits_to_f32(f32_to_f16_bits(x_))
+        MI_R16(q0.x); MI_R16(q0.y); MI_R16(q0.z); MI_R16(q0.w); MI_R16(q1.x); MI_R16(q1.y); MI_R16(q1.z); MI_R16(q1.w);
+    }
     const char * kbase = p.k + (size_t) hk*p.k_nb2 + (KQ ? (sub >> 2)*34 : sub*16) + (size_t) kv_lo*p.k_nb1;
     const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 + (size_t) kv_lo*(p.mask_f16 ? 2 : 4) : nullptr;
     // transposed V: the first 128 cells' worth of every lane's V rows is requested NOW, next to q and K — the soft_max in between does
@@ -274,7 +282,11 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     sum = block_sum4(sum, sh);
     if (p.sinks && !split) sum += expf(p.sinks[h] - mx);
     const float inv = sum > 0.0f ? 1.0f/sum : 0.0f;
-    for (int j = threadIdx.x; j < kv_n; j += 256) s[j] *= inv;   // the unfused SOFT_MAX normalises before V.p
+    // the unfused SOFT_MAX normalises before V.p; and V.p is MUL_MAT(F16 cache, F32 p): the CPU converts p to F16 like q above (one range only:
+    // a range of a split cache does not know the denominator yet)
+    // (p = e / sum, a division like the CPU's soft_max — not e * (1 / sum) — so that the value the f16 rounding sees is the CPU's)
+    if (VT && !split) { for (int j = threadIdx.x; j < kv_n; j += 256) { float pj = sum > 0.0f ? s[j]/sum : 0.0f; MI_R16(pj); s[j] = pj; } }
+    else for (int j = threadIdx.x; j < kv_n; j += 256) s[j] *= inv;
     __syncthreads();
     // where the result goes: the output row, or this range's slot of the partial buffer (+ its max and denominator)
     float * orow = split ? p.part + ((size_t)(t*p.n_head + h)*p.nsplit + blockIdx.z)*(HD + 2) : (float *) ((char *) p.dst + (size_t) t*p.dst_nb1) + (size_t) h*HD;

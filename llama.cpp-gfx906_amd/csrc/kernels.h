@@ -222,25 +222,12 @@ struct mmvq_rope { const int32_t * pos; const float * freq_factors; int head_dim
 void mul_mat_vec_q_fused_rope_table(const mmvq_rope & rope, float * table, hipStream_t stream);
 
 // where the activation vector comes from
-enum mmvq_prologue { PRO_Q8 = 0, PRO_QUANT = 1, PRO_NORM = 2, PRO_ATTN = 3 };
-// PRO_ATTN: the activation is the output of the one-token attention that precedes the mat-vec in the graph (build_attn_mha without flash
-// attention -> wo), and the launch computes it itself: workgroup h < n_head does head h (K.q, soft_max with mask / sink, V^T.p), stores its
-// head_dim results (write-through) and signals; every workgroup then waits for all heads, reads the vector and quantizes it as PRO_QUANT does.
-struct mmvq_attn {
-    const char * q; size_t q_nb2;                       // q [hd, 1, n_head] f32: head stride
-    const char * k; size_t k_nb1, k_nb2;                // k [hd, n_kv, n_head_kv] f16
-    const char * v; size_t v_nb1, v_nb2;                // v [n_kv, hd, n_head_kv] f16 (transposed cache)
-    const char * mask; int mask_f16;                    // row 0 of the mask [n_kv]
-    const float * sinks;
-    int n_kv, n_head, n_head_kv, head_dim; float scale;
-    unsigned * cnt;                                     // two zero-initialised words: heads done, workgroups past the wait (the last one re-arms both)
-};
+enum mmvq_prologue { PRO_Q8 = 0, PRO_QUANT = 1, PRO_NORM = 2 };
 struct mmvq_input {
     int mode;
     act_q8 act;            // PRO_Q8: one quantized column laid out by act_q8_carve(…, n = 1) (one contiguous image)
     const float * x;       // PRO_QUANT / PRO_NORM: the f32 vector (16-byte aligned, k % 256 == 0)
     const float * norm_w;  // PRO_NORM: y = (x * rsqrt(mean(x^2) + eps)) * norm_w, then quantized — RMS_NORM -> MUL folded in
-    const mmvq_attn * attn; // PRO_ATTN: x is where the attention output goes (and is read back from)
     float eps;
     int act_kind;
 };

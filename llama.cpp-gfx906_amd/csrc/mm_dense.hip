@@ -56,7 +56,9 @@ __global__ void __launch_bounds__(256) k_mm_dense(const mm_dense_args p) {
                     const int2v bv = ld_b64(b + (c0 + c)*p.nb11 + k*4);
                     // NB: __builtin_bit_cast on an ext-vector ELEMENT (bv.y) reads element 0 with this toolchain (ROCm 7.2 clang) — go through scalars
                     const int bx = bv.x, by = bv.y;
-                    acc[c] += a0*__int_as_float(bx) + a1*__int_as_float(by);
+                    // src1 is converted to src0's vec_dot_type first (F16), as the CPU backend's mat-mul does (tests/test-quantize-fns.cpp:82-99):
+                    // the fused decode attention (decode_fused.hip) follows the same rule, so fused and node-by-node execution agree
+                    acc[c] += a0*f16_bits_to_f32(f32_to_f16_bits(__int_as_float(bx))) + a1*f16_bits_to_f32(f32_to_f16_bits(__int_as_float(by)));
                 }
             }
         }
@@ -65,7 +67,11 @@ __global__ void __launch_bounds__(256) k_mm_dense(const mm_dense_args p) {
             const float av = ld_a(a + k*p.nb00, p.type_a);
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                if (c0 + c < p.ne11) acc[c] += av*ld_a(b + (c0 + c)*p.nb11 + k*p.nb10, p.type_b);
+                if (c0 + c < p.ne11) {
+                    float bv = ld_a(b + (c0 + c)*p.nb11 + k*p.nb10, p.type_b);
+                    if (p.type_a == T_F16 && p.type_b == T_F32) bv = f16_bits_to_f32(f32_to_f16_bits(bv));
+                    acc[c] += av*bv;
+                }
             }
         }
     }

@@ -63,7 +63,6 @@ struct fused_mmvq_args {
     // ---- end of the header ----
     fused_rope rope;
     mmvq_fin fin;                         // GLU launches: the producer quantizes its own output for the mat-vec that reads it next (kind == 0: off)
-    mmvq_attn at;                         // PRO_ATTN: the attention whose output is this launch's activation
     mmvq_group g[MMVQ_MAX_GROUPS];
 #ifdef MI_STAMPS
     unsigned long long * stamps;          // [workgroup][MI_STAMP_N] stamps (tools/stamp_timeline.py), NULL = off
@@ -295,93 +294,6 @@ static __device__ __forceinline__ void glu_flush8(const float (&hg)[8], const fl
     }
 }
 
-// ---- one-token attention for ONE head on an 8-wave workgroup (PRO_ATTN): decode_fused.hip's k_attn_decode (transposed V cache) restated
-//      for 512 threads: scores s[j] = scale*K[j].q + mask[j] in LDS, soft_max (with the sink), out[d] = V^T[d].p; the first 128 cells'
-//      V rows are requested at the start, beside q and K. Results leave with write-through stores (other workgroups read them next) ----
-static __device__ __forceinline__ float mi_dot8_f16_f32(const int4v kv, const float4v a, const float4v b) {
-    const uint32_t k0 = (uint32_t) kv.x, k1 = (uint32_t) kv.y, k2 = (uint32_t) kv.z, k3 = (uint32_t) kv.w;
-    float acc;
-    acc  = f16_bits_to_f32((uint16_t) k0)*a.x + f16_bits_to_f32((uint16_t)(k0 >> 16))*a.y;
-    acc += f16_bits_to_f32((uint16_t) k1)*a.z + f16_bits_to_f32((uint16_t)(k1 >> 16))*a.w;
-    acc += f16_bits_to_f32((uint16_t) k2)*b.x + f16_bits_to_f32((uint16_t)(k2 >> 16))*b.y;
-    acc += f16_bits_to_f32((uint16_t) k3)*b.z + f16_bits_to_f32((uint16_t)(k3 >> 16))*b.w;
-    return acc;
-}
-template <int HD>
-static __device__ __forceinline__ void attn_head_8w(const mmvq_attn & p, float * dst, int h, char * smem, int lane, int wave) {
-    constexpr int NW = 8, LPC = HD/8, CPW = 64/LPC, U = 4, NG = HD/32;
-    float * s = (float *) smem;                                           // [n_kv] scores -> probabilities
-    float * sh = (float *) (smem + (((size_t) p.n_kv*4 + 15) & ~(size_t) 15));   // [NW]
-    const int hk = h/(p.n_head/p.n_head_kv), n_kv = p.n_kv;
-    const int sub = lane % LPC, cw = lane / LPC, l16 = lane & 15, rw = lane >> 4;
-    const float * qp = (const float *) (p.q + (size_t) h*p.q_nb2) + sub*8;
-    const float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
-    const char * vbase = p.v + (size_t) hk*p.v_nb2 + (size_t)(wave*4 + rw)*p.v_nb1;      // V row d = g*32 + wave*4 + rw
-    const int nchunk = n_kv >> 3;
-    int4v vpre[NG];
-    {
-        const int c0 = min(l16, max(nchunk - 1, 0));
-#pragma unroll
-        for (int g = 0; g < NG; g++) vpre[g] = ld_b128(vbase + (size_t)(g*32)*p.v_nb1 + (size_t) c0*16);
-    }
-    const char * kbase = p.k + (size_t) hk*p.k_nb2 + sub*16;
-    float mx = p.sinks ? p.sinks[h] : -INFINITY;
-    for (int j0 = wave*CPW + cw; j0 < n_kv; j0 += NW*CPW*U) {
-        int4v kreg[U]; float mreg[U];
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int j = min(j0 + u*NW*CPW, n_kv - 1);
-            kreg[u] = *(const int4v *) (kbase + (size_t) j*p.k_nb1);
-            mreg[u] = 0.0f;
-            if (p.mask) mreg[u] = p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (p.mask + (size_t) j*2)) : *(const float *) (p.mask + (size_t) j*4);
-        }
-#pragma unroll
-        for (int u = 0; u < U; u++) {
-            const int j = j0 + u*NW*CPW;
-            float acc = mi_dot8_f16_f32(kreg[u], q0, q1);
-            acc += dpp_f<0xB1>(acc); acc += dpp_f<0x4E>(acc); acc += dpp_f<0x141>(acc);   // sum over the LPC lanes of the row
-            if (LPC == 16) acc += dpp_f<0x140>(acc);
-            if (j < n_kv) {
-                const float v = acc*p.scale + mreg[u];
-                if (sub == 0) s[j] = v;
-                mx = fmaxf(mx, v);
-            }
-        }
-    }
-    mx = wave_max(mx);
-    if (lane == 0) sh[wave] = mx;
-    __syncthreads();
-    mx = fmaxf(fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])), fmaxf(fmaxf(sh[4], sh[5]), fmaxf(sh[6], sh[7])));
-    __syncthreads();
-    float sum = 0.0f;
-    const float mxs = mx == -INFINITY ? 0.0f : mx;
-    for (int j = threadIdx.x; j < n_kv; j += NW*64) { const float e = expf(s[j] - mxs); s[j] = e; sum += e; }
-    sum = wave_sum(sum);
-    if (lane == 0) sh[wave] = sum;
-    __syncthreads();
-    sum = ((sh[0] + sh[1]) + (sh[2] + sh[3])) + ((sh[4] + sh[5]) + (sh[6] + sh[7]));
-    if (p.sinks) sum += expf(p.sinks[h] - mx);
-    const float inv = sum > 0.0f ? 1.0f/sum : 0.0f;
-    for (int j = threadIdx.x; j < n_kv; j += NW*64) s[j] *= inv;          // the unfused SOFT_MAX normalises before V.p
-    __syncthreads();
-    float acc[NG];
-#pragma unroll
-    for (int g = 0; g < NG; g++) acc[g] = 0.0f;
-    for (int c = l16; c < nchunk; c += 16) {
-        int4v vreg[NG];
-#pragma unroll
-        for (int g = 0; g < NG; g++) vreg[g] = c == l16 ? vpre[g] : ld_b128(vbase + (size_t)(g*32)*p.v_nb1 + (size_t) c*16);
-        const float4v p0 = *(const float4v *) (s + c*8), p1 = *(const float4v *) (s + c*8 + 4);
-#pragma unroll
-        for (int g = 0; g < NG; g++) acc[g] += mi_dot8_f16_f32(vreg[g], p0, p1);
-    }
-#pragma unroll
-    for (int g = 0; g < NG; g++) {
-        const float r = row16_sum(acc[g]);
-        if (l16 == 0) st_f32_sc1(dst + (size_t) h*HD + g*32 + wave*4 + rw, r);
-    }
-}
-
 //   PRO  : where the activation comes from (mmvq_prologue)
 //   NA   : PRO_Q8: 16-byte image chunks per thread; PRO_QUANT/PRO_NORM: 256-element chunks per wave (k <= NA*256*waves)
 //   D    : ring depth (2; 4 for the one-row GLU units and for long single-tensor streams)
@@ -412,7 +324,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
             const int idx = min((int) threadIdx.x + i*(FWT*64), sel.act_chunks - 1);
             areg[i] = *(const int4v *) (sel.act + (size_t) idx*16);
         }
-    } else if (PRO != PRO_ATTN) {
+    } else {
 #pragma unroll
         for (int i = 0; i < NA; i++) { xv[i] = *(const float4v *) (gx + MI_XOFF(i)); if (!MI_XLIVE(i)) xv[i] = float4v{ 0.0f, 0.0f, 0.0f, 0.0f }; }
     }
@@ -476,47 +388,10 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
     // either, so the D steps are not issued in one burst: one step now, the others between the phases of the prologue (FENCE keeps
     // the compiler from hoisting them back up). HBM then has work from the first 0.2 us on and the prologue math starts as soon as
     // the activation is there.
-    // (PRO_ATTN: the workgroups that compute a head first request q / K / V, not weights — loads return in request order)
-    const bool attn_producer = PRO == PRO_ATTN && (int) blockIdx.x < p.at.n_head;
-    if (!attn_producer) { MI_FETCH(0) }
+    { MI_FETCH(0) }
     MI_FENCE;
     pair_pre epre = pair_prefetch<GLU, EXT>(g, p.rope, sel.W, g_m, MI_ROW_A(p_cur), R > 1 ? MI_ROW_B(p_cur) : MI_ROW_A(p_cur), eid0);      // behind the first weight step: needed only after the pair's last dot
     MI_FENCE;
-
-    if constexpr (PRO == PRO_ATTN) {
-        // ---- the attention that produces this launch's activation (mmvq_attn): heads on the first n_head workgroups, then everybody waits ----
-        const mmvq_attn & at = p.at;
-        if (!attn_producer) { MI_FETCH(1) }
-        MI_FENCE;
-        if (attn_producer) {
-            if (at.head_dim == 128) attn_head_8w<128>(at, (float *) gx, (int) blockIdx.x, smem, lane, wave);
-            else                    attn_head_8w<64>(at, (float *) gx, (int) blockIdx.x, smem, lane, wave);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have left
-            __syncthreads();
-            if (threadIdx.x == 0) __hip_atomic_fetch_add(at.cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            MI_FETCH(0)
-            MI_FETCH(1)
-            MI_FENCE;
-        }
-        if (threadIdx.x == 0) {
-            // producers are the lowest workgroups of this launch (dispatched first, never waiting on anybody): the wait ends; bounded anyway
-            for (int spin = 0; spin < (1 << 22); spin++) {
-                if ((int) __hip_atomic_load(at.cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= at.n_head) break;
-                __builtin_amdgcn_s_sleep(2);
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NA; i++) { xv[i] = ld_f4_sc1(gx + MI_XOFF(i)); if (!MI_XLIVE(i)) xv[i] = float4v{ 0.0f, 0.0f, 0.0f, 0.0f }; }
-        if (threadIdx.x == 0) {      // the last workgroup past the wait re-arms both counters for the next launch
-            const unsigned old = __hip_atomic_fetch_add(at.cnt + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (old == gridDim.x - 1) {
-                __hip_atomic_store(at.cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(at.cnt + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        }
-        __syncthreads();       // the attention's LDS (scores) is free again: the image goes over it
-    }
 
     // ---- (3) prologue: build the quantized activation image in LDS ----
     // the image this workgroup BUILDS (PRO_QUANT / PRO_NORM) is laid out for its own group's activation format — a launch may mix K-quant
@@ -562,7 +437,7 @@ static __device__ __forceinline__ void fused_body(const fused_mmvq_args & p, con
         MI_FENCE;
         // the steps must be fetched in ring order: set d holds stream step d
         if constexpr (PRO == PRO_QUANT && D > 1) { MI_FETCH(1) }
-        else if constexpr (D > 2 && PRO != PRO_ATTN) { MI_FETCH(2) }
+        else if constexpr (D > 2) { MI_FETCH(2) }
         MI_FENCE;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
@@ -723,11 +598,6 @@ void NAME_(const fused_launch & L, hipStream_t stream) { \
     const bool deep = L.deep; \
     constexpr int FW = 8; \
     if (L.fw == 16) { MI_FLX((TA_, TB_, false, PRO_NORM, 1, 2), 16, grid, dim3(1024), lds, stream, a); return; } \
-    if (mode == PRO_ATTN) { \
-        if (na == 2) MI_FLX((TA_, TB_, false, PRO_ATTN, 2, 2), 8, grid, dim3(FW*64), lds, stream, a); \
-        else         MI_FLX((TA_, TB_, false, PRO_ATTN, 8, 2), 8, grid, dim3(FW*64), lds, stream, a); \
-        return; \
-    } \
     if (HAS_GLU_ && L.glu) {     /* one-row units: 4 steps = the bytes 2 steps of pairs held */ \
         if (mode == PRO_Q8) { \
             if (na == 1)      MI_FL((TA_, TB_, HAS_GLU_, PRO_Q8, 1, 4), grid, dim3(FW*64), lds, stream, a); \

@@ -181,10 +181,6 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         }
     } else {
         a.x = in.x; a.norm_w = in.norm_w; a.eps = in.eps;
-        if (in.mode == PRO_ATTN) {
-            if (!in.attn || FW != 8 || in.attn->n_head > blocks) { fprintf(stderr, "mul_mat_vec_q_fused: PRO_ATTN needs an 8-wave launch with at least n_head workgroups\n"); abort(); }
-            a.at = *in.attn;
-        }
     }
     a.pos = nullptr;
     if (rope) {
@@ -201,7 +197,6 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         }
     }
     size_t lds = img_max + 64 + 64;           // + FW floats for the RMS reduction + the finaliser's chunk list
-    if (in.mode == PRO_ATTN) lds = std::max(lds, (((size_t) in.attn->n_kv*4 + 15) & ~(size_t) 15) + 64);     // the scores of a head + 8 floats
     int ta = groups[0].type, tb = groups[0].type;
     for (int i = 1; i < n_groups; i++) if (groups[i].type != ta) tb = groups[i].type;
     if (tb < ta) { const int t = ta; ta = tb; tb = t; }
@@ -234,7 +229,7 @@ static fused_launch fused_prepare(const mmvq_group * groups, int n_groups, int64
         const int64_t it = kd == T_Q8_0 ? (nblk + 63)/64 : (nblk + 7)/8;      // <= the steps per row pair of every type
         if (per_wave*it > max_steps) max_steps = per_wave*it;
     }
-    const bool deep = mode == PRO_ATTN ? false : (depth_env ? depth_env > 2 : max_steps >= 16);
+    const bool deep = depth_env ? depth_env > 2 : max_steps >= 16;
     L.ext = false;      // does any group need the extended epilogue
     for (int i = 0; i < n_groups; i++)
         if ((groups[i].epi == EPI_ROPE && (groups[i].res || (rope && (rope->p.mode & 2)))) || groups[i].res2 || groups[i].res_eid) L.ext = true;

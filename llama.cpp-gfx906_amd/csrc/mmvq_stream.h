@@ -643,13 +643,16 @@ static __device__ __forceinline__ int st_phase_slots(const st_args & a, const st
 }
 
 // ---- one grouped launch ----
-template <int TA, int TB, bool NT>
+// GLU (compile-time, single-group launches only): the gate/up/SwiGLU launch — the dominant kernel of a decode step — is an instantiation
+// of its own, so that kernel traces (rocprofv3) tell it from the other mat-vecs of the same weight format
+template <int TA, int TB, bool NT, bool GLU>
 __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int first, nwg;
     const int gi = st_group_of(p, (int) blockIdx.x, first, nwg);
     const st_group & g = p.g[gi];
+    __builtin_assume((g.epi == EPI_GLU) == GLU);
     const int wg = (int) blockIdx.x - first;
     const bool is_a = TA == TB || g.type == TA;
     const st_lds L = st_carve(lds, p.nb, g.npart_max, ((64*(is_a ? st_unit<TA>::UB : st_unit<TB>::UB) + 1023)/1024)*1024, p.S);

@@ -12,18 +12,18 @@
 
 namespace mi355x {
 
-template <int TA, int TB> static void st_launch_t(const st_args & a, int blocks, size_t lds, bool nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, const char ** kname) {
+template <int TA, int TB, bool GLU> static void st_launch_t(const st_args & a, int blocks, size_t lds, bool nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, const char ** kname) {
     static char name_nt[64] = "", name_pl[64] = "";
-    if (!name_nt[0]) { snprintf(name_nt, sizeof(name_nt), "k_mmvq_stream<%d, %d, true>", TA, TB); snprintf(name_pl, sizeof(name_pl), "k_mmvq_stream<%d, %d, false>", TA, TB); }
+    if (!name_nt[0]) { snprintf(name_nt, sizeof(name_nt), "k_mmvq_stream<%d, %d, true, %s>", TA, TB, GLU ? "true" : "false"); snprintf(name_pl, sizeof(name_pl), "k_mmvq_stream<%d, %d, false, %s>", TA, TB, GLU ? "true" : "false"); }
     *kname = nt ? name_nt : name_pl;
-    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, true>);
-    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, false>);
+    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, true, GLU>);
+    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, false, GLU>);
     if (e0) {
-        if (nt) hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, true>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
-        else    hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, false>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
+        if (nt) hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, true, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
+        else    hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, false, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
     } else {
-        if (nt) hipLaunchKernelGGL((k_mmvq_stream<TA, TB, true>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
-        else    hipLaunchKernelGGL((k_mmvq_stream<TA, TB, false>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
+        if (nt) hipLaunchKernelGGL((k_mmvq_stream<TA, TB, true, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
+        else    hipLaunchKernelGGL((k_mmvq_stream<TA, TB, false, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
     }
 }
 
@@ -185,12 +185,13 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
     }
 #endif
     const bool nt = nt_env != 0;
-    if (ta == T_Q4_K && tb == T_Q4_K) st_launch_t<T_Q4_K, T_Q4_K>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q5_K && tb == T_Q5_K) st_launch_t<T_Q5_K, T_Q5_K>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q6_K && tb == T_Q6_K) st_launch_t<T_Q6_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q4_K && tb == T_Q5_K) st_launch_t<T_Q4_K, T_Q5_K>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q4_K && tb == T_Q6_K) st_launch_t<T_Q4_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q5_K && tb == T_Q6_K) st_launch_t<T_Q5_K, T_Q6_K>(a, blocks, lds, nt, stream, e0, e1, kname);
+    const bool glu = groups[0].epi == EPI_GLU;
+    if (ta == T_Q4_K && tb == T_Q4_K)      { if (glu) st_launch_t<T_Q4_K, T_Q4_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q4_K, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == T_Q5_K && tb == T_Q5_K) { if (glu) st_launch_t<T_Q5_K, T_Q5_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q5_K, T_Q5_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == T_Q6_K && tb == T_Q6_K) { if (glu) st_launch_t<T_Q6_K, T_Q6_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q6_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == T_Q4_K && tb == T_Q5_K) st_launch_t<T_Q4_K, T_Q5_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q4_K && tb == T_Q6_K) st_launch_t<T_Q4_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q5_K && tb == T_Q6_K) st_launch_t<T_Q5_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
     else { fprintf(stderr, "mul_mat_vec_q_stream: type pair (%d, %d) has no kernel\n", ta, tb); abort(); }
 }
 

@@ -85,3 +85,22 @@ def run_steps(transport: Transport, n_steps: int, stage_fn: Callable[[int, int, 
             transport.send(j)
     transport.flush()
     return n_steps
+
+
+def run_chain_steps(transport: Transport, n_steps: int, stage_fn: Callable[[int, int, bool], None], token_done: Callable[[int], None]):
+    """llama-bench's own `-sm layer` protocol (tools/llama-bench/llama-bench.cpp:1791-1810): ONE sequence, one llama_decode per token followed by
+    llama_synchronize — token j + 1 does not start before token j has passed the last stage. Every rank runs n_steps local steps on sequence 0;
+    token_done(j) is the per-token synchronisation: the last rank reports (a 1-element message to rank 0), rank 0 blocks on it, the ranks in
+    between do nothing (they block on their next receive anyway). Tokens/s of this loop is the single-sequence chain rate: a sequential chain
+    through the G stages, so it does not grow with G."""
+    r, G = transport.rank, transport.world
+    for j in range(n_steps):
+        if r > 0:
+            transport.post_recv(j)
+            transport.wait_recv(j)
+        stage_fn(0, j, r > 0)
+        if r < G - 1:
+            transport.send(j)
+        token_done(j)
+    transport.flush()
+    return n_steps

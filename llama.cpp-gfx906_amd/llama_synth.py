@@ -65,6 +65,11 @@ MODELS = {
     # Q5_K bump of attn_v, layer 1 the use_more_bits Q6_K) with a small vocabulary
     "llama3-70b-2l": dict(n_embd=8192, n_ff=28672, n_layer=2, n_head=64, n_head_kv=8, n_embd_head=128, n_vocab=512,
                           rope_freq_base=500000.0, n_ctx_orig=8192, is_70b=1),
+    # the perplexity-statistics model: wide enough that ONE flipped int8 rounding in an activation block is a small perturbation (the 256-wide
+    # models amplify such flips into 1e-4 of KL divergence between two implementations of the same arithmetic), small enough that the oracle
+    # evaluates 8192 positions twice in about a minute
+    "mid-1k": dict(n_embd=1024, n_ff=2816, n_layer=2, n_head=8, n_head_kv=2, n_embd_head=128, n_vocab=512,
+                   rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),
     # small model for graph-level parity tests (oracle finishes in seconds)
     "tiny": dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=512,
                  rope_freq_base=10000.0, n_ctx_orig=256, is_70b=0),

@@ -227,3 +227,132 @@ def logit_parity(m, gg, n_seq=8, seq_len=128, modes=("cpu", "cpu16", "exact"), s
             "delta_ln_ppl": dn, "delta_ln_ppl_se": se_dn, "ln_ppl_base": float(a[:, 4].mean()),
             "rms_dp_next": float(np.sqrt(np.mean(a[:, 5]**2))), "top1_agree": float(a[:, 6].mean())}
     return out
+
+
+class RefLlamaStreams:
+    """RefLlama for S INDEPENDENT token streams advanced in lockstep (one token per stream per call, every stream at the same position): the
+    same arithmetic, step for step (tests/test_oracle_golden.py holds it equal to S separate RefLlama instances), but the mat-muls take all S
+    columns in one call and the attention is one einsum per layer instead of S * n_head small products — the perplexity statistics evaluate
+    tens of thousands of positions (logit_parity_peaked), which S separate numpy models cannot do in the time a test has. Plain llama
+    architecture with an f16 cache only (no experts, sinks, sliding windows, quantized cache)."""
+
+    def __init__(self, cfg, W, n_streams, kv_size, mode):
+        assert cfg.get("arch", 0) == 0 and cfg.get("n_expert", 0) == 0 and not cfg.get("type_k", 0)
+        self.f16_attn = mode == "cpu16"
+        self.mode = "cpu" if mode == "cpu16" else mode
+        self.c, self.W, self.S = cfg, W, n_streams
+        hd, hkv = cfg["n_embd_head"], cfg["n_head_kv"]
+        self.k = np.zeros((cfg["n_layer"], n_streams, kv_size, hkv, hd), np.float16)
+        self.v = np.zeros((cfg["n_layer"], n_streams, kv_size, hkv, hd), np.float16)
+        self.n_past = 0
+
+    def decode(self, emb):
+        """emb [S, n_embd]: the next token of every stream; returns logits [S, n_vocab]"""
+        c, W, S = self.c, self.W, self.S
+        hd, nh, hkv = c["n_embd_head"], c["n_head"], c["n_head_kv"]
+        g = nh // hkv
+        t = self.n_past
+        pos = np.full(S, t, np.int32)
+        x = emb.astype(np.float32)
+        for il in range(c["n_layer"]):
+            h = (ref.rms_norm(x, 1e-5) * W[(il, "attn_norm")][1]).astype(np.float32)
+            q = mm(W, (il, "attn_q"), h, self.mode); k = mm(W, (il, "attn_k"), h, self.mode); v = mm(W, (il, "attn_v"), h, self.mode)
+            q = ref.rope(q.reshape(1, S, nh, hd), pos, hd, c.get("rope_type", 0), c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
+            k = ref.rope(k.reshape(1, S, hkv, hd), pos, hd, c.get("rope_type", 0), c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
+            self.k[il, :, t] = k.astype(np.float16); self.v[il, :, t] = v.reshape(S, hkv, hd).astype(np.float16)
+            K = self.k[il, :, :t + 1].astype(np.float64); V = self.v[il, :, :t + 1].astype(np.float64)       # [S, T, hkv, hd]
+            qh = (q.astype(np.float16) if self.f16_attn else q).astype(np.float64).reshape(S, hkv, g, hd)
+            sc = np.einsum("skgd,stkd->skgt", qh, K).astype(np.float32).astype(np.float64) / np.sqrt(hd)     # kq as an f32 result, then the scale
+            mx = sc.max(-1, keepdims=True)
+            p = np.exp(sc - mx); p = (p / p.sum(-1, keepdims=True)).astype(np.float32)
+            if self.f16_attn:
+                p = p.astype(np.float16).astype(np.float32)
+            out = np.einsum("skgt,stkd->skgd", p.astype(np.float64), V).astype(np.float32).reshape(S, nh*hd)
+            ffn_inp = mm(W, (il, "attn_output"), out, self.mode) + x
+            h = (ref.rms_norm(ffn_inp, 1e-5) * W[(il, "ffn_norm")][1]).astype(np.float32)
+            up = mm(W, (il, "ffn_up"), h, self.mode); gate = mm(W, (il, "ffn_gate"), h, self.mode)
+            act = ref.swiglu(gate, up).astype(np.float32)
+            x = mm(W, (il, "ffn_down"), act, self.mode) + ffn_inp
+        h = (ref.rms_norm(x, 1e-5) * W["output_norm"][1]).astype(np.float32)
+        self.n_past += 1
+        return mm(W, "output", h, self.mode)
+
+
+def logit_parity_peaked(m, gg, n_seq=64, seq_len=128, target_ppl=8.0, base="cpu16", others=("cpu",), seed=78, W=None, progress=None):
+    """The same statistics on a model WITH STRUCTURE (a random-init model scores every token at chance level, PPL ~ n_vocab, the least
+    sensitive probe there is). Two changes make the evaluation behave like a perplexity run of a trained model on real text
+    (tools/perplexity/perplexity.cpp:541-642):
+      * the lm_head is scaled by a scalar s (applied to the logits of every evaluator alike, which is the same thing), chosen once so that the
+        reference model is confident: its perplexity on its own text is ~target_ppl instead of ~n_vocab;
+      * the text is what the REFERENCE model (oracle mode `base` = the CPU backend's arithmetic) generates itself: token t + 1 is sampled from
+        its softmax(s * logits_t). A model evaluated on its own samples has ln PPL = its entropy, so the reference is well calibrated on the
+        text, and a backend whose logits differ pays for it in the next-token likelihood of tokens that matter (the likely ones).
+    Decode path only (one token per step, the kernels tg128 runs on). Returns, per evaluator, the paired statistics against `base`."""
+    W = W if W is not None else read_weights(m, gg)
+    nv = m.cfg["n_vocab"]
+    rng = np.random.default_rng(seed)
+
+    def lsm(z):
+        z = z.astype(np.float64); z = z - z.max()
+        return z - np.log(np.exp(z).sum())
+
+    # the scale: on a short random-token stream, the s at which the reference's mean entropy is ln(target_ppl)
+    cal = RefLlama(m.cfg, W, 72, base)
+    cl = [cal.decode(np.stack([m.embedding(int(t))])) for t in rng.integers(0, nv, size=64)]
+    def mean_entropy(sc):
+        return float(np.mean([-(np.exp(lsm(l*sc))*lsm(l*sc)).sum() for l in cl]))
+    lo, hi = 0.05, 200.0
+    for _ in range(40):
+        mid = np.sqrt(lo*hi)
+        if mean_entropy(mid) > np.log(target_ppl): lo = mid
+        else: hi = mid
+    scale = float(np.sqrt(lo*hi))
+
+    rows = {k: [] for k in ("backend",) + tuple(others)}
+    # the streams advance in lockstep, `batch` of them at a time: one oracle step serves a whole batch (RefLlamaStreams), the backend decodes
+    # each stream's token in its own sequence of the model's cache when it has that many (n_seq_max), else stream after stream
+    n_slot = getattr(m, "n_seq_max", 1)
+    batch = min(n_seq, 64)
+    for b0 in range(0, n_seq, batch):
+        nb_ = min(batch, n_seq - b0)
+        refs = {k: RefLlamaStreams(m.cfg, W, nb_, seq_len + 8, k) for k in (base,) + tuple(others)}
+        toks = rng.integers(0, nv, size=nb_).astype(np.int64)
+        hist = [[int(toks[i])] for i in range(nb_)]
+        blg = np.zeros((nb_, seq_len, nv), np.float32); nxts = np.zeros((nb_, seq_len), np.int64)
+        lcs_all = {k: np.zeros((nb_, seq_len, nv), np.float32) for k in refs}
+        for t in range(seq_len):
+            emb = np.stack([m.embedding(int(tk)) for tk in toks])
+            lcs = {k: refs[k].decode(emb) for k in refs}
+            for k in refs:
+                lcs_all[k][:, t] = lcs[k]
+            nxt = np.zeros(nb_, np.int64)
+            for i in range(nb_):
+                lpb = lsm(lcs[base][i]*scale)
+                nxt[i] = int(rng.choice(nv, p=np.exp(lpb)))              # the reference model writes the text
+            nxts[:, t] = nxt
+            toks = nxt
+            for i in range(nb_):
+                hist[i].append(int(nxt[i]))
+        # the backend: every stream token by token through the decode kernels (its own cache, cleared per stream)
+        for i in range(nb_):
+            m.kv_clear()
+            for t in range(seq_len):
+                blg[i, t] = m.decode([hist[i][t]])
+        for i in range(nb_):
+            for t in range(seq_len):
+                lpb = lsm(lcs_all[base][i, t]*scale); pb = np.exp(lpb); nxt = int(nxts[i, t])
+                for name, l in (("backend", blg[i, t]),) + tuple((k, lcs_all[k][i, t]) for k in others):
+                    lpo = lsm(l*scale)
+                    rows[name].append((float((pb*(lpb - lpo)).sum()), float(-lpo[nxt]), float(-lpb[nxt]), int(np.argmax(l) == np.argmax(lcs_all[base][i, t])),
+                                       float(np.sqrt(np.mean((l.astype(np.float64) - lcs_all[base][i, t].astype(np.float64))**2))*scale)))
+        if progress:
+            progress(min(b0 + batch, n_seq), n_seq)
+    m.kv_clear()
+    out = {"positions": n_seq*seq_len, "sequences": n_seq, "seq_len": seq_len, "logit_scale": scale, "base": base, "target_ppl": target_ppl}
+    for name, r in rows.items():
+        a = np.array(r, np.float64)
+        kl, se_kl = _mean_se(a[:, 0]); dn, se_dn = _mean_se(a[:, 1] - a[:, 2])
+        out[name] = {"positions": int(len(a)), "kl_mean": kl, "kl_se": se_kl, "delta_ln_ppl": dn, "delta_ln_ppl_se": se_dn,
+                     "ln_ppl_base": float(a[:, 2].mean()), "ppl_base": float(np.exp(a[:, 2].mean())), "top1_agree": float(a[:, 3].mean()),
+                     "rms_dlogit_scaled_mean": float(a[:, 4].mean())}
+    return out

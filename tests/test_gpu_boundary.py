@@ -146,7 +146,7 @@ def test_cpy_tensor_async_between_two_backends_on_one_device():
 def test_cpy_tensor_async_between_two_devices():
     L = gg.base()
     if L.ggml_backend_reg_dev_count(backend().reg) < 2:
-        pytest.skip("one MI355X visible: the xGMI peer copy needs two")
+        pytest.skip("one MI355X visible here: tests/test_gpu_inproc_layer_split.py runs this copy between two devices of a GGML_MI355X_VIRTUAL_DEVICES=2 registry")
     b = gg.Backend(1)
     _copy_between(backend(), b); _copy_between(b, backend())
     b.free()

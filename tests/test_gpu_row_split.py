@@ -112,7 +112,7 @@ def worker():
             m = ls.SynthLlama(be, "tiny", ftype, n_ctx=64, seed=3, row_split=rs)
             try:
                 if rs:
-                    rc = ref_llama.RefLlama(m.cfg, ref_llama.read_weights(m, gg), 64, "cpu")
+                    rc = ref_llama.RefLlama(m.cfg, ref_llama.read_weights(m, gg), 64, "cpu16")
                 res = []
                 tight = True            # until a > 8-token prompt pass has gone through the bf16 matrix-core kernels (their K / V rows stay in the cache)
                 be.reset_counters()
@@ -122,7 +122,7 @@ def worker():
                     if rs:
                         exp = rc.decode(np.stack([m.embedding(t) for t in toks]))
                         tight = tight and len(toks) <= 8
-                        assert orc.nmse(exp, got) <= (5e-4 if tight else 2e-3), (ftype, toks, orc.nmse(exp, got))
+                        assert orc.nmse(exp, got) <= (1e-3 if tight else 2e-3), (ftype, toks, orc.nmse(exp, got))
                 cnt = be.counters()
                 assert cnt["split_mul_mats"] == (6*(2*7 + 1) if rs else 0), cnt["split_mul_mats"]
                 if rs:

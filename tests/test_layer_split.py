@@ -102,3 +102,73 @@ def test_pipelined_handoff_matches_single_process_chain(world):
             x = a * x + b + np.float32(state[r][seq])
             state[r][seq] += 1
         assert np.array_equal(x, y), (j, seq)
+
+
+def _chain_worker(rank, world, port, n_steps, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    lsp_ = graft_pkg.load().layer_split
+    a, b = _stage_params(rank)
+    recv = [torch.zeros(8) for _ in range(lsp_.N_BUF)]; send = [torch.zeros(8) for _ in range(lsp_.N_BUF)]
+    rw = [None] * lsp_.N_BUF; sw = [None] * lsp_.N_BUF
+    outs, order = [], []
+    state = [0]
+    ack = torch.zeros(1)
+
+    def post_recv(j): rw[j % lsp_.N_BUF] = dist.irecv(recv[j % lsp_.N_BUF], src=rank - 1)
+    def wait_recv(j): rw[j % lsp_.N_BUF].wait()
+    def send_(j): sw[j % lsp_.N_BUF] = dist.isend(send[j % lsp_.N_BUF], dst=rank + 1)
+    def flush():
+        for w in sw:
+            if w is not None: w.wait()
+
+    def stage(seq, j, has_input):
+        bi = j % lsp_.N_BUF
+        if sw[bi] is not None:
+            sw[bi].wait(); sw[bi] = None
+        x = recv[bi].numpy().copy() if has_input else np.full(8, float(state[0]), np.float32)
+        y = a * x + b + np.float32(state[0])
+        state[0] += 1
+        order.append(("stage", j))
+        if rank < world - 1:
+            send[bi].copy_(torch.from_numpy(y))
+        else:
+            outs.append(y.copy())
+
+    def token_done(j):
+        if rank == world - 1:
+            ack[0] = float(j); dist.send(ack, dst=0)
+        elif rank == 0:
+            dist.recv(ack, src=world - 1)
+            assert int(ack[0]) == j                       # token j is through the last stage before rank 0 starts token j + 1
+            order.append(("done", j))
+    done = lsp_.run_chain_steps(lsp_.Transport(rank, world, post_recv, wait_recv, send_, flush), n_steps, stage, token_done)
+    dist.barrier()
+    q.put((rank, done, outs, order))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_single_sequence_chain_is_token_by_token(world):
+    """llama-bench's own -sm layer protocol (tools/llama-bench/llama-bench.cpp:1791-1810; bench.py `single_sequence_chain_tok_s`): one sequence,
+    rank 0 does not start token j + 1 before the last stage has finished token j; the results equal the single-process chain."""
+    n_steps = 7
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_chain_worker, args=(r, world, port, n_steps, q)) for r in range(world)]
+    for p in procs: p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs: p.join(timeout=60)
+    assert all(p.exitcode == 0 for p in procs)
+    res = {r: (d, o, od) for r, d, o, od in res}
+    assert all(res[r][0] == n_steps for r in range(world))
+    assert res[0][2] == [e for j in range(n_steps) for e in (("stage", j), ("done", j))]      # strictly alternating on rank 0
+    outs = res[world - 1][1]
+    assert len(outs) == n_steps
+    for j, y in enumerate(outs):
+        x = np.full(8, float(j), np.float32)
+        for r in range(world):
+            a, b = _stage_params(r)
+            x = a * x + b + np.float32(j)
+        assert np.array_equal(x, y), j

@@ -109,3 +109,29 @@ def test_avx2_dot_is_bit_identical_to_the_scalar_restatement(tname):
         finally:
             orc.set_simd(True)
         assert np.array_equal(ref.view(np.uint32), got.view(np.uint32)), (tname, k)
+
+
+def test_streams_oracle_equals_single_stream_oracle():
+    """oracle/ref_llama.py: RefLlamaStreams (S independent streams in lockstep, used by the perplexity statistics) is the SAME arithmetic as S
+    instances of RefLlama — bit for bit, in every mode — on a small random model."""
+    import ref_llama
+    rng = np.random.default_rng(5)
+    cfg = dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=96, rope_freq_base=10000.0, n_ctx_orig=256)
+    ne, nff, hd, nh, nkv, nv = cfg["n_embd"], cfg["n_ff"], cfg["n_embd_head"], cfg["n_head"], cfg["n_head_kv"], cfg["n_vocab"]
+    rb = lambda qt, m, k: orc.random_blocks(rng, qt, (m,), k, scale=1.0/np.sqrt(k))
+    W = {}
+    for il in range(cfg["n_layer"]):
+        W[(il, "attn_norm")] = (0, rng.uniform(0.5, 1.5, ne).astype(np.float32)); W[(il, "ffn_norm")] = (0, rng.uniform(0.5, 1.5, ne).astype(np.float32))
+        W[(il, "attn_q")] = (orc.Q4_K, rb(orc.Q4_K, nh*hd, ne)); W[(il, "attn_k")] = (orc.Q4_K, rb(orc.Q4_K, nkv*hd, ne)); W[(il, "attn_v")] = (orc.Q6_K, rb(orc.Q6_K, nkv*hd, ne))
+        W[(il, "attn_output")] = (orc.Q4_K, rb(orc.Q4_K, ne, nh*hd)); W[(il, "ffn_gate")] = (orc.Q4_K, rb(orc.Q4_K, nff, ne))
+        W[(il, "ffn_up")] = (orc.Q4_K, rb(orc.Q4_K, nff, ne)); W[(il, "ffn_down")] = (orc.Q6_K, rb(orc.Q6_K, ne, nff))
+    W["output_norm"] = (0, np.ones(ne, np.float32)); W["output"] = (orc.Q6_K, rb(orc.Q6_K, nv, ne))
+    S, T = 3, 6
+    for mode in ("cpu16", "cpu", "exact"):
+        st = ref_llama.RefLlamaStreams(cfg, W, S, 16, mode)
+        singles = [ref_llama.RefLlama(cfg, W, 16, mode) for _ in range(S)]
+        for _ in range(T):
+            emb = rng.standard_normal((S, ne)).astype(np.float32)
+            a = st.decode(emb)
+            b = np.stack([singles[i].decode(emb[i:i + 1]) for i in range(S)])
+            assert np.array_equal(a, b), mode

@@ -8,7 +8,7 @@ ls = pkg.llama_synth
 be = backend(); be.set_option("graphs", 1); be.set_option("fusion", 1)
 m = ls.SynthLlama(be, "llama3-8b", "Q4_K_M", n_ctx=32, seed=5, n_layer=2, n_vocab=512)
 W = ref_llama.read_weights(m, gg)
-rc = ref_llama.RefLlama(m.cfg, W, 32, "cpu")
+rc = ref_llama.RefLlama(m.cfg, W, 32, "cpu16")
 for t in (3, 7, 9, 11):
     got = m.decode([t]); exp = rc.decode(np.stack([m.embedding(t)]))
     print("token", t, "nmse vs cpu-style oracle", orc.nmse(exp, got))
