@@ -417,7 +417,8 @@ struct mi_backend_ctx {
     // opt-in (GGML_MI355X_CHAIN=1 / option "chain"): correct, and at the end of round 3 slower than one launch per group (505 vs 628 tok/s): a phase's
     // hand-off + activation load + prologue (~7 us) is longer than the stream the LDS ring can hold ahead (117 KB = 4.7 us) — DESIGN.md section 4
     bool use_chain = false, rec_on = false, capturing = false;
-    unsigned * chain_err = nullptr;                  // host-mapped word: a bounded wait inside the kernel gave up
+    unsigned * chain_err = nullptr;                  // host-mapped words: a bounded wait inside a kernel gave up ([0] the chained decode kernel, [1] the MoE router)
+    unsigned * err_dev = nullptr;                    // ... their device address
     void * chain_prog_dev = nullptr; void * chain_prog_host = nullptr; unsigned * chain_ws = nullptr;    // eager runs (captured graphs own theirs)
     size_t chain_prog_used = 0, chain_ws_used = 0;   // eager: carved per graph pass (reset in run_nodes)
     struct pending_upload { void * dev; std::vector<char> host; };
@@ -559,6 +560,9 @@ static void be_synchronize(ggml_backend_t backend) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     MI_CHECK(hipStreamSynchronize(c->stream));
+    if (c->chain_err && c->chain_err[1] != 0) {
+        GGML_ABORT("MI355X backend: the MoE router kernel timed out waiting for an expert's logit (GGML_MI355X_MOE_ROUTE_WIDE=0 selects the one-workgroup router)");
+    }
     if (c->chain_err && c->chain_err[0] != 0) {
         // a bounded wait inside the chained decode kernel gave up (a workgroup was not resident, e.g. the device was shared): the results of
         // that graph are not valid. Hard internal error (GGML_ABORT), reported instead of hanging the device.
@@ -1540,9 +1544,9 @@ static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i
     if (norm) {
         if (!moe_route_norm_supported(K, E, c->moe_ws) || ((uintptr_t) normw->data % 16) || ((uintptr_t) norm->src[0]->data % 16) || ((uintptr_t) x->data % 16)) return 0;
         moe_route((const float *) w->data, w->nb[1], (const float *) norm->src[0]->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws,
-                  (const float *) normw->data, op_f32(norm, 0), (float *) x->data);
+                  (const float *) normw->data, op_f32(norm, 0), (float *) x->data, c->err_dev);
     } else {
-        moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws);
+        moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws, nullptr, 0.0f, nullptr, c->err_dev);
     }
     c->cnt.kernels_launched++;
     return j - i + 1;
@@ -2030,9 +2034,9 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         if (hipMalloc((void **) &c->moe_ws, 4096) == hipSuccess) { MI_CHECK_G(hipMemsetAsync(c->moe_ws, 0, 4096, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
     }
-    if (!c->chain_err && c->use_chain) {     // chained decode: the error word (host-mapped)
-        if (hipHostMalloc((void **) &c->chain_err, 64, hipHostMallocMapped) == hipSuccess) c->chain_err[0] = 0;
-        else { (void) hipGetLastError(); c->chain_err = nullptr; c->use_chain = false; }
+    if (!c->chain_err) {     // the error words of the kernels with bounded waits (host-mapped)
+        if (hipHostMalloc((void **) &c->chain_err, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **) &c->err_dev, c->chain_err, 0) == hipSuccess) memset(c->chain_err, 0, 64);
+        else { (void) hipGetLastError(); c->chain_err = nullptr; c->err_dev = nullptr; c->use_chain = false; }
     }
     if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
         if (hipMalloc(&c->fin_img, mi_backend_ctx::FIN_IMG_BYTES) != hipSuccess) { (void) hipGetLastError(); c->fin_img = nullptr; }

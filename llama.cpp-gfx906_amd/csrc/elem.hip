@@ -596,7 +596,8 @@ void soft_max(const tensor_desc & src, const tensor_desc * mask, const float * s
 struct moe_route_args { const float * w; size_t w_nb1; const float * x; const float * bias; int k, n_expert, softmax; float * logits; float * probs; int32_t * sorted;
                         // norm_w != NULL (the wide kernel only): x is the RAW residual stream and the router's input is y = (x * rsqrt(mean(x^2) + eps)) * norm_w
                         // (build_norm's RMS_NORM -> MUL folded in); workgroup 0 also writes y to y_out, where the expert mat-vecs read it
-                        const float * norm_w; float eps; float * y_out; };
+                        const float * norm_w; float eps; float * y_out;
+                        unsigned * err; };      // host-mapped error words (may be NULL): [1] = the ranking workgroup gave up waiting for a logit
 __global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
     __shared__ float v[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 16 waves: the rows of 32 experts are 2 per wave
@@ -770,7 +771,8 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
     if (e < p.n_expert) {
         unsigned long long gv = 0; int spins = 0;
         do { gv = __hip_atomic_load(gran + e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((unsigned)(gv >> 32) != tag && ++spins < (1 << 22));   // bounded: a lost
-        v[e] = __builtin_bit_cast(float, (unsigned) gv);                                                // workgroup must not hang the device (it would rank a stale logit)
+        v[e] = __builtin_bit_cast(float, (unsigned) gv);                                                // workgroup must not hang the device ...
+        if ((unsigned)(gv >> 32) != tag && p.err) __hip_atomic_store(p.err + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);   // ... and a stale logit must not be ranked silently: the host aborts at its next synchronize
     }
     __syncthreads();
     if (threadIdx.x == 0) __hip_atomic_store(epoch, tag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -795,8 +797,8 @@ bool moe_route_norm_supported(int64_t k, int64_t n_expert, const float * ws) {
     return ws && wide_on && n_expert >= 4 && n_expert <= 256 && k % 4 == 0;
 }
 void moe_route(const float * w, size_t w_nb1, const float * x, const float * bias, int64_t k, int64_t n_expert, bool softmax,
-               float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws, const float * norm_w, float eps, float * y_out) {
-    moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted, norm_w, eps, y_out };
+               float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws, const float * norm_w, float eps, float * y_out, unsigned * err) {
+    moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted, norm_w, eps, y_out, err };
     static const bool wide_on = !getenv("GGML_MI355X_MOE_ROUTE_WIDE") || atoi(getenv("GGML_MI355X_MOE_ROUTE_WIDE")) != 0;
     if (norm_w && !moe_route_norm_supported(k, n_expert, ws)) { fprintf(stderr, "moe_route: the norm is folded into the multi-workgroup kernel only\n"); abort(); }
     if (ws && wide_on && n_expert >= 4 && n_expert <= 256) hipLaunchKernelGGL(k_moe_route_wide, dim3((unsigned)((n_expert + MR_EPW - 1)/MR_EPW)), dim3(256), 0, stream, a, ws);

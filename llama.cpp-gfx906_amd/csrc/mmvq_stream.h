@@ -42,6 +42,9 @@ struct st_group {
     const float * res; const float * res2;    // EPI_ADD addends; EPI_ROPE: res = a bias added before the rotation
     uint16_t * st16; const int64_t * st_idx; long long st_row_elems;
     int m, type, epi, st_mode;
+    // MUL_MAT_ID for one token (src/llama-graph.cpp:569-595): the group's matrices are expert eid[0] of a stack (a device value: W += eid[0]*estride,
+    // W2 likewise); x_off: this group's activation starts x_off floats into the launch's x (the down projection reads one vector per used expert)
+    const int32_t * eid; long long estride; int x_off;
     int ralign;                               // rows are dealt to workgroups in multiples of this (2: rotation pairs, head size: NEOX pairs)
     int npart_max;                            // floats of partial sums the largest workgroup of this group needs (the LDS carve is the same in all of them)
     float glu_alpha, glu_limit;
@@ -275,6 +278,42 @@ template <> struct st_unit<T_Q6_K> {
     }
 };
 
+// Q8_0: 34-byte blocks of 32 weights (f16 d | 32 int8) — a unit is EIGHT of them (272 bytes = 17 chunks: odd, conflict-free, and a unit
+// starts on a 16-byte boundary). Block j's quants start 34 j + 2 bytes in: dword-aligned for odd j, two bytes off for even j (one
+// v_alignbit per dword, the shift known at compile time). The activation is the CPU path's Q8_0 (vec_dot_type of Q8_0,
+// ggml/src/ggml-cpu/ggml-cpu.c type traits): the unit's 256 int8 at ab, its eight f16-rounded scales as floats at ab + 256; per block
+// sumi * (d_w * d_a), added block after block (ggml_vec_dot_q8_0_q8_0, ggml/src/ggml-cpu/quants.c).
+template <> struct st_unit<T_Q8_0> {
+    static constexpr int UB = 272;
+    struct wfrag { int4v c[17]; };
+    static __device__ __forceinline__ wfrag load(uint32_t a) {
+        wfrag w;
+#pragma unroll
+        for (int j = 0; j < 17; j++) w.c[j] = st_ld16(a + 16*j);
+        return w;
+    }
+    static __device__ __forceinline__ uint32_t dw(const wfrag & w, int i) { return (uint32_t) w.c[i >> 2][i & 3]; }
+    static __device__ __forceinline__ float dot(const wfrag & w, const char * ab, float) {
+        float acc = 0.0f;
+        const float4v da0 = *(const float4v *) (ab + 256), da1 = *(const float4v *) (ab + 272);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int B = 34*j, q = (B + 2) >> 2;
+            const uint32_t dbits = (B & 2) ? dw(w, B >> 2) >> 16 : dw(w, B >> 2) & 0xFFFF;
+            const int4v A0 = *(const int4v *) (ab + 32*j), A1 = *(const int4v *) (ab + 32*j + 16);
+            int isum = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t qv = ((B + 2) & 2) ? __builtin_amdgcn_alignbit(dw(w, q + i + 1), dw(w, q + i), 16) : dw(w, q + i);
+                isum = dot4((int) qv, i < 4 ? A0[i] : A1[i - 4], isum);
+            }
+            const float da = j < 4 ? da0[j] : da1[j - 4];
+            acc += (float) isum*(f16_bits_to_f32((uint16_t) dbits)*da);
+        }
+        return acc;
+    }
+};
+
 #ifdef MI_STAMPS
 #define ST_STAMP(i_) do { if (stamps && lane == 0) __hip_atomic_store(&stamps[((size_t) blockIdx.x*(ST_NC + 1) + wave)*8 + (i_)], (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
@@ -363,7 +402,8 @@ static __device__ __forceinline__ void st_loader_phase(const st_args & p, const 
     }
     ls.p_slot0 = ls.c_slot0; ls.p_base = ls.c_base; ls.c_slot0 = slot0; ls.c_base = ls.pieces;
     const long long row_off = (long long) r0*nb*U::UB;
-    const char * const w0 = g.W + row_off; const char * const w1 = GLU ? g.W2 + row_off : w0;
+    const long long e_off = g.eid ? (long long) __builtin_amdgcn_readfirstlane(g.eid[0])*g.estride : 0;      // (the expert the router picked: read here, on the device)
+    const char * const w0 = g.W + e_off + row_off; const char * const w1 = GLU ? g.W2 + e_off + row_off : w0;
     const long long lim_all = (long long) g.m*nb*U::UB - 16 - row_off;      // the tensor's last 16 bytes, relative to this workgroup's first
     int ring_i = slot0 % S;
     for (int i = 0; i < nslots; i++) {
@@ -437,15 +477,16 @@ static __device__ __forceinline__ void st_prologue_q8(const st_args & p, const s
 // PRO_QUANT / PRO_NORM: x (f32) -> [RMS_NORM * w ->] Q8_K blocks, quant_core.h's arithmetic. Consumer wave w owns the 256-element chunks
 // w, w + 8, ...: NA of them, all quantized in straight-line code (a chunk past the end is a clamped duplicate that is not stored) so that
 // the dependent chains of the wave-wide maxima and sums interleave — chunk after chunk behind a branch each cost ~0.5 us per chunk
-template <int NA, bool CHAIN, bool FIRST>
-static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const st_lds & L, int seq, int & n_norm, int lane, int wave) {
+// Q80: the workgroup's weights are Q8_0 — the image is the CPU path's Q8_0 instead (32-element blocks, f16-rounded scales: quant_core.h)
+template <int NA, bool CHAIN, bool FIRST, bool Q80>
+static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const st_lds & L, int x_off, int seq, int & n_norm, int lane, int wave) {
     const int nchunk = p.nb;
     const bool norm = p.mode == PRO_NORM;
     float4v xv[NA], wv[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int c = min(wave + ST_NC*i, nchunk - 1);
-        xv[i] = st_ldx4<CHAIN>(p.x, c*256 + lane*4);
+        xv[i] = st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4);
         wv[i] = norm ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
     }
     if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
@@ -466,7 +507,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
     for (int i = 0; i < NA; i++) {
         float4v v = xv[i];
         if (norm) { v.x = (v.x*scale)*wv[i].x; v.y = (v.y*scale)*wv[i].y; v.z = (v.z*scale)*wv[i].z; v.w = (v.w*scale)*wv[i].w; }
-        q4[i] = quant_frag_q8_K(v, d8[i], bs16[i]);
+        q4[i] = Q80 ? quant_frag_q8_0(v, d8[i], bs16[i]) : quant_frag_q8_K(v, d8[i], bs16[i]);
     }
 #pragma unroll
     for (int i = 0; i < NA; i++) {
@@ -474,6 +515,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
         if (c < nchunk) {
             char * ab = L.act + (size_t) c*ST_ACT_STRIDE;
             *(uint32_t *) (ab + lane*4) = q4[i];
+            if (Q80) { if ((lane & 7) == 0) ((float *) (ab + 256))[lane >> 3] = d8[i]; continue; }
             // the 16-element sum of quad q = lane >> 2 (valid in its four lanes); the 32-element sum j at lane 8j + 4 (row_shr:4 brings lane 8j's)
             const int bs32 = bs16[i] + dpp_i<0x114>(bs16[i]);
             int h, l;
@@ -506,10 +548,10 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
     // ---- the activation image (FIRST: the loads are requested before any weight is — a CU returns loads in request order) ----
     const int mode = p.mode;
     if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
-    else if (nb <= 8)   st_prologue_f32<1, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
-    else if (nb <= 16)  st_prologue_f32<2, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
-    else if (nb <= 32)  st_prologue_f32<4, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
-    else                st_prologue_f32<8, CHAIN, FIRST>(p, L, seq, n_norm, lane, wave);
+    else if (nb <= 8)   st_prologue_f32<1, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (nb <= 16)  st_prologue_f32<2, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (nb <= 32)  st_prologue_f32<4, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else                st_prologue_f32<8, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
     ST_STAMP(1);
     st_consumers_meet(&sync[2], lane, seq);
     ST_STAMP(2);
@@ -652,7 +694,7 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) 
     int first, nwg;
     const int gi = st_group_of(p, (int) blockIdx.x, first, nwg);
     const st_group & g = p.g[gi];
-    __builtin_assume((g.epi == EPI_GLU) == GLU);
+    if (GLU) __builtin_assume(g.epi == EPI_GLU);
     const int wg = (int) blockIdx.x - first;
     const bool is_a = TA == TB || g.type == TA;
     const st_lds L = st_carve(lds, p.nb, g.npart_max, ((64*(is_a ? st_unit<TA>::UB : st_unit<TB>::UB) + 1023)/1024)*1024, p.S);

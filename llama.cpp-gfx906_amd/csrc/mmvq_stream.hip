@@ -27,7 +27,7 @@ template <int TA, int TB, bool GLU> static void st_launch_t(const st_args & a, i
     }
 }
 
-static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : 0; }
+static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : type == T_Q8_0 ? 272 : 0; }
 static int st_cu_count() {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -73,7 +73,7 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     if (!mul_mat_vec_q_stream_enabled() || n_groups < 1 || n_groups > MMVQ_MAX_GROUPS) return false;
     if (k % 256 != 0 || k > 16384 || k < 256) return false;
     if (in.mode != PRO_Q8 && in.mode != PRO_QUANT && in.mode != PRO_NORM) return false;
-    if (in.act_kind != T_Q8_K) return false;
+    if (in.mode == PRO_Q8 && in.act_kind != T_Q8_K) return false;      // (a ready-made image: Q8_K only; the launch's own prologue quantizes per workgroup, in the format its group's weights ask for)
     if (in.mode == PRO_Q8) { if (((uintptr_t) in.act.qs % 16) || ((uintptr_t) in.act.bsums % 16) || !in.act.d) return false; }
     else { if (((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
     const int64_t nb = k/256;
@@ -81,11 +81,13 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     for (int i = 0; i < n_groups; i++) {
         const mmvq_group & g = groups[i];
         const int ub = st_unit_bytes(g.type);
-        if (!ub) return false;
+        if (!ub || (g.type == T_Q8_0 && in.mode == PRO_Q8)) return false;
         if (g.type != ta && g.type != tb) { if (ta < 0) ta = g.type; else if (tb < 0) tb = g.type; else return false; }
-        if (g.eid || g.x_off || g.b_gate || g.b_up || g.res_eid) return false;             // (MUL_MAT_ID stacks: the register-ring kernels)
+        if (g.b_gate || g.b_up || g.res_eid) return false;             // (gpt-oss's per-expert biases: the register-ring kernels)
+        if (g.eid && (g.estride % 16 || in.mode == PRO_NORM)) return false;
+        if (g.x_off && (in.mode == PRO_Q8 || g.x_off % 4)) return false;
         if (g.row_stride != (size_t)(nb*ub) || ((uintptr_t) g.W % 16) || (g.W2 && ((uintptr_t) g.W2 % 16))) return false;
-        if (g.epi == EPI_GLU && (n_groups != 1 || !g.W2)) return false;
+        if (g.epi == EPI_GLU && !g.W2) return false;
         if (g.epi == EPI_ROPE) {
             if (!rope || !rope->table || (g.m & 1)) return false;
             if (rope->p.mode & 2) { const int hd = rope->head_dim; if (hd <= 0 || (hd & (hd - 1)) || rope->p.n_dims != hd || g.m % hd) return false; }
@@ -127,6 +129,7 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
         st_group & s = a.g[i];
         s.W = g.W; s.W2 = g.W2; s.dst = g.dst; s.res = g.res; s.res2 = g.res2; s.st16 = g.st16; s.st_idx = g.st_idx; s.st_row_elems = g.st_row_elems;
         s.m = g.m; s.type = g.type; s.epi = g.epi; s.st_mode = g.st_mode; s.glu_alpha = g.glu_alpha; s.glu_limit = g.glu_limit;
+        s.eid = g.eid; s.estride = (long long) g.estride; s.x_off = g.x_off;
         s.ralign = 1;
         if (g.epi == EPI_ROPE) s.ralign = (rope->p.mode & 2) ? rope->head_dim : 2;
         while (((int64_t) s.ralign*nb*st_unit_bytes(g.type)) % 16 != 0) s.ralign *= 2;      // a workgroup's rows start on a 16-byte boundary (LDS-DMA source)
@@ -185,10 +188,13 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
     }
 #endif
     const bool nt = nt_env != 0;
-    const bool glu = groups[0].epi == EPI_GLU;
+    const bool glu = n_groups == 1 && groups[0].epi == EPI_GLU;
     if (ta == T_Q4_K && tb == T_Q4_K)      { if (glu) st_launch_t<T_Q4_K, T_Q4_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q4_K, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q5_K && tb == T_Q5_K) { if (glu) st_launch_t<T_Q5_K, T_Q5_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q5_K, T_Q5_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q6_K && tb == T_Q6_K) { if (glu) st_launch_t<T_Q6_K, T_Q6_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q6_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == T_Q8_0 && tb == T_Q8_0) { if (glu) st_launch_t<T_Q8_0, T_Q8_0, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q8_0, T_Q8_0, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == T_Q8_0 && tb == T_Q4_K) st_launch_t<T_Q8_0, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
+    else if (ta == T_Q8_0 && tb == T_Q6_K) st_launch_t<T_Q8_0, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
     else if (ta == T_Q4_K && tb == T_Q5_K) st_launch_t<T_Q4_K, T_Q5_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
     else if (ta == T_Q4_K && tb == T_Q6_K) st_launch_t<T_Q4_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
     else if (ta == T_Q5_K && tb == T_Q6_K) st_launch_t<T_Q5_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
@@ -209,6 +215,7 @@ bool mul_mat_vec_q_chain_build(const mmvq_chain_item * items, int n, void * prog
         size_t fixed; int slot, nslots, npart, ta, tb; double bytes;
         st_phase & P = prog[j];
         const int blocks = st_fill(it.grp, it.n_groups, it.k, it.in, it.has_rope ? &it.rope : nullptr, P.a, fixed, slot, nslots, npart, ta, tb, bytes);
+        if (ta == T_Q8_0 || tb == T_Q8_0) return false;      // (the chain kernel instantiates the K-quant units only)
         P.a.stamps = nullptr;
         P.n_active = blocks;
         P.wait_idx = j > 0 ? j - 1 : -1; P.wait_target = j > 0 ? (unsigned) prog[j - 1].n_active : 0;

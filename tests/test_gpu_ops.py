@@ -235,6 +235,46 @@ def test_add_id_and_argsort_topk():
         assert np.array_equal(got, ref.argsort_desc(logits))
 
 
+@pytest.mark.parametrize("n_expert,k,bias,softmax", [(8, 4096, False, True), (32, 2880, True, False), (32, 2880, False, True), (128, 2048, False, True),
+                                                    (128, 4096, True, False), (256, 7168, False, True)])
+def test_moe_router_at_model_widths(n_expert, k, bias, softmax):
+    """build_moe_ffn's router for one token (src/llama-graph.cpp:838-883): logits = gate_inp . x (+ bias) [-> soft_max] -> argsort desc, at the
+    widths of Mixtral (8 x 4096), gpt-oss (32 x 2880, bias, SOFTMAX_WEIGHT gating: the logits are ranked) and the 128 / 256-expert models the
+    reference's perf cases name (tests/test-backend-ops.cpp:6226-6229). From 16 experts on this is k_moe_route_wide: one workgroup per 16
+    experts, every logit handed to the ranking workgroup as an 8-byte {value, launch tag} granule that workgroup polls — run three times on
+    the same buffers so that stale granules of the launch before would be caught."""
+    rng = np.random.default_rng(n_expert + k)
+    w_ = (rng.standard_normal((1, 1, n_expert, k))/np.sqrt(k)).astype(np.float32)
+    b_ = rng.uniform(-0.5, 0.5, size=(1, 1, 1, n_expert)).astype(np.float32)
+    be = backend(); be.set_option("fusion", 1)
+    with gg.Context() as ctx:
+        w = ctx.new_tensor(gg.F32, (k, n_expert)); x = ctx.new_tensor(gg.F32, (k, 1)); bt = ctx.new_tensor(gg.F32, (n_expert,))
+        lg = L.ggml_mul_mat(ctx.ctx, w, x)
+        if bias:
+            lg = L.ggml_add(ctx.ctx, lg, bt)
+        pr = L.ggml_soft_max(ctx.ctx, lg) if softmax else lg
+        srt = L.ggml_argsort(ctx.ctx, pr, gg.GGML_SORT_ORDER_DESC)
+        assert ctx.alloc(be)
+        gg.tensor_set(w, w_); gg.tensor_set(bt, b_)
+        graph = gg.graph_of(ctx, srt, pr)
+        for rep in range(3):
+            x_ = rng.standard_normal((1, 1, 1, k)).astype(np.float32)
+            gg.tensor_set(x, x_)
+            be.reset_counters()
+            be.compute(graph)
+            assert be.counters()["kernels_launched"] == 1, be.counters()      # the whole router is ONE launch
+            got_p = gg.tensor_get(pr)[0, 0, 0].copy(); got_s = gg.tensor_get(srt)[0, 0, 0].copy()
+            logits = w_[0, 0].astype(np.float64) @ x_[0, 0, 0].astype(np.float64) + (b_[0, 0, 0] if bias else 0.0)
+            exp_p = np.exp(logits - logits.max())/np.exp(logits - logits.max()).sum() if softmax else logits
+            assert np.abs(got_p - exp_p).max() <= 1e-5*max(1.0, np.abs(exp_p).max()), (rep, float(np.abs(got_p - exp_p).max()))
+            # the ranking must be THE descending order of the values the kernel itself produced (index breaks ties, as ggml's argsort leaves them)
+            assert sorted(got_s.tolist()) == list(range(n_expert))
+            assert np.all(np.diff(got_p[got_s]) <= 0), rep
+            top = np.argsort(-exp_p, kind="stable")[:4]
+            if np.min(np.abs(np.diff(np.sort(exp_p)[::-1][:5]))) > 1e-4*np.abs(exp_p).max():      # no near-tie among the leaders: the choice is the oracle's
+                assert np.array_equal(got_s[:4], top), (rep, got_s[:4], top)
+
+
 @pytest.mark.parametrize("name", list(QTYPES))
 @pytest.mark.parametrize("n_mats,n_used,bcast_b,n", [(4, 1, False, 1), (4, 2, True, 1), (8, 2, False, 1), (8, 4, False, 5), (8, 2, True, 32), (8, 8, False, 3)])
 def test_mul_mat_id(name, n_mats, n_used, bcast_b, n):
