@@ -133,7 +133,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=128)
     ap.add_argument("--model", default="llama3-8b")
     ap.add_argument("--ftype", default="Q4_K_M")
-    ap.add_argument("--ctk", default="f16", choices=["f16", "q8_0", "q4_0"], help="llama-bench -ctk: K cache type (no flash attention: V stays f16)")
+    ap.add_argument("--ctk", default="f16", choices=["f16", "q8_0", "q4_0", "bf16"], help="llama-bench -ctk: K cache type")
+    ap.add_argument("--ctv", default="f16", choices=["f16", "q8_0", "q4_0", "bf16"], help="llama-bench -ctv: V cache type (anything but f16 needs --fa 1, as in the reference)")
     ap.add_argument("--row-split", type=int, default=0, help="-sm row inside ONE process: spread the weight matrices' rows over this many devices of the "
                     "registry (csrc/backend.cpp: the split buffer type); on a one-GPU box set GGML_MI355X_VIRTUAL_DEVICES to list the GPU several times")
     ap.add_argument("--gguf", default=None, help="run the same protocol on a model read from this GGUF file (llama / gpt-oss architectures) instead of the "
@@ -189,8 +190,10 @@ def main():
     gg, ls, lsp = pkg.ggml, pkg.llama_synth, pkg.layer_split
 
     be = gg.Backend(dev_index)
-    if args.gguf and (args.ctk != "f16" or args.row_split):
-        raise SystemExit("bench.py: --ctk / --row-split apply to the synthetic models only (a --gguf model runs with an f16 cache, unsplit)")
+    if args.gguf and (args.ctk != "f16" or args.ctv != "f16" or args.row_split):
+        raise SystemExit("bench.py: --ctk / --ctv / --row-split apply to the synthetic models only (a --gguf model runs with an f16 cache, unsplit)")
+    if args.ctv != "f16" and not args.fa:
+        raise SystemExit("bench.py: --ctv other than f16 requires --fa 1 (V cache quantization requires flash_attn)")
     if args.gguf:     # hyper-parameters from the file's metadata (csrc/harness/gguf_file.h); the model label follows the file
         d = ls.gguf_describe(args.gguf)
         kvs = {e["key"]: e["value"] for e in d["kv"]}
@@ -207,7 +210,8 @@ def main():
         cfg = ls.MODELS[args.model]
 
         def new_model(n_ctx, **kw):
-            return ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, row_split=args.row_split, type_k={"f16": 0, "q8_0": 8, "q4_0": 2}[args.ctk], **kw)
+            return ls.SynthLlama(be, args.model, args.ftype, n_ctx=n_ctx, seed=1, row_split=args.row_split, type_k={"f16": 0, "q8_0": 8, "q4_0": 2, "bf16": 30}[args.ctk],
+                                 type_v={"f16": 0, "q8_0": 8, "q4_0": 2, "bf16": 30}[args.ctv], **kw)
     K, W = args.steps, args.warmup
     ranges = lsp.layer_ranges(cfg["n_layer"], world)
     lb, le, has_out = ranges[rank]
@@ -434,7 +438,7 @@ def main():
             "ms_per_step": round(result["ms_per_step"], 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int8 dot (4-6 bit weights x Q8 activations), f32 accumulate", "data": f"gguf file {args.model}" if args.gguf else "synthetic",
             "config": {"workload": f"{args.model} {args.ftype}, llama-bench tg{K} protocol (BASELINE.json configs[1]): 1 token/step, sync per token, "
-                                   f"{'f16 KV cache' if args.ctk == 'f16' else args.ctk + ' K / f16 V cache'}, {'flash-attn' if args.fa else 'no flash-attn'}, n_ctx={n_ctx}",
+                                   f"{'f16 KV cache' if args.ctk == 'f16' and args.ctv == 'f16' else args.ctk + ' K / ' + args.ctv + ' V cache'}, {'flash-attn' if args.fa else 'no flash-attn'}, n_ctx={n_ctx}",
                        "parallelism": (f"rows of the weight matrices split over {args.row_split} devices in one process" if args.row_split > 1 else "single GPU") if world == 1 else f"layer split over {world} GPUs, {world} sequences in flight, {'RCCL' if transport == 'nccl' else 'gloo (host memory)'} p2p hand-off"},
             "roofline": result.get("roofline"), "cpu_baseline": result.get("cpu_baseline"),
         }

@@ -15,6 +15,7 @@
 // The C-layout of S^T (cell = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) IS a valid B-operand k-slot order as long as V^T's k-slots use
 // the same cell permutation — a sum over cells does not care about their order — so the probabilities never leave the registers.
 #include "dev_common.h"
+#include "kv_types.h"
 #include "kernels.h"
 
 namespace mi355x {
@@ -33,6 +34,7 @@ struct attn_pf_args {
     uint16_t * y16; int kp16;                           // != NULL: the result also as bf16 rows of kp16 elements — the activation copy the wo mat-mul reads (mmq.hip)
     int n_kv, n_head, n_head_kv, T;
     float scale;
+    float softcap, max_bias, m0, m1; int n_head_log2;      // logit_softcap (scale already divided by it) and ALiBi, as in decode_fused.hip
 };
 
 static __device__ __forceinline__ float xhalf(float v, int lane) {      // the value lane ^ 32 holds
@@ -83,6 +85,7 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
     float m = -INFINITY, l = 0.0f;     // running maximum (common to both halves; base-2 domain) and this half's share of the denominator
     constexpr float LOG2E = 1.4426950408889634f;
     const float scale2 = p.scale*LOG2E;
+    const float slope = p.max_bias > 0.0f ? (h < p.n_head_log2 ? powf(p.m0, (float)(h + 1)) : powf(p.m1, (float)(2*(h - p.n_head_log2) + 1))) : 1.0f;
 
     // staging roles. K (and a row-major V): thread -> (cell = tid / CPR, 16-byte chunk); transposed V: thread -> (dim row = tid / 4, 8 cells)
     const bool k_role = tid < 32*CPR, v_role = VT ? tid < HD*4 : k_role;
@@ -169,6 +172,10 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
             // ---- scale + mask; s[r] belongs to cell kv0 + (r & 3) + 8 (r >> 2) + 4 hf of query t. The softmax runs in the base-2 domain
             //      (scores times log2 e, v_exp_f32 is 2^x): one instruction per exponential instead of expf's six ----
             float bm = -INFINITY;
+            if (p.softcap != 0.0f || p.max_bias > 0.0f) {
+#pragma unroll
+                for (int r = 0; r < 16; r++) { float x = s[r]*p.scale; if (p.softcap != 0.0f) x = p.softcap*tanhf(x); s[r] = (x + slope*mk[r])*LOG2E; bm = fmaxf(bm, s[r]); }
+            } else
 #pragma unroll
             for (int r = 0; r < 16; r++) { s[r] = s[r]*scale2 + mk[r]*LOG2E; bm = fmaxf(bm, s[r]); }
             bm = fmaxf(bm, xhalf(bm, lane));
@@ -253,9 +260,15 @@ bool attn_prefill_supported(int64_t head_dim, int64_t n_kv) { return (head_dim =
 
 void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                   const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
-                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans, uint16_t * y16) {
+                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans, uint16_t * y16, const attn_extra * ex) {
     attn_pf_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
-                       (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, y16, (int)((head_dim*n_head + 63) & ~(int64_t) 63), (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale };
+                       (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, y16, (int)((head_dim*n_head + 63) & ~(int64_t) 63), (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale,
+                       0.0f, 0.0f, 1.0f, 1.0f, 1 };
+    if (ex) {
+        attn_alibi(ex->max_bias, n_head, a.m0, a.m1, a.n_head_log2);
+        a.softcap = ex->softcap; a.max_bias = ex->max_bias;
+        if (ex->softcap != 0.0f) a.scale = scale/ex->softcap;
+    }
     const int64_t R = n_head/n_head_kv;
     const int hpw = R % 8 == 0 ? 8 : R % 4 == 0 ? 4 : R % 2 == 0 ? 2 : 1;          // heads of one kv head per workgroup
     // few workgroups (short prompts): pairs of waves split the cell blocks of an iteration, halving the loop that is the critical path
@@ -275,6 +288,51 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
 #undef MI_APF
 #undef MI_APF1
 #undef MI_APF2
+}
+
+// ---- the cache as the kernels above want it: f16, cells as rows or transposed (kv_types.h has the element types) ----
+struct kvc_args { const char * src; size_t nb1, nb2; int hd, n_kv, n_head_kv; uint16_t * dst; };
+template <int TY>
+__global__ void __launch_bounds__(256) k_kv_rows_f16(const kvc_args p) {
+    const int c8 = p.hd >> 3;
+    const long long e = (long long) blockIdx.x*256 + threadIdx.x, tot = (long long) p.n_head_kv*p.n_kv*c8;
+    if (e >= tot) return;
+    const int sub = (int)(e % c8); const long long cj = e / c8; const int j = (int)(cj % p.n_kv), hk = (int)(cj / p.n_kv);
+    float f[8];
+    kv_cvt8<TY>(kv_raw8<TY>(p.src + (size_t) hk*p.nb2 + (size_t) j*p.nb1, sub), sub, f);
+    uint32_t w[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) w[i] = (uint32_t) f32_to_f16_bits(f[2*i]) | ((uint32_t) f32_to_f16_bits(f[2*i + 1]) << 16);
+    *(int4v *) (p.dst + ((size_t) hk*p.n_kv + j)*p.hd + sub*8) = int4v{ (int) w[0], (int) w[1], (int) w[2], (int) w[3] };
+}
+// one workgroup = 64 cells of one kv head: cells are read as rows (coalesced), turned in LDS, written as 128-byte pieces of the rows over cells
+template <int TY>
+__global__ void __launch_bounds__(256) k_kv_trans_f16(const kvc_args p) {
+    constexpr int LROW = 64 + 8;       // halves per LDS row (16-byte aligned rows)
+    __shared__ __attribute__((aligned(16))) uint16_t tile[128*LROW];
+    const int hk = blockIdx.y, j0 = blockIdx.x*64, c8 = p.hd >> 3;
+    for (int e = threadIdx.x; e < 64*c8; e += 256) {
+        const int cell = e / c8, sub = e % c8, j = min(j0 + cell, p.n_kv - 1);
+        float f[8];
+        kv_cvt8<TY>(kv_raw8<TY>(p.src + (size_t) hk*p.nb2 + (size_t) j*p.nb1, sub), sub, f);
+#pragma unroll
+        for (int i = 0; i < 8; i++) tile[(sub*8 + i)*LROW + cell] = f32_to_f16_bits(f[i]);
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < p.hd*8; e += 256) {
+        const int d = e >> 3, g8 = e & 7;
+        if (j0 + g8*8 < p.n_kv) *(int4v *) (p.dst + ((size_t) hk*p.hd + d)*p.n_kv + j0 + g8*8) = *(const int4v *) (tile + d*LROW + g8*8);
+    }
+}
+void kv_to_f16(int type, const void * src, size_t nb1, size_t nb2, int64_t hd, int64_t n_kv, int64_t n_head_kv, uint16_t * dst, bool transpose, hipStream_t stream) {
+    if ((hd != 64 && hd != 128) || n_kv % 8 || n_kv < 8) { fprintf(stderr, "kv_to_f16: unsupported shape (hd %lld, n_kv %lld)\n", (long long) hd, (long long) n_kv); abort(); }
+    const kvc_args a = { (const char *) src, nb1, nb2, (int) hd, (int) n_kv, (int) n_head_kv, dst };
+    const long long tot = (long long) n_head_kv*n_kv*(hd/8);
+#define MI_KVC(TY_) do { if (transpose) hipLaunchKernelGGL((k_kv_trans_f16<TY_>), dim3((unsigned)((n_kv + 63)/64), (unsigned) n_head_kv), dim3(256), 0, stream, a); \
+                         else hipLaunchKernelGGL((k_kv_rows_f16<TY_>), dim3((unsigned)((tot + 255)/256)), dim3(256), 0, stream, a); } while (0)
+    if (type == T_F16) MI_KVC(T_F16); else if (type == T_BF16) MI_KVC(T_BF16); else if (type == T_Q8_0) MI_KVC(T_Q8_0); else if (type == T_Q4_0) MI_KVC(T_Q4_0);
+    else { fprintf(stderr, "kv_to_f16: cache type %d is not supported\n", type); abort(); }
+#undef MI_KVC
 }
 
 } // namespace mi355x

@@ -387,6 +387,7 @@ struct mi_backend_ctx {
     // first rotated mat-vec launch comes up (and again if a launch asks for other rope parameters), read by every such launch after it
     float * rope_tab = nullptr; mmvq_rope rope_tab_key = {}; bool rope_tab_valid = false;
     static constexpr size_t FIN_IMG_BYTES = 64*1024; static constexpr int FIN_COUNTERS = 256;
+    void * kv16 = nullptr; size_t kv16_size = 0;                // FLASH_ATTN_EXT: dense f16 copies of a quantized / bf16 cache view, and the transposed V of the prefill kernel (kv_to_f16)
     float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
     // activation-quantisation reuse inside one graph_compute
@@ -490,6 +491,7 @@ static void be_free(ggml_backend_t backend) {
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
+    if (c->kv16) (void) hipFree(c->kv16);
     if (c->chain_prog_dev) (void) hipFree(c->chain_prog_dev);
     if (c->chain_prog_host) (void) hipHostFree(c->chain_prog_host);
     if (c->chain_ws) (void) hipFree(c->chain_ws);
@@ -575,6 +577,16 @@ static bool is_view_op(enum ggml_op op) {
     return op == GGML_OP_NONE || op == GGML_OP_RESHAPE || op == GGML_OP_VIEW || op == GGML_OP_PERMUTE || op == GGML_OP_TRANSPOSE;
 }
 static bool float_type(enum ggml_type t) { return t == GGML_TYPE_F32 || t == GGML_TYPE_F16 || t == GGML_TYPE_BF16; }
+static bool fa_kv_type(enum ggml_type t) { return t == GGML_TYPE_F16 || t == GGML_TYPE_BF16 || t == GGML_TYPE_Q8_0 || t == GGML_TYPE_Q4_0; }
+// FLASH_ATTN_EXT: the dense f16 copies its kernels need — the V cache transposed for the matrix-core prefill kernel (always: rows over cells are what it
+// stages with coalesced loads), K when it is not f16; for a few tokens only what the decode kernel does not read directly (attn_decode_kv_types_fused)
+static void fa_kv16_plan(const struct ggml_tensor * n, size_t & k_bytes, size_t & v_bytes) {
+    const struct ggml_tensor * q = n->src[0]; const struct ggml_tensor * k = n->src[1]; const struct ggml_tensor * v = n->src[2];
+    const size_t dense = (((size_t) k->ne[0]*k->ne[1]*k->ne[2]*2) + 255) & ~(size_t) 255;
+    if (q->ne[1] > 8) { k_bytes = k->type != GGML_TYPE_F16 ? dense : 0; v_bytes = dense; }
+    else if (attn_decode_kv_types_fused((int) k->type, (int) v->type)) { k_bytes = v_bytes = 0; }
+    else { k_bytes = k->type != GGML_TYPE_F16 ? dense : 0; v_bytes = v->type != GGML_TYPE_F16 ? dense : 0; }
+}
 
 static float op_f32(const struct ggml_tensor * t, int i) { float f; memcpy(&f, &t->op_params[i], 4); return f; }
 
@@ -612,17 +624,20 @@ static bool mi_supports_op(const struct ggml_tensor * op) {
             if (s1->nb[0] != sizeof(float)) return false;
             return op->src[2]->type == GGML_TYPE_I32;
         }
-        case GGML_OP_FLASH_ATTN_EXT: {     // f16 KV, head size 64 / 128, no ALiBi, no logit soft-cap (src/llama-graph.cpp:1245-1265)
+        case GGML_OP_FLASH_ATTN_EXT: {     // head size 64 / 128; K / V cache types F16, BF16, Q8_0, Q4_0; ALiBi and logit soft-cap (src/llama-graph.cpp:1245-1265)
             const struct ggml_tensor * k = op->src[1]; const struct ggml_tensor * v = op->src[2]; const struct ggml_tensor * mask = op->src[3];
-            if (s0->type != GGML_TYPE_F32 || k->type != GGML_TYPE_F16 || v->type != GGML_TYPE_F16 || op->type != GGML_TYPE_F32) return false;
+            if (s0->type != GGML_TYPE_F32 || !fa_kv_type(k->type) || !fa_kv_type(v->type) || op->type != GGML_TYPE_F32) return false;
             if (s0->ne[3] != 1 || k->ne[3] != 1 || v->ne[3] != 1 || v->ne[0] != k->ne[0] || s0->ne[2] % k->ne[2] != 0) return false;
-            if (op_f32(op, 1) != 0.0f || op_f32(op, 2) != 0.0f) return false;
+            if (op_f32(op, 1) < 0.0f) return false;
             if (mask && (mask->type != GGML_TYPE_F16 || mask->ne[2] != 1 || mask->ne[3] != 1 || mask->ne[0] != k->ne[1] || mask->ne[1] < s0->ne[1] || mask->nb[1] % 16)) return false;
             if (op->nb[1] != (size_t) k->ne[0]*4) return false;
             // few tokens: the whole score row in LDS, or the cell ranges through the fixed partial-result buffer (8 tokens x 128 heads x 32 ranges)
             if (s0->ne[1] <= 8 && !attn_decode_supported(k->ne[0], k->ne[1]) &&
                 !(attn_decode_supported_split(k->ne[0], k->ne[1]) && attn_decode_part_bytes(k->ne[0], k->ne[1], s0->ne[2], s0->ne[1]) <= (size_t) 8*128*32*130*4)) return false;
-            if (s0->nb[0] != 4 || k->nb[0] != 2 || v->nb[0] != 2 || s0->nb[1] % 16 || s0->nb[2] % 16 || k->nb[1] % 16 || k->nb[2] % 16 || v->nb[1] % 16 || v->nb[2] % 16) return false;
+            if (s0->nb[0] != 4 || k->nb[0] != ggml_type_size(k->type) || v->nb[0] != ggml_type_size(v->type) || s0->nb[1] % 16 || s0->nb[2] % 16) return false;
+            // (f16 rows are read 16 bytes at a time; block rows 2-byte aligned)
+            if (k->nb[1] % (k->type == GGML_TYPE_F16 || k->type == GGML_TYPE_BF16 ? 16 : 2) || k->nb[2] % (k->type == GGML_TYPE_F16 || k->type == GGML_TYPE_BF16 ? 16 : 2)) return false;
+            if (v->nb[1] % (v->type == GGML_TYPE_F16 || v->type == GGML_TYPE_BF16 ? 16 : 2) || v->nb[2] % (v->type == GGML_TYPE_F16 || v->type == GGML_TYPE_BF16 ? 16 : 2)) return false;
             return s0->ne[1] <= 8 ? (attn_decode_supported(k->ne[0], k->ne[1]) || attn_decode_supported_split(k->ne[0], k->ne[1])) : attn_prefill_supported(k->ne[0], k->ne[1]);
         }
         case GGML_OP_RMS_NORM:
@@ -1785,14 +1800,31 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             const struct ggml_tensor * mask = node->src[3]; const struct ggml_tensor * sinks = node->src[4];
             const int64_t hd = k->ne[0], n_kv = k->ne[1], T = q->ne[1];
             // what supports_op cannot see (data alignment of the views handed in) fails the graph instead of the process
-            MI_REQUIRE_G(node->nb[1] == (size_t) hd*4 && ((uintptr_t) q->data % 16) == 0 && ((uintptr_t) k->data % 16) == 0 && ((uintptr_t) v->data % 16) == 0);
+            MI_REQUIRE_G(node->nb[1] == (size_t) hd*4 && ((uintptr_t) q->data % 16) == 0);
+            MI_REQUIRE_G(((uintptr_t) k->data % (k->type == GGML_TYPE_F16 || k->type == GGML_TYPE_BF16 ? 16 : 2)) == 0 && ((uintptr_t) v->data % (v->type == GGML_TYPE_F16 || v->type == GGML_TYPE_BF16 ? 16 : 2)) == 0);
             MI_REQUIRE_G(!mask || (mask->ne[0] == n_kv && mask->ne[1] >= T && ((uintptr_t) mask->data % 16) == 0 && mask->nb[1] % 16 == 0));
             MI_REQUIRE_G(T > 8 || attn_decode_supported(hd, n_kv) || (c->attn_part && attn_decode_supported_split(hd, n_kv) && attn_decode_part_bytes(hd, n_kv, q->ne[2], T) <= c->attn_part_bytes));
-            if (T <= 8) attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
+            attn_extra ex = { op_f32(node, 2), op_f32(node, 1), (int) k->type, (int) v->type };
+            const void * kd = k->data; const void * vd = v->data;
+            size_t k_nb1 = k->nb[1], k_nb2 = k->nb[2], v_nb1 = v->nb[1], v_nb2 = v->nb[2];
+            size_t kb, vb; fa_kv16_plan(node, kb, vb);
+            MI_REQUIRE_G(kb + vb <= c->kv16_size);
+            bool v_trans = false;
+            if (kb) {
+                kv_to_f16((int) k->type, k->data, k->nb[1], k->nb[2], hd, n_kv, k->ne[2], (uint16_t *) c->kv16, false, c->stream);
+                kd = c->kv16; k_nb1 = (size_t) hd*2; k_nb2 = (size_t) n_kv*hd*2; ex.k_type = T_F16; c->cnt.kernels_launched++;
+            }
+            if (vb) {
+                v_trans = T > 8;
+                kv_to_f16((int) v->type, v->data, v->nb[1], v->nb[2], hd, n_kv, v->ne[2], (uint16_t *) ((char *) c->kv16 + kb), v_trans, c->stream);
+                vd = (char *) c->kv16 + kb; ex.v_type = T_F16; c->cnt.kernels_launched++;
+                if (v_trans) { v_nb1 = (size_t) n_kv*2; v_nb2 = (size_t) hd*n_kv*2; } else { v_nb1 = (size_t) hd*2; v_nb2 = (size_t) n_kv*hd*2; }
+            }
+            if (T <= 8) attn_decode(q->data, q->nb[1], q->nb[2], kd, k_nb1, k_nb2, vd, v_nb1, v_nb2, mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
                                     sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false,
-                                    c->attn_part, c->attn_part_bytes);
-            else        attn_prefill(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
-                                     sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, false);
+                                    c->attn_part, c->attn_part_bytes, false, &ex);
+            else        attn_prefill(q->data, q->nb[1], q->nb[2], kd, k_nb1, k_nb2, vd, v_nb1, v_nb2, mask ? mask->data : nullptr, mask ? mask->nb[1] : 0, true,
+                                     sinks ? (const float *) sinks->data : nullptr, (float *) node->data, node->nb[2], hd, n_kv, q->ne[2], k->ne[2], T, op_f32(node, 0), c->stream, v_trans, nullptr, &ex);
             c->cnt.kernels_launched++;
         } break;
         case GGML_OP_RMS_NORM: {
@@ -2061,6 +2093,20 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         const size_t sz = need + (need >> 2);
         if (hipMalloc(&c->scratch, sz) != hipSuccess) { (void) hipGetLastError(); return GGML_STATUS_ALLOC_FAILED; }
         c->scratch_size = sz;
+    }
+
+    {
+        size_t kv_need = 0;
+        for (int i = 0; i < g->n_nodes; i++) if (g->nodes[i]->op == GGML_OP_FLASH_ATTN_EXT) { size_t kb, vb; fa_kv16_plan(g->nodes[i], kb, vb); kv_need = std::max(kv_need, kb + vb); }
+        if (kv_need > c->kv16_size) {
+            MI_CHECK_G(hipStreamSynchronize(c->stream));
+            if (c->kv16) MI_CHECK_G(hipFree(c->kv16));
+            c->kv16 = nullptr; c->kv16_size = 0;
+            drop_graphs(c);   // captured graphs hold the old pointer
+            const size_t sz = kv_need + (kv_need >> 1);      // (the cache view grows with the context: fewer re-allocations)
+            if (hipMalloc(&c->kv16, sz) != hipSuccess) { (void) hipGetLastError(); return GGML_STATUS_ALLOC_FAILED; }
+            c->kv16_size = sz;
+        }
     }
 
     // hipGraph path: launch-bound decode graphs (~10^3 tiny kernels per token) are captured the second time their

@@ -18,6 +18,7 @@
 // through it, against the oracle.
 #include "mmvq_core.h"
 #include "quant_core.h"
+#include "kv_types.h"
 #include "rope_dev.h"
 
 #include <math.h>
@@ -164,7 +165,13 @@ struct attn_args {
     // k_attn_merge combines them (and adds the sink). nsplit = 1: the kernel finishes the row itself.
     int kv_chunk, nsplit; float * part;
     int live_scan;      // row-major V, one workgroup per head: stop at the last unmasked cell
+    // FLASH_ATTN_EXT's other two parameters (ggml/src/ggml-cpu/ops.cpp ggml_compute_forward_flash_attn_ext_f16): logit_softcap != 0: the scaled score
+    // (scale already divided by it on the host) goes through softcap * tanh(.); max_bias > 0: ALiBi — head h's mask values are multiplied by its slope
+    float softcap, max_bias, m0, m1; int n_head_log2;
 };
+static __device__ __forceinline__ float attn_slope(float max_bias, float m0, float m1, int n_head_log2, int h) {
+    return max_bias > 0.0f ? (h < n_head_log2 ? powf(m0, (float)(h + 1)) : powf(m1, (float)(2*(h - n_head_log2) + 1))) : 1.0f;
+}
 
 static __device__ __forceinline__ float dot8_f16_f32(const int4v kv, const float4v a, const float4v b) {
     const uint32_t k0 = (uint32_t) kv.x, k1 = (uint32_t) kv.y, k2 = (uint32_t) kv.z, k3 = (uint32_t) kv.w;
@@ -181,8 +188,11 @@ static __device__ __forceinline__ float dot8_f16_f32(const int4v kv, const float
 // VT: V is the transposed cache [n_kv, hd] (rows over cells; the graph without flash attention). !VT: V rows are cells [hd, n_kv]
 // (FLASH_ATTN_EXT, src/llama-graph.cpp:1245-1265): v_nb1 is then the cell stride.
 // KQ: the K cache is Q8_0 (-ctk q8_0): a head's row is HD/32 blocks of {f16 d, 32 int8}; a lane's 8 elements are 8 bytes of one block
-template <int HD, bool VT = true, bool KQ = false>
+// KT / VY: the element types of the K and V rows (kv_types.h). The transposed-V form (VT) takes F16 or Q8_0 K and F16 V only.
+template <int HD, bool VT = true, int KT = T_F16, int VY = T_F16>
 __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
+    constexpr bool KQ = KT == T_Q8_0;
+    static_assert(!VT || ((KT == T_F16 || KT == T_Q8_0) && VY == T_F16), "transposed V: f16 V, f16 or Q8_0 K");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float * s = (float *) smem;                          // [n_kv] scores -> probabilities
     __shared__ float sh[4];
@@ -225,7 +235,9 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
 #define MI_R16(x_) x_ = f16_bits_to_f32(f32_to_f16_bits(x_))
         MI_R16(q0.x); MI_R16(q0.y); MI_R16(q0.z); MI_R16(q0.w); MI_R16(q1.x); MI_R16(q1.y); MI_R16(q1.z); MI_R16(q1.w);
     }
-    const char * kbase = p.k + (size_t) hk*p.k_nb2 + (KQ ? (sub >> 2)*34 : sub*16) + (size_t) kv_lo*p.k_nb1;
+    const char * kbase = p.k + (size_t) hk*p.k_nb2 + (KT == T_F16 ? sub*16 : KQ ? (sub >> 2)*34 : 0) + (size_t) kv_lo*p.k_nb1;
+    const bool alibi = p.max_bias > 0.0f;
+    const float slope = attn_slope(p.max_bias, p.m0, p.m1, p.n_head_log2, h);
     const char * mrow = p.mask ? p.mask + (size_t) t*p.m_nb1 + (size_t) kv_lo*(p.mask_f16 ? 2 : 4) : nullptr;
     // transposed V: the first 128 cells' worth of every lane's V rows is requested NOW, next to q and K — the soft_max in between does
     // not need them and the loads do not need the soft_max (one memory round trip less on the chain for n_kv <= 128: tg128)
@@ -247,8 +259,9 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
             if (KQ) {     // .x, .y: the lane's 8 quants; .z: the block's scale (blocks are 34 bytes: 2-byte aligned loads)
                 const int2v qq = ld_b64(kbase + (size_t) j*p.k_nb1 + 2 + (sub & 3)*8);
                 kreg[u] = int4v{ qq.x, qq.y, (int) ld_u16(kbase + (size_t) j*p.k_nb1), 0 };
-            } else
+            } else if (KT == T_F16)
             kreg[u] = *(const int4v *) (kbase + (size_t) j*p.k_nb1);
+            else kreg[u] = kv_raw8<KT>(kbase + (size_t) j*p.k_nb1, sub);
             mreg[u] = 0.0f;
             if (mrow) mreg[u] = p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (mrow + (size_t) j*2)) : *(const float *) (mrow + (size_t) j*4);
         }
@@ -261,11 +274,17 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
                 acc = ((float)(int8_t) a0*q0.x + (float)(int8_t)(a0 >> 8)*q0.y) + ((float)(int8_t)(a0 >> 16)*q0.z + (float)(a0 >> 24)*q0.w)
                     + ((float)(int8_t) a1*q1.x + (float)(int8_t)(a1 >> 8)*q1.y) + ((float)(int8_t)(a1 >> 16)*q1.z + (float)(a1 >> 24)*q1.w);
                 acc *= f16_bits_to_f32((uint16_t) kreg[u].z);
-            } else acc = dot8_f16_f32(kreg[u], q0, q1);
+            } else if (KT == T_F16) acc = dot8_f16_f32(kreg[u], q0, q1);
+            else {
+                float f[8]; kv_cvt8<KT>(kreg[u], sub, f);
+                acc  = f[0]*q0.x + f[1]*q0.y; acc += f[2]*q0.z + f[3]*q0.w; acc += f[4]*q1.x + f[5]*q1.y; acc += f[6]*q1.z + f[7]*q1.w;
+            }
             acc += dpp_f<0xB1>(acc); acc += dpp_f<0x4E>(acc); acc += dpp_f<0x141>(acc);   // sum over the LPC lanes of the row
             if (LPC == 16) acc += dpp_f<0x140>(acc);
             if (j < kv_n) {
-                const float v = acc*p.scale + mreg[u];
+                float v;
+                if (p.softcap != 0.0f || alibi) { v = acc*p.scale; if (p.softcap != 0.0f) v = p.softcap*tanhf(v); v += slope*mreg[u]; }
+                else v = acc*p.scale + mreg[u];
                 if (sub == 0) s[j] = v;
                 mx = fmaxf(mx, v);
             }
@@ -297,18 +316,25 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
         constexpr int DCH = HD/8, NGR = 256/DCH, UV = 4;
         float * red = (float *) (smem + (((size_t)(split ? p.kv_chunk : p.n_kv)*4 + 15) & ~(size_t) 15));     // [NGR][HD]
         const int dch = threadIdx.x % DCH, cg = threadIdx.x / DCH;
-        const char * vb = p.v + (size_t) hk*p.v_nb2 + (size_t) dch*16 + (size_t) kv_lo*p.v_nb1;
+        const char * vb = p.v + (size_t) hk*p.v_nb2 + (VY == T_F16 ? (size_t) dch*16 : 0) + (size_t) kv_lo*p.v_nb1;
         float a8[8] = { 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f };
         for (int j0 = cg; j0 < kv_n; j0 += NGR*UV) {
             int4v vr[UV]; float pj[UV];
 #pragma unroll
             for (int u = 0; u < UV; u++) {
                 const int j = min(j0 + u*NGR, kv_n - 1);
-                vr[u] = *(const int4v *) (vb + (size_t) j*p.v_nb1);
+                if (VY == T_F16) vr[u] = *(const int4v *) (vb + (size_t) j*p.v_nb1);
+                else vr[u] = kv_raw8<VY>(vb + (size_t) j*p.v_nb1, dch);
                 pj[u] = j0 + u*NGR < kv_n ? s[j] : 0.0f;
             }
 #pragma unroll
             for (int u = 0; u < UV; u++) {
+                if (VY != T_F16) {
+                    float f[8]; kv_cvt8<VY>(vr[u], dch, f);
+#pragma unroll
+                    for (int i = 0; i < 8; i++) a8[i] += pj[u]*f[i];
+                    continue;
+                }
                 const uint32_t w0 = (uint32_t) vr[u].x, w1 = (uint32_t) vr[u].y, w2 = (uint32_t) vr[u].z, w3 = (uint32_t) vr[u].w;
                 a8[0] += pj[u]*f16_bits_to_f32((uint16_t) w0); a8[1] += pj[u]*f16_bits_to_f32((uint16_t)(w0 >> 16));
                 a8[2] += pj[u]*f16_bits_to_f32((uint16_t) w1); a8[3] += pj[u]*f16_bits_to_f32((uint16_t)(w1 >> 16));
@@ -379,12 +405,32 @@ size_t attn_decode_part_bytes(int64_t head_dim, int64_t n_kv, int64_t n_head, in
     return (size_t) T*n_head*ns*(head_dim + 2)*4;
 }
 
+// which (K, V) type pairs the row-major-V (flash attention) kernel reads directly; the others go through kv_to_f16 first
+bool attn_decode_kv_types_fused(int k_type, int v_type) {
+    return (k_type == v_type && (k_type == T_F16 || k_type == T_Q8_0 || k_type == T_Q4_0 || k_type == T_BF16)) || (k_type == T_Q8_0 && (v_type == T_F16 || v_type == T_Q4_0));
+}
+// ALiBi slopes (ggml_compute_forward_flash_attn_ext_f16 / soft_max: m0 = 2^(-max_bias / n), m1 = 2^(-max_bias / 2 / n), n = 2^floor(log2 n_head))
+void attn_alibi(float max_bias, int64_t n_head, float & m0, float & m1, int & n_head_log2) {
+    n_head_log2 = 1; while (2*n_head_log2 <= (int) n_head) n_head_log2 *= 2;
+    m0 = powf(2.0f, -max_bias/(float) n_head_log2); m1 = powf(2.0f, -(max_bias/2.0f)/(float) n_head_log2);
+}
+
 void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                  const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans,
-                 float * part, size_t part_bytes, bool k_q8_0) {
+                 float * part, size_t part_bytes, bool k_q8_0, const attn_extra * ex) {
     attn_args a = { (const char *) q, q_nb1, q_nb2, (const char *) k, k_nb1, k_nb2, (const char *) v, v_nb1, v_nb2,
                     (const char *) mask, m_nb1, mask_f16 ? 1 : 0, sinks, dst, dst_nb1, (int) n_kv, (int) n_head, (int) n_head_kv, (int) T, scale, 0, 1, nullptr };
+    a.softcap = 0.0f; a.max_bias = 0.0f; a.m0 = a.m1 = 1.0f; a.n_head_log2 = 1;
+    int kt = k_q8_0 ? T_Q8_0 : T_F16, vy = T_F16;
+    if (ex) {
+        attn_alibi(ex->max_bias, n_head, a.m0, a.m1, a.n_head_log2);
+        a.softcap = ex->softcap; a.max_bias = ex->max_bias;
+        if (ex->softcap != 0.0f) a.scale = scale/ex->softcap;
+        if (ex->k_type) kt = ex->k_type;
+        if (ex->v_type) vy = ex->v_type;
+    }
+    if (v_trans ? !((kt == T_F16 || kt == T_Q8_0) && vy == T_F16) : !attn_decode_kv_types_fused(kt, vy)) { fprintf(stderr, "attn_decode: KV types (%d, %d) have no kernel\n", kt, vy); abort(); }
     // long contexts: one workgroup per (head, token) walks every cell alone — 32 workgroups on 256 CUs. With a partial buffer the cells
     // are split into ranges of >= 256 (at most 32 ranges) that run side by side and a small second kernel merges them.
     static const bool split_on = !getenv("GGML_MI355X_ATTN_SPLIT") || atoi(getenv("GGML_MI355X_ATTN_SPLIT")) != 0;
@@ -403,12 +449,19 @@ void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, siz
     const dim3 grid((unsigned) n_head, (unsigned) T, (unsigned) a.nsplit);
     const size_t lds = (((size_t)(a.nsplit > 1 ? a.kv_chunk : n_kv)*4 + 15) & ~(size_t) 15) + (v_trans ? 0 : 8192);     // !v_trans: + [256/(hd/8)][hd] partial sums
     if (!v_trans) {
-        if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, false>), grid, dim3(256), lds, stream, a);
-        else                 hipLaunchKernelGGL((k_attn_decode<64, false>),  grid, dim3(256), lds, stream, a);
+#define MI_AD(KT_, VY_) do { if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, false, KT_, VY_>), grid, dim3(256), lds, stream, a); \
+                             else                 hipLaunchKernelGGL((k_attn_decode<64, false, KT_, VY_>),  grid, dim3(256), lds, stream, a); } while (0)
+        if (kt == T_F16 && vy == T_F16)        MI_AD(T_F16, T_F16);
+        else if (kt == T_Q8_0 && vy == T_Q8_0) MI_AD(T_Q8_0, T_Q8_0);
+        else if (kt == T_Q4_0 && vy == T_Q4_0) MI_AD(T_Q4_0, T_Q4_0);
+        else if (kt == T_BF16 && vy == T_BF16) MI_AD(T_BF16, T_BF16);
+        else if (kt == T_Q8_0 && vy == T_F16)  MI_AD(T_Q8_0, T_F16);
+        else                                   MI_AD(T_Q8_0, T_Q4_0);
+#undef MI_AD
     }
-    if (v_trans && k_q8_0) {
-        if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, true, true>), grid, dim3(256), lds, stream, a);
-        else                 hipLaunchKernelGGL((k_attn_decode<64, true, true>),  grid, dim3(256), lds, stream, a);
+    if (v_trans && kt == T_Q8_0) {
+        if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128, true, T_Q8_0>), grid, dim3(256), lds, stream, a);
+        else                 hipLaunchKernelGGL((k_attn_decode<64, true, T_Q8_0>),  grid, dim3(256), lds, stream, a);
     } else
     if (v_trans) {
         if (head_dim == 128) hipLaunchKernelGGL((k_attn_decode<128>), grid, dim3(256), lds, stream, a);

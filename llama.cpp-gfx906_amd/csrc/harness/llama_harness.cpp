@@ -58,6 +58,8 @@ struct mi_llama_hparams {
                                       // src0 of the K.q mat-mul; src/llama-kv-cache-unified.cpp:114-132). V stays F16: a quantized V cache needs flash attention
     int32_t row_split;                // -sm row over this many devices (0 / 1 = off): the 2-D weight matrices go to the backend's split buffer type, equal shares
                                       // (make_gpu_buft_list, src/llama-model.cpp:368-387); everything else, the KV cache and the graph stay on `backend`'s device
+    int32_t type_v;                   // V cache type (llama-bench -ctv): 0 = F16; Q8_0 / Q4_0 / BF16 need flash attention (the V cache is then rows of cells,
+                                      // src/llama-context.cpp "V cache quantization requires flash_attn")
 };
 
 struct mi_llama;
@@ -400,9 +402,10 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
         const enum ggml_type tk = L.k_cache[seq]->type;
         ggml_tensor * k = ggml_view_4d(ctx0, L.k_cache[seq], hd, n_head_kv, n_kv_l, 1,
                 ggml_row_size(tk, hd), ggml_row_size(tk, n_embd_k_gqa), ggml_row_size(tk, n_embd_k_gqa*kv_size), 0);
+        const enum ggml_type tv = L.v_cache[seq]->type;
         ggml_tensor * v = hp.flash_attn
             ? ggml_view_4d(ctx0, L.v_cache[seq], hd, n_head_kv, n_kv_l, 1,      // !v_trans (:1087-1096)
-                ggml_row_size(GGML_TYPE_F16, hd), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa), ggml_row_size(GGML_TYPE_F16, n_embd_v_gqa*kv_size), 0)
+                ggml_row_size(tv, hd), ggml_row_size(tv, n_embd_v_gqa), ggml_row_size(tv, n_embd_v_gqa*kv_size), 0)
             : ggml_view_4d(ctx0, L.v_cache[seq], n_kv_l, n_head_kv, hd, 1,
                 ggml_row_size(GGML_TYPE_F16, kv_size*hd), ggml_row_size(GGML_TYPE_F16, kv_size), ggml_row_size(GGML_TYPE_F16, kv_size*n_embd_v_gqa), 0);
         if (hp.flash_attn) {   // build_attn_mha with flash attention (src/llama-graph.cpp:1245-1265, :1337): n_kv % 256 == 0 by the cache's padding
@@ -548,6 +551,7 @@ mi_llama * create_body(mi_llama * m) {
     const int64_t n_embd = hp.n_embd, hd = hp.n_embd_head, n_ff = hp.n_ff;
     const int64_t n_embd_k_gqa = hd*hp.n_head_kv, n_embd_v_gqa = hd*hp.n_head_kv;
     const int kv_size = hp.n_ctx;
+    if (hp.type_v && hp.type_v != GGML_TYPE_F16 && !hp.flash_attn) throw std::runtime_error("V cache quantization requires flash_attn");      // as llama_init_from_model says
     if (kv_size % (hp.flash_attn ? 256 : KV_PAD) != 0) { fprintf(stderr, "mi_llama: n_ctx must be a multiple of %d\n", hp.flash_attn ? 256 : KV_PAD); throw std::runtime_error("n_ctx is not a multiple of the KV padding"); }
     if (hp.n_swa > 0) {    // llama_kv_cache_unified_iswa (src/llama-kv-cache-unified-iswa.cpp:46-60): size_swa = min(size_base, PAD(n_swa*n_seq + n_ubatch, n_pad)); one stream per sequence here
         const int pad = hp.flash_attn ? 256 : KV_PAD;
@@ -607,7 +611,7 @@ mi_llama * create_body(mi_llama * m) {
         L.swa = hp.n_swa > 0 && (hp.swa_pattern <= 0 || il % hp.swa_pattern < hp.swa_pattern - 1);     // llama_hparams::set_swa_pattern
         for (int sq = 0; sq < std::max(1, hp.n_seq_max); sq++) {
             L.k_cache.push_back(ggml_new_tensor_2d(m->kvctx, hp.type_k ? (enum ggml_type) hp.type_k : GGML_TYPE_F16, n_embd_k_gqa, L.swa ? m->swa_size : kv_size));
-            L.v_cache.push_back(ggml_new_tensor_2d(m->kvctx, GGML_TYPE_F16, n_embd_v_gqa, L.swa ? m->swa_size : kv_size));
+            L.v_cache.push_back(ggml_new_tensor_2d(m->kvctx, hp.type_v ? (enum ggml_type) hp.type_v : GGML_TYPE_F16, n_embd_v_gqa, L.swa ? m->swa_size : kv_size));
         }
         m->layers.push_back(L);
     }

@@ -174,11 +174,19 @@ void swiglu_quant(const float * g, size_t g_stride, const float * u, size_t u_st
 void kv_store_f16(const float * k_src, size_t k_src_nb1, const int64_t * k_idx, void * k_dst, size_t k_dst_nb1, int64_t k_ne0, int64_t k_rows,
                   const float * v_src, const int64_t * v_idx, void * v_dst, int64_t v_n, hipStream_t stream);
 // K.q -> softmax -> V^T.p -> [hd*n_head, T] for T query tokens over the f16 cache
+// FLASH_ATTN_EXT's remaining parameters: logit_softcap, max_bias (ALiBi) and the cache's element types (0 = F16)
+struct attn_extra { float softcap, max_bias; int k_type, v_type; };
+bool attn_decode_kv_types_fused(int k_type, int v_type);      // read directly by the row-major-V decode kernel (others: kv_to_f16 first)
+void attn_alibi(float max_bias, int64_t n_head, float & m0, float & m1, int & n_head_log2);
+// K / V cache views [hd, n_kv, n_head_kv] of type F16 / BF16 / Q8_0 / Q4_0 -> dense f16: rows of cells [n_head_kv][n_kv][hd], or transposed
+// (rows over cells, the layout the matrix-core prefill kernel stages with coalesced loads) [n_head_kv][hd][n_kv]; n_kv % 8 == 0, hd 64 / 128
+void kv_to_f16(int type, const void * src, size_t nb1, size_t nb2, int64_t hd, int64_t n_kv, int64_t n_head_kv, uint16_t * dst, bool transpose, hipStream_t stream);
 bool attn_decode_supported(int64_t head_dim, int64_t n_kv);
 void attn_decode(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                  const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
                  int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans = true,
-                 float * part = nullptr, size_t part_bytes = 0, bool k_q8_0 = false);     // k_q8_0: K rows are Q8_0 blocks (transposed-V form only)
+                 float * part = nullptr, size_t part_bytes = 0, bool k_q8_0 = false,      // k_q8_0: K rows are Q8_0 blocks (transposed-V form only)
+                 const attn_extra * ex = nullptr);
 // long contexts (n_kv >= 384, or 256 with row-major V; a multiple of 32; GGML_MI355X_ATTN_SPLIT_MIN): with a partial buffer of attn_decode_part_bytes() the cells are split over up to 32 workgroups per
 // (head, token) and merged by a second small kernel; attn_decode_supported_split: shapes that only work with the buffer (scores beyond one LDS)
 size_t attn_decode_part_bytes(int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t T);
@@ -189,7 +197,8 @@ bool attn_prefill_supported(int64_t head_dim, int64_t n_kv);
 void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
                   const void * mask, size_t m_nb1, bool mask_f16, const float * sinks, float * dst, size_t dst_nb1,
                   int64_t head_dim, int64_t n_kv, int64_t n_head, int64_t n_head_kv, int64_t T, float scale, hipStream_t stream, bool v_trans = true,
-                  uint16_t * y16 = nullptr);     // y16 != NULL: also (dst == NULL: only) the bf16 copy the following mat-mul reads, rows of hd*n_head (a multiple of 64)
+                  uint16_t * y16 = nullptr,      // y16 != NULL: also (dst == NULL: only) the bf16 copy the following mat-mul reads, rows of hd*n_head (a multiple of 64)
+                  const attn_extra * ex = nullptr);     // (K and V are f16 here: other cache types are converted by kv_to_f16 first)
 
 // grouped mat-vec (n = 1): up to MMVQ_MAX_GROUPS weight tensors that share one activation vector, each with an epilogue
 constexpr int MMVQ_MAX_GROUPS = 4;

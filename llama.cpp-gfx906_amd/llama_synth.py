@@ -21,7 +21,7 @@ class hparams(C.Structure):
                                          "ftype", "rope_type", "n_ctx_orig", "has_rope_freqs", "is_70b")] + \
                [(n, C.c_float) for n in ("rope_freq_base", "rope_freq_scale", "f_norm_rms_eps")] + \
                [(n, C.c_int32) for n in ("layer_begin", "layer_end", "has_output", "n_seq_max", "n_expert", "n_expert_used", "arch", "flash_attn",
-                                         "n_swa", "swa_pattern", "n_ubatch", "type_k", "row_split")]
+                                         "n_swa", "swa_pattern", "n_ubatch", "type_k", "row_split", "type_v")]
 
 
 # model shapes used by the configs
@@ -109,7 +109,7 @@ def harness():
 
 class SynthLlama:
     def __init__(self, backend: gg.Backend, model="llama3-8b", ftype="Q4_K_M", n_ctx=128, seed=1, layer_begin=0, layer_end=None,
-                 has_output=None, rope_type=0, has_rope_freqs=False, n_seq_max=1, flash_attn=False, row_split=0, type_k=0, **over):
+                 has_output=None, rope_type=0, has_rope_freqs=False, n_seq_max=1, flash_attn=False, row_split=0, type_k=0, type_v=0, **over):
         cfg = dict(MODELS[model]); cfg.update(over)
         self.cfg = cfg
         n_layer = cfg["n_layer"]
@@ -131,6 +131,8 @@ class SynthLlama:
         hp.n_swa, hp.swa_pattern, hp.n_ubatch = cfg.get("n_swa", 0), cfg.get("swa_pattern", 0), cfg.get("n_ubatch", 512)
         hp.type_k = type_k             # K cache type (ggml type id; 0 = F16): llama-bench -ctk q8_0 = 8
         cfg["type_k"] = type_k
+        hp.type_v = type_v             # V cache type (llama-bench -ctv; anything but F16 needs flash_attn)
+        cfg["type_v"] = type_v; cfg["flash_attn"] = int(flash_attn)
         hp.row_split = row_split       # -sm row: the weight matrices' rows spread over this many devices (csrc/backend.cpp: the split buffer type)
         self.hp = hp
         self.backend = backend

@@ -21,13 +21,13 @@ import numpy as np
 _HERE = Path(__file__).resolve().parent
 
 # ggml_type ids — gguf-py/gguf/constants.py:2698-2730
-F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, MXFP4 = 0, 1, 2, 8, 12, 13, 14, 15, 39
+F32, F16, Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, Q8_K, BF16, MXFP4 = 0, 1, 2, 8, 12, 13, 14, 15, 30, 39
 I32, I64 = 26, 27
 TYPE_NAMES = {F32: "f32", F16: "f16", Q4_0: "q4_0", Q8_0: "q8_0", Q4_K: "q4_K", Q5_K: "q5_K",
               Q6_K: "q6_K", Q8_K: "q8_K", MXFP4: "mxfp4"}
 QUANT_TYPES = (Q4_0, Q8_0, Q4_K, Q5_K, Q6_K, MXFP4)
 # (block size, type size) — gguf-py/gguf/constants.py:2839-2872
-QUANT_SIZES = {F32: (1, 4), F16: (1, 2), Q4_0: (32, 18), Q8_0: (32, 34), Q4_K: (256, 144), Q5_K: (256, 176),
+QUANT_SIZES = {F32: (1, 4), F16: (1, 2), BF16: (1, 2), Q4_0: (32, 18), Q8_0: (32, 34), Q4_K: (256, 144), Q5_K: (256, 176),
                Q6_K: (256, 210), Q8_K: (256, 292), MXFP4: (32, 17)}
 
 

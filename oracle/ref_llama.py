@@ -49,8 +49,15 @@ class RefLlama:
         # a quantized K cache (cfg["type_k"], -ctk q8_0 / q4_0): rows are quantized on the way in by the reference row quantizer (SET_ROWS) and K.q
         # becomes a quantized mat-mul (src0 = the cache), evaluated per head over the head's blocks of the row
         self.tk = cfg.get("type_k", 0)
-        if self.tk:
+        if self.tk and not cfg.get("flash_attn", 0):
             self.kq = np.zeros((cfg["n_layer"], kv_size, orc.row_size(self.tk, hkv*hd)), np.uint8)
+        # -fa 1 with a quantized / bf16 cache (cfg["flash_attn"], type_k / type_v): FLASH_ATTN_EXT dequantizes the rows it reads (ggml/src/ggml-cpu/ops.cpp
+        # ggml_compute_forward_flash_attn_ext_f16: V through v_to_float; K through a dot with the Q8_0-quantized q — restated here as the exact product
+        # with the dequantized K row, the dot's own quantization of q being below the 5e-4 the reference's test allows)
+        self.fa = bool(cfg.get("flash_attn", 0))
+        self.tv = cfg.get("type_v", 0)
+        if self.tv or (self.fa and self.tk):
+            self.kd = np.zeros((cfg["n_layer"], kv_size, hkv, hd), np.float32); self.vd = np.zeros((cfg["n_layer"], kv_size, hkv, hd), np.float32)
         self.n_past = 0
         self.selected = []      # expert choices, so that a test can tell a routing flip from an arithmetic error
 
@@ -103,11 +110,22 @@ class RefLlama:
             q = ref.rope(q, pos, hd, rmode, c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
             k = ref.rope(k, pos, hd, rmode, c["n_ctx_orig"], c["rope_freq_base"]).astype(np.float32)[0]
             self.k[il, pos] = k.astype(np.float16)
-            if self.tk:
+            if self.tk and not self.fa:
                 self.kq[il, pos] = orc.quantize(k.reshape(n_tok, hkv*hd), self.tk)
             self.v[il, pos] = v.astype(np.float16)
             n_kv = self.n_past + n_tok
             K = self.k[il, :n_kv].astype(np.float32); V = self.v[il, :n_kv].astype(np.float32)
+            fa_deq = self.tv or (self.fa and self.tk)
+            if fa_deq:
+                def through(x, t):      # the row as the cache holds it, read back
+                    if t in (0, orc.F16):
+                        return x.astype(np.float16).astype(np.float32)
+                    if t == orc.BF16:
+                        u = np.ascontiguousarray(x, np.float32).view(np.uint32)
+                        return (((u + 0x7FFF + ((u >> 16) & 1)) >> 16) << 16).astype(np.uint32).view(np.float32)
+                    return orc.dequantize(orc.quantize(x.reshape(n_tok, hkv*hd), t), t).reshape(x.shape)
+                self.kd[il, pos] = through(k, self.tk); self.vd[il, pos] = through(v, self.tv)
+                K = self.kd[il, :n_kv]; V = self.vd[il, :n_kv]
             out = np.zeros((n_tok, nh, hd), np.float32)
             for hh in range(nh):
                 kvh = hh // (nh // hkv)
@@ -115,7 +133,7 @@ class RefLlama:
                 # the probabilities, are rounded to f16 before the dot; sums in f32. Mode "cpu16" restates that too (used where the CPU path as
                 # a whole is the yardstick: the perplexity delta); "cpu" and "exact" keep q and p in f32, as this backend's decode kernel does.
                 qh = q[:, hh, :].astype(np.float16).astype(np.float64) if self.f16_attn else q[:, hh, :].astype(np.float64)
-                if self.tk:
+                if self.tk and not fa_deq:
                     hb = orc.row_size(self.tk, hd)
                     s = orc.mul_mat_2d(np.ascontiguousarray(self.kq[il, :n_kv, kvh*hb:(kvh + 1)*hb]), self.tk, q[:, hh, :], self.mode).astype(np.float32)
                 else:

@@ -561,6 +561,29 @@ def test_quantized_k_cache(type_k, model):
         assert orc.nmse(b_, a_) <= (2e-3 if type_k == 8 else 1e-5)
 
 
+@pytest.mark.parametrize("type_k,type_v,model", [(8, 8, "tiny"), (2, 2, "tiny"), (8, 2, "tiny-hd128"), (30, 30, "tiny"), (0, 8, "tiny-hd128"), (8, 8, "tiny-oai")])
+def test_flash_attention_with_quantized_kv_cache(type_k, type_v, model):
+    """llama-bench -fa 1 -ctk / -ctv q8_0 | q4_0 | bf16 (a quantized V cache exists only with flash attention: its rows are cells): SET_ROWS quantizes K and V
+    rows into the caches, FLASH_ATTN_EXT reads the blocks (decode: in the kernel, kv_types.h; prompt passes: kv_to_f16 + the matrix-core kernel with V
+    transposed on the way). The oracle holds the same caches read back through the reference row quantizers. Prompt pass, decode steps, a second
+    prompt chunk on top of the cache; gpt-oss-shaped too (sinks, the sliding-window cache pair). Gate: the whole-graph 2e-3 (tests/test-backend-ops.cpp:4972-5096)."""
+    be = backend()
+    be.set_option("graphs", 1); be.set_option("fusion", 1)
+    ftype = "MXFP4_MOE" if model == "tiny-oai" else "Q4_K_M"
+    m = ls.SynthLlama(be, model, ftype, n_ctx=256, seed=5, type_k=type_k, type_v=type_v, flash_attn=True)
+    try:
+        rc = RefLlama(m.cfg, read_weights(m), 256, "cpu16")
+        for toks in [[5, 9, 200, 17, 3, 44, 101], [7], [8], [300], list(range(50, 62)), [2], [11]]:
+            got = m.decode(toks)
+            assert np.isfinite(got).all()
+            exp_c = rc.decode(np.stack([m.embedding(t) for t in toks]))
+            # (Q4_0 rows: a K / V value that differs in its last bits from the oracle's — bf16 activations in the prompt pass — can land in the next of
+            # its 16 bins; the same allowance as the quantized-K test without flash attention)
+            assert orc.nmse(exp_c, got) <= (4e-3 if 2 in (type_k, type_v) else 2e-3), (toks, orc.nmse(exp_c, got))
+    finally:
+        m.free()
+
+
 def test_full_size_llama3_8b_execution_modes_agree():
     """BASELINE.json configs[1] at its FULL size (32 layers, vocabulary 128256, 4.6 GB of Q4_K_M weights; the oracle cannot walk that in test time, so the
     check is a size-independent property): the three ways the backend can run the same decode graph — fused launches replayed from a captured hipGraph (the
