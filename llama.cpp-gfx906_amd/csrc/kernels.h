@@ -48,6 +48,10 @@ void mul_mat_vec_q(int type_a, const void * W, size_t w_row_stride, int64_t m, i
 void mul_mat_vec_q_batched(int type_a, const void * W, size_t w_row_stride, size_t w_batch_stride, int r2, int64_t m, int64_t k,
                            const act_q8 & act, int64_t n, int64_t n_batch, float * dst, size_t dst_col_stride_bytes, size_t dst_batch_stride_bytes, hipStream_t stream);
 
+// 2 <= n <= 8 columns of Q4_K / Q5_K / Q6_K on the streamed weight path (mmvq_stream_cols.hip: LDS-DMA ring, every unit multiplied with all columns);
+// false = not taken (k % 2048, the column images + two slots must fit LDS)
+bool mul_mat_vec_q_stream_cols(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
+                               const act_q8 & act, int64_t n, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
 // 2 <= n <= 8 columns of Q4_K / Q5_K / Q6_K on the int8 matrix cores; false = not taken (the caller runs its own kernel)
 bool mul_mat_vec_q_cols_mfma(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                              const act_q8 & act, int64_t n, float * dst, size_t dst_col_stride_bytes, hipStream_t stream);

@@ -301,7 +301,8 @@ static void launch_mmvq(int type_a, const mmvq_args & a, int act_kind, int64_t n
 void mul_mat_vec_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                    const act_q8 & act, int64_t n, float * dst, size_t dst_col_stride_bytes, hipStream_t stream) {
     if (m == 0 || n == 0) return;
-    // 2..8 columns of a K-quant: the int8 matrix-core kernel (mmvq_cols_mfma.hip) when the column images fit in LDS
+    // 2..8 columns of a K-quant: the streamed kernel (mmvq_stream_cols.hip), else the int8 matrix-core kernel (mmvq_cols_mfma.hip) when the column images fit in LDS
+    if (n >= 2 && mul_mat_vec_q_stream_cols(type_a, W, w_row_stride, m, k, act, n, dst, dst_col_stride_bytes, stream)) return;
     if (n >= 2 && mul_mat_vec_q_cols_mfma(type_a, W, w_row_stride, m, k, act, n, dst, dst_col_stride_bytes, stream)) return;
     mmvq_args a = {};
     a.W = (const char *) W; a.w_row_stride = w_row_stride; a.m = m; a.k = k;

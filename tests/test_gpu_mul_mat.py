@@ -104,6 +104,11 @@ def test_mul_mat_golden(name, k, golden_dir):
     # blocks than waves, the reference's perf shape, and a k whose images do not fit in LDS at n = 8 (falls back)
     ("q4_K", 5003, 4096, 5), ("q5_K", 4100, 1024, 7), ("q6_K", 515, 4096, 3), ("q4_K", 4096, 14336, 8), ("q6_K", 4096, 14336, 2),
     ("q5_K", 64, 14336, 8), ("q4_K", 48, 28672, 8), ("q4_K", 48, 28672, 4), ("q6_K", 31, 512, 6),
+    # ... and on the streamed weight path (mmvq_stream_cols.hip, k % 2048 == 0): three 9 KiB slots next to eight column images at k = 14336, 8- and
+    # 16-lane row reductions (k / 256 = 56, 24, 8 vs 16), rows that do not divide by the workgroups, Q6_K's 16-byte-aligned row pairs, 7 columns
+    # of Q6_K at k = 14336 (8 do not leave two slots: the matrix-core kernel takes those)
+    ("q4_K", 4096, 14336, 3), ("q5_K", 1000, 6144, 4), ("q6_K", 4096, 4096, 8), ("q4_K", 300, 2048, 6), ("q6_K", 4097, 14336, 7), ("q5_K", 4096, 14336, 8),
+    ("q4_K", 14336, 4096, 2), ("q6_K", 7, 2048, 5),
 ])
 def test_mul_mat_model_shapes(name, m, k, n):
     rng = np.random.default_rng(m * 131 + k)
@@ -184,9 +189,23 @@ def test_mfma_column_kernel_forced_for_every_n_and_q6_k():
     import sys
     if os.environ.get("MI_NESTED_PYTEST"):
         pytest.skip("already the child run")
-    env = dict(os.environ, GGML_MI355X_MMVQ_COLS_MFMA="2", MI_NESTED_PYTEST="1")
+    env = dict(os.environ, GGML_MI355X_MMVQ_COLS_MFMA="2", GGML_MI355X_STREAM_COLS="0", MI_NESTED_PYTEST="1")
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
                         "-k", "test_mul_mat_small or test_mul_mat_model_shapes"], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
+
+
+def test_streamed_column_kernel_forced_for_q6_k():
+    """mmvq_stream_cols.hip takes Q4_K / Q5_K by default; GGML_MI355X_STREAM_COLS=2 sends Q6_K through it too (slower there, kept correct)."""
+    import os
+    import subprocess
+    import sys
+    if os.environ.get("MI_NESTED_PYTEST"):
+        pytest.skip("already the child run")
+    env = dict(os.environ, GGML_MI355X_STREAM_COLS="2", MI_NESTED_PYTEST="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider",
+                        "-k", "test_mul_mat_model_shapes and q6_K"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
 
