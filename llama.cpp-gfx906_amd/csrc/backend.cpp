@@ -388,6 +388,10 @@ struct mi_backend_ctx {
     float * rope_tab = nullptr; mmvq_rope rope_tab_key = {}; bool rope_tab_valid = false;
     static constexpr size_t FIN_IMG_BYTES = 64*1024; static constexpr int FIN_COUNTERS = 256;
     void * kv16 = nullptr; size_t kv16_size = 0;                // FLASH_ATTN_EXT: dense f16 copies of a quantized / bf16 cache view, and the transposed V of the prefill kernel (kv_to_f16)
+    // attention + wo as one launch (attn_wo.hip): its partial planes, and what is pending — the vector x_out = res + sum of the planes does not exist until the
+    // launch that reads it (norm + gate/up, streamed kernel) has added them up, or pp_flush has
+    float * wo_planes = nullptr; static constexpr int WO_PLANE_STRIDE = 16384, WO_PLANES_MAX = 16;
+    struct { bool active = false; const float * res = nullptr; float * x_out = nullptr; int n_planes = 0; int64_t m = 0; } pp;
     float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
     // activation-quantisation reuse inside one graph_compute
@@ -491,6 +495,7 @@ static void be_free(ggml_backend_t backend) {
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
+    if (c->wo_planes) (void) hipFree(c->wo_planes);
     if (c->kv16) (void) hipFree(c->kv16);
     if (c->chain_prog_dev) (void) hipFree(c->chain_prog_dev);
     if (c->chain_prog_host) (void) hipHostFree(c->chain_prog_host);
@@ -954,9 +959,17 @@ static void rec_flush(mi_backend_ctx * c) {
     c->rec.clear();
 }
 
+// the pending sum of attn_wo's planes is needed as a tensor after all (its reader is not the launch that would have added them up itself)
+static void pp_flush(mi_backend_ctx * c) {
+    if (!c->pp.active) return;
+    planes_sum(c->pp.res, c->wo_planes, c->pp.n_planes, mi_backend_ctx::WO_PLANE_STRIDE, c->pp.x_out, c->pp.m, c->stream);
+    c->cnt.kernels_launched++;
+    c->pp.active = false;
+}
+
 static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin, float * norm_out) {
     // only what the streamed kernel takes can be a phase of a chain; anything else ends the recorded run and goes out by itself
-    if (!c->rec_on || fin || !mul_mat_vec_q_stream_takes(grp, nc, K, in, rope) || (int) c->rec.size() >= mi_backend_ctx::CHAIN_MAX_PHASES) {
+    if (!c->rec_on || fin || in.planes || !mul_mat_vec_q_stream_takes(grp, nc, K, in, rope) || (int) c->rec.size() >= mi_backend_ctx::CHAIN_MAX_PHASES) {
         if (c->rec_on) rec_flush(c);
         mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
         c->cnt.kernels_launched++;
@@ -1257,6 +1270,11 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
         }
         rope_l = *rope; rope_l.table = c->rope_tab; rope = &rope_l;
     }
+    if (c->pp.active && in.mode == PRO_NORM && (const void *) in.x == (const void *) c->pp.x_out && K == c->pp.m) {
+        // the norm's input is the sum attn_wo left as partial planes: this launch adds them up in its prologue (and stores the sum)
+        in.x = c->pp.res; in.planes = c->wo_planes; in.n_planes = c->pp.n_planes; in.plane_stride = mi_backend_ctx::WO_PLANE_STRIDE; in.x_out = c->pp.x_out;
+        c->pp.active = false;
+    }
     emit_mmv(c, grp, nc, K, in, rope, fin_t ? &fin : nullptr, in.mode == PRO_NORM && normw ? (float *) norm_mul_data : nullptr);
     if (fin_t) {
         c->aq = { fin_t->data, grp[0].m, 1, 1, fin_t->nb[1], 0, fin.kind, fin_q, true, (size_t) grp[0].m*4, 0 };
@@ -1354,6 +1372,37 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                     hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream, true, use_part ? c->attn_part : nullptr, use_part ? c->attn_part_bytes : 0, true);
         c->cnt.kernels_launched++;
         return j3 - i + 1;
+    }
+    // attention + wo -> + residual as ONE launch (attn_wo.hip) when the sum's only readers are the norm of a grouped mat-vec launch (which adds the
+    // partial planes up in its prologue) and later residual adds
+    if (T == 1 && c->wo_planes && !c->rec_on && hd == 128 && n_head_kv <= mi_backend_ctx::WO_PLANES_MAX && (!mask || mask->ne[1] >= 1)) {
+        const int jw = next_real(g, j3);
+        if (jw > 0 && fusable_mmv(g->nodes[jw]) && g->nodes[jw]->src[1] == ct && is_internal(c, ct)) {
+            const struct ggml_tensor * wo = g->nodes[jw]->src[0];
+            const mmv_chain ch = match_mmv_chain(c, g, jw);
+            const int jn = ch.grp.epi == EPI_ADD ? next_real(g, ch.last) : -1;
+            const int jm = jn > 0 ? next_real(g, jn) : -1;
+            const int jq = jm > 0 ? next_real(g, jm) : -1;
+            if (jq > 0 && !ch.grp.res2 && !ch.grp.st_mode && !ch.has_rope && wo->ne[0] == hd*n_head && wo->ne[1] <= mi_backend_ctx::WO_PLANE_STRIDE &&
+                wo->nb[1] == ggml_row_size(wo->type, wo->ne[0]) && ((uintptr_t) wo->data % 16) == 0 && ((uintptr_t) ch.grp.res % 16) == 0 && ((uintptr_t) ch.grp.dst % 16) == 0 &&
+                (const void *) ch.grp.res != (const void *) ch.grp.dst &&
+                attn_wo_supported((int) wo->type, wo->ne[1], wo->ne[0], hd, n_kv, n_head, n_head_kv) && wo->ne[1] == wo->ne[0] &&
+                g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0]->data == (void *) ch.grp.dst && is_row_vec_f32(g->nodes[jn]->src[0]) &&
+                g->nodes[jm]->op == GGML_OP_MUL && (g->nodes[jm]->src[0] == g->nodes[jn] || g->nodes[jm]->src[1] == g->nodes[jn]) &&
+                fusable_mmv(g->nodes[jq]) && g->nodes[jq]->src[1] == g->nodes[jm] &&
+                (g->nodes[jq]->src[0]->type == GGML_TYPE_Q4_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q5_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q6_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q8_0) &&
+                g->nodes[jq]->src[0]->ne[0] % 256 == 0 && g->nodes[jq]->src[0]->ne[0] <= 4096 && mul_mat_vec_q_stream_enabled()) {
+                rec_flush(c);
+                pp_flush(c);
+                attn_wo(q->data, q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask && mask->type == GGML_TYPE_F16,
+                        sm->src[2] ? (const float *) sm->src[2]->data : nullptr, hd, n_kv, n_head, n_head_kv, op_f32(sm, 0),
+                        (int) wo->type, wo->data, wo->nb[1], wo->ne[1], c->wo_planes, mi_backend_ctx::WO_PLANE_STRIDE, c->stream);
+                c->pp.active = true; c->pp.res = ch.grp.res; c->pp.x_out = ch.grp.dst; c->pp.n_planes = (int) n_head_kv; c->pp.m = wo->ne[1];
+                c->cnt.kernels_launched++; c->cnt.mmvq_launches++;
+                c->cnt.weight_bytes += (uint64_t) wo->ne[1]*wo->nb[1];
+                return ch.last - i + 1;
+            }
+        }
     }
     {
         mi_backend_ctx::rec_item it = {};
@@ -1771,6 +1820,8 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
 
     int consumed = 1;
     bool fresh_aq = false;   // this step produced the cached quantized activations itself
+    // attn_wo's planes are pending: only the norm that reads their sum may go on without it (its grouped launch adds them up)
+    if (c->pp.active && !(node->op == GGML_OP_RMS_NORM && s0 && s0->data == (void *) c->pp.x_out && c->use_fusion)) pp_flush(c);
     if (c->use_fusion) {
         int f = 0;
         if (node->op == GGML_OP_MUL_MAT && !tensor_is_split(s0)) {
@@ -1850,6 +1901,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                             const int l = try_fused_mmv(c, g, jn, node, w);
                             if (l >= 0) { consumed = l - i + 1; fresh_aq = c->aq_fresh; c->aq_fresh = false; break; }
                         }
+                        pp_flush(c);       // (no grouped launch took the pending planes)
                         // MoE: the router's F32 mat-mul reads the product first (build_moe_ffn, src/llama-graph.cpp:838): the norm runs inside the
                         // router kernel, which also writes the product for the expert mat-vecs that follow
                         if (mm && mm->op == GGML_OP_MUL_MAT && mm->src[1] == mul && mm->src[0]->type == GGML_TYPE_F32 && node->ne[1] == 1 && w->ne[0] == node->ne[0] &&
@@ -1894,6 +1946,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                 }
             }
             rec_flush(c);
+            pp_flush(c);
             rms_norm(desc(s0), desc(node), op_f32(node, 0), c->stream);
             c->cnt.kernels_launched++;
         } break;
@@ -1964,8 +2017,10 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
             for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[i]->src[s]) c->uses[g->nodes[i]->src[s]]++;
         }
     }
+    c->pp.active = false;
     for (int i = 0; i < g->n_nodes; ) i += compute_node(c, g, i);
     rec_flush(c);
+    pp_flush(c);
     c->rec_on = false;
     c->aq.valid = false;
 }
@@ -2075,6 +2130,9 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         if (c->fin_img && hipMalloc((void **) &c->fin_cnt, (mi_backend_ctx::FIN_COUNTERS + 8)*4) == hipSuccess) {
             MI_CHECK_G(hipMemsetAsync(c->fin_cnt, 0, (mi_backend_ctx::FIN_COUNTERS + 8)*4, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream));
         } else if (c->fin_img) { (void) hipGetLastError(); (void) hipFree(c->fin_img); c->fin_img = nullptr; c->fin_cnt = nullptr; }
+    }
+    if (!c->wo_planes) {
+        if (hipMalloc((void **) &c->wo_planes, (size_t) mi_backend_ctx::WO_PLANES_MAX*mi_backend_ctx::WO_PLANE_STRIDE*4) != hipSuccess) { (void) hipGetLastError(); c->wo_planes = nullptr; }
     }
     if (!c->attn_part) {     // <= 8 tokens x 128 heads x 32 ranges x (128 + 2) floats: allocated once, outside any capture
         const size_t pb = (size_t) 8*128*32*130*4;

@@ -244,7 +244,16 @@ struct mmvq_input {
     const float * norm_w;  // PRO_NORM: y = (x * rsqrt(mean(x^2) + eps)) * norm_w, then quantized — RMS_NORM -> MUL folded in
     float eps;
     int act_kind;
+    // PRO_NORM only: the vector is not materialized yet — it is x[i] + planes[0][i] + planes[1][i] + ... (added in that order: the partial planes of the
+    // k-sliced attention + wo launch, attn_wo.hip, on top of the residual x) and the launch also stores that sum to x_out (the graph's ADD result)
+    const float * planes; int n_planes; int plane_stride; float * x_out;
 };
+// one token: attention + output projection as one launch writing n_head_kv partial planes (attn_wo.hip); planes_sum: the stand-alone consumer
+bool attn_wo_supported(int type, int64_t m, int64_t k, int64_t hd, int64_t n_kv, int64_t n_head, int64_t n_head_kv);
+void attn_wo(const void * q, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
+             const void * mask, bool mask_f16, const float * sinks, int64_t hd, int64_t n_kv, int64_t n_head, int64_t n_head_kv, float scale,
+             int type, const void * W, size_t w_row_stride, int64_t m, float * planes, int64_t plane_stride, hipStream_t stream);
+void planes_sum(const float * res, const float * planes, int n_planes, int plane_stride, float * x_out, int64_t m, hipStream_t stream);
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind);        // PRO_QUANT / PRO_NORM limits (k % 256, or k % 32 with Q8_0 activations)
 bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);         // may these two weight types share one grouped launch

@@ -263,8 +263,14 @@ static void fused_launch_kernel(const fused_launch & L, hipStream_t stream) {
 int mul_mat_vec_q_fused_pending(uint64_t * wbytes) { if (wbytes) *wbytes = 0; return 0; }     // nothing is ever held back (the round-1 chained launch is gone)
 void mul_mat_vec_q_fused_flush(hipStream_t) { }
 
-void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
+void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in_, const mmvq_rope * rope, hipStream_t stream,
                          const mmvq_fin * fin) {
+    mmvq_input in = in_;
+    if (in.planes && !mul_mat_vec_q_stream_takes(groups, n_groups, k, in, rope)) {
+        // partial planes (attn_wo.hip) and a consumer that is not the streamed kernel: add them up first, then the vector exists like any other
+        planes_sum(in.x, in.planes, in.n_planes, in.plane_stride, in.x_out, k, stream);
+        in.x = in.x_out; in.planes = nullptr; in.n_planes = 0; in.x_out = nullptr;
+    }
     if (mul_mat_vec_q_stream_takes(groups, n_groups, k, in, rope)) {      // the streamed kernel (mmvq_stream.h); callers do not pass it a `fin`
         uint64_t wbytes = 0;
         for (int i = 0; i < n_groups; i++) wbytes += (uint64_t) groups[i].m*groups[i].row_stride*(groups[i].epi == EPI_GLU ? 2 : 1);

@@ -57,6 +57,9 @@ struct st_args {
     const int8_t * a_qs; const float * a_d; const int16_t * a_bs;      // PRO_Q8: the n = 1 image act_q8_carve lays out
     fused_rope rope;
     st_group g[MMVQ_MAX_GROUPS];
+    // PRO_NORM, at most 16 blocks: x is the residual and the vector is x + plane 0 + plane 1 + ... (attn_wo.hip's partial planes, in this order);
+    // workgroup 0 also stores the sum to x_out
+    const float * planes; int n_planes, plane_stride; float * x_out;
     unsigned long long * stamps;              // diagnostic builds (-DMI_STAMPS): [workgroup][wave][8]
 };
 // ---- a CHAIN of such launches as ONE launch (k_mmvq_chain): consecutive mat-vecs of the decode graph (wo -> gate/up/SwiGLU -> down -> the next
@@ -489,6 +492,25 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
         xv[i] = st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4);
         wv[i] = norm ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
     }
+    if constexpr (NA <= 2 && !CHAIN) {
+        if (p.planes) {
+            float4v pv[NA][8];
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+                const int c = min(wave + ST_NC*i, nchunk - 1);
+#pragma unroll
+                for (int pl = 0; pl < 8; pl++) pv[i][pl] = *(const float4v *) (p.planes + (size_t) min(pl, p.n_planes - 1)*p.plane_stride + (size_t) c*256 + lane*4);
+            }
+            if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#pragma unroll
+            for (int i = 0; i < NA; i++) {
+#pragma unroll
+                for (int pl = 0; pl < 8; pl++) if (pl < p.n_planes) { xv[i].x += pv[i][pl].x; xv[i].y += pv[i][pl].y; xv[i].z += pv[i][pl].z; xv[i].w += pv[i][pl].w; }
+                const int c = wave + ST_NC*i;
+                if (blockIdx.x == 0 && c < nchunk) *(float4v *) (p.x_out + (size_t) c*256 + lane*4) = xv[i];
+            }
+        } else if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+    } else
     if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     float scale = 1.0f;
     if (norm) {

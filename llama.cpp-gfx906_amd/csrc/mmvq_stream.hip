@@ -77,6 +77,7 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     if (in.mode == PRO_Q8) { if (((uintptr_t) in.act.qs % 16) || ((uintptr_t) in.act.bsums % 16) || !in.act.d) return false; }
     else { if (((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
     const int64_t nb = k/256;
+    if (in.planes && (in.mode != PRO_NORM || nb > 16 || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
     int ta = -1, tb = -1;
     for (int i = 0; i < n_groups; i++) {
         const mmvq_group & g = groups[i];
@@ -108,6 +109,7 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
     a.n_groups = n_groups; a.k = (int) k; a.nb = nb; a.mode = in.mode; a.eps = in.eps;
     a.magic = nb == 1 ? 0u : (uint32_t)((0x100000000ull + nb - 1)/nb);
     a.x = in.x; a.norm_w = in.norm_w;
+    a.planes = in.planes; a.n_planes = in.n_planes; a.plane_stride = in.plane_stride; a.x_out = in.x_out;
     if (in.mode == PRO_Q8) { a.a_qs = in.act.qs; a.a_d = in.act.d; a.a_bs = in.act.bsums; }
     if (rope) a.rope = make_fused_rope(*rope);
 

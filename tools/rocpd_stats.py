@@ -1,26 +1,23 @@
-"""rocpd_stats.py — per-kernel totals from the rocpd sqlite database rocprofv3 writes (`rocprofv3 --kernel-trace -d DIR -- ...`).
-usage: python tools/rocpd_stats.py DIR_OR_DB [out.csv]"""
-import glob
-import os
+"""rocpd_stats.py — per-kernel totals from a rocprofv3 run's rocpd SQLite database (rocprofv3 --kernel-trace writes <prefix>_results.db on this
+image; --output-format csv is not always there): the table rocprofv3 --stats would print.  python tools/rocpd_stats.py DB [out.csv] [min_start_frac]"""
+import collections
 import sqlite3
 import sys
 
-src = sys.argv[1]
-dbs = [src] if os.path.isfile(src) else sorted(glob.glob(os.path.join(src, "**", "*.db"), recursive=True))
-rows = {}
-for db in dbs:
-    con = sqlite3.connect(db)
-    tabs = [r[0] for r in con.execute("select name from sqlite_master where type='table'")]
-    kd = [t for t in tabs if t.startswith("rocpd_kernel_dispatch")][0]
-    ks = [t for t in tabs if t.startswith("rocpd_info_kernel_symbol")][0]
-    for name, n, tot, mn, mx in con.execute(
-            f"select s.kernel_name, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start) from {kd} d join {ks} s on d.kernel_id = s.id group by s.kernel_name"):
-        r = rows.setdefault(name, [0, 0, 1 << 62, 0]); r[0] += n; r[1] += tot; r[2] = min(r[2], mn); r[3] = max(r[3], mx)
-total = sum(r[1] for r in rows.values())
-lines = ["name,calls,total_ns,avg_ns,pct,min_ns,max_ns"]
-for name, r in sorted(rows.items(), key=lambda kv: -kv[1][1]):
-    lines.append(f'"{name}",{r[0]},{r[1]},{r[1]/r[0]:.0f},{100.0*r[1]/total:.2f},{r[2]},{r[3]}')
-out = "\n".join(lines)
-if len(sys.argv) > 2:
-    open(sys.argv[2], "w").write(out + "\n")
-print("\n".join(l[:230] for l in lines[:25]))
+db = sqlite3.connect(sys.argv[1])
+rows = list(db.execute("select name, start, end from kernels order by start"))
+frac = float(sys.argv[3]) if len(sys.argv) > 3 else 0.0
+if rows and frac > 0:
+    t0, t1 = rows[0][1], rows[-1][2]
+    rows = [r for r in rows if r[1] >= t0 + frac*(t1 - t0)]
+agg = collections.OrderedDict()
+for n, s, e in rows:
+    a = agg.setdefault(n, [0, 0, 1 << 62, 0]); a[0] += 1; a[1] += e - s; a[2] = min(a[2], e - s); a[3] = max(a[3], e - s)
+tot = sum(a[1] for a in agg.values())
+lines = ['"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"']
+for n, a in sorted(agg.items(), key=lambda x: -x[1][1]):
+    lines.append(f'"{n}",{a[0]},{a[1]},{a[1]/a[0]:.1f},{100.0*a[1]/tot:.2f},{a[2]},{a[3]}')
+if len(sys.argv) > 2 and sys.argv[2] != "-":
+    open(sys.argv[2], "w").write("\n".join(lines) + "\n")
+for l in lines[:28]:
+    print(l[:230])
