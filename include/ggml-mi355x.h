@@ -55,8 +55,10 @@ GGML_BACKEND_API ggml_backend_buffer_type_t ggml_backend_mi355x_host_buffer_type
 //   "ggml_backend_mi355x_get_stream"   -> void * (*)(ggml_backend_t)        : the backend's hipStream_t
 //   "ggml_backend_mi355x_get_counters" -> see struct below
 //   "ggml_backend_mi355x_set_option"   -> int (*)(ggml_backend_t, const char * key, int value)
-// not provided (returns NULL): "ggml_backend_split_buffer_type" (row-split TP is SURVEY §8f "next"),
-// "ggml_backend_set_n_threads" (GPU backend), "ggml_backend_dev_get_extra_bufts".
+//   "ggml_backend_split_buffer_type"   -> ggml_backend_split_buffer_type_t  : -sm row (EXPERIMENTAL: functional, eager fork / join per mat-mul,
+//                                         measured 117 vs 564 tok/s on virtual devices; every device that receives rows must be peer-accessible
+//                                         from the main device — checked when the buffer type is made)
+// not provided (returns NULL): "ggml_backend_set_n_threads" (GPU backend), "ggml_backend_dev_get_extra_bufts".
 
 // per-backend counters for the measurement leg (SURVEY.md §5 "expose per-kernel bytes/time counters")
 struct ggml_backend_mi355x_counters {

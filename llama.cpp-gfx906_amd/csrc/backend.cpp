@@ -198,7 +198,10 @@ static const struct ggml_backend_buffer_type_i mi_buft_iface = {
 };
 
 // ---------------------------------------------------------------------------------------------
-// row-split buffer type (-sm row; the host binds it through the "ggml_backend_split_buffer_type" proc, src/llama-model.cpp:368-387):
+// row-split buffer type (-sm row; the host binds it through the "ggml_backend_split_buffer_type" proc, src/llama-model.cpp:368-387).
+// EXPERIMENTAL until it has run on two real GPUs: so far only under GGML_MI355X_VIRTUAL_DEVICES (both "devices" the same HIP device, no peer traffic).
+// Peer kernels store their row ranges straight into the main device's compute buffer through the peer mapping, ordered by events only; that the main device
+// sees those stores without stale L2 lines is unproven here (the reference computes into a per-device dst and copies: ggml-cuda.cu ggml_cuda_op_mul_mat).
 // a weight matrix's ROWS are spread over the devices in the proportions of tensor_split; every device holds its slice in its own HBM.
 // A MUL_MAT on such a weight runs one launch per device, each on its own stream: the devices read the (small) activations straight from the
 // main device's memory and write their rows of the result straight into the main device's dst — both through the peer mappings over xGMI, no
@@ -363,8 +366,9 @@ struct node_sig {
     uint32_t params_hash; uint32_t flags;
 };
 
+static_assert(sizeof(node_sig) == 16 + 8 + 32 + 24 + 8*GGML_MAX_SRC + 4*GGML_MAX_SRC + 8, "node_sig has no padding bytes: signatures are compared with memcmp");
 struct graph_entry {
-    std::vector<node_sig> sig;
+    std::vector<node_sig> sig; uint64_t digest = 0;      // digest: a cheap hash of the signature — only the entry that shares it is compared in full
     std::vector<void *> owned_dev;      // device buffers a captured graph refers to (persistent-decode program tables and their signal words)
     hipGraphExec_t exec = nullptr;
     uint64_t last_use = 0;
@@ -404,7 +408,7 @@ struct mi_backend_ctx {
     bool use_fusion = true;
     std::unordered_map<const struct ggml_tensor *, int> uses;   // consumers per tensor in the graph being run (fusion legality)
     std::vector<graph_entry> graphs;     // small LRU: decode graphs differ only in n_kv (one per 32 tokens of context)
-    std::vector<node_sig> cur_sig;
+    std::vector<node_sig> cur_sig; uint64_t cur_digest = 0;
     uint64_t graph_tick = 0;
 
     struct ggml_backend_mi355x_counters cnt = {};
@@ -2025,10 +2029,16 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
     c->aq.valid = false;
 }
 
+// (round 3: 64-bit lanes — one multiply per 8 bytes instead of one per 4, two independent chains for the op parameters — and only the sources that
+// exist are walked: the per-token signature of a 1125-node decode graph was 21 us of host time)
+static inline uint64_t sig_mix(uint64_t h, uint64_t v) { h = (h ^ v)*0x9E3779B97F4A7C15ull; return h ^ (h >> 32); }
 static inline uint32_t hash_params(const int32_t * p) {
-    uint32_t h = 2166136261u;
-    for (int i = 0; i < (int)(GGML_MAX_OP_PARAMS/sizeof(int32_t)); i++) { h ^= (uint32_t) p[i]; h *= 16777619u; }
-    return h;
+    uint64_t w[GGML_MAX_OP_PARAMS/8];
+    memcpy(w, p, sizeof(w));
+    uint64_t h0 = 0x243F6A8885A308D3ull, h1 = 0x13198A2E03707344ull;
+    for (int i = 0; i < (int)(GGML_MAX_OP_PARAMS/8); i += 2) { h0 = sig_mix(h0, w[i]); h1 = sig_mix(h1, w[i + 1]); }
+    const uint64_t h = sig_mix(h0, h1);
+    return (uint32_t)(h ^ (h >> 32));
 }
 
 static inline void fill_sig(node_sig & s, const struct ggml_tensor * n) {
@@ -2037,14 +2047,13 @@ static inline void fill_sig(node_sig & s, const struct ggml_tensor * n) {
     for (int d = 0; d < 3; d++) s.nb[d] = n->nb[d + 1];
     for (int j = 0; j < GGML_MAX_SRC; j++) {
         const struct ggml_tensor * t = n->src[j];
-        s.src_data[j] = t ? t->data : NULL;
-        uint32_t h = 2166136261u;
-        if (t) {
-            auto mix = [&](uint64_t v) { h ^= (uint32_t) v; h *= 16777619u; h ^= (uint32_t)(v >> 32); h *= 16777619u; };
-            mix((uint64_t) t->type);
-            for (int d = 0; d < 4; d++) { mix((uint64_t) t->ne[d]); mix((uint64_t) t->nb[d]); }
-        }
-        s.src_hash[j] = t ? h : 0u;
+        if (!t) { s.src_data[j] = NULL; s.src_hash[j] = 0u; continue; }
+        s.src_data[j] = t->data;
+        uint64_t h0 = sig_mix(0x452821E638D01377ull, (uint64_t) t->type), h1 = 0xBE5466CF34E90C6Cull;
+        for (int d = 0; d < 4; d++) { h0 = sig_mix(h0, (uint64_t) t->ne[d]); h1 = sig_mix(h1, (uint64_t) t->nb[d]); }
+        const uint64_t h = sig_mix(h0, h1);
+        const uint32_t h32 = (uint32_t)(h ^ (h >> 32));
+        s.src_hash[j] = h32 ? h32 : 1u;
     }
     s.params_hash = hash_params(n->op_params);
     s.flags = (uint32_t) n->flags;
@@ -2058,14 +2067,21 @@ static void drop_graphs(mi_backend_ctx * c) {
 // find (or create) the cache entry whose signature equals this graph's
 static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph * g) {
     c->cur_sig.resize(g->n_nodes);
-    memset(c->cur_sig.data(), 0, sizeof(node_sig)*g->n_nodes);   // padding bytes take part in memcmp
-    for (int i = 0; i < g->n_nodes; i++) fill_sig(c->cur_sig[i], g->nodes[i]);
+    uint64_t d0 = 0x9E3779B97F4A7C15ull, d1 = 0xC2B2AE3D27D4EB4Full;
+    for (int i = 0; i < g->n_nodes; i++) {
+        node_sig & ns = c->cur_sig[i];
+        fill_sig(ns, g->nodes[i]);
+        d0 = sig_mix(d0, (uint64_t)(uintptr_t) ns.data ^ ((uint64_t) ns.ne[1] << 20) ^ ((uint64_t) ns.ne[0] << 44) ^ ns.params_hash);
+        d1 = sig_mix(d1, (uint64_t)(uintptr_t) ns.src_data[0] ^ ((uint64_t)(uintptr_t) ns.src_data[1] << 1) ^ ((uint64_t) ns.src_hash[0] << 32) ^ ns.src_hash[1] ^ ((uint64_t) ns.nb[0] << 13));
+    }
+    const uint64_t digest = sig_mix(d0, d1);
+    c->cur_digest = digest;
     graph_entry * lru = nullptr;
     // most recently used first: consecutive decode steps re-submit the same graph (src/llama-context.cpp:728)
     graph_entry * best = nullptr;
     for (auto & e : c->graphs) {
         if (!lru || e.last_use < lru->last_use) lru = &e;
-        if ((int) e.sig.size() == g->n_nodes && (!best || e.last_use > best->last_use) &&
+        if (e.digest == digest && (int) e.sig.size() == g->n_nodes && (!best || e.last_use > best->last_use) &&
             memcmp(e.sig.data(), c->cur_sig.data(), sizeof(node_sig)*g->n_nodes) == 0) best = &e;
     }
     if (best) { best->last_use = ++c->graph_tick; best->seen++; return *best; }
@@ -2073,12 +2089,12 @@ static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph *
         if (lru->exec) { MI_CHECK_G(hipStreamSynchronize(c->stream)); MI_CHECK_G(hipGraphExecDestroy(lru->exec)); }
         for (void * p : lru->owned_dev) (void) hipFree(p);
         *lru = graph_entry();
-        lru->sig = c->cur_sig; lru->last_use = ++c->graph_tick; lru->seen = 1;
+        lru->sig = c->cur_sig; lru->digest = c->cur_digest; lru->last_use = ++c->graph_tick; lru->seen = 1;
         return *lru;
     }
     c->graphs.emplace_back();
     graph_entry & e = c->graphs.back();
-    e.sig = c->cur_sig; e.last_use = ++c->graph_tick; e.seen = 1;
+    e.sig = c->cur_sig; e.digest = c->cur_digest; e.last_use = ++c->graph_tick; e.seen = 1;
     return e;
 }
 
@@ -2086,6 +2102,7 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
 static double g_host_ns = 0.0; static long g_host_calls = 0;     // GGML_MI355X_HOST_TIMING=1: host time spent inside graph_compute
 static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgraph * g) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    (void) hipGetLastError();      // a stale thread-level error (another library's probe, a failed allocation elsewhere) is not this graph's: only what this call raises counts
     try {
         static const bool timing = getenv("GGML_MI355X_HOST_TIMING") != nullptr;
         const auto t0 = std::chrono::steady_clock::now();
@@ -2106,7 +2123,13 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
             if (graph) (void) hipGraphDestroy(graph);
             c->capturing = false; c->cap_entry = nullptr; c->chain_uploads.clear();
         }
-        c->rec.clear(); c->rec_on = false; c->aq.valid = false;
+        c->rec.clear(); c->rec_on = false; c->aq.valid = false; c->pp.active = false;
+        // a throw inside the row-split fork leaves the current device on a peer, and peer streams that were already launched may still write dst:
+        // back to this backend's device, and nothing is returned before they have finished
+        set_device(c->device);
+        for (int i = 0; i < G().n_devices; i++) if (c->peers[i].stream) { set_device(G().devices[i].id); (void) hipStreamSynchronize(c->peers[i].stream); }
+        set_device(c->device);
+        (void) hipStreamSynchronize(c->stream);
         (void) hipGetLastError();
         return GGML_STATUS_FAILED;
     }
@@ -2461,8 +2484,16 @@ ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device
     double acc = 0;
     for (int i = 0; i < n; i++) { want.cum[i] = (float)(acc/sum); acc += share[i]; }
     want.cum[n] = 1.0f;
-    for (int i = 0; i < n; i++) {                           // every device that holds rows must be mapped into the main device's address space and back
-        if (share[i] == 0 || G().devices[i].id == G().devices[main_device].id) continue;
+    // every device that CAN receive rows must be mapped into the main device's address space and back: not only those with a share — the rounding of
+    // split_rows hands remainder rows to the devices behind the last share too (shares [1, 0], 300 rows: 44 rows on device 1)
+    bool gets_rows[GGML_MI355X_MAX_DEVICES] = {};
+    for (const int64_t nrows : { (int64_t) 1, (int64_t) 44, (int64_t) 300, (int64_t) 4096, (int64_t) 14336, (int64_t) 128256 }) {
+        int64_t row_lo[GGML_MI355X_MAX_DEVICES + 1];
+        split_rows(&want, nrows, row_lo);
+        for (int i = 0; i < n; i++) if (row_lo[i + 1] > row_lo[i]) gets_rows[i] = true;
+    }
+    for (int i = 0; i < n; i++) {
+        if ((share[i] == 0 && !gets_rows[i]) || G().devices[i].id == G().devices[main_device].id) continue;
         int ab = 0, ba = 0;
         if (hipDeviceCanAccessPeer(&ab, G().devices[i].id, G().devices[main_device].id) != hipSuccess || hipDeviceCanAccessPeer(&ba, G().devices[main_device].id, G().devices[i].id) != hipSuccess || !ab || !ba) {
             (void) hipGetLastError();
@@ -2473,6 +2504,7 @@ ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device
     std::lock_guard<std::mutex> lock(mu);
     for (mi_split_buft_ctx * m : made) if (m->main_device == main_device && memcmp(m->cum, want.cum, sizeof(want.cum)) == 0) return &m->buft;
     mi_split_buft_ctx * m = new mi_split_buft_ctx(want);
+    if (made.empty()) MI_LOG("row split (-sm row) is EXPERIMENTAL on this backend: functional, not tuned, and so far exercised on virtual devices only\n");
     m->name = std::string(GGML_MI355X_NAME) + "_Split";
     m->buft = { mi_split_buft_iface, &G().devices[main_device].dev, m };
     made.push_back(m);

@@ -41,233 +41,11 @@ constexpr int i8_buf_bytes(int rows) { return I8_ACT + rows*144; }
 static __device__ __forceinline__ i32x16 mfma_i8(int4v a, int4v b, i32x16 c) {
     return __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, c, 0, 0, 0);
 }
-static __device__ __forceinline__ int mad24(int a, int b, int c) { return __mul24(a, b) + c; }
 
-struct wraw { uint32_t s0, s1, s2, dd; };      // a block's header: d | dmin, 12 scale bytes
 
-// NT: 32-token tiles per wave. NT = 2: the 4 waves are 4 row groups (256 rows x 64 tokens); NT = 1: 2 row groups x 2 token tiles (128 rows x 64 tokens)
-template <int NT>
-__global__ void __launch_bounds__(256, 2) k_mmq_i8_q4_K(const mmq_i8_args p) {
-    constexpr int WT = 2/NT, WR = 4/WT, ROWS = WR*64, I8_BUF = i8_buf_bytes(ROWS);
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int col = lane & 31, kh = lane >> 5;
-    const int nb = p.k >> 8;
-    // workgroup id -> (row block, token tile): ids are dealt round-robin to the 8 XCDs, so id % 8 picks the XCD; inside an XCD consecutive
-    // workgroups walk the token tiles of ONE row block, whose weights are then read from HBM once and from that XCD's L2 afterwards
-    const int ntok = (p.n + I8_TOK - 1)/I8_TOK;
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int rblk = (slot/ntok)*8 + xcd;
-    if (rblk*ROWS >= p.m) return;
-    const int tok0 = (slot % ntok)*I8_TOK;
-    const int row0 = rblk*ROWS + (wave/WT)*64;
-    const int tw = (wave % WT)*32*NT;                             // this wave's first token inside the workgroup's 64
-    const bool active = row0 < p.m;                               // (m is a multiple of 64: a wave is all rows or none)
-    const int wrow = (wave/WT)*64;                                // this wave's first weight row inside the workgroup's slab
-    // weight staging: the slab of ROWS rows x 144 bytes of one 256-block is copied as it is, 16 bytes per thread and step, coalesced
-    constexpr int WCH = ROWS*9;                                   // 16-byte chunks per slab
-    constexpr int WST = (WCH + 255)/256;
-    int4v wstage[WST];
-    auto wstage_load = [&](int kb) {
-#pragma unroll
-        for (int i = 0; i < WST; i++) {
-            const int ch = tid + 256*i;
-            if (ch < WCH) {
-                const int r = min(rblk*ROWS + ch/9, p.m - 1);
-                wstage[i] = ld_b128(p.W + (size_t) r*p.w_stride + (size_t) kb*144 + (ch % 9)*16);
-            }
-        }
-    };
-    auto wstage_store = [&](int buf) {
-        char * b = smem + buf*I8_BUF + I8_ACT;
-#pragma unroll
-        for (int i = 0; i < WST; i++) { const int ch = tid + 256*i; if (ch < WCH) *(int4v *) (b + ch*16) = wstage[i]; }
-    };
+// (round 3: the first variant of this kernel — one integer multiply-add per matrix result and sub-block, GGML_MI355X_MMQ_I8_VARIANT=0 — is removed: it was
+// 20 % slower than the split-scale kernel below on every shape measured in round 2 and nothing was built on it)
 
-    // staging role: thread -> (token, 16-byte chunk) x 4
-    const int s_chunk = tid & 15, s_tok = tid >> 4;               // tokens s_tok + 16*i
-    int4v stage[4];
-    auto stage_load = [&](int kb) {
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int t = min(tok0 + s_tok + 16*i, p.n - 1);
-            stage[i] = *(const int4v *) (p.qs + (size_t) t*p.k + kb*256 + s_chunk*16);
-        }
-    };
-    float stage_d = 0.0f;
-    auto stage_load_d = [&](int kb) { if (tid < I8_TOK) stage_d = p.d[(size_t) min(tok0 + tid, p.n - 1)*nb + kb]; };
-    auto stage_store = [&](int buf) {
-        char * b = smem + buf*I8_BUF;
-#pragma unroll
-        for (int i = 0; i < 4; i++) *(int4v *) (b + (s_tok + 16*i)*I8_PITCH + s_chunk*16) = stage[i];
-        if (tid < I8_TOK) *(float *) (b + I8_TOK*I8_PITCH + tid*4) = stage_d;
-    };
-
-    f32x16 accf[2][NT];
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int t = 0; t < NT; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) accf[a][t][r] = 0.0f;
-    f16x8 minw[2];                                                // -(dmin*m_j) of the block this lane supplies to the min-term instruction
-#pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int j = 0; j < 8; j++) minw[a][j] = (_Float16) 0.0f;
-
-    stage_load(0); stage_load_d(0); wstage_load(0);
-    stage_store(0); wstage_store(0);
-    __syncthreads();
-
-    for (int kb = 0; kb < nb; kb++) {
-        const int buf = kb & 1;
-        const char * lb = smem + buf*I8_BUF;
-        if (kb + 1 < nb) { stage_load(kb + 1); stage_load_d(kb + 1); wstage_load(kb + 1); }   // next block into the staging registers
-        if (active) {
-            const char * wl = lb + I8_ACT + (wrow + col)*144;     // this lane's row of tile 0; tile 1 is 32 rows on
-            wraw wc[2];
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const int4v hd = *(const int4v *) (wl + a*32*144);
-                wc[a].dd = (uint32_t) hd.x; wc[a].s0 = (uint32_t) hd.y; wc[a].s1 = (uint32_t) hd.z; wc[a].s2 = (uint32_t) hd.w;
-            }
-            // ---- scales and mins of this block (12 bytes -> 8 + 8 six-bit values, packed four to a register)
-            uint32_t scp[2][2];
-#pragma unroll
-            for (int a = 0; a < 2; a++) {
-                const uint32_t s0 = wc[a].s0, s1 = wc[a].s1, s2 = wc[a].s2;
-                scp[a][0] = s0 & 0x3F3F3F3Fu;
-                scp[a][1] = (s2 & 0x0F0F0F0Fu) | ((s0 >> 2) & 0x30303030u);
-                const uint32_t m0 = s1 & 0x3F3F3F3Fu, m1 = ((s2 >> 4) & 0x0F0F0F0Fu) | ((s1 >> 2) & 0x30303030u);
-                const float ndmin = -f16_bits_to_f32((uint16_t)(wc[a].dd >> 16));
-                f16x8 mw;
-#pragma unroll
-                for (int j = 0; j < 4; j++) {
-                    mw[j]     = (_Float16)(ndmin*(float)((m0 >> (8*j)) & 0xFF));
-                    mw[j + 4] = (_Float16)(ndmin*(float)((m1 >> (8*j)) & 0xFF));
-                }
-                if ((kb & 1) == kh) minw[a] = mw;                 // kh = 0 lanes supply the even block of a pair, kh = 1 lanes the odd one
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // Software pipeline over the eight sub-blocks, written out stage by stage (a sched_barrier after each keeps the order): stage s issues
-            // the LDS reads for sub-block s + 2, the matrix instructions of sub-block s + 1, and then the 16 multiply-adds per tile of sub-block s —
-            // so a wave's integer work runs under its own next matrix instructions, and LDS latency is two stages away.
-            i32x16 acci[2][NT];
-            i32x16 prod[2][2][NT];                                // [stage parity][row tile][token tile]
-            int4v aop[3][NT], wq[2][2];                           // A operands of three sub-blocks in flight; the raw 16 bytes of two groups per row tile
-            auto read_a = [&](int sub) {
-#pragma unroll
-                for (int t = 0; t < NT; t++) aop[sub % 3][t] = *(const int4v *) (lb + (tw + t*32 + col)*I8_PITCH + sub*32 + kh*16);
-            };
-            auto read_w = [&](int g) {
-#pragma unroll
-                for (int a = 0; a < 2; a++) wq[g & 1][a] = *(const int4v *) (wl + a*32*144 + 16 + g*32 + kh*16);
-            };
-            auto mfmas = [&](int sub) {
-                i32x16 z;
-#pragma unroll
-                for (int r = 0; r < 16; r++) z[r] = 0;
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const int4v raw = wq[(sub >> 1) & 1][a];
-                    const int4v wop = (sub & 1) ? ((raw >> 4) & 0x0F0F0F0F) : (raw & 0x0F0F0F0F);
-#pragma unroll
-                    for (int t = 0; t < NT; t++) prod[sub & 1][a][t] = mfma_i8(aop[sub % 3][t], wop, z);
-                }
-            };
-            auto mads = [&](int sub) {
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const int sc = (int)((scp[a][sub >> 2] >> (8*(sub & 3))) & 0xFF);
-#pragma unroll
-                    for (int t = 0; t < NT; t++) {
-                        // (the empty asm pins each partial sum: left alone, the sum over the eight sub-blocks is re-associated into a tree that keeps
-                        // every product alive. The multiply-add itself must stay a compiler instruction: behind inline asm the matrix-result
-                        // read hazard is not tracked and the first eight reads come too early)
-#pragma unroll
-                        for (int r = 0; r < 16; r++) {
-                            int o = sub == 0 ? __mul24(prod[sub & 1][a][t][r], sc) : mad24(prod[sub & 1][a][t][r], sc, acci[a][t][r]);
-                            asm volatile("" : "+v"(o));
-                            acci[a][t][r] = o;
-                        }
-                    }
-                }
-            };
-            read_w(0); read_a(0); read_a(1);
-            mfmas(0);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int sub = 0; sub < 8; sub++) {
-                if (sub + 2 < 8) { if (((sub + 2) & 1) == 0) read_w((sub + 2) >> 1); read_a(sub + 2); }
-                if (sub + 1 < 8) mfmas(sub + 1);
-                mads(sub);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-            // ---- block end: acc += isum * d_w * d_a(token)
-            const float * dl = (const float *) (lb + I8_TOK*I8_PITCH);
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                float da[16];
-#pragma unroll
-                for (int q4 = 0; q4 < 4; q4++) {
-                    const float4v v = *(const float4v *) (dl + tw + t*32 + q4*8 + kh*4);
-                    da[q4*4 + 0] = v.x; da[q4*4 + 1] = v.y; da[q4*4 + 2] = v.z; da[q4*4 + 3] = v.w;
-                }
-#pragma unroll
-                for (int a = 0; a < 2; a++) {
-                    const float dw = f16_bits_to_f32((uint16_t)(wc[a].dd & 0xFFFF));
-#pragma unroll
-                    for (int r = 0; r < 16; r++) accf[a][t][r] = fmaf((float) acci[a][t][r], dw*da[r], accf[a][t][r]);
-                }
-            }
-            // ---- every second block (and after an odd last one): the mins of the pair, one f16 matrix instruction per tile
-            if ((kb & 1) || kb == nb - 1) {
-                const int blk = (kb & ~1) + kh;                   // the block this lane's k-half stands for
-#pragma unroll
-                for (int t = 0; t < NT; t++) {
-                    const int tok = min(tok0 + tw + t*32 + col, p.n - 1);
-                    f16x8 ab;
-                    if (blk < nb) {
-                        const float dtok = p.d[(size_t) tok*nb + blk];
-                        const int4v b0 = *(const int4v *) (p.bs + (size_t) tok*(p.k >> 4) + blk*16);
-                        const int4v b1 = *(const int4v *) (p.bs + (size_t) tok*(p.k >> 4) + blk*16 + 8);
-                        const int w[8] = { b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w };      // two 16-element sums per word: one sub-block
-#pragma unroll
-                        for (int j = 0; j < 8; j++) ab[j] = (_Float16)(dtok*(float)((int)(short)(w[j] & 0xFFFF) + (w[j] >> 16)));
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; j++) ab[j] = (_Float16) 0.0f;
-                    }
-#pragma unroll
-                    for (int a = 0; a < 2; a++) {
-                        f16x8 bw = minw[a];
-                        if ((kb & 1) == 0 && kh == 1) {           // odd block count: the last pair has no second block
-#pragma unroll
-                            for (int j = 0; j < 8; j++) bw[j] = (_Float16) 0.0f;
-                        }
-                        accf[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ab, bw, accf[a][t], 0, 0, 0);
-                    }
-                }
-            }
-        }
-        if (kb + 1 < nb) { stage_store(buf ^ 1); wstage_store(buf ^ 1); }
-        __syncthreads();
-    }
-
-    if (!active) return;
-#pragma unroll
-    for (int t = 0; t < NT; t++)
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int tok = tok0 + tw + t*32 + (r >> 2)*8 + kh*4 + (r & 3);
-            if (tok < p.n) {
-                p.dst[(size_t) tok*p.ldd + row0 + col]      = accf[0][t][r];
-                p.dst[(size_t) tok*p.ldd + row0 + 32 + col] = accf[1][t][r];
-            }
-        }
-}
 
 // ---- variant "split scale": no integer work on the matrix results inside a block. The 6-bit sub-block scale is folded into the B operand instead:
 // sc = 8*hi + lo with hi, lo in 0..7, so q*hi and q*lo (<= 105) are int8 again — four of them per register by ONE v_pk_mul_lo_u16 (a 16-bit lane
@@ -453,12 +231,8 @@ bool mul_mat_q_i8(int type_a, const void * W, size_t w_row_stride, int64_t m, in
     a.dst = dst; a.ldd = dst_col_stride_bytes/4; a.m = (int) m; a.k = (int) k; a.n = (int) n;
     static const int dbg = getenv("GGML_MI355X_MMQ_I8_DBG") ? atoi(getenv("GGML_MI355X_MMQ_I8_DBG")) : 0;
     a.dbg = dbg;
-    static const int nt = getenv("GGML_MI355X_MMQ_I8_NT") ? atoi(getenv("GGML_MI355X_MMQ_I8_NT")) : 1;
-    const int rows = nt == 2 ? 256 : 128;
-    const int64_t ntok = (n + I8_TOK - 1)/I8_TOK, nrow = (m + rows - 1)/rows;
-    const dim3 grid((unsigned)(((nrow + 7)/8)*8*ntok));
-    static const int variant = getenv("GGML_MI355X_MMQ_I8_VARIANT") ? atoi(getenv("GGML_MI355X_MMQ_I8_VARIANT")) : 1;     // 1 = split scale, 0 = multiply-add per result
-    if (variant == 1) {
+    const int64_t ntok = (n + I8_TOK - 1)/I8_TOK;
+    {
         const dim3 gs((unsigned)((((m + 127)/128 + 7)/8)*8*ntok));
         static const int nw = getenv("GGML_MI355X_MMQ_I8_WAVES") ? atoi(getenv("GGML_MI355X_MMQ_I8_WAVES")) : 8;      // 8 | 4 | 1 (= 4 waves, 128-token tiles)
         if (nw == 1) {
@@ -469,10 +243,7 @@ bool mul_mat_q_i8(int type_a, const void * W, size_t w_row_stride, int64_t m, in
         }
         else if (nw == 4) { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<4, 64>); hipLaunchKernelGGL((k_mmq_i8s_q4_K<4, 64>), gs, dim3(256), 2*i8_buf_bytes(128), stream, a); }
         else              { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8s_q4_K<8, 64>); hipLaunchKernelGGL((k_mmq_i8s_q4_K<8, 64>), gs, dim3(512), 2*i8_buf_bytes(128), stream, a); }
-        return true;
     }
-    if (nt == 2) { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(256), k_mmq_i8_q4_K<2>); hipLaunchKernelGGL(k_mmq_i8_q4_K<2>, grid, dim3(256), 2*i8_buf_bytes(256), stream, a); }
-    else         { MI_LDS_LIMIT_OR_DIE(2*i8_buf_bytes(128), k_mmq_i8_q4_K<1>); hipLaunchKernelGGL(k_mmq_i8_q4_K<1>, grid, dim3(256), 2*i8_buf_bytes(128), stream, a); }
     return true;
 }
 

@@ -8,6 +8,7 @@ run --model llama3-8b --ftype Q4_0
 run --model llama3-8b --ftype Q6_K
 run --model llama3-8b --ftype Q8_0
 run --model llama3-8b --ftype Q4_K_M --fa 1
+run --model llama3-8b --ftype Q4_K_M --fa 1 --ctk q8_0 --ctv q8_0
 run --model mixtral-8x7b --ftype Q4_K_M
 run --model gpt-oss-20b --ftype MXFP4_MOE
 run --model llama3-70b --ftype Q4_K_M --steps 64 --warmup 16
