@@ -35,6 +35,11 @@ constexpr int ST_MAX_RING = 48;          // slots
 // (Q6_K's -32 offset) — 19 chunks = 304 bytes per block, an odd number of 16-byte slots: lanes that hold consecutive blocks read
 // conflict-free. The block's Q8_K scale sits in a float array of its own.
 constexpr int ST_ACT_STRIDE = 304;
+// Rows whose length is a multiple of 32 but not of 256 (gpt-oss: k = 2880 = 90 blocks of 32): a unit is TEN 32-element blocks (320 weights) of a Q8_0 or
+// MXFP4 row — 9 units per row at k = 2880 — against the CPU path's Q8_0 activation: 320 int8 + the ten f16-rounded block scales as floats = 360 bytes,
+// held 368 apart (23 chunks: odd). Pseudo type ids for the unit templates:
+constexpr int ST_Q8_0_B10 = 1008, ST_MXFP4_B10 = 1039;
+constexpr int ST_ACT_STRIDE_B10 = 368;
 
 struct st_group {
     const char * W; const char * W2;          // W2: the second tensor of EPI_GLU
@@ -45,12 +50,16 @@ struct st_group {
     // MUL_MAT_ID for one token (src/llama-graph.cpp:569-595): the group's matrices are expert eid[0] of a stack (a device value: W += eid[0]*estride,
     // W2 likewise); x_off: this group's activation starts x_off floats into the launch's x (the down projection reads one vector per used expert)
     const int32_t * eid; long long estride; int x_off;
+    // gpt-oss's expert FFN (src/llama-graph.cpp:927-983): per-expert biases added to the two products before swiglu_oai (rows eid[0] of [m, n_expert] tables),
+    // and res_eid != 0: EPI_ADD's res is such a table too (MUL_MAT_ID -> ADD_ID)
+    const float * b_gate; const float * b_up; int res_eid;
     int ralign;                               // rows are dealt to workgroups in multiples of this (2: rotation pairs, head size: NEOX pairs)
     int npart_max;                            // floats of partial sums the largest workgroup of this group needs (the LDS carve is the same in all of them)
     float glu_alpha, glu_limit;
 };
 struct st_args {
-    int n_groups, k, nb, mode;
+    int n_groups, k, nb, mode;                // nb: units per row (k / 256, or k / 320 for the ten-block units)
+    int nchunk, act_stride;                   // 256-element pieces of the activation vector ((k + 255) / 256); bytes between the image's units
     int block_end[MMVQ_MAX_GROUPS];
     uint32_t magic; int S; float eps; int pad0;
     const float * x; const float * norm_w;
@@ -105,9 +114,9 @@ static __device__ __forceinline__ void st_dma_4(const char * gbase, uint32_t vof
 // the PPS pieces of one slot (source bytes gbase .. gbase + PPS KiB, contiguous)
 template <bool NT, int PPS>
 static __device__ __forceinline__ void st_dma_slot(const char * gbase, uint32_t voff, uint32_t lds_dst) {
-    static_assert(PPS >= 1 && PPS <= 20, "a slot is at most 20 KiB");
+    static_assert(PPS >= 1 && PPS <= 24, "a slot is at most 24 KiB");
 #define MI_G(q4_) if constexpr (PPS > 4*(q4_)) st_dma_4<NT, (PPS - 4*(q4_) >= 4 ? 4 : PPS - 4*(q4_))>(gbase + (q4_)*4096, voff, lds_dst + (q4_)*4096);
-    MI_G(0) MI_G(1) MI_G(2) MI_G(3) MI_G(4)
+    MI_G(0) MI_G(1) MI_G(2) MI_G(3) MI_G(4) MI_G(5)
 #undef MI_G
 }
 
@@ -317,6 +326,71 @@ template <> struct st_unit<T_Q8_0> {
     }
 };
 
+// ---- ten-block units (k % 256 != 0) ----
+// Q8_0: 340 bytes = 85 dwords, dword-aligned in the slot (odd number of dwords: conflict-free ds_read_b32). Block j: d at byte 34 j, quants at 34 j + 2.
+template <> struct st_unit<ST_Q8_0_B10> {
+    static constexpr int UB = 340;
+    struct wfrag { uint32_t d[85]; };
+    static __device__ __forceinline__ wfrag load(uint32_t a) {
+        wfrag w;
+#pragma unroll
+        for (int j = 0; j < 85; j++) w.d[j] = st_ld4(a + 4*j);
+        return w;
+    }
+    static __device__ __forceinline__ float dot(const wfrag & w, const char * ab, float) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            const int B = 34*j, q = (B + 2) >> 2;
+            const uint32_t dbits = (B & 2) ? w.d[B >> 2] >> 16 : w.d[B >> 2] & 0xFFFF;
+            const int4v A0 = *(const int4v *) (ab + 32*j), A1 = *(const int4v *) (ab + 32*j + 16);
+            int isum = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint32_t qv = ((B + 2) & 2) ? __builtin_amdgcn_alignbit(w.d[q + i + 1], w.d[q + i], 16) : w.d[q + i];
+                isum = dot4((int) qv, i < 4 ? A0[i] : A1[i - 4], isum);
+            }
+            acc += (float) isum*(f16_bits_to_f32((uint16_t) dbits)*((const float *) (ab + 320))[j]);
+        }
+        return acc;
+    }
+};
+// MXFP4: 170 bytes (ten blocks of {e8m0 scale, 16 bytes of nibbles: elements 0..15 low, 16..31 high}) — a unit starts on a 2-byte boundary: the 44 aligned
+// dwords that cover it are read and realigned once (v_alignbit, shift 0 or 16 as for Q6_K); block j's bytes then sit at the compile-time offset 17 j.
+// Values through the 16-entry table (mxfp4_lut4, mmvq_core.h); per block sumi * (d_a * 2^(e - 127) / 2) as ggml_vec_dot_mxfp4_q8_0 has it.
+template <> struct st_unit<ST_MXFP4_B10> {
+    static constexpr int UB = 170;
+    struct wfrag { uint32_t d[44]; };
+    static __device__ __forceinline__ wfrag load(uint32_t a) {
+        wfrag w; uint32_t r[45];
+        const uint32_t a4 = a & ~3u, sh = (a & 2u)*8;
+#pragma unroll
+        for (int j = 0; j < 45; j++) r[j] = st_ld4(a4 + 4*j);
+#pragma unroll
+        for (int j = 0; j < 44; j++) w.d[j] = __builtin_amdgcn_alignbit(r[j + 1], r[j], sh);
+        return w;
+    }
+    static __device__ __forceinline__ float dot(const wfrag & w, const char * ab, float) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            const int o = 17*j;
+            const uint32_t e = (w.d[o >> 2] >> (8*(o & 3))) & 0xFF;
+            const int q = (o + 1) >> 2, bs = (o + 1) & 3;
+            const int4v A0 = *(const int4v *) (ab + 32*j), A1 = *(const int4v *) (ab + 32*j + 16);
+            int sumi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t qs = bs ? __builtin_amdgcn_alignbyte(w.d[q + i + 1], w.d[q + i], bs) : w.d[q + i];
+                sumi = dot4(mxfp4_lut4(qs), A0[i], sumi);
+                sumi = dot4(mxfp4_lut4(qs >> 4), A1[i], sumi);
+            }
+            acc += (((const float *) (ab + 320))[j]*e8m0_to_f32_half(e))*(float) sumi;
+        }
+        return acc;
+    }
+};
+
 #ifdef MI_STAMPS
 #define ST_STAMP(i_) do { if (stamps && lane == 0) __hip_atomic_store(&stamps[((size_t) blockIdx.x*(ST_NC + 1) + wave)*8 + (i_)], (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
@@ -376,7 +450,7 @@ constexpr int ST_INFLIGHT = 36;
 // because a phase that issued fewer than ST_INFLIGHT pieces is followed by a full drain.
 struct st_loader_state {
     int landed, pieces;                       // slots published; pieces issued so far
-    int c_slot0, c_base, p_slot0, p_base, p_magic;      // the current / the previous phase: its first slot, the pieces issued before it; 65536 / pieces-per-slot (rounded up) of the previous one
+    int c_slot0, c_base, p_slot0, p_base, p_magic, c_pps;      // the current / the previous phase: its first slot, the pieces issued before it; 65536 / pieces-per-slot (rounded up) of the previous one
 };
 template <int PPS>
 static __device__ __forceinline__ void st_loader_publish(const st_lds & L, st_loader_state & s, int issued_slots, int outstanding, int lane) {
@@ -403,11 +477,14 @@ static __device__ __forceinline__ void st_loader_phase(const st_args & p, const 
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (slot0 > ls.landed) { ls.landed = slot0; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) slot0); }
     }
-    ls.p_slot0 = ls.c_slot0; ls.p_base = ls.c_base; ls.c_slot0 = slot0; ls.c_base = ls.pieces;
+    ls.p_slot0 = ls.c_slot0; ls.p_base = ls.c_base; ls.c_slot0 = slot0; ls.c_base = ls.pieces; ls.c_pps = PPS;
     const long long row_off = (long long) r0*nb*U::UB;
     const long long e_off = g.eid ? (long long) __builtin_amdgcn_readfirstlane(g.eid[0])*g.estride : 0;      // (the expert the router picked: read here, on the device)
     const char * const w0 = g.W + e_off + row_off; const char * const w1 = GLU ? g.W2 + e_off + row_off : w0;
-    const long long lim_all = (long long) g.m*nb*U::UB - 16 - row_off;      // the tensor's last 16 bytes, relative to this workgroup's first
+    // the tensor's last 16-byte chunk (the grid of chunks starts at this workgroup's first byte, which is 16-byte aligned), relative to that byte. A tensor
+    // whose size is not a multiple of 16 ends inside that chunk: it is read in place — up to 15 bytes of the zeroed padding every quantized tensor of this
+    // backend's buffers carries (MI_TENSOR_PAD) — and only chunks that start past the end are redirected to it
+    const long long lim_all = (((long long) g.m*nb*U::UB - row_off - 1) & ~15ll);
     int ring_i = slot0 % S;
     for (int i = 0; i < nslots; i++) {
         const int gi = slot0 + i;                            // slot number in the workgroup's sequence
@@ -434,9 +511,8 @@ static __device__ __forceinline__ void st_loader_phase(const st_args & p, const 
 }
 // after the last phase: everything lands
 static __device__ __forceinline__ void st_loader_drain(const st_lds & L, int nslots_total, st_loader_state & ls, int lane) {
-    // (the last phase's slot size is not known here: 27 / 14 / 0 outstanding pieces cover whole slots of every format well enough)
     asm volatile("s_waitcnt vmcnt(18)" ::: "memory");
-    { const int done = ls.pieces - 18; const int l = min(nslots_total, done >= ls.c_base ? ls.c_slot0 + (done - ls.c_base)/14 : ls.c_slot0);      // /14: never more than have landed
+    { const int done = ls.pieces - 18; const int l = min(nslots_total, done >= ls.c_base ? ls.c_slot0 + (done - ls.c_base)/max(ls.c_pps, 1) : ls.c_slot0);
       if (l > ls.landed) { ls.landed = l; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) l); } }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (nslots_total > ls.landed) { ls.landed = nslots_total; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) nslots_total); }
@@ -480,17 +556,20 @@ static __device__ __forceinline__ void st_prologue_q8(const st_args & p, const s
 // PRO_QUANT / PRO_NORM: x (f32) -> [RMS_NORM * w ->] Q8_K blocks, quant_core.h's arithmetic. Consumer wave w owns the 256-element chunks
 // w, w + 8, ...: NA of them, all quantized in straight-line code (a chunk past the end is a clamped duplicate that is not stored) so that
 // the dependent chains of the wave-wide maxima and sums interleave — chunk after chunk behind a branch each cost ~0.5 us per chunk
-// Q80: the workgroup's weights are Q8_0 — the image is the CPU path's Q8_0 instead (32-element blocks, f16-rounded scales: quant_core.h)
-template <int NA, bool CHAIN, bool FIRST, bool Q80>
+// IMG: 0 = Q8_K blocks (K-quant weights); 1 = the workgroup's weights are Q8_0 in 256-weight units — the image is the CPU path's Q8_0 instead (32-element
+// blocks, f16-rounded scales: quant_core.h); 2 = the same Q8_0 activation for the ten-block units (k % 256 != 0: the last 256-piece is partial)
+template <int NA, bool CHAIN, bool FIRST, int IMG>
 static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const st_lds & L, int x_off, int seq, int & n_norm, int lane, int wave) {
-    const int nchunk = p.nb;
+    constexpr bool Q80 = IMG != 0;
+    const int nchunk = p.nchunk;
     const bool norm = p.mode == PRO_NORM;
     float4v xv[NA], wv[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int c = min(wave + ST_NC*i, nchunk - 1);
-        xv[i] = st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4);
-        wv[i] = norm ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
+        const bool in_k = IMG != 2 || c*256 + lane*4 < p.k;
+        xv[i] = in_k ? st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
+        wv[i] = norm && in_k ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
     }
     if constexpr (NA <= 2 && !CHAIN) {
         if (p.planes) {
@@ -535,6 +614,16 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
     for (int i = 0; i < NA; i++) {
         const int c = wave + ST_NC*i;
         if (c < nchunk) {
+            if (IMG == 2) {
+                const int e = c*256 + lane*4;
+                if (e < p.k) {
+                    const int un = e/320, off = e - un*320;
+                    char * ab = L.act + (size_t) un*ST_ACT_STRIDE_B10;
+                    *(uint32_t *) (ab + off) = q4[i];
+                    if ((lane & 7) == 0) ((float *) (ab + 320))[off >> 5] = d8[i];
+                }
+                continue;
+            }
             char * ab = L.act + (size_t) c*ST_ACT_STRIDE;
             *(uint32_t *) (ab + lane*4) = q4[i];
             if (Q80) { if ((lane & 7) == 0) ((float *) (ab + 256))[lane >> 3] = d8[i]; continue; }
@@ -569,17 +658,20 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
 
     // ---- the activation image (FIRST: the loads are requested before any weight is — a CU returns loads in request order) ----
     const int mode = p.mode;
+    constexpr int ST_IMG = (TYPE == ST_Q8_0_B10 || TYPE == ST_MXFP4_B10) ? 2 : TYPE == T_Q8_0 ? 1 : 0;
     if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
-    else if (nb <= 8)   st_prologue_f32<1, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else if (nb <= 16)  st_prologue_f32<2, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else if (nb <= 32)  st_prologue_f32<4, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else                st_prologue_f32<8, CHAIN, FIRST, TYPE == T_Q8_0>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (p.nchunk <= 8)   st_prologue_f32<1, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (p.nchunk <= 16)  st_prologue_f32<2, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (p.nchunk <= 32)  st_prologue_f32<4, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else                st_prologue_f32<8, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
     ST_STAMP(1);
     st_consumers_meet(&sync[2], lane, seq);
     ST_STAMP(2);
 
     // ---- the epilogue's operands of this thread's first row / pair: requested now, needed after the last slot ----
     float e_r0 = 0.0f, e_r1 = 0.0f, e_q0 = 0.0f, e_c = 1.0f, e_s = 0.0f; long long e_i0 = 0, e_i1 = 0;
+    // row offset into the [m, n_expert] bias tables of gpt-oss's experts (the expert index is a device value)
+    const int e_tab = (g.eid && (g.res_eid || g.b_gate)) ? __builtin_amdgcn_readfirstlane(g.eid[0])*g.m : 0;
     const long long idx0 = g.st_mode == 1 ? g.st_idx[0] : 0;
     if (g.epi == EPI_ROPE) {
         const fused_rope & rp = p.rope;
@@ -594,7 +686,8 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
         }
     } else if (ctid < R) {
         const int row = r0 + ctid;
-        if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, row); if (g.res2) e_q0 = st_ldx1<CHAIN>(g.res2, row); }
+        if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, e_tab + row); if (g.res2) e_q0 = st_ldx1<CHAIN>(g.res2, row); }
+        if (g.epi == EPI_GLU && g.b_gate) { e_r0 = g.b_gate[e_tab + row]; e_q0 = g.b_up[e_tab + row]; }
         if (g.st_mode == 2) e_i0 = g.st_idx[row];
     }
 
@@ -609,7 +702,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
         const bool live = u < n1;
         const int uc = live ? u : n1 - 1;
         const int ib = nb == 1 ? 0 : uc - (int) __umulhi((uint32_t) uc, magic)*nb;      // (the magic number of nb = 1 does not fit 32 bits)
-        const char * ab = act + (size_t) ib*ST_ACT_STRIDE;
+        const char * ab = act + (size_t) ib*(ST_IMG == 2 ? ST_ACT_STRIDE_B10 : ST_ACT_STRIDE);
         const float d8 = dd[ib];
         st_wait_ge(&sync[0], (uint32_t)(gi + 1));
         if (first) { ST_STAMP(3); first = false; }
@@ -657,11 +750,13 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
             float s0 = st_row_sum(part, rr, npr);
             const int row = r0 + rr;
             if (rr != ctid) {
-                if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, row); e_q0 = g.res2 ? st_ldx1<CHAIN>(g.res2, row) : 0.0f; }
+                if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, e_tab + row); e_q0 = g.res2 ? st_ldx1<CHAIN>(g.res2, row) : 0.0f; }
+                if (g.epi == EPI_GLU && g.b_gate) { e_r0 = g.b_gate[e_tab + row]; e_q0 = g.b_up[e_tab + row]; }
                 if (g.st_mode == 2) e_i0 = g.st_idx[row];
             }
             if (GLU) {
-                const float up_s = st_row_sum(part2, rr, npr);
+                float up_s = st_row_sum(part2, rr, npr);
+                if (g.b_gate) { s0 += e_r0; up_s += e_q0; }      // ADD_ID on both products, then the activation
                 if (g.glu_alpha != 0.0f) {      // swiglu_oai, as elem.hip k_glu
                     const float xc = fminf(s0, g.glu_limit), gc = fmaxf(fminf(up_s, g.glu_limit), -g.glu_limit);
                     s0 = (xc/(1.0f + expf(-xc*g.glu_alpha)))*(gc + 1.0f);
@@ -688,11 +783,11 @@ static __device__ __forceinline__ int st_group_of(const st_args & p, int b, int 
     first = gi ? p.block_end[gi - 1] : 0; nwg = p.block_end[gi] - first;
     return gi;
 }
-static __device__ __forceinline__ st_lds st_carve(char * lds, int nb_max, int npart_max, int slot_stride, int S) {
+static __device__ __forceinline__ st_lds st_carve(char * lds, int nb_max, int npart_max, int slot_stride, int S, int act_stride = ST_ACT_STRIDE) {
     st_lds L;
     L.sync = (uint32_t *) lds;
     L.act = lds + 2*ST_SYNC_WORDS*4;
-    L.dd = (float *) (L.act + (size_t) nb_max*ST_ACT_STRIDE);
+    L.dd = (float *) (L.act + (size_t) nb_max*act_stride);
     L.red = L.dd + ((nb_max + 3) & ~3);              // [2][ST_NC] sums of squares (PRO_NORM)
     L.part = L.red + 16;
     L.ring_a = st_lds_addr((char *) (((size_t)(L.part + npart_max) + 15) & ~(size_t) 15));
@@ -719,14 +814,14 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) 
     if (GLU) __builtin_assume(g.epi == EPI_GLU);
     const int wg = (int) blockIdx.x - first;
     const bool is_a = TA == TB || g.type == TA;
-    const st_lds L = st_carve(lds, p.nb, g.npart_max, ((64*(is_a ? st_unit<TA>::UB : st_unit<TB>::UB) + 1023)/1024)*1024, p.S);
+    const st_lds L = st_carve(lds, p.nb, g.npart_max, ((64*(is_a ? st_unit<TA>::UB : st_unit<TB>::UB) + 1023)/1024)*1024, p.S, p.act_stride);
     unsigned long long * stamps = p.stamps;
     ST_STAMP(0);
     if (threadIdx.x < ST_SYNC_WORDS) L.sync[threadIdx.x] = 0;
     if (wave == ST_NC) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0 };
+        st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if (is_a) st_loader_phase<TA, NT>(p, g, wg, nwg, L, 0, ls, lane);
         else      st_loader_phase<TB, NT>(p, g, wg, nwg, L, 0, ls, lane);
         st_loader_drain(L, st_phase_slots(p, g, wg, nwg), ls, lane);
@@ -752,7 +847,7 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_chain(const st_phase * _
     __builtin_amdgcn_s_barrier();            // (the chain's first phase queues its activation loads behind this barrier: one barrier per wave, and the loader must not wait for consumers)
     int slot0 = 0;
     if (wave == ST_NC) {
-        st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0 };
+        st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0, 0 };
         for (int ph = 0; ph < n_phases; ph++) {
             const st_phase & P = prog[ph];
             if (b >= P.n_active) continue;

@@ -27,7 +27,15 @@ template <int TA, int TB, bool GLU> static void st_launch_t(const st_args & a, i
     }
 }
 
-static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : type == T_Q8_0 ? 272 : 0; }
+static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : type == T_Q8_0 ? 272 : type == ST_Q8_0_B10 ? 340 : type == ST_MXFP4_B10 ? 170 : 0; }
+// the unit a weight type is streamed in at row length k: 256 weights, or ten 32-blocks where k is not a multiple of 256 (gpt-oss: 2880); 0: none
+static int st_utype(int type, int64_t k) {
+    if (k % 256 == 0) return type == T_MXFP4 ? 0 : type;
+    if (k % 320 == 0 && type == T_Q8_0) return ST_Q8_0_B10;
+    if (k % 320 == 0 && type == T_MXFP4) return ST_MXFP4_B10;
+    return 0;
+}
+static int st_unit_weights(int utype) { return utype == ST_Q8_0_B10 || utype == ST_MXFP4_B10 ? 320 : 256; }
 static int st_cu_count() {
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -71,20 +79,24 @@ bool mul_mat_vec_q_stream_enabled(void) {
 // can (and does) this grouped launch go to the streamed kernel?
 bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope) {
     if (!mul_mat_vec_q_stream_enabled() || n_groups < 1 || n_groups > MMVQ_MAX_GROUPS) return false;
-    if (k % 256 != 0 || k > 16384 || k < 256) return false;
+    if ((k % 256 != 0 && k % 320 != 0) || k > 16384 || k < 256) return false;
+    const bool b10 = k % 256 != 0;         // ten-block units (Q8_0 / MXFP4 rows of 320 n weights)
+    if (b10 && in.mode == PRO_Q8) return false;
     if (in.mode != PRO_Q8 && in.mode != PRO_QUANT && in.mode != PRO_NORM) return false;
     if (in.mode == PRO_Q8 && in.act_kind != T_Q8_K) return false;      // (a ready-made image: Q8_K only; the launch's own prologue quantizes per workgroup, in the format its group's weights ask for)
     if (in.mode == PRO_Q8) { if (((uintptr_t) in.act.qs % 16) || ((uintptr_t) in.act.bsums % 16) || !in.act.d) return false; }
     else { if (((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
-    const int64_t nb = k/256;
-    if (in.planes && (in.mode != PRO_NORM || nb > 16 || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
+    const int64_t nb = b10 ? k/320 : k/256;
+    if (in.planes && (in.mode != PRO_NORM || b10 || nb > 16 || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
     int ta = -1, tb = -1;
     for (int i = 0; i < n_groups; i++) {
         const mmvq_group & g = groups[i];
-        const int ub = st_unit_bytes(g.type);
+        const int ut = st_utype(g.type, k);
+        const int ub = st_unit_bytes(ut);
         if (!ub || (g.type == T_Q8_0 && in.mode == PRO_Q8)) return false;
-        if (g.type != ta && g.type != tb) { if (ta < 0) ta = g.type; else if (tb < 0) tb = g.type; else return false; }
-        if (g.b_gate || g.b_up || g.res_eid) return false;             // (gpt-oss's per-expert biases: the register-ring kernels)
+        if (ut != ta && ut != tb) { if (ta < 0) ta = ut; else if (tb < 0) tb = ut; else return false; }
+        if (b10 && tb >= 0) return false;                              // (one kernel per ten-block format: no mixed launches)
+        if ((g.b_gate != nullptr) != (g.b_up != nullptr) || (g.b_gate && (g.epi != EPI_GLU || !g.eid)) || (g.res_eid && (g.epi != EPI_ADD || !g.eid))) return false;
         if (g.eid && (g.estride % 16 || in.mode == PRO_NORM)) return false;
         if (g.x_off && (in.mode == PRO_Q8 || g.x_off % 4)) return false;
         if (g.row_stride != (size_t)(nb*ub) || ((uintptr_t) g.W % 16) || (g.W2 && ((uintptr_t) g.W2 % 16))) return false;
@@ -105,8 +117,10 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
 static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, st_args & a,
                    size_t & fixed_max, int & slot_max, int & nslots_max, int & npart_max, int & ta, int & tb, double & bytes_total) {
     a = st_args{};
-    const int nb = (int)(k/256);
+    const bool b10 = k % 256 != 0;
+    const int nb = (int)(b10 ? k/320 : k/256);
     a.n_groups = n_groups; a.k = (int) k; a.nb = nb; a.mode = in.mode; a.eps = in.eps;
+    a.nchunk = (int)((k + 255)/256); a.act_stride = b10 ? ST_ACT_STRIDE_B10 : ST_ACT_STRIDE;
     a.magic = nb == 1 ? 0u : (uint32_t)((0x100000000ull + nb - 1)/nb);
     a.x = in.x; a.norm_w = in.norm_w;
     a.planes = in.planes; a.n_planes = in.n_planes; a.plane_stride = in.plane_stride; a.x_out = in.x_out;
@@ -116,11 +130,11 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
     // workgroups per group: in proportion to the weight bytes, at least one each, never more than the group has row units
     const int budget = st_cu_count();
     bytes_total = 0; double gbytes[MMVQ_MAX_GROUPS];
-    ta = groups[0].type; tb = groups[0].type;
+    ta = st_utype(groups[0].type, k); tb = ta;
     for (int i = 0; i < n_groups; i++) {
-        gbytes[i] = (double) groups[i].m*nb*st_unit_bytes(groups[i].type)*(groups[i].epi == EPI_GLU ? 2 : 1);
+        gbytes[i] = (double) groups[i].m*nb*st_unit_bytes(st_utype(groups[i].type, k))*(groups[i].epi == EPI_GLU ? 2 : 1);
         bytes_total += gbytes[i];
-        if (groups[i].type != ta) tb = groups[i].type;
+        if (st_utype(groups[i].type, k) != ta) tb = st_utype(groups[i].type, k);
     }
     if (tb < ta) std::swap(ta, tb);
     int blocks = 0; slot_max = 0; fixed_max = 0; nslots_max = 0; npart_max = 0;
@@ -130,11 +144,12 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
         const mmvq_group & g = groups[i];
         st_group & s = a.g[i];
         s.W = g.W; s.W2 = g.W2; s.dst = g.dst; s.res = g.res; s.res2 = g.res2; s.st16 = g.st16; s.st_idx = g.st_idx; s.st_row_elems = g.st_row_elems;
-        s.m = g.m; s.type = g.type; s.epi = g.epi; s.st_mode = g.st_mode; s.glu_alpha = g.glu_alpha; s.glu_limit = g.glu_limit;
+        s.m = g.m; s.type = st_utype(g.type, k); s.epi = g.epi; s.st_mode = g.st_mode; s.glu_alpha = g.glu_alpha; s.glu_limit = g.glu_limit;
         s.eid = g.eid; s.estride = (long long) g.estride; s.x_off = g.x_off;
+        s.b_gate = g.b_gate; s.b_up = g.b_up; s.res_eid = g.res_eid;
         s.ralign = 1;
         if (g.epi == EPI_ROPE) s.ralign = (rope->p.mode & 2) ? rope->head_dim : 2;
-        while (((int64_t) s.ralign*nb*st_unit_bytes(g.type)) % 16 != 0) s.ralign *= 2;      // a workgroup's rows start on a 16-byte boundary (LDS-DMA source)
+        while (((int64_t) s.ralign*nb*st_unit_bytes(s.type)) % 16 != 0) s.ralign *= 2;      // a workgroup's rows start on a 16-byte boundary (LDS-DMA source)
         const int nru = std::max(1, g.m/s.ralign);
         int sh = (int)((double) budget*gbytes[i]/bytes_total);
         sh = sh < 1 ? 1 : (sh > nru ? nru : sh);
@@ -155,9 +170,9 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
         const bool row16 = (nb & 15) == 0;
         s.npart_max = (row16 ? Rmax*(nb >> 4) : Rmax*nb)*(g.epi == EPI_GLU ? 2 : 1);
         npart_max = std::max(npart_max, s.npart_max);
-        const size_t fixed = 2*ST_SYNC_WORDS*4 + (size_t) nb*ST_ACT_STRIDE + (size_t)((nb + 3) & ~3)*4 + 64 + (size_t) s.npart_max*4 + 16;
+        const size_t fixed = 2*ST_SYNC_WORDS*4 + (size_t) nb*a.act_stride + (size_t)((nb + 3) & ~3)*4 + 64 + (size_t) s.npart_max*4 + 16;
         fixed_max = std::max(fixed_max, fixed);
-        const int pps = (64*st_unit_bytes(g.type) + 1023)/1024;
+        const int pps = (64*st_unit_bytes(s.type) + 1023)/1024;
         slot_max = std::max(slot_max, pps*1024);
         nslots_max = std::max(nslots_max, (int)(((int64_t) Rmax*nb + 63)/64)*(g.epi == EPI_GLU ? 2 : 1));
         blocks += sh;
@@ -194,6 +209,8 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
     if (ta == T_Q4_K && tb == T_Q4_K)      { if (glu) st_launch_t<T_Q4_K, T_Q4_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q4_K, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q5_K && tb == T_Q5_K) { if (glu) st_launch_t<T_Q5_K, T_Q5_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q5_K, T_Q5_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q6_K && tb == T_Q6_K) { if (glu) st_launch_t<T_Q6_K, T_Q6_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q6_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == ST_Q8_0_B10)  { if (glu) st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == ST_MXFP4_B10) { if (glu) st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q8_0 && tb == T_Q8_0) { if (glu) st_launch_t<T_Q8_0, T_Q8_0, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q8_0, T_Q8_0, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q8_0 && tb == T_Q4_K) st_launch_t<T_Q8_0, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
     else if (ta == T_Q8_0 && tb == T_Q6_K) st_launch_t<T_Q8_0, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
@@ -217,7 +234,7 @@ bool mul_mat_vec_q_chain_build(const mmvq_chain_item * items, int n, void * prog
         size_t fixed; int slot, nslots, npart, ta, tb; double bytes;
         st_phase & P = prog[j];
         const int blocks = st_fill(it.grp, it.n_groups, it.k, it.in, it.has_rope ? &it.rope : nullptr, P.a, fixed, slot, nslots, npart, ta, tb, bytes);
-        if (ta == T_Q8_0 || tb == T_Q8_0) return false;      // (the chain kernel instantiates the K-quant units only)
+        if (ta == T_Q8_0 || tb == T_Q8_0 || it.k % 256 != 0) return false;      // (the chain kernel instantiates the K-quant units only)
         P.a.stamps = nullptr;
         P.n_active = blocks;
         P.wait_idx = j > 0 ? j - 1 : -1; P.wait_target = j > 0 ? (unsigned) prog[j - 1].n_active : 0;
