@@ -40,6 +40,13 @@ constexpr int ST_ACT_STRIDE = 304;
 // held 368 apart (23 chunks: odd). Pseudo type ids for the unit templates:
 constexpr int ST_Q8_0_B10 = 1008, ST_MXFP4_B10 = 1039;
 constexpr int ST_ACT_STRIDE_B10 = 368;
+// MXFP4 weights are E2M1 floats (x 2 = the reference's integer table): gfx950 converts a byte's two of them to f16 in ONE instruction
+// (v_cvt_scalef32_pk_f16_fp4) and v_dot2_f32_f16 multiplies the pair with two activations — 2 instructions per 2 weights where the table lookup
+// through v_perm_b32 took ~6. The sums stay exact (multiples of 1/2 below 2^15 in f32), so 2 x sum is the reference's integer sumi bit for bit.
+// For that the activation of an MXFP4 unit is held as f16 PAIRS (a_i, a_{i+16}) — a byte of a block holds elements i (low nibble) and i + 16 —
+// 64 bytes per block, 640 + 40 (the ten block scales) per unit, 688 apart (43 chunks).
+constexpr int ST_ACT_STRIDE_FP4 = 688;
+typedef _Float16 st_h2 __attribute__((ext_vector_type(2)));
 
 struct st_group {
     const char * W; const char * W2;          // W2: the second tensor of EPI_GLU
@@ -377,15 +384,19 @@ template <> struct st_unit<ST_MXFP4_B10> {
             const int o = 17*j;
             const uint32_t e = (w.d[o >> 2] >> (8*(o & 3))) & 0xFF;
             const int q = (o + 1) >> 2, bs = (o + 1) & 3;
-            const int4v A0 = *(const int4v *) (ab + 32*j), A1 = *(const int4v *) (ab + 32*j + 16);
-            int sumi = 0;
+            float sf = 0.0f;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t qs = bs ? __builtin_amdgcn_alignbyte(w.d[q + i + 1], w.d[q + i], bs) : w.d[q + i];
-                sumi = dot4(mxfp4_lut4(qs), A0[i], sumi);
-                sumi = dot4(mxfp4_lut4(qs >> 4), A1[i], sumi);
+                const int4v A = *(const int4v *) (ab + 64*j + 16*i);      // the pairs (a_e, a_{e+16}) of elements e = 4 i .. 4 i + 3
+                // (scalars first: __builtin_bit_cast applied directly to an element of an ext-vector reads element 0 with this compiler, ROCm 7.2 clang)
+                const int a0 = A.x, a1 = A.y, a2 = A.z, a3 = A.w;
+                sf = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp4(qs, 1.0f, 0), __builtin_bit_cast(st_h2, a0), sf, false);
+                sf = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp4(qs, 1.0f, 1), __builtin_bit_cast(st_h2, a1), sf, false);
+                sf = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp4(qs, 1.0f, 2), __builtin_bit_cast(st_h2, a2), sf, false);
+                sf = __builtin_amdgcn_fdot2(__builtin_amdgcn_cvt_scalef32_pk_f16_fp4(qs, 1.0f, 3), __builtin_bit_cast(st_h2, a3), sf, false);
             }
-            acc += (((const float *) (ab + 320))[j]*e8m0_to_f32_half(e))*(float) sumi;
+            acc += (((const float *) (ab + 640))[j]*e8m0_to_f32_half(e))*(2.0f*sf);      // 2 sf = sumi of ggml_vec_dot_mxfp4_q8_0, exactly
         }
         return acc;
     }
@@ -567,7 +578,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
 #pragma unroll
     for (int i = 0; i < NA; i++) {
         const int c = min(wave + ST_NC*i, nchunk - 1);
-        const bool in_k = IMG != 2 || c*256 + lane*4 < p.k;
+        const bool in_k = IMG < 2 || c*256 + lane*4 < p.k;
         xv[i] = in_k ? st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
         wv[i] = norm && in_k ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
     }
@@ -614,6 +625,26 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
     for (int i = 0; i < NA; i++) {
         const int c = wave + ST_NC*i;
         if (c < nchunk) {
+            if (IMG == 3) {
+                // f16 pairs (a_i, a_{i+16}): the lane 4 further holds the elements 16 further of the same 32-block
+                const uint32_t other = (uint32_t) __builtin_amdgcn_ds_bpermute((lane ^ 4) << 2, (int) q4[i]);
+                const int e = c*256 + lane*4;
+                if (e < p.k) {
+                    const int un = e/320, off = e - un*320, blk = off >> 5, e32 = off & 31;
+                    char * ab = L.act + (size_t) un*ST_ACT_STRIDE_FP4;
+                    if (e32 < 16) {
+                        uint32_t w4[4];
+#pragma unroll
+                        for (int t = 0; t < 4; t++) {
+                            const st_h2 pr = { (_Float16)(int)(int8_t)(q4[i] >> (8*t)), (_Float16)(int)(int8_t)(other >> (8*t)) };
+                            w4[t] = __builtin_bit_cast(uint32_t, pr);
+                        }
+                        *(int4v *) (ab + 64*blk + 4*e32) = int4v{ (int) w4[0], (int) w4[1], (int) w4[2], (int) w4[3] };
+                    }
+                    if ((lane & 7) == 0) ((float *) (ab + 640))[blk] = d8[i];
+                }
+                continue;
+            }
             if (IMG == 2) {
                 const int e = c*256 + lane*4;
                 if (e < p.k) {
@@ -658,7 +689,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
 
     // ---- the activation image (FIRST: the loads are requested before any weight is — a CU returns loads in request order) ----
     const int mode = p.mode;
-    constexpr int ST_IMG = (TYPE == ST_Q8_0_B10 || TYPE == ST_MXFP4_B10) ? 2 : TYPE == T_Q8_0 ? 1 : 0;
+    constexpr int ST_IMG = TYPE == ST_MXFP4_B10 ? 3 : TYPE == ST_Q8_0_B10 ? 2 : TYPE == T_Q8_0 ? 1 : 0;
     if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
     else if (p.nchunk <= 8)   st_prologue_f32<1, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
     else if (p.nchunk <= 16)  st_prologue_f32<2, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
@@ -702,7 +733,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
         const bool live = u < n1;
         const int uc = live ? u : n1 - 1;
         const int ib = nb == 1 ? 0 : uc - (int) __umulhi((uint32_t) uc, magic)*nb;      // (the magic number of nb = 1 does not fit 32 bits)
-        const char * ab = act + (size_t) ib*(ST_IMG == 2 ? ST_ACT_STRIDE_B10 : ST_ACT_STRIDE);
+        const char * ab = act + (size_t) ib*(ST_IMG == 3 ? ST_ACT_STRIDE_FP4 : ST_IMG == 2 ? ST_ACT_STRIDE_B10 : ST_ACT_STRIDE);
         const float d8 = dd[ib];
         st_wait_ge(&sync[0], (uint32_t)(gi + 1));
         if (first) { ST_STAMP(3); first = false; }

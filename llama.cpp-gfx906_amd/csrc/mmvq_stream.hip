@@ -120,7 +120,7 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
     const bool b10 = k % 256 != 0;
     const int nb = (int)(b10 ? k/320 : k/256);
     a.n_groups = n_groups; a.k = (int) k; a.nb = nb; a.mode = in.mode; a.eps = in.eps;
-    a.nchunk = (int)((k + 255)/256); a.act_stride = b10 ? ST_ACT_STRIDE_B10 : ST_ACT_STRIDE;
+    a.nchunk = (int)((k + 255)/256); a.act_stride = !b10 ? ST_ACT_STRIDE : st_utype(groups[0].type, k) == ST_MXFP4_B10 ? ST_ACT_STRIDE_FP4 : ST_ACT_STRIDE_B10;
     a.magic = nb == 1 ? 0u : (uint32_t)((0x100000000ull + nb - 1)/nb);
     a.x = in.x; a.norm_w = in.norm_w;
     a.planes = in.planes; a.n_planes = in.n_planes; a.plane_stride = in.plane_stride; a.x_out = in.x_out;
