@@ -333,6 +333,44 @@ template <> struct st_unit<T_Q8_0> {
     }
 };
 
+// Q4_0: 18-byte blocks of 32 weights (f16 d | 16 bytes of nibbles: elements 0..15 low, 16..31 high; value = nibble - 8) — a unit is eight of them
+// (144 bytes = 9 chunks). Against the Q8_0 activation image (as for Q8_0 weights) plus the eight 32-element sums of its quants as int16 at ab + 288:
+// sum (nib - 8) q = sum nib q - 8 sum q, the integers of ggml_vec_dot_q4_0_q8_0; per block sumi * (d_w * d_a), block after block.
+template <> struct st_unit<T_Q4_0> {
+    static constexpr int UB = 144;
+    struct wfrag { int4v c[9]; };
+    static __device__ __forceinline__ wfrag load(uint32_t a) {
+        wfrag w;
+#pragma unroll
+        for (int j = 0; j < 9; j++) w.c[j] = st_ld16(a + 16*j);
+        return w;
+    }
+    static __device__ __forceinline__ uint32_t dw(const wfrag & w, int i) { return (uint32_t) w.c[i >> 2][i & 3]; }
+    static __device__ __forceinline__ float dot(const wfrag & w, const char * ab, float) {
+        float acc = 0.0f;
+        const float4v da0 = *(const float4v *) (ab + 256), da1 = *(const float4v *) (ab + 272);
+        const int4v bsv = *(const int4v *) (ab + 288);
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int B = 18*j, q = (B + 2) >> 2;
+            const uint32_t dbits = (B & 2) ? dw(w, B >> 2) >> 16 : dw(w, B >> 2) & 0xFFFF;
+            const int4v A0 = *(const int4v *) (ab + 32*j), A1 = *(const int4v *) (ab + 32*j + 16);
+            int isum = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t qv = ((B + 2) & 2) ? __builtin_amdgcn_alignbit(dw(w, q + i + 1), dw(w, q + i), 16) : dw(w, q + i);
+                isum = dot4((int)(qv & 0x0F0F0F0Fu), A0[i], isum);
+                isum = dot4((int)((qv >> 4) & 0x0F0F0F0Fu), A1[i], isum);
+            }
+            const uint32_t bw = (uint32_t) bsv[j >> 1];
+            const int bsum = (int)(int16_t)((j & 1) ? bw >> 16 : bw & 0xFFFF);
+            const float da = j < 4 ? da0[j] : da1[j - 4];
+            acc += (float)(isum - 8*bsum)*(f16_bits_to_f32((uint16_t) dbits)*da);
+        }
+        return acc;
+    }
+};
+
 // ---- ten-block units (k % 256 != 0) ----
 // Q8_0: 340 bytes = 85 dwords, dword-aligned in the slot (odd number of dwords: conflict-free ds_read_b32). Block j: d at byte 34 j, quants at 34 j + 2.
 template <> struct st_unit<ST_Q8_0_B10> {
@@ -657,7 +695,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
             }
             char * ab = L.act + (size_t) c*ST_ACT_STRIDE;
             *(uint32_t *) (ab + lane*4) = q4[i];
-            if (Q80) { if ((lane & 7) == 0) ((float *) (ab + 256))[lane >> 3] = d8[i]; continue; }
+            if (Q80) { if ((lane & 7) == 0) { ((float *) (ab + 256))[lane >> 3] = d8[i]; ((int16_t *) (ab + 288))[lane >> 3] = (int16_t) bs16[i]; } continue; }      // (the sums: Q4_0's - 8 offset)
             // the 16-element sum of quad q = lane >> 2 (valid in its four lanes); the 32-element sum j at lane 8j + 4 (row_shr:4 brings lane 8j's)
             const int bs32 = bs16[i] + dpp_i<0x114>(bs16[i]);
             int h, l;
@@ -689,7 +727,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
 
     // ---- the activation image (FIRST: the loads are requested before any weight is — a CU returns loads in request order) ----
     const int mode = p.mode;
-    constexpr int ST_IMG = TYPE == ST_MXFP4_B10 ? 3 : TYPE == ST_Q8_0_B10 ? 2 : TYPE == T_Q8_0 ? 1 : 0;
+    constexpr int ST_IMG = TYPE == ST_MXFP4_B10 ? 3 : TYPE == ST_Q8_0_B10 ? 2 : (TYPE == T_Q8_0 || TYPE == T_Q4_0) ? 1 : 0;
     if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
     else if (p.nchunk <= 8)   st_prologue_f32<1, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
     else if (p.nchunk <= 16)  st_prologue_f32<2, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);

@@ -27,7 +27,7 @@ template <int TA, int TB, bool GLU> static void st_launch_t(const st_args & a, i
     }
 }
 
-static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : type == T_Q8_0 ? 272 : type == ST_Q8_0_B10 ? 340 : type == ST_MXFP4_B10 ? 170 : 0; }
+static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : type == T_Q8_0 ? 272 : type == T_Q4_0 ? 144 : type == ST_Q8_0_B10 ? 340 : type == ST_MXFP4_B10 ? 170 : 0; }
 // the unit a weight type is streamed in at row length k: 256 weights, or ten 32-blocks where k is not a multiple of 256 (gpt-oss: 2880); 0: none
 static int st_utype(int type, int64_t k) {
     if (k % 256 == 0) return type == T_MXFP4 ? 0 : type;
@@ -93,7 +93,7 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
         const mmvq_group & g = groups[i];
         const int ut = st_utype(g.type, k);
         const int ub = st_unit_bytes(ut);
-        if (!ub || (g.type == T_Q8_0 && in.mode == PRO_Q8)) return false;
+        if (!ub || ((g.type == T_Q8_0 || g.type == T_Q4_0) && in.mode == PRO_Q8)) return false;
         if (ut != ta && ut != tb) { if (ta < 0) ta = ut; else if (tb < 0) tb = ut; else return false; }
         if (b10 && tb >= 0) return false;                              // (one kernel per ten-block format: no mixed launches)
         if ((g.b_gate != nullptr) != (g.b_up != nullptr) || (g.b_gate && (g.epi != EPI_GLU || !g.eid)) || (g.res_eid && (g.epi != EPI_ADD || !g.eid))) return false;
@@ -211,6 +211,7 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
     else if (ta == T_Q6_K && tb == T_Q6_K) { if (glu) st_launch_t<T_Q6_K, T_Q6_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q6_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == ST_Q8_0_B10)  { if (glu) st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == ST_MXFP4_B10) { if (glu) st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
+    else if (ta == T_Q4_0 && tb == T_Q4_0) { if (glu) st_launch_t<T_Q4_0, T_Q4_0, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q4_0, T_Q4_0, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q8_0 && tb == T_Q8_0) { if (glu) st_launch_t<T_Q8_0, T_Q8_0, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q8_0, T_Q8_0, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
     else if (ta == T_Q8_0 && tb == T_Q4_K) st_launch_t<T_Q8_0, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
     else if (ta == T_Q8_0 && tb == T_Q6_K) st_launch_t<T_Q8_0, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
@@ -234,7 +235,7 @@ bool mul_mat_vec_q_chain_build(const mmvq_chain_item * items, int n, void * prog
         size_t fixed; int slot, nslots, npart, ta, tb; double bytes;
         st_phase & P = prog[j];
         const int blocks = st_fill(it.grp, it.n_groups, it.k, it.in, it.has_rope ? &it.rope : nullptr, P.a, fixed, slot, nslots, npart, ta, tb, bytes);
-        if (ta == T_Q8_0 || tb == T_Q8_0 || it.k % 256 != 0) return false;      // (the chain kernel instantiates the K-quant units only)
+        if (ta == T_Q8_0 || tb == T_Q8_0 || ta == T_Q4_0 || tb == T_Q4_0 || it.k % 256 != 0) return false;      // (the chain kernel instantiates the K-quant units only)
         P.a.stamps = nullptr;
         P.n_active = blocks;
         P.wait_idx = j > 0 ? j - 1 : -1; P.wait_target = j > 0 ? (unsigned) prog[j - 1].n_active : 0;

@@ -92,8 +92,8 @@ def worker():
                 be.reset_counters()
                 for shares in ([0.0] * 16, [3.0, 1.0], [0.0, 1.0], [1.0, 0.0]):
                     got = mul_mat(split_buft(shares), qt, w, x, m, k, check_probe=(n == 1))
-                    if n == 1 and tname in ("q4_K", "q5_K", "q6_K", "q8_0") and k % 256 == 0:
-                        # one column of K-quant / Q8_0 weights, unsplit, runs on the streamed kernel (csrc/mmvq_stream.h): the same integer sub-sums,
+                    if n == 1 and tname in ("q4_K", "q5_K", "q6_K", "q8_0", "q4_0") and k % 256 == 0:
+                        # one column of K-quant / Q8_0 / Q4_0 weights, unsplit, runs on the streamed kernel (csrc/mmvq_stream.h): the same integer sub-sums,
                         # another order of the f32 additions than the per-slice kernel of the split path
                         assert float(np.abs(got - ref).max()) <= 2e-5*float(np.abs(ref).max()), (tname, m, k, n, shares)
                     elif n <= 8:
