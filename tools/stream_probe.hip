@@ -6,6 +6,8 @@
 #include <algorithm>
 #include <math.h>
 using namespace mi355x;
+// (the probe predates two renames in mmvq_stream.h: the sync area's size and the number of 16-byte chunks of a unit)
+static constexpr int ST_SYNC_BYTES = 2*ST_SYNC_WORDS*4;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
 
 struct probe_args {
@@ -124,20 +126,20 @@ __global__ void __launch_bounds__((ST_NC + NL)*64, 3) k_stream_probe(const probe
         const float d8 = dd[ib];
         if (MODE != 2) st_wait_ge(&sync[i % NL], (uint32_t)(i/NL + 1));
         if (first) { STAMP(3); first = false; }
-        int4v c[U::CH];
+        int4v c[(U::UB/16)];
         const char * sp = ring + (size_t)(i % S)*SLOT + (size_t)(live ? lane : 0)*U::UB;
 #pragma unroll
-        for (int j = 0; j < U::CH; j++) c[j] = *(const int4v *) (sp + 16*j);
+        for (int j = 0; j < (U::UB/16); j++) c[j] = *(const int4v *) (sp + 16*j);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (nslots > S && lane == 0) st_flag_st(&sync[16 + i % S], (uint32_t)(i + 1));
         float res;
         if (MODE == 1) { int x = 0;
 #pragma unroll
-            for (int j = 0; j < U::CH; j++) x ^= c[j].x ^ c[j].y ^ c[j].z ^ c[j].w;
+            for (int j = 0; j < (U::UB/16); j++) x ^= c[j].x ^ c[j].y ^ c[j].z ^ c[j].w;
 #pragma unroll
             for (int j = 0; j < 16; j++) x ^= A[j].x ^ A[j].y ^ A[j].z ^ A[j].w;
             res = (float)(x ^ HL.x) + d8;
-        } else res = U::dot(c, A, HL, d8);
+        } else { typename U::wfrag wf; for (int j = 0; j < (U::UB/16); j++) wf.c[j] = c[j]; res = U::dot(wf, ap, d8); }      // (the kernel's own unit arithmetic: mmvq_stream.h)
         if (!live) res = 0.0f;
         if (nb == 16) {        // 16 lanes = one row
             res = row16_sum(res);
