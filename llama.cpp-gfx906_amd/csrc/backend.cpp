@@ -395,7 +395,9 @@ struct mi_backend_ctx {
     // attention + wo as one launch (attn_wo.hip): its partial planes, and what is pending — the vector x_out = res + sum of the planes does not exist until the
     // launch that reads it (norm + gate/up, streamed kernel) has added them up, or pp_flush has
     float * wo_planes = nullptr; static constexpr int WO_PLANE_STRIDE = 16384, WO_PLANES_MAX = 16;
-    struct { bool active = false; const float * res = nullptr; float * x_out = nullptr; int n_planes = 0; int64_t m = 0; } pp;
+    struct { bool active = false; const float * res = nullptr; float * x_out = nullptr; int n_planes = 0; int64_t m = 0;
+             const float * planes = nullptr; int stride = 0;                                     // where the planes are (floats between them)
+             const float * probs = nullptr; const int32_t * ids = nullptr; int mode = 0; } pp;      // probs != NULL: the MoE combine left pending (weighted planes = the used experts' outputs)
     float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
     // activation-quantisation reuse inside one graph_compute
@@ -966,7 +968,8 @@ static void rec_flush(mi_backend_ctx * c) {
 // the pending sum of attn_wo's planes is needed as a tensor after all (its reader is not the launch that would have added them up itself)
 static void pp_flush(mi_backend_ctx * c) {
     if (!c->pp.active) return;
-    planes_sum(c->pp.res, c->wo_planes, c->pp.n_planes, mi_backend_ctx::WO_PLANE_STRIDE, c->pp.x_out, c->pp.m, c->stream);
+    if (c->pp.probs) moe_combine(c->pp.probs, c->pp.ids, c->pp.n_planes, c->pp.mode, c->pp.planes, (size_t) c->pp.stride*4, c->pp.m, c->pp.res, c->pp.x_out, c->stream);
+    else planes_sum(c->pp.res, c->pp.planes, c->pp.n_planes, c->pp.stride, c->pp.x_out, c->pp.m, c->stream);
     c->cnt.kernels_launched++;
     c->pp.active = false;
 }
@@ -1276,7 +1279,8 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     }
     if (c->pp.active && in.mode == PRO_NORM && (const void *) in.x == (const void *) c->pp.x_out && K == c->pp.m) {
         // the norm's input is the sum attn_wo left as partial planes: this launch adds them up in its prologue (and stores the sum)
-        in.x = c->pp.res; in.planes = c->wo_planes; in.n_planes = c->pp.n_planes; in.plane_stride = mi_backend_ctx::WO_PLANE_STRIDE; in.x_out = c->pp.x_out;
+        in.x = c->pp.res; in.planes = c->pp.planes; in.n_planes = c->pp.n_planes; in.plane_stride = c->pp.stride; in.x_out = c->pp.x_out;
+        in.pl_probs = c->pp.probs; in.pl_ids = c->pp.ids; in.pl_mode = c->pp.mode;
         c->pp.active = false;
     }
     emit_mmv(c, grp, nc, K, in, rope, fin_t ? &fin : nullptr, in.mode == PRO_NORM && normw ? (float *) norm_mul_data : nullptr);
@@ -1402,6 +1406,7 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                         sm->src[2] ? (const float *) sm->src[2]->data : nullptr, hd, n_kv, n_head, n_head_kv, op_f32(sm, 0),
                         (int) wo->type, wo->data, wo->nb[1], wo->ne[1], c->wo_planes, mi_backend_ctx::WO_PLANE_STRIDE, c->stream);
                 c->pp.active = true; c->pp.res = ch.grp.res; c->pp.x_out = ch.grp.dst; c->pp.n_planes = (int) n_head_kv; c->pp.m = wo->ne[1];
+                c->pp.planes = c->wo_planes; c->pp.stride = mi_backend_ctx::WO_PLANE_STRIDE; c->pp.probs = nullptr; c->pp.ids = nullptr; c->pp.mode = 0;
                 c->cnt.kernels_launched++; c->cnt.mmvq_launches++;
                 c->cnt.weight_bytes += (uint64_t) wo->ne[1]*wo->nb[1];
                 return ch.last - i + 1;
@@ -1479,6 +1484,27 @@ static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int
         }
     }
     if (!ggml_is_contiguous(out) || ((uintptr_t) out->data % 16)) return 0;
+    // the sum's first reader is the norm of a grouped mat-vec launch (the next layer's norm + QKV, or the final norm + lm_head): that launch's prologue
+    // evaluates the combine itself (weighted planes, mmvq_stream.h) — this kernel and its boundary go. Anything else: pp_flush runs it after all.
+    static const bool defer_on = !getenv("GGML_MI355X_MOE_COMBINE_DEFER") || atoi(getenv("GGML_MI355X_MOE_COMBINE_DEFER")) != 0;
+    {
+        const int jn = next_real(g, jl);
+        const int jm2 = jn > 0 ? next_real(g, jn) : -1;
+        const int jq = jm2 > 0 ? next_real(g, jm2) : -1;
+        if (defer_on && jq > 0 && !c->rec_on && c->use_fusion && mul_mat_vec_q_stream_enabled() && n_embd <= 4096 && ex->nb[1] % 16 == 0 &&
+            g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0] == out && is_row_vec_f32(out) &&
+            g->nodes[jm2]->op == GGML_OP_MUL && (g->nodes[jm2]->src[0] == g->nodes[jn] || g->nodes[jm2]->src[1] == g->nodes[jn]) &&
+            fusable_mmv(g->nodes[jq]) && g->nodes[jq]->src[1] == g->nodes[jm2] && g->nodes[jq]->src[0]->ne[0] == n_embd &&
+            (n_embd % 256 == 0 ? (g->nodes[jq]->src[0]->type == GGML_TYPE_Q4_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q5_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q6_K ||
+                                  g->nodes[jq]->src[0]->type == GGML_TYPE_Q8_0 || g->nodes[jq]->src[0]->type == GGML_TYPE_Q4_0)
+                               : (n_embd % 320 == 0 && (g->nodes[jq]->src[0]->type == GGML_TYPE_Q8_0 || g->nodes[jq]->src[0]->type == GGML_TYPE_MXFP4)))) {
+            pp_flush(c);
+            c->pp.active = true; c->pp.res = res; c->pp.x_out = (float *) out->data; c->pp.n_planes = (int) n_used; c->pp.m = n_embd;
+            c->pp.planes = (const float *) ex->data; c->pp.stride = (int)(ex->nb[1]/4);
+            c->pp.probs = (const float *) pr->data; c->pp.ids = (const int32_t *) ids->data; c->pp.mode = mode;
+            return jl - i + 1;
+        }
+    }
     moe_combine((const float *) pr->data, (const int32_t *) ids->data, (int) n_used, mode, ex->data, ex->nb[1], n_embd, res, (float *) out->data, c->stream);
     c->cnt.kernels_launched++;
     return jl - i + 1;

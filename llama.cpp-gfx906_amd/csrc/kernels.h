@@ -247,6 +247,10 @@ struct mmvq_input {
     // PRO_NORM only: the vector is not materialized yet — it is x[i] + planes[0][i] + planes[1][i] + ... (added in that order: the partial planes of the
     // k-sliced attention + wo launch, attn_wo.hip, on top of the residual x) and the launch also stores that sum to x_out (the graph's ADD result)
     const float * planes; int n_planes; int plane_stride; float * x_out;
+    // ... or, pl_probs != NULL, the tail of build_moe_ffn (src/llama-graph.cpp:887-1012) left unevaluated: the planes are the used experts' outputs and the vector
+    // is sum_u planes[u][i] * w_u (+ x[i], the residual, when x != NULL), w_u from pl_probs[pl_ids[u]] normalised (pl_mode 0) or soft_max'ed (1) — k_moe_combine's
+    // arithmetic in k_moe_combine's order
+    const float * pl_probs; const int32_t * pl_ids; int pl_mode;
 };
 // one token: attention + output projection as one launch writing n_head_kv partial planes (attn_wo.hip); planes_sum: the stand-alone consumer
 bool attn_wo_supported(int type, int64_t m, int64_t k, int64_t hd, int64_t n_kv, int64_t n_head, int64_t n_head_kv);

@@ -76,6 +76,7 @@ struct st_args {
     // PRO_NORM, at most 16 blocks: x is the residual and the vector is x + plane 0 + plane 1 + ... (attn_wo.hip's partial planes, in this order);
     // workgroup 0 also stores the sum to x_out
     const float * planes; int n_planes, plane_stride; float * x_out;
+    const float * pl_probs; const int32_t * pl_ids; int pl_mode;      // != NULL: weighted planes (the MoE combine, kernels.h mmvq_input)
     unsigned long long * stamps;              // diagnostic builds (-DMI_STAMPS): [workgroup][wave][8]
 };
 // ---- a CHAIN of such launches as ONE launch (k_mmvq_chain): consecutive mat-vecs of the decode graph (wo -> gate/up/SwiGLU -> down -> the next
@@ -617,7 +618,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
     for (int i = 0; i < NA; i++) {
         const int c = min(wave + ST_NC*i, nchunk - 1);
         const bool in_k = IMG < 2 || c*256 + lane*4 < p.k;
-        xv[i] = in_k ? st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
+        xv[i] = in_k && p.x ? st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
         wv[i] = norm && in_k ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
     }
     if constexpr (NA <= 2 && !CHAIN) {
@@ -626,16 +627,50 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
 #pragma unroll
             for (int i = 0; i < NA; i++) {
                 const int c = min(wave + ST_NC*i, nchunk - 1);
+                const bool in_k = IMG < 2 || c*256 + lane*4 < p.k;
 #pragma unroll
-                for (int pl = 0; pl < 8; pl++) pv[i][pl] = *(const float4v *) (p.planes + (size_t) min(pl, p.n_planes - 1)*p.plane_stride + (size_t) c*256 + lane*4);
+                for (int pl = 0; pl < 8; pl++) pv[i][pl] = in_k ? *(const float4v *) (p.planes + (size_t) min(pl, p.n_planes - 1)*p.plane_stride + (size_t) c*256 + lane*4) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
+            }
+            // the planes' weights (MoE combine): every thread derives the same few numbers — probs[ids[u]], then the normalisation of k_moe_combine (elem.hip)
+            float w[8];
+            if (p.pl_probs) {
+                float pr[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) pr[u] = u < p.n_planes ? p.pl_probs[p.pl_ids[u]] : 0.0f;
+                if (p.pl_mode == 0) {
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (u < p.n_planes) sum += pr[u];
+#pragma unroll
+                    for (int u = 0; u < 8; u++) w[u] = pr[u]/sum;
+                } else {
+                    float mx = -INFINITY;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (u < p.n_planes) mx = fmaxf(mx, pr[u]);
+                    float sum = 0.0f;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) { w[u] = u < p.n_planes ? expf(pr[u] - mx) : 0.0f; sum += w[u]; }
+                    const float inv = 1.0f/sum;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) w[u] *= inv;
+                }
             }
             if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #pragma unroll
             for (int i = 0; i < NA; i++) {
+                if (p.pl_probs) {
+                    float4v acc = pv[i][0];
+                    acc.x *= w[0]; acc.y *= w[0]; acc.z *= w[0]; acc.w *= w[0];
 #pragma unroll
-                for (int pl = 0; pl < 8; pl++) if (pl < p.n_planes) { xv[i].x += pv[i][pl].x; xv[i].y += pv[i][pl].y; xv[i].z += pv[i][pl].z; xv[i].w += pv[i][pl].w; }
+                    for (int pl = 1; pl < 8; pl++) if (pl < p.n_planes) { acc.x += pv[i][pl].x*w[pl]; acc.y += pv[i][pl].y*w[pl]; acc.z += pv[i][pl].z*w[pl]; acc.w += pv[i][pl].w*w[pl]; }
+                    if (p.x) { acc.x += xv[i].x; acc.y += xv[i].y; acc.z += xv[i].z; acc.w += xv[i].w; }
+                    xv[i] = acc;
+                } else {
+#pragma unroll
+                    for (int pl = 0; pl < 8; pl++) if (pl < p.n_planes) { xv[i].x += pv[i][pl].x; xv[i].y += pv[i][pl].y; xv[i].z += pv[i][pl].z; xv[i].w += pv[i][pl].w; }
+                }
                 const int c = wave + ST_NC*i;
-                if (blockIdx.x == 0 && c < nchunk) *(float4v *) (p.x_out + (size_t) c*256 + lane*4) = xv[i];
+                if (blockIdx.x == 0 && c < nchunk && (IMG < 2 || c*256 + lane*4 < p.k)) *(float4v *) (p.x_out + (size_t) c*256 + lane*4) = xv[i];
             }
         } else if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     } else

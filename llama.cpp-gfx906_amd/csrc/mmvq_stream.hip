@@ -85,9 +85,9 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     if (in.mode != PRO_Q8 && in.mode != PRO_QUANT && in.mode != PRO_NORM) return false;
     if (in.mode == PRO_Q8 && in.act_kind != T_Q8_K) return false;      // (a ready-made image: Q8_K only; the launch's own prologue quantizes per workgroup, in the format its group's weights ask for)
     if (in.mode == PRO_Q8) { if (((uintptr_t) in.act.qs % 16) || ((uintptr_t) in.act.bsums % 16) || !in.act.d) return false; }
-    else { if (((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
+    else { if ((!in.x && !(in.planes && in.pl_probs)) || ((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
     const int64_t nb = b10 ? k/320 : k/256;
-    if (in.planes && (in.mode != PRO_NORM || b10 || nb > 16 || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
+    if (in.planes && (in.mode != PRO_NORM || (k + 255)/256 > 16 || (in.pl_probs && !in.pl_ids) || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
     int ta = -1, tb = -1;
     for (int i = 0; i < n_groups; i++) {
         const mmvq_group & g = groups[i];
@@ -124,6 +124,7 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
     a.magic = nb == 1 ? 0u : (uint32_t)((0x100000000ull + nb - 1)/nb);
     a.x = in.x; a.norm_w = in.norm_w;
     a.planes = in.planes; a.n_planes = in.n_planes; a.plane_stride = in.plane_stride; a.x_out = in.x_out;
+    a.pl_probs = in.pl_probs; a.pl_ids = in.pl_ids; a.pl_mode = in.pl_mode;
     if (in.mode == PRO_Q8) { a.a_qs = in.act.qs; a.a_d = in.act.d; a.a_bs = in.act.bsums; }
     if (rope) a.rope = make_fused_rope(*rope);
 
