@@ -1393,7 +1393,7 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             const int jq = jm > 0 ? next_real(g, jm) : -1;
             if (jq > 0 && !ch.grp.res2 && !ch.grp.st_mode && !ch.has_rope && wo->ne[0] == hd*n_head && wo->ne[1] <= mi_backend_ctx::WO_PLANE_STRIDE &&
                 wo->nb[1] == ggml_row_size(wo->type, wo->ne[0]) && ((uintptr_t) wo->data % 16) == 0 && ((uintptr_t) ch.grp.res % 16) == 0 && ((uintptr_t) ch.grp.dst % 16) == 0 &&
-                (const void *) ch.grp.res != (const void *) ch.grp.dst &&
+                !ranges_overlap(ch.grp.dst, (size_t) wo->ne[1]*4, ch.grp.res, (size_t) wo->ne[1]*4) &&      // (the consumer reads res in every workgroup while one stores the sum)
                 attn_wo_supported((int) wo->type, wo->ne[1], wo->ne[0], hd, n_kv, n_head, n_head_kv) && wo->ne[1] == wo->ne[0] &&
                 g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0]->data == (void *) ch.grp.dst && is_row_vec_f32(g->nodes[jn]->src[0]) &&
                 g->nodes[jm]->op == GGML_OP_MUL && (g->nodes[jm]->src[0] == g->nodes[jn] || g->nodes[jm]->src[1] == g->nodes[jn]) &&
@@ -1491,7 +1491,10 @@ static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int
         const int jn = next_real(g, jl);
         const int jm2 = jn > 0 ? next_real(g, jn) : -1;
         const int jq = jm2 > 0 ? next_real(g, jm2) : -1;
-        if (defer_on && jq > 0 && !c->rec_on && c->use_fusion && mul_mat_vec_q_stream_enabled() && n_embd <= 4096 && ex->nb[1] % 16 == 0 &&
+        // (every workgroup of that launch reads the residual and the experts' outputs while one of them stores the sum: the sum's tensor must not share memory
+        // with either — an allocator that made the ADD in place, as ggml-alloc does when the residual has no later reader, keeps the stand-alone kernel)
+        const bool aliased = (res && ranges_overlap(out->data, ggml_nbytes(out), res, (size_t) n_embd*4)) || ranges_overlap(out->data, ggml_nbytes(out), ex->data, ggml_nbytes(ex));
+        if (defer_on && !aliased && jq > 0 && !c->rec_on && c->use_fusion && mul_mat_vec_q_stream_enabled() && n_embd <= 4096 && ex->nb[1] % 16 == 0 &&
             g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0] == out && is_row_vec_f32(out) &&
             g->nodes[jm2]->op == GGML_OP_MUL && (g->nodes[jm2]->src[0] == g->nodes[jn] || g->nodes[jm2]->src[1] == g->nodes[jn]) &&
             fusable_mmv(g->nodes[jq]) && g->nodes[jq]->src[1] == g->nodes[jm2] && g->nodes[jq]->src[0]->ne[0] == n_embd &&
