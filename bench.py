@@ -121,6 +121,25 @@ def cpu_baseline(model_cfg, ftype, budget_s=20.0):
                       f"mat-vec work only (attention/norm/rope excluded)"}
 
 
+
+def roofline_from_profile(prof):
+    """the dominant kernel's achieved HBM rate from the backend's per-dispatch timings (option "profile": each grouped mat-vec dispatch carries its own
+    start/stop event pair = the interval rocprofv3's kernel trace reports)"""
+    prof.sort(key=lambda e: -e["total_ms"])
+    top = prof[0]
+    avg_s = top["total_ms"] / top["launches"] * 1e-3
+    ach = top["bytes_per_launch"] / avg_s / 1e9
+    roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
+            "traffic": None, "traffic_source": None,
+            "kernel": top.get("kernel") or f"k_mmvq<{TYPE_NAMES.get(top['type'], top['type'])}> m={top['m']} k={top['k']} n={top['n']}",
+            "timing": "eager launches, each dispatch's own start/stop events (hipExtLaunchKernelGGL) on the backend stream = the interval "
+                      "rocprofv3 --kernel-trace reports for that kernel name",
+            "bytes_per_launch": top["bytes_per_launch"], "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": top["launches"],
+            "all": [{"type": TYPE_NAMES.get(e["type"], e["type"]), "m": e["m"], "k": e["k"], "n": e["n"], "launches": e["launches"],
+                     "kernel": e.get("kernel", ""), "avg_us": round(e["total_ms"] / e["launches"] * 1e3, 2),
+                     "GBps": round(e["bytes_per_launch"] / (e["total_ms"] / e["launches"] * 1e-3) / 1e9, 1)} for e in prof]}
+    return roof, top
+
 def main():
     # the one JSON line is the ONLY thing on stdout: libraries that write to file descriptor 1 (gloo's "[Gloo] Rank 0 is connected ..." during
     # the rendezvous, the HIP runtime) are sent to stderr, and the result is written to the saved descriptor at the end
@@ -267,19 +286,7 @@ def main():
             if not prof and pmode == 2:
                 be.set_option("profile", 1); m.kv_clear(); run_tokens(min(K, 32)); prof = be.profile()
             be.set_option("profile", 0)
-            prof.sort(key=lambda e: -e["total_ms"])
-            top = prof[0]
-            avg_s = top["total_ms"] / top["launches"] * 1e-3
-            ach = top["bytes_per_launch"] / avg_s / 1e9
-            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBPS, 4),
-                    "traffic": None, "traffic_source": None,
-                    "kernel": top.get("kernel") or f"k_mmvq<{TYPE_NAMES.get(top['type'], top['type'])}> m={top['m']} k={top['k']} n={top['n']}",
-                    "timing": "eager launches, each dispatch's own start/stop events (hipExtLaunchKernelGGL) on the backend stream = the interval "
-                              "rocprofv3 --kernel-trace reports for that kernel name",
-                    "bytes_per_launch": top["bytes_per_launch"], "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": top["launches"],
-                    "all": [{"type": TYPE_NAMES.get(e["type"], e["type"]), "m": e["m"], "k": e["k"], "n": e["n"], "launches": e["launches"],
-                             "kernel": e.get("kernel", ""), "avg_us": round(e["total_ms"] / e["launches"] * 1e3, 2),
-                             "GBps": round(e["bytes_per_launch"] / (e["total_ms"] / e["launches"] * 1e-3) / 1e9, 1)} for e in prof]}
+            roof, top = roofline_from_profile(prof)
             # HBM bytes per launch of that kernel from the PMC pass (a separate rocprofv3 --pmc FETCH_SIZE run, doubled as the guide's
             # gfx950 correction prescribes; tools/pmc_traffic.py) — it cannot be collected inside this run, so the committed summary
             # of the same workload is quoted (the newest round's), and only when its kernel is the dominant launch found live
@@ -424,7 +431,22 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         result["extra"]["single_sequence_chain_tok_s"] = round(kc / float(tmax.item()), 2)
         result["extra"]["single_sequence_chain_note"] = "llama-bench's -sm layer protocol: one sequence, per-token synchronisation through all stages; does not scale with the GPU count by construction"
+        # the dominant kernel's roofline, from rank 0's own stage (the same kernel on every rank: each streams its layers' weights from its own HBM)
         result["roofline"] = None
+        if rank == 0 and not args.no_profile:
+            try:
+                be.set_option("profile", 1); m.kv_clear(); pos[0] = 0
+                for j in range(min(kc, 16)):
+                    stage(0, j, False)
+                flush()
+                prof = be.profile(); be.set_option("profile", 0)
+                if prof:
+                    roof, _ = roofline_from_profile(prof)
+                    roof["note"] = "rank 0's stage only, timed after the throughput measurement"
+                    result["roofline"] = roof
+            except Exception as e:   # noqa: BLE001 — reporting only
+                log(f"[rank 0] roofline leg failed: {e}")
+        dist.barrier()
         if dump is not None and has_out:
             np.savez(os.environ["BENCH_DUMP_LOGITS"], seq=np.array([r[0] for r in dump["rows"]]), pos=np.array([r[1] for r in dump["rows"]]),
                      logits=np.stack([r[2] for r in dump["rows"]]), tokens=tokens, n_seq=n_seq)
