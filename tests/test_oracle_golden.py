@@ -135,3 +135,32 @@ def test_streams_oracle_equals_single_stream_oracle():
             a = st.decode(emb)
             b = np.stack([singles[i].decode(emb[i:i + 1]) for i in range(S)])
             assert np.array_equal(a, b), mode
+
+
+def test_flash_attention_cache_oracle_is_consistent():
+    """oracle/ref_llama.py, the -fa 1 branch with typed caches (used by the GPU tests of FLASH_ATTN_EXT with -ctk / -ctv): with F16 caches it is the plain f16-cache
+    oracle bit for bit; a Q8_0 / Q4_0 / BF16 cache changes the logits by no more than its row quantization can (and does change them)."""
+    import ref_llama
+    rng = np.random.default_rng(11)
+    cfg = dict(n_embd=256, n_ff=512, n_layer=2, n_head=4, n_head_kv=2, n_embd_head=64, n_vocab=64, rope_freq_base=10000.0, n_ctx_orig=256)
+    ne, nff, hd, nh, nkv, nv = cfg["n_embd"], cfg["n_ff"], cfg["n_embd_head"], cfg["n_head"], cfg["n_head_kv"], cfg["n_vocab"]
+    rb = lambda qt, m, k: orc.random_blocks(rng, qt, (m,), k, scale=1.0/np.sqrt(k))
+    W = {}
+    for il in range(cfg["n_layer"]):
+        W[(il, "attn_norm")] = (0, rng.uniform(0.5, 1.5, ne).astype(np.float32)); W[(il, "ffn_norm")] = (0, rng.uniform(0.5, 1.5, ne).astype(np.float32))
+        W[(il, "attn_q")] = (orc.Q4_K, rb(orc.Q4_K, nh*hd, ne)); W[(il, "attn_k")] = (orc.Q4_K, rb(orc.Q4_K, nkv*hd, ne)); W[(il, "attn_v")] = (orc.Q6_K, rb(orc.Q6_K, nkv*hd, ne))
+        W[(il, "attn_output")] = (orc.Q4_K, rb(orc.Q4_K, ne, nh*hd)); W[(il, "ffn_gate")] = (orc.Q4_K, rb(orc.Q4_K, nff, ne))
+        W[(il, "ffn_up")] = (orc.Q4_K, rb(orc.Q4_K, nff, ne)); W[(il, "ffn_down")] = (orc.Q6_K, rb(orc.Q6_K, ne, nff))
+    W["output_norm"] = (0, np.ones(ne, np.float32)); W["output"] = (orc.Q6_K, rb(orc.Q6_K, nv, ne))
+    embs = [rng.standard_normal((n, ne)).astype(np.float32) for n in (5, 1, 1, 3, 1)]
+    def run(**kw):
+        m = ref_llama.RefLlama(dict(cfg, **kw), W, 32, "cpu16")
+        return [m.decode(e) for e in embs]
+    base = run()
+    fa16 = run(flash_attn=1, type_k=0, type_v=0)
+    for a, b in zip(base, fa16):
+        assert np.array_equal(a, b)
+    for tk, tv, lim in ((orc.Q8_0, orc.Q8_0, 2e-4), (orc.Q4_0, orc.Q4_0, 2e-2), (orc.BF16, orc.BF16, 2e-4), (orc.Q8_0, 0, 2e-4)):
+        got = run(flash_attn=1, type_k=tk, type_v=tv)
+        errs = [orc.nmse(a, b) for a, b in zip(base, got)]
+        assert 0.0 < max(errs) <= lim, (tk, tv, errs)
