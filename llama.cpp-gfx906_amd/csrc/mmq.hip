@@ -187,6 +187,7 @@ struct mmq_args {
     int moe_max_tiles, n_used, n_b;            // pair = token*n_used + slot; X row of a pair = token*n_b + slot % n_b
     fused_rope rope;                           // for segments with .rope (wq, wk): RESHAPE -> ROPE of build_attn folded into the epilogue / the combine pass
     int nseg; mmq_seg seg[3];                  // nseg > 0: W / m / dst / strides per segment; p.m = the summed rows (the width of a split-k plane)
+    int dbg;                                   // -DMI_MMQ_DBG builds only (a runtime branch in this loop costs 10 % of pp512): GGML_MI355X_MMQ_DBG ablations for timing, wrong results: 1 = no weight decode, 2 = no MFMAs, 4 = no global loads inside the loop, 8 = no LDS commits
 };
 
 // TYPE = a block format (bf16 MFMA on dequantized weights) or T_F16 (f16 MFMA, weights copied as they are: the attention
@@ -267,6 +268,9 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
         constexpr bool WR = decltype(w_role_tag)::value;
         constexpr int TY = decltype(type_tag)::value;      // the block format this workgroup's segment is decoded as
         auto fetch = [&](stage_regs & r, int step) {
+#ifdef MI_MMQ_DBG
+            if ((p.dbg & 4) && step > step0 + 1) return;
+#endif
             const int kc = step*MQ_BK + 32*shalf, kcl = min(kc, k - 32);
             if (WR) {
                 if (TY == T_F16) {
@@ -281,14 +285,21 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
         };
         // one eighth of a thread's staging work for step `step`: 16 bytes of activations into LDS, 8 weights decoded, packed and stored
         auto commit_piece = [&](const stage_regs & r, const dq_head & h, int step, int buf, int g) {
+#ifdef MI_MMQ_DBG
+            if (p.dbg & 8) return;
+#endif
             const int kcl = min(step*MQ_BK + 32*shalf, k - 32);
             char * wp = lds + buf*STAGE + wt*WTILE + (srow & (MQ_BM - 1))*MQ_LD + shalf*64;
             char * xp = lds + buf*STAGE + WT*WTILE + srow*MQ_LD + shalf*64;
             *(int4v *) (xp + 16*g) = r.xv[g];
             if (WR) {
                 int4v wpk;
+#ifdef MI_MMQ_DBG
+                if (TY == T_F16 || (p.dbg & 1)) {
+#else
                 if (TY == T_F16) {
-                    wpk = r.rw.v[g];
+#endif
+                    wpk = r.rw.v[g & 3];
                 } else {
                     float lo[4], hi[4];
                     decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g, 2*g, lo);
@@ -315,6 +326,9 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
             }
         };
         auto mfma_row = [&](const frags & f, int i) {       // the MFMAs of token sub-tile i: 2 (4 with the second weight tile)
+#ifdef MI_MMQ_DBG
+            if (p.dbg & 2) return;
+#endif
 #pragma unroll
             for (int j = 0; j < 2; j++) {
                 if (TY == T_F16) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, f.a[i]), __builtin_bit_cast(f16x8, f.b[j]), acc[i][j], 0, 0, 0);
@@ -795,6 +809,7 @@ void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_st
     }
     mmq_args a = { (const char *) Wg, w_row_stride, 0, 0, (int) m, (int) k, xb, (int) n, (char *) dst, dst_col_stride_bytes, 0, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, y16, (const char *) Wu, nullptr, 0, 0, 0 };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
+    { static const int dbg = getenv("GGML_MI355X_MMQ_DBG") ? atoi(getenv("GGML_MI355X_MMQ_DBG")) : 0; a.dbg = dbg; }
     const dim3 grid((unsigned)((n + 255)/256), (unsigned) a.mtiles, 1);
     switch (type_a) {
         case T_Q4_0:  launch_mmq_dual<T_Q4_0>(grid, a, stream);  break;
