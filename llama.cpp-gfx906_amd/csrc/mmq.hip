@@ -599,6 +599,7 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
     }
 }
 
+
 constexpr size_t MQ_LDS_BYTES = 4*(size_t) MQ_BM*MQ_LD;
 constexpr size_t MQ_LDS_BYTES_256 = 2*(size_t)(MQ_BM + 256)*MQ_LD;
 constexpr size_t MQ_LDS_BYTES_DUAL = 2*(size_t)(2*MQ_BM + 256)*MQ_LD;
