@@ -62,7 +62,7 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
     char * const ldsk_base = lds_all, * const ldsv_base = lds_all + 2*KS*KBLK;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, ql = lane & 31, hf = lane >> 5;
     const int h = blockIdx.y*hpw + wave % hpw, hk = h/(p.n_head/p.n_head_kv);
-    const int ks = KS == 2 ? (wave/hpw) & 1 : 0;                        // which of the iteration's blocks this wave multiplies
+    const int ks = KS > 1 ? (wave/hpw) & (KS - 1) : 0;                  // which of the iteration's blocks this wave multiplies
     const int q0 = (blockIdx.x*(APF_NW/(hpw*KS)) + wave/(hpw*KS))*32;
     const bool active = q0 < p.T;                        // wave-uniform; an idle wave still stages and meets the barriers
     const int t = min(q0 + ql, p.T - 1);
@@ -210,26 +210,37 @@ __global__ void __launch_bounds__(64*APF_NW) k_attn_prefill(const attn_pf_args p
         take_mask();
         __syncthreads();
     }
-    if (KS == 2) {       // the odd wave of a pair hands its state over (the staging buffers are free: the loop's last barrier is behind us)
+    if (KS > 1) {        // the waves of a (head, query tile) merge their states pairwise (KS = 4: 1 -> 0 and 3 -> 2, then 2 -> 0); the staging buffers are free: the loop's last barrier is behind us
         constexpr int PS = 16*NDT + 2;
-        float * part = (float *) lds_all + (size_t)(wave/(2*hpw)*hpw + wave % hpw)*PS*64 + lane;
-        if (ks == 1) {
+        bool gone = false;
 #pragma unroll
-            for (int d = 0; d < NDT; d++)
+        for (int step = 1; step < KS; step <<= 1) {
+            const bool give = !gone && (ks & (2*step - 1)) == step, take = !gone && (ks & (2*step - 1)) == 0;
+            // the slot of the RECEIVING wave: (query tile of the workgroup, head, receiver's ks)
+            const int rk = give ? ks - step : ks;
+            float * part = (float *) lds_all + (size_t)((wave/(KS*hpw)*hpw + wave % hpw)*(KS/2) + rk/2)*PS*64 + lane;      // (receivers have even ks: KS/2 slots per (tile, head))
+            if (give) {
 #pragma unroll
-                for (int r = 0; r < 16; r++) part[(16*d + r)*64] = o[d][r];
-            part[(16*NDT)*64] = m; part[(16*NDT + 1)*64] = l;
+                for (int d = 0; d < NDT; d++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) part[(16*d + r)*64] = o[d][r];
+                part[(16*NDT)*64] = m; part[(16*NDT + 1)*64] = l;
+                gone = true;
+            }
+            __syncthreads();
+            if (take) {
+                const float mw = part[(16*NDT)*64], lw = part[(16*NDT + 1)*64];
+                const float m_new = fmaxf(m, mw);
+                const float a = m == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m - m_new), b = mw == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mw - m_new);
+                l = l*a + lw*b; m = m_new;
+#pragma unroll
+                for (int d = 0; d < NDT; d++)
+#pragma unroll
+                    for (int r = 0; r < 16; r++) o[d][r] = o[d][r]*a + part[(16*d + r)*64]*b;
+            }
+            if (step*2 < KS) __syncthreads();      // (the slots are written again in the next round)
         }
-        __syncthreads();
-        if (ks == 1) return;
-        const float mw = part[(16*NDT)*64], lw = part[(16*NDT + 1)*64];
-        const float m_new = fmaxf(m, mw);
-        const float a = m == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(m - m_new), b = mw == -INFINITY ? 0.0f : __builtin_amdgcn_exp2f(mw - m_new);
-        l = l*a + lw*b; m = m_new;
-#pragma unroll
-        for (int d = 0; d < NDT; d++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) o[d][r] = o[d][r]*a + part[(16*d + r)*64]*b;
+        if (gone) return;
     }
     if (!active) return;
     // ---- finish: both halves' denominators, the sink logit (src/llama-graph.cpp:1313), normalise, store ----
@@ -270,10 +281,16 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
         if (ex->softcap != 0.0f) a.scale = scale/ex->softcap;
     }
     const int64_t R = n_head/n_head_kv;
-    const int hpw = R % 8 == 0 ? 8 : R % 4 == 0 ? 4 : R % 2 == 0 ? 2 : 1;          // heads of one kv head per workgroup
-    // few workgroups (short prompts): pairs of waves split the cell blocks of an iteration, halving the loop that is the critical path
+    int hpw = R % 8 == 0 ? 8 : R % 4 == 0 ? 4 : R % 2 == 0 ? 2 : 1;          // heads of one kv head per workgroup
+    // few workgroups (short prompts): the waves of a (head, query tile) split the cell blocks of an iteration two or four ways, shortening the loop that is the critical path
     const int64_t wgs1 = ((T + 32*(APF_NW/hpw) - 1)/(32*(APF_NW/hpw)))*(n_head/hpw);
-    const int ksp = (hpw <= 4 && wgs1 < 160 && n_kv >= 128) ? 2 : 1;
+    int ksp = (hpw <= 4 && wgs1 < 160 && n_kv >= 128) ? 2 : 1;
+    static const bool ks4_on = !getenv("GGML_MI355X_ATTN_PF_KS4") || atoi(getenv("GGML_MI355X_ATTN_PF_KS4")) != 0;
+    if (ks4_on && ksp == 2 && R % 2 == 0 && n_kv >= 256 && head_dim == 128 && v_trans) {
+        // ... four ways with two heads per workgroup when even the pairs leave half the chip idle (pp512 of a 32-head model: 128 workgroups -> 256)
+        const int64_t wgs2 = ((T + 32*(APF_NW/(hpw*2)) - 1)/(32*(APF_NW/(hpw*2))))*(n_head/hpw);
+        if (wgs2 < 200) { hpw = 2; ksp = 4; }
+    }
     const int qpw = APF_NW/(hpw*ksp);                                                // query tiles per workgroup
     const dim3 grid((unsigned)((T + 32*qpw - 1)/(32*qpw)), (unsigned)(n_head/hpw));
     const int mk = !mask ? 0 : (mask_f16 ? 2 : 1);
@@ -281,7 +298,7 @@ void attn_prefill(const void * q, size_t q_nb1, size_t q_nb2, const void * k, si
         constexpr size_t lds_ = (size_t) 2*KS_*(32*(HD_*2 + APF_KLD) + HD_*(64 + 8)); \
         MI_LDS_LIMIT_OR_DIE(lds_, k_attn_prefill<HD_, VT_, MK_, KS_>); \
         hipLaunchKernelGGL((k_attn_prefill<HD_, VT_, MK_, KS_>), grid, dim3(64*APF_NW), lds_, stream, a, hpw); } while (0)
-#define MI_APF1(HD_, VT_, MK_) do { if (ksp == 2) MI_APF2(HD_, VT_, MK_, 2); else MI_APF2(HD_, VT_, MK_, 1); } while (0)
+#define MI_APF1(HD_, VT_, MK_) do { if (ksp == 4) { if constexpr (HD_ == 128 && VT_) MI_APF2(HD_, VT_, MK_, 4); } else if (ksp == 2) MI_APF2(HD_, VT_, MK_, 2); else MI_APF2(HD_, VT_, MK_, 1); } while (0)
 #define MI_APF(HD_, VT_) do { if (mk == 0) MI_APF1(HD_, VT_, 0); else if (mk == 1) MI_APF1(HD_, VT_, 1); else MI_APF1(HD_, VT_, 2); } while (0)
     if (!v_trans) { if (head_dim == 128) MI_APF(128, false); else MI_APF(64, false); }
     else          { if (head_dim == 128) MI_APF(128, true);  else MI_APF(64, true); }
