@@ -113,6 +113,25 @@ template <> __device__ __forceinline__ void decode4<T_MXFP4>(const raw32 & r, co
         o[b] = __builtin_bit_cast(float, __builtin_bit_cast(uint32_t, v) ^ ((q & 8) << 28));      // -v for the upper half of the table
     }
 }
+// MXFP4 on gfx950's FP4 conversion (round 3): the 8 consecutive weights [8 g, 8 g + 8) of a 32-block as bf16, ready for the LDS tile. An MXFP4 element IS an E2M1 float
+// times 2^(e - 127) (the reference's integer table is 2 x E2M1, its scale 2^(e - 127) / 2): v_cvt_scalef32_pk_bf16_fp4 turns a byte's two nibbles into two bf16 with the scale
+// applied — exact, as the float path is — and one v_perm_b32 per pair puts neighbours side by side (a byte holds elements i and i + 16): 12 instructions per 8 weights
+// where the table lookup + int -> float -> multiply -> sign -> pack took ~60.
+typedef __bf16 mq_bf2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ int4v decode8_bf16_mxfp4(const raw32 & r, const dq_head & h, int g) {
+    const float scale = 2.0f*h.a;
+    const uint32_t sel = (g & 2) ? 0x07060302u : 0x05040100u;      // the high-nibble elements (16..31) or the low-nibble ones of two converted bytes
+    uint32_t out[4];
+#pragma unroll
+    for (int d = 0; d < 2; d++) {
+        const uint32_t w = raw_word(r, (2*g + d) & 3);
+        const uint32_t c0 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 0)), c1 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 1));
+        const uint32_t c2 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 2)), c3 = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_bf16_fp4(w, scale, 3));
+        out[2*d]     = __builtin_amdgcn_perm(c1, c0, sel);
+        out[2*d + 1] = __builtin_amdgcn_perm(c3, c2, sel);
+    }
+    return int4v{ (int) out[0], (int) out[1], (int) out[2], (int) out[3] };
+}
 // Q4_K — quants.py:504-522
 template <> __device__ __forceinline__ raw32 load_raw32<T_Q4_K>(const char * row, int c32) {
     raw32 r; const int sb = c32 & 7; const char * b = row + (size_t)(c32 >> 3)*144;
@@ -300,6 +319,8 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
                 if (TY == T_F16) {
 #endif
                     wpk = r.rw.v[g & 3];
+                } else if (TY == T_MXFP4) {
+                    wpk = decode8_bf16_mxfp4(r.rw, h, g);
                 } else {
                     float lo[4], hi[4];
                     decode4<TY == T_F16 ? T_Q8_0 : TY>(r.rw, h, kcl >> 5, 2*g, 2*g, lo);
