@@ -253,16 +253,21 @@ def main():
     if world == 1:
         def run_tokens(n):
             for i in range(n):
-                m.decode(tokens[i:i + 1], want_host=True, sync=True)     # llama_decode + llama_synchronize per token
+                m.decode(tokens[i:i + 1], want_host=True, sync=True, view=True)     # llama_decode + llama_synchronize per token; the logits land in the pinned output buffer (llama_get_logits' view)
         # warm-up: builds the graphs for every n_kv bucket and lets the backend capture them
         done = 0
         while done < W:
             m.kv_clear(); n = min(W - done, n_ctx); run_tokens(n); done += n
         m.kv_clear()
         be.reset_counters()
+        # (the interpreter's cyclic garbage collector once took 52 ms out of ONE token of a 128-token run — a full collection over torch's objects: it is a property of
+        # this Python harness, not of the path measured, and stays out of the timed region; tools/tg_reps_probe.py)
+        import gc
+        gc.collect(); gc.disable()
         sync_all(); t0 = time.perf_counter()
         run_tokens(K)
         sync_all(); dt = time.perf_counter() - t0
+        gc.enable()
         cnt = be.counters()
         tok_s = K / dt
         result.update(value=tok_s, ms_per_step=dt / K * 1e3)

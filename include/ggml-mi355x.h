@@ -80,6 +80,11 @@ struct ggml_backend_mi355x_counters {
 // equal shares). NULL when a device that would hold rows has no peer mapping to the main device.
 GGML_BACKEND_API ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device, const float * tensor_split);
 GGML_BACKEND_API void * ggml_backend_mi355x_get_stream(ggml_backend_t backend);
+// Layer-split hand-off through buffers that are not ggml tensors (one process per GPU: the RCCL send / recv buffers of bench.py --gpus N; inside ONE
+// process the reference's scheduler uses backend_i.cpy_tensor_async, src/llama-context.cpp:255-285): device-to-device copies between a tensor and a raw
+// device pointer, ordered on the backend's stream. (set_tensor_async / get_tensor_async take HOST memory, as in ggml-backend.h.) Also procs by name.
+GGML_BACKEND_API void   ggml_backend_mi355x_tensor_set_from_device_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * dev_src, size_t offset, size_t size);
+GGML_BACKEND_API void   ggml_backend_mi355x_tensor_get_to_device_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * dev_dst, size_t offset, size_t size);
 GGML_BACKEND_API void   ggml_backend_mi355x_get_counters(ggml_backend_t backend, struct ggml_backend_mi355x_counters * out);
 GGML_BACKEND_API void   ggml_backend_mi355x_reset_counters(ggml_backend_t backend);
 // options: "graphs" (0/1 hipGraph capture+replay), "fusion" (0/1 node fusion),

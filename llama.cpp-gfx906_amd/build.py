@@ -27,7 +27,7 @@ COMMON = ["-O3", "-fPIC", "-std=c++17", "-Wall", "-Wextra", "-Wno-unused-paramet
           "-Wno-missing-field-initializers", "-Wno-array-bounds"]
 HIPFLAGS = [f"--offload-arch={ARCH}", "-fno-gpu-rdc", "-ffp-contract=off", "-fhip-fp32-correctly-rounded-divide-sqrt"] + os.environ.get("MI_EXTRA_HIPFLAGS", "").split()
 
-KERNEL_SRCS = ["quantize_act.hip", "mmvq.hip", "mmvq_cols_mfma.hip", "mmq_i8.hip", "mmq.hip", "mm_dense.hip", "elem.hip", "decode_fused.hip", "attn_prefill.hip", "mmvq_fused.hip", "mmvq_stream.hip", "mmvq_stream_cols.hip", "attn_wo.hip",
+KERNEL_SRCS = ["quantize_act.hip", "mmvq.hip", "mmvq_cols_mfma.hip", "mmq.hip", "mm_dense.hip", "elem.hip", "decode_fused.hip", "attn_prefill.hip", "mmvq_fused.hip", "mmvq_stream.hip", "mmvq_stream_cols.hip", 
                # the persistent grouped mat-vec, one translation unit per weight format (they compile in parallel)
                "mmvq_fused_q4_K.hip", "mmvq_fused_q5_K.hip", "mmvq_fused_q6_K.hip", "mmvq_fused_q8_0.hip", "mmvq_fused_q4_0.hip", "mmvq_fused_mxfp4.hip",
                "mmvq_fused_q4_K_q5_K.hip", "mmvq_fused_q4_K_q6_K.hip", "mmvq_fused_q5_K_q6_K.hip", "mmvq_fused_q8_0_q4_K.hip"]

@@ -360,17 +360,18 @@ static const struct ggml_backend_buffer_type_i mi_host_buft_iface = {
 // split graphs carry no leaf list, so their placement is pinned through the nodes that read them).
 struct node_sig {
     const void * node; const void * data;
+    const void * src[GGML_MAX_SRC];                                            // the source TENSORS: the graph's topology (checked for the whole graph before any segment is launched)
     int32_t op, type;
     int64_t ne[4]; size_t nb[3];
     const void * src_data[GGML_MAX_SRC]; uint32_t src_hash[GGML_MAX_SRC];      // every source: placement + a hash of its type, shape and strides
     uint32_t params_hash; uint32_t flags;
 };
 
-static_assert(sizeof(node_sig) == 16 + 8 + 32 + 24 + 8*GGML_MAX_SRC + 4*GGML_MAX_SRC + 8, "node_sig has no padding bytes: signatures are compared with memcmp");
+static_assert(sizeof(node_sig) == 16 + 8*GGML_MAX_SRC + 8 + 32 + 24 + 8*GGML_MAX_SRC + 4*GGML_MAX_SRC + 8, "node_sig has no padding bytes: signatures are compared with memcmp");
+struct graph_seg { int begin, end; hipGraphExec_t exec; };      // nodes [begin, end) as one executable graph (exec == NULL: view ops only, nothing to launch)
 struct graph_entry {
     std::vector<node_sig> sig; uint64_t digest = 0;      // digest: a cheap hash of the signature — only the entry that shares it is compared in full
-    std::vector<void *> owned_dev;      // device buffers a captured graph refers to (persistent-decode program tables and their signal words)
-    hipGraphExec_t exec = nullptr;
+    std::vector<graph_seg> segs;                          // empty: not captured (yet)
     uint64_t last_use = 0;
     int seen = 0;              // identical submissions observed (capture on the 2nd)
 };
@@ -392,12 +393,11 @@ struct mi_backend_ctx {
     float * rope_tab = nullptr; mmvq_rope rope_tab_key = {}; bool rope_tab_valid = false;
     static constexpr size_t FIN_IMG_BYTES = 64*1024; static constexpr int FIN_COUNTERS = 256;
     void * kv16 = nullptr; size_t kv16_size = 0;                // FLASH_ATTN_EXT: dense f16 copies of a quantized / bf16 cache view, and the transposed V of the prefill kernel (kv_to_f16)
-    // attention + wo as one launch (attn_wo.hip): its partial planes, and what is pending — the vector x_out = res + sum of the planes does not exist until the
-    // launch that reads it (norm + gate/up, streamed kernel) has added them up, or pp_flush has
-    float * wo_planes = nullptr; static constexpr int WO_PLANE_STRIDE = 16384, WO_PLANES_MAX = 16;
+    // a MoE combine left pending (try_fused_moe_combine): the vector x_out = res + sum_u w_u * plane u does not exist until the launch that reads it (the next
+    // norm + mat-vec launch, streamed kernel) has evaluated it in its prologue, or pp_flush has
     struct { bool active = false; const float * res = nullptr; float * x_out = nullptr; int n_planes = 0; int64_t m = 0;
              const float * planes = nullptr; int stride = 0;                                     // where the planes are (floats between them)
-             const float * probs = nullptr; const int32_t * ids = nullptr; int mode = 0; } pp;      // probs != NULL: the MoE combine left pending (weighted planes = the used experts' outputs)
+             const float * probs = nullptr; size_t probs_bytes = 0; const int32_t * ids = nullptr; int mode = 0; } pp;      // planes = the used experts' outputs, weights from probs[ids[u]]
     float * attn_part = nullptr; size_t attn_part_bytes = 0;   // partial results of the decode attention's cell ranges at long contexts (attn_decode)
 
     // activation-quantisation reuse inside one graph_compute
@@ -415,27 +415,15 @@ struct mi_backend_ctx {
 
     struct ggml_backend_mi355x_counters cnt = {};
 
-    // ---- chained decode (k_mmvq_chain, mmvq_stream.h): the grouped single-token mat-vec launches of a graph are recorded instead of launched;
-    // at the next op that is not one of them (or at the end of the graph) a recorded run of two or more becomes ONE persistent launch whose
-    // phases hand their vectors over inside the kernel (the loader wave streams the next phase's weights meanwhile); a run of one goes out as it is ----
-    struct rec_item {
-        int kind;                                   // 0: grouped mat-vec, 1: attention (never held back: launched when it comes up)
-        mmvq_group grp[MMVQ_MAX_GROUPS]; int nc; int64_t K; mmvq_input in; bool has_rope; mmvq_rope rope;
-        struct { const void * q; size_t q_nb1, q_nb2; const void * k; size_t k_nb1, k_nb2; const void * v; size_t v_nb1, v_nb2; const void * mask; size_t m_nb1;
-                 bool mask_f16; const float * sinks; float * dst; size_t dst_nb1; int64_t hd, n_kv, n_head, n_head_kv, T; float scale; bool v_trans; } at;
-    };
-    std::vector<rec_item> rec;
-    // opt-in (GGML_MI355X_CHAIN=1 / option "chain"): correct, and at the end of round 3 slower than one launch per group (505 vs 628 tok/s): a phase's
-    // hand-off + activation load + prologue (~7 us) is longer than the stream the LDS ring can hold ahead (117 KB = 4.7 us) — DESIGN.md section 4
-    bool use_chain = false, rec_on = false, capturing = false;
-    unsigned * chain_err = nullptr;                  // host-mapped words: a bounded wait inside a kernel gave up ([0] the chained decode kernel, [1] the MoE router)
+    bool capturing = false;
+    graph_entry * cap_entry = nullptr;               // the cache entry a capture in progress fills (dropped if the capture fails)
+    // small uploads (set_tensor_async of <= UP_SMALL_MAX bytes: a decode step's inputs) are staged in a pinned, device-mapped ring and go out as ONE
+    // launch in front of whatever the stream is asked to do next (uploads_flush), instead of one copy each
+    struct { char * host = nullptr; char * dev = nullptr; int cur = 0; size_t off = 0; hipEvent_t ev[2] = { nullptr, nullptr }; bool ev_pending[2] = { false, false };
+             int n = 0; upload_batch b = {}; bool failed = false; } up;
+    static constexpr size_t UP_HALF = 1u << 20, UP_SMALL_MAX = 64u << 10;
+    unsigned * err_host = nullptr;                   // host-mapped words: a bounded wait inside a kernel gave up ([1] the MoE router)
     unsigned * err_dev = nullptr;                    // ... their device address
-    void * chain_prog_dev = nullptr; void * chain_prog_host = nullptr; unsigned * chain_ws = nullptr;    // eager runs (captured graphs own theirs)
-    size_t chain_prog_used = 0, chain_ws_used = 0;   // eager: carved per graph pass (reset in run_nodes)
-    struct pending_upload { void * dev; std::vector<char> host; };
-    std::vector<pending_upload> chain_uploads;       // phase tables built during a capture: copied once the capture has ended
-    graph_entry * cap_entry = nullptr; size_t cap_prog_used = 0, cap_ws_used = 0;
-    static constexpr int CHAIN_MAX_PHASES = 192;     // per graph (a 32-layer token: 129 grouped launches)
 
     // "profile" option: every quantized mat-mul launch is bracketed by a hipEvent pair on this stream (eager mode)
     struct prof_rec { int type; int64_t m, k, n; uint64_t bytes; hipEvent_t e0, e1; const char * kernel = nullptr; };
@@ -497,16 +485,13 @@ static void be_free(ggml_backend_t backend) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     if (c->stream) (void) hipStreamSynchronize(c->stream);
-    for (auto & e : c->graphs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); for (void * p : e.owned_dev) (void) hipFree(p); }
+    for (auto & e : c->graphs) for (auto & sg : e.segs) if (sg.exec) (void) hipGraphExecDestroy(sg.exec);
     if (c->scratch) (void) hipFree(c->scratch);
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
-    if (c->wo_planes) (void) hipFree(c->wo_planes);
     if (c->kv16) (void) hipFree(c->kv16);
-    if (c->chain_prog_dev) (void) hipFree(c->chain_prog_dev);
-    if (c->chain_prog_host) (void) hipHostFree(c->chain_prog_host);
-    if (c->chain_ws) (void) hipFree(c->chain_ws);
-    if (c->chain_err) (void) hipHostFree(c->chain_err);
+    if (c->err_host) (void) hipHostFree(c->err_host);
+    if (c->up.host) { (void) hipHostFree(c->up.host); (void) hipEventDestroy(c->up.ev[0]); (void) hipEventDestroy(c->up.ev[1]); }
     if (c->fin_img) (void) hipFree(c->fin_img);
     if (c->fin_cnt) (void) hipFree(c->fin_cnt);
     if (c->rope_tab) (void) hipFree(c->rope_tab);
@@ -526,15 +511,54 @@ static void be_free(ggml_backend_t backend) {
     delete backend;
 }
 
+// ---- small uploads, batched -------------------------------------------------------------------------------------
+static void uploads_flush(mi_backend_ctx * c) {
+    if (c->up.n == 0) return;
+    upload_batch_launch(c->up.b, c->stream);
+    c->cnt.kernels_launched++;
+    c->up.n = 0;
+}
+static bool uploads_stage(mi_backend_ctx * c, void * dst, const void * data, size_t size) {
+    auto & u = c->up;
+    if (u.failed) return false;
+    if (!u.host) {
+        if (hipHostMalloc((void **) &u.host, 2*mi_backend_ctx::UP_HALF, hipHostMallocMapped) != hipSuccess || hipHostGetDevicePointer((void **) &u.dev, u.host, 0) != hipSuccess ||
+            hipEventCreateWithFlags(&u.ev[0], hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&u.ev[1], hipEventDisableTiming) != hipSuccess) {
+            (void) hipGetLastError(); u.failed = true; return false;
+        }
+    }
+    const size_t need = (size + 255) & ~(size_t) 255;
+    if (u.off + need > mi_backend_ctx::UP_HALF) {
+        // this half is full: everything that reads it is on the stream once the pending batch is; the other half may be reused when ITS event has passed
+        uploads_flush(c);
+        MI_CHECK(hipEventRecord(u.ev[u.cur], c->stream)); u.ev_pending[u.cur] = true;
+        u.cur ^= 1; u.off = 0;
+        if (u.ev_pending[u.cur]) { MI_CHECK(hipEventSynchronize(u.ev[u.cur])); u.ev_pending[u.cur] = false; }
+    }
+    if (u.n == UPLOAD_BATCH_MAX) uploads_flush(c);
+    const size_t o = (size_t) u.cur*mi_backend_ctx::UP_HALF + u.off;
+    memcpy(u.host + o, data, size);
+    u.b.src[u.n] = u.dev + o; u.b.dst[u.n] = dst; u.b.bytes[u.n] = (uint32_t) size; u.b.blocks[u.n] = (int)((size + 4095)/4096);
+    u.n++; u.b.n = u.n;
+    u.off += need;
+    return true;
+}
+
+// `data` is HOST memory (pageable or pinned), as the interface says; device-to-device copies have entry points of their own below
 static void be_set_tensor_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * data, size_t offset, size_t size) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
-    MI_CHECK(hipMemcpyAsync((char *) tensor->data + offset, data, size, hipMemcpyDefault, c->stream));   // `data` may be pinned host or device memory
+    if (size == 0) return;
+    static const bool batch = !getenv("GGML_MI355X_UPLOAD_BATCH") || atoi(getenv("GGML_MI355X_UPLOAD_BATCH")) != 0;
+    if (batch && size <= mi_backend_ctx::UP_SMALL_MAX && uploads_stage(c, (char *) tensor->data + offset, data, size)) return;
+    uploads_flush(c);       // stream order: what was set before this goes first
+    MI_CHECK(hipMemcpyAsync((char *) tensor->data + offset, data, size, hipMemcpyHostToDevice, c->stream));
 }
 static void be_get_tensor_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * data, size_t offset, size_t size) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
-    MI_CHECK(hipMemcpyAsync(data, (const char *) tensor->data + offset, size, hipMemcpyDefault, c->stream));
+    uploads_flush(c);
+    MI_CHECK(hipMemcpyAsync(data, (const char *) tensor->data + offset, size, hipMemcpyDeviceToHost, c->stream));
 }
 
 // layer-split hand-off: a point-to-point copy of [n_embd, n_tokens] F32 over one xGMI link,
@@ -549,6 +573,8 @@ static bool be_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backe
     mi_buffer_ctx * bs = (mi_buffer_ctx *) sbuf->context;
     mi_buffer_ctx * bd = (mi_buffer_ctx *) dbuf->context;
     if (cs->device != bs->device || cd->device != bd->device) return false;
+    set_device(cs->device); uploads_flush(cs);
+    if (backend_src != backend_dst) { set_device(cd->device); uploads_flush(cd); }
     if (backend_src != backend_dst) {
         set_device(cs->device);
         if (cs->device == cd->device) {
@@ -572,14 +598,10 @@ static bool be_cpy_tensor_async(ggml_backend_t backend_src, ggml_backend_t backe
 static void be_synchronize(ggml_backend_t backend) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
+    uploads_flush(c);
     MI_CHECK(hipStreamSynchronize(c->stream));
-    if (c->chain_err && c->chain_err[1] != 0) {
+    if (c->err_host && c->err_host[1] != 0) {
         GGML_ABORT("MI355X backend: the MoE router kernel timed out waiting for an expert's logit (GGML_MI355X_MOE_ROUTE_WIDE=0 selects the one-workgroup router)");
-    }
-    if (c->chain_err && c->chain_err[0] != 0) {
-        // a bounded wait inside the chained decode kernel gave up (a workgroup was not resident, e.g. the device was shared): the results of
-        // that graph are not valid. Hard internal error (GGML_ABORT), reported instead of hanging the device.
-        GGML_ABORT("MI355X backend: the chained decode kernel timed out waiting for a hand-off (GGML_MI355X_CHAIN=0 selects one launch per mat-vec group)");
     }
 }
 
@@ -743,7 +765,6 @@ static act_q8 get_act(mi_backend_ctx * c, const void * x, int64_t k, int64_t n_i
     return q;
 }
 
-static bool mmq_i8_on() { static const bool on = getenv("GGML_MI355X_MMQ_I8") && atoi(getenv("GGML_MI355X_MMQ_I8")) != 0; return on; }
 static constexpr int ACT_KIND_BF16 = -16;   // aq.kind of the dense bf16 copy the MFMA prefill kernel reads
 
 // out/res: the prefill residual fusion (try_fused_prefill_add) writes W.x + res into `out` instead of W.x into dst
@@ -774,10 +795,6 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml
                     const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
                     mul_mat_vec_q((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
                     c->cnt.mmvq_launches++;
-                } else if (!out && mmq_i8_on() && mul_mat_q_i8_supported((int) a->type, M, K, N) && act_q8_bytes(kind, K, N) <= c->scratch_size) {
-                    const act_q8 q = get_act(c, bp, K, N, 1, b->nb[1], 0, kind);
-                    mul_mat_q_i8((int) a->type, W, a->nb[1], M, K, q, N, d, dst->nb[1], c->stream);
-                    c->cnt.mmq_launches++;
                 } else {
                     // the scratch holds the bf16 copy of the activations; wq/wk/wv and gate/up read the same ones: convert once
                     const bool ready = c->aq.valid && c->aq.kind == ACT_KIND_BF16 && c->aq.data == bp && c->aq.k == K && c->aq.n_inner == N &&
@@ -889,103 +906,17 @@ static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
     c->cnt.weight_bytes += (uint64_t) n_used*n_tokens*M*ggml_row_size(as->type, K);
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// chained decode: recorder (k_mmvq_chain, mmvq_stream.h)
-// ---------------------------------------------------------------------------------------------------------------
-static void launch_rec_item(mi_backend_ctx * c, const mi_backend_ctx::rec_item & it) {
-    if (it.kind == 0) {
-        mul_mat_vec_q_fused(it.grp, it.nc, it.K, it.in, it.has_rope ? &it.rope : nullptr, c->stream, nullptr);
-    } else {
-        attn_decode(it.at.q, it.at.q_nb1, it.at.q_nb2, it.at.k, it.at.k_nb1, it.at.k_nb2, it.at.v, it.at.v_nb1, it.at.v_nb2, it.at.mask, it.at.m_nb1, it.at.mask_f16,
-                    it.at.sinks, it.at.dst, it.at.dst_nb1, it.at.hd, it.at.n_kv, it.at.n_head, it.at.n_head_kv, it.at.T, it.at.scale, c->stream, it.at.v_trans,
-                    c->attn_part, c->attn_part_bytes);
-    }
-    c->cnt.kernels_launched++;
-}
-
-// the recorded run: two or more grouped launches become one chained launch (phase j + 1 waits for phase j inside the kernel)
-static void rec_flush(mi_backend_ctx * c) {
-    if (c->rec.empty()) return;
-    const int n = (int) c->rec.size();
-    static const bool dbg = getenv("GGML_MI355X_CHAIN_DEBUG") != nullptr;
-    bool ok = n >= 2 && c->chain_err != nullptr;
-    const size_t pb = mul_mat_vec_q_chain_phase_bytes();
-    const size_t prog_bytes = (size_t) n*pb, ws_words = (size_t) mul_mat_vec_q_chain_ws_words(n);
-    const size_t pcap = mi_backend_ctx::CHAIN_MAX_PHASES*pb, wcap = (size_t) mul_mat_vec_q_chain_ws_words(mi_backend_ctx::CHAIN_MAX_PHASES)*4;
-    void * prog_dev = nullptr; unsigned * ws = nullptr;
-    if (ok) {
-        if (c->capturing) {       // a captured graph owns its tables and counters: carved from buffers allocated before the capture began
-            if (c->cap_entry->owned_dev.size() != 2 || c->cap_prog_used + prog_bytes > pcap || c->cap_ws_used + ws_words*4 > wcap) ok = false;
-            else {
-                prog_dev = (char *) c->cap_entry->owned_dev[0] + c->cap_prog_used; ws = (unsigned *) ((char *) c->cap_entry->owned_dev[1] + c->cap_ws_used);
-            }
-        } else {
-            if (!c->chain_prog_dev) {
-                if (hipMalloc(&c->chain_prog_dev, pcap) != hipSuccess || hipHostMalloc(&c->chain_prog_host, pcap, hipHostMallocDefault) != hipSuccess ||
-                    hipMalloc((void **) &c->chain_ws, wcap) != hipSuccess) { (void) hipGetLastError(); ok = false; }
-            }
-            if (ok && (c->chain_prog_used + prog_bytes > pcap || c->chain_ws_used + ws_words*4 > wcap)) ok = false;
-            if (ok) { prog_dev = (char *) c->chain_prog_dev + c->chain_prog_used; ws = (unsigned *) ((char *) c->chain_ws + c->chain_ws_used); }
-        }
-    }
-    std::vector<char> host(ok ? prog_bytes : 0);
-    mmvq_chain_launch L = {};
-    if (ok) {
-        std::vector<mmvq_chain_item> items((size_t) n);
-        for (int j = 0; j < n; j++) {
-            const auto & it = c->rec[j];
-            mmvq_chain_item & ci = items[(size_t) j];
-            for (int q = 0; q < it.nc; q++) ci.grp[q] = it.grp[q];
-            ci.n_groups = it.nc; ci.k = it.K; ci.in = it.in; ci.has_rope = it.has_rope; ci.rope = it.rope;
-        }
-        ok = mul_mat_vec_q_chain_build(items.data(), n, host.data(), &L);
-    }
-    if (dbg) fprintf(stderr, "ggml-mi355x: recorded run of %d grouped launches -> %s%s\n", n, ok ? "one chained launch" : "separate launches", c->capturing ? " [capture]" : "");
-    if (!ok) {
-        for (const auto & it : c->rec) launch_rec_item(c, it);
-        c->rec.clear();
-        return;
-    }
-    if (c->capturing) {
-        mi_backend_ctx::pending_upload up; up.dev = prog_dev; up.host = std::move(host);
-        c->chain_uploads.push_back(std::move(up));     // copied when the capture has ended (be_graph_compute), before the graph's first launch
-        c->cap_prog_used += (prog_bytes + 255) & ~(size_t) 255; c->cap_ws_used += (ws_words*4 + 255) & ~(size_t) 255;
-    } else {
-        // eager: the host table of this pass is carved from the pinned staging area at the same offset as the device table (the stream
-        // was synchronized before the pass reused the area: be_graph_compute)
-        memcpy((char *) c->chain_prog_host + c->chain_prog_used, host.data(), prog_bytes);
-        MI_CHECK_G(hipMemcpyAsync(prog_dev, (char *) c->chain_prog_host + c->chain_prog_used, prog_bytes, hipMemcpyHostToDevice, c->stream));
-        c->chain_prog_used += (prog_bytes + 255) & ~(size_t) 255; c->chain_ws_used += (ws_words*4 + 255) & ~(size_t) 255;
-    }
-    MI_CHECK_G(hipMemsetAsync(ws, 0, ws_words*4, c->stream));
-    unsigned * err_dev = nullptr;
-    MI_CHECK_G(hipHostGetDevicePointer((void **) &err_dev, c->chain_err, 0));
-    mul_mat_vec_q_chain_launch(prog_dev, L, ws, err_dev, c->stream);
-    c->cnt.kernels_launched += 2;
-    c->rec.clear();
-}
-
-// the pending sum of attn_wo's planes is needed as a tensor after all (its reader is not the launch that would have added them up itself)
+// the pending MoE combine is needed as a tensor after all (its reader is not the launch that would have evaluated it itself)
 static void pp_flush(mi_backend_ctx * c) {
     if (!c->pp.active) return;
-    if (c->pp.probs) moe_combine(c->pp.probs, c->pp.ids, c->pp.n_planes, c->pp.mode, c->pp.planes, (size_t) c->pp.stride*4, c->pp.m, c->pp.res, c->pp.x_out, c->stream);
-    else planes_sum(c->pp.res, c->pp.planes, c->pp.n_planes, c->pp.stride, c->pp.x_out, c->pp.m, c->stream);
+    moe_combine(c->pp.probs, c->pp.ids, c->pp.n_planes, c->pp.mode, c->pp.planes, (size_t) c->pp.stride*4, c->pp.m, c->pp.res, c->pp.x_out, c->stream);
     c->cnt.kernels_launched++;
     c->pp.active = false;
 }
 
-static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin, float * norm_out) {
-    // only what the streamed kernel takes can be a phase of a chain; anything else ends the recorded run and goes out by itself
-    if (!c->rec_on || fin || in.planes || !mul_mat_vec_q_stream_takes(grp, nc, K, in, rope) || (int) c->rec.size() >= mi_backend_ctx::CHAIN_MAX_PHASES) {
-        if (c->rec_on) rec_flush(c);
-        mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
-        c->cnt.kernels_launched++;
-        return;
-    }
-    mi_backend_ctx::rec_item it = {};
-    it.kind = 0; it.nc = nc; it.K = K; it.in = in; it.has_rope = rope != nullptr; if (rope) it.rope = *rope;
-    for (int q = 0; q < nc; q++) it.grp[q] = grp[q];
-    c->rec.push_back(it);
+static void emit_mmv(mi_backend_ctx * c, const mmvq_group * grp, int nc, int64_t K, const mmvq_input & in, const mmvq_rope * rope, const mmvq_fin * fin) {
+    mul_mat_vec_q_fused(grp, nc, K, in, rope, c->stream, fin);
+    c->cnt.kernels_launched++;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -1113,7 +1044,6 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i);
 static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm, const struct ggml_tensor * normw) {
     struct ggml_tensor * n = g->nodes[i];
     if (!fusable_mmv(n)) return -1;
-    bool mixed = false;     // groups of two activation formats in the launch
     int deferred[MMVQ_MAX_GROUPS]; int n_def = 0;      // ROPE nodes between the grouped mat-vecs that the epilogue cannot do (NEOX): run after the launch
     const struct ggml_tensor * b = n->src[1];
     const int kind = act_kind_for((int) n->src[0]->type);
@@ -1144,7 +1074,6 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
             const bool cached_b = c->aq.valid && c->aq.data == b->data;
             if (!(norm || !cached_b) || !mul_mat_vec_q_fused_can_group_mixed(chains[0].grp.type, (int) m->src[0]->type) ||
                 !mul_mat_vec_q_fused_prologue_supported(n->src[0]->ne[0], kind) || !mul_mat_vec_q_fused_prologue_supported(n->src[0]->ne[0], act_kind_for((int) m->src[0]->type))) break;
-            mixed = true;
         }
         mmv_chain ch = match_mmv_chain(c, g, j);
         if (ch.grp.epi == EPI_GLU) break;   // the dual (GLU) kernel runs alone
@@ -1225,7 +1154,6 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
         wbytes += (uint64_t) grp[q].m*grp[q].row_stride*(grp[q].epi == EPI_GLU ? 2 : 1);
     }
     const int64_t K = n->src[0]->ne[0];
-    void * norm_mul_data = b->data;      // with `norm`: b is the RMS_NORM*w tensor the launch path never writes
     mmvq_input in = {};
     in.act_kind = kind;
     const bool cached = c->aq.valid && c->aq.data == b->data && c->aq.k == K && c->aq.n_inner == 1 && c->aq.n_outer == 1 && c->aq.kind == kind;
@@ -1244,14 +1172,13 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     } else if (mul_mat_vec_q_fused_prologue_supported(K, kind)) {
         in.mode = PRO_QUANT; in.x = (const float *) b->data;
     } else {
-        rec_flush(c);     // the quantizer below reads what a recorded launch writes
         in.mode = PRO_Q8; in.act = get_act(c, b->data, K, 1, 1, b->nb[1], 0, kind);
     }
     // gate/up/SwiGLU whose output the down projection reads next (build_ffn, src/llama-graph.cpp:691-748): the launch also writes the quantized
     // image of its output (mmvq_fin) — the f32 tensor is written as always, so any other reader still finds it
     mmvq_fin fin = {}; act_q8 fin_q = {}; const struct ggml_tensor * fin_t = nullptr;
     static const bool fin_env = !getenv("GGML_MI355X_FIN") || atoi(getenv("GGML_MI355X_FIN")) != 0;
-    if (fin_env && !c->rec_on && nc == 1 && grp[0].epi == EPI_GLU && !grp[0].eid && c->fin_img && !mul_mat_vec_q_stream_takes(grp, nc, K, in, rope)) {
+    if (fin_env && nc == 1 && grp[0].epi == EPI_GLU && !grp[0].eid && c->fin_img && !mul_mat_vec_q_stream_takes(grp, nc, K, in, rope)) {
         const int jn = next_real(g, last);
         const struct ggml_tensor * gl = g->nodes[last];
         const struct ggml_tensor * mm = jn > 0 ? g->nodes[jn] : nullptr;
@@ -1270,7 +1197,6 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
     if (rope) {
         if (!c->rope_tab || rope->p.n_dims/2 > 512) return -1;
         if (!c->rope_tab_valid || memcmp(&c->rope_tab_key, rope, sizeof(*rope)) != 0) {
-            rec_flush(c);      // recorded launches still to go out read the table as it is
             mul_mat_vec_q_fused_rope_table(*rope, c->rope_tab, c->stream);
             c->cnt.kernels_launched++;
             c->rope_tab_key = *rope; c->rope_tab_valid = true;
@@ -1278,12 +1204,25 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
         rope_l = *rope; rope_l.table = c->rope_tab; rope = &rope_l;
     }
     if (c->pp.active && in.mode == PRO_NORM && (const void *) in.x == (const void *) c->pp.x_out && K == c->pp.m) {
-        // the norm's input is the sum attn_wo left as partial planes: this launch adds them up in its prologue (and stores the sum)
-        in.x = c->pp.res; in.planes = c->pp.planes; in.n_planes = c->pp.n_planes; in.plane_stride = c->pp.stride; in.x_out = c->pp.x_out;
-        in.pl_probs = c->pp.probs; in.pl_ids = c->pp.ids; in.pl_mode = c->pp.mode;
-        c->pp.active = false;
+        // the norm's input is the MoE combine left pending: this launch evaluates it in its prologue (and stores the sum). EVERY workgroup's prologue reads the
+        // residual, the experts' outputs, the router's probabilities and the ids while other workgroups already store their rows — and by graph order all four are
+        // dead after the combine, so an allocator that reuses memory (ggml-alloc) may have put this launch's outputs there: then the combine runs as
+        // its own kernel first
+        bool clash = false;
+        const size_t planes_bytes = ((size_t)(c->pp.n_planes - 1)*c->pp.stride + (size_t) c->pp.m)*4;
+        for (int q = 0; q < nc && !clash; q++) {
+            const void * d = chains[q].out_ptr; const size_t nb = chains[q].out_bytes;
+            clash = (c->pp.res && ranges_overlap(d, nb, c->pp.res, (size_t) c->pp.m*4)) || ranges_overlap(d, nb, c->pp.planes, planes_bytes) ||
+                    ranges_overlap(d, nb, c->pp.probs, c->pp.probs_bytes) || ranges_overlap(d, nb, c->pp.ids, (size_t) c->pp.n_planes*4);
+        }
+        if (clash) pp_flush(c);
+        else {
+            in.x = c->pp.res; in.planes = c->pp.planes; in.n_planes = c->pp.n_planes; in.plane_stride = c->pp.stride; in.x_out = c->pp.x_out;
+            in.pl_probs = c->pp.probs; in.pl_ids = c->pp.ids; in.pl_mode = c->pp.mode;
+            c->pp.active = false;
+        }
     }
-    emit_mmv(c, grp, nc, K, in, rope, fin_t ? &fin : nullptr, in.mode == PRO_NORM && normw ? (float *) norm_mul_data : nullptr);
+    emit_mmv(c, grp, nc, K, in, rope, fin_t ? &fin : nullptr);
     if (fin_t) {
         c->aq = { fin_t->data, grp[0].m, 1, 1, fin_t->nb[1], 0, fin.kind, fin_q, true, (size_t) grp[0].m*4, 0 };
         c->aq_fresh = true;
@@ -1355,7 +1294,6 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
     if (pm->ne[0] != hd || pm->ne[1] != n_head || pm->ne[2] != T || pm->ne[3] != 1) return 0;
     if (ct->type != GGML_TYPE_F32 || !ggml_is_contiguous(ct) || ggml_nelements(ct) != hd*n_head*T) return 0;
     if (prefill) {
-        rec_flush(c);
         if (mask && (mask->ne[1] < T || ((uintptr_t) mask->data % 16) || mask->nb[1] % 16)) return 0;
         if (v->nb[1] % 8 || v->nb[2] % 8 || ((uintptr_t) v->data % 8)) return 0;
         // wo reads the result next: hand it the bf16 copy directly (nothing reads the scratch's offset 0 during this kernel)
@@ -1373,7 +1311,6 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         return j3 - i + 1;
     }
     if (kq8) {
-        rec_flush(c);
         const bool use_part = c->attn_part && attn_decode_part_bytes(hd, n_kv, n_head, T) <= c->attn_part_bytes;
         attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0,
                     mask && mask->type == GGML_TYPE_F16, sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
@@ -1381,46 +1318,12 @@ static int try_fused_attn(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         c->cnt.kernels_launched++;
         return j3 - i + 1;
     }
-    // attention + wo -> + residual as ONE launch (attn_wo.hip) when the sum's only readers are the norm of a grouped mat-vec launch (which adds the
-    // partial planes up in its prologue) and later residual adds
-    if (T == 1 && c->wo_planes && !c->rec_on && hd == 128 && n_head_kv <= mi_backend_ctx::WO_PLANES_MAX && (!mask || mask->ne[1] >= 1)) {
-        const int jw = next_real(g, j3);
-        if (jw > 0 && fusable_mmv(g->nodes[jw]) && g->nodes[jw]->src[1] == ct && is_internal(c, ct)) {
-            const struct ggml_tensor * wo = g->nodes[jw]->src[0];
-            const mmv_chain ch = match_mmv_chain(c, g, jw);
-            const int jn = ch.grp.epi == EPI_ADD ? next_real(g, ch.last) : -1;
-            const int jm = jn > 0 ? next_real(g, jn) : -1;
-            const int jq = jm > 0 ? next_real(g, jm) : -1;
-            if (jq > 0 && !ch.grp.res2 && !ch.grp.st_mode && !ch.has_rope && wo->ne[0] == hd*n_head && wo->ne[1] <= mi_backend_ctx::WO_PLANE_STRIDE &&
-                wo->nb[1] == ggml_row_size(wo->type, wo->ne[0]) && ((uintptr_t) wo->data % 16) == 0 && ((uintptr_t) ch.grp.res % 16) == 0 && ((uintptr_t) ch.grp.dst % 16) == 0 &&
-                !ranges_overlap(ch.grp.dst, (size_t) wo->ne[1]*4, ch.grp.res, (size_t) wo->ne[1]*4) &&      // (the consumer reads res in every workgroup while one stores the sum)
-                attn_wo_supported((int) wo->type, wo->ne[1], wo->ne[0], hd, n_kv, n_head, n_head_kv) && wo->ne[1] == wo->ne[0] &&
-                g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0]->data == (void *) ch.grp.dst && is_row_vec_f32(g->nodes[jn]->src[0]) &&
-                g->nodes[jm]->op == GGML_OP_MUL && (g->nodes[jm]->src[0] == g->nodes[jn] || g->nodes[jm]->src[1] == g->nodes[jn]) &&
-                fusable_mmv(g->nodes[jq]) && g->nodes[jq]->src[1] == g->nodes[jm] &&
-                (g->nodes[jq]->src[0]->type == GGML_TYPE_Q4_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q5_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q6_K || g->nodes[jq]->src[0]->type == GGML_TYPE_Q8_0) &&
-                g->nodes[jq]->src[0]->ne[0] % 256 == 0 && g->nodes[jq]->src[0]->ne[0] <= 4096 && mul_mat_vec_q_stream_enabled()) {
-                rec_flush(c);
-                pp_flush(c);
-                attn_wo(q->data, q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask && mask->type == GGML_TYPE_F16,
-                        sm->src[2] ? (const float *) sm->src[2]->data : nullptr, hd, n_kv, n_head, n_head_kv, op_f32(sm, 0),
-                        (int) wo->type, wo->data, wo->nb[1], wo->ne[1], c->wo_planes, mi_backend_ctx::WO_PLANE_STRIDE, c->stream);
-                c->pp.active = true; c->pp.res = ch.grp.res; c->pp.x_out = ch.grp.dst; c->pp.n_planes = (int) n_head_kv; c->pp.m = wo->ne[1];
-                c->pp.planes = c->wo_planes; c->pp.stride = mi_backend_ctx::WO_PLANE_STRIDE; c->pp.probs = nullptr; c->pp.ids = nullptr; c->pp.mode = 0;
-                c->cnt.kernels_launched++; c->cnt.mmvq_launches++;
-                c->cnt.weight_bytes += (uint64_t) wo->ne[1]*wo->nb[1];
-                return ch.last - i + 1;
-            }
-        }
-    }
     {
-        mi_backend_ctx::rec_item it = {};
-        it.kind = 1;
-        it.at = { q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0,
-                  mask && mask->type == GGML_TYPE_F16, sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
-                  hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), true };
-        rec_flush(c);
-        launch_rec_item(c, it);
+        const bool use_part = c->attn_part && attn_decode_part_bytes(hd, n_kv, n_head, T) <= c->attn_part_bytes;
+        attn_decode(q->data, q->nb[1], q->nb[2], k->data, k->nb[1], k->nb[2], v->data, v->nb[1], v->nb[2], mask ? mask->data : nullptr, mask ? mask->nb[1] : 0,
+                    mask && mask->type == GGML_TYPE_F16, sm->src[2] ? (const float *) sm->src[2]->data : nullptr, (float *) ct->data, (size_t) hd*n_head*4,
+                    hd, n_kv, n_head, n_head_kv, T, op_f32(sm, 0), c->stream, true, use_part ? c->attn_part : nullptr, use_part ? c->attn_part_bytes : 0);
+        c->cnt.kernels_launched++;
     }
     return j3 - i + 1;
 }
@@ -1493,8 +1396,9 @@ static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int
         const int jq = jm2 > 0 ? next_real(g, jm2) : -1;
         // (every workgroup of that launch reads the residual and the experts' outputs while one of them stores the sum: the sum's tensor must not share memory
         // with either — an allocator that made the ADD in place, as ggml-alloc does when the residual has no later reader, keeps the stand-alone kernel)
-        const bool aliased = (res && ranges_overlap(out->data, ggml_nbytes(out), res, (size_t) n_embd*4)) || ranges_overlap(out->data, ggml_nbytes(out), ex->data, ggml_nbytes(ex));
-        if (defer_on && !aliased && jq > 0 && !c->rec_on && c->use_fusion && mul_mat_vec_q_stream_enabled() && n_embd <= 4096 && ex->nb[1] % 16 == 0 &&
+        const bool aliased = (res && ranges_overlap(out->data, ggml_nbytes(out), res, (size_t) n_embd*4)) || ranges_overlap(out->data, ggml_nbytes(out), ex->data, ggml_nbytes(ex)) ||
+                             ranges_overlap(out->data, ggml_nbytes(out), pr->data, ggml_nbytes(pr)) || ranges_overlap(out->data, ggml_nbytes(out), ids->data, ggml_nbytes(ids));
+        if (defer_on && !aliased && jq > 0 && c->use_fusion && mul_mat_vec_q_stream_enabled() && n_embd <= 4096 && ex->nb[1] % 16 == 0 &&
             g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0] == out && is_row_vec_f32(out) &&
             g->nodes[jm2]->op == GGML_OP_MUL && (g->nodes[jm2]->src[0] == g->nodes[jn] || g->nodes[jm2]->src[1] == g->nodes[jn]) &&
             fusable_mmv(g->nodes[jq]) && g->nodes[jq]->src[1] == g->nodes[jm2] && g->nodes[jq]->src[0]->ne[0] == n_embd &&
@@ -1504,7 +1408,7 @@ static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int
             pp_flush(c);
             c->pp.active = true; c->pp.res = res; c->pp.x_out = (float *) out->data; c->pp.n_planes = (int) n_used; c->pp.m = n_embd;
             c->pp.planes = (const float *) ex->data; c->pp.stride = (int)(ex->nb[1]/4);
-            c->pp.probs = (const float *) pr->data; c->pp.ids = (const int32_t *) ids->data; c->pp.mode = mode;
+            c->pp.probs = (const float *) pr->data; c->pp.probs_bytes = ggml_nbytes(pr); c->pp.ids = (const int32_t *) ids->data; c->pp.mode = mode;
             return jl - i + 1;
         }
     }
@@ -1576,7 +1480,6 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
                                bg ? (const float *) bg->src[1]->data : nullptr, bu ? (const float *) bu->src[1]->data : nullptr,
                                oai ? op_f32(gl, 2) : 0.0f, oai ? op_f32(gl, 3) : 0.0f };
                 }
-                rec_flush(c);
                 mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
                 c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
                 c->cnt.weight_bytes += (uint64_t) 2*n_used*M*ggml_row_size(as->type, K);
@@ -1601,7 +1504,6 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
                    bias ? (const float *) bias->data : nullptr, nullptr, nullptr, 0, 0, (const int32_t *) ids->data + u, as->nb[2], b->ne[1] > 1 ? (int)((size_t) u*b->nb[1]/4) : 0 };
         grp[u].res_eid = bias ? 1 : 0;
     }
-    rec_flush(c);
     mul_mat_vec_q_fused(grp, n_used, K, in, nullptr, c->stream);
     c->cnt.mmvq_launches++; c->cnt.kernels_launched++;
     c->cnt.weight_bytes += (uint64_t) n_used*M*ggml_row_size(as->type, K);
@@ -1853,19 +1755,19 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
 
     int consumed = 1;
     bool fresh_aq = false;   // this step produced the cached quantized activations itself
-    // attn_wo's planes are pending: only the norm that reads their sum may go on without it (its grouped launch adds them up)
+    // a MoE combine is pending: only the norm that reads its sum may go on without it (its grouped launch evaluates it)
     if (c->pp.active && !(node->op == GGML_OP_RMS_NORM && s0 && s0->data == (void *) c->pp.x_out && c->use_fusion)) pp_flush(c);
     if (c->use_fusion) {
         int f = 0;
         if (node->op == GGML_OP_MUL_MAT && !tensor_is_split(s0)) {
             const int l = try_fused_mmv(c, g, i, nullptr, nullptr); f = l >= 0 ? l - i + 1 : 0;
             if (!f) f = try_fused_attn(c, g, i);       // (one token: recorded; many tokens: flushes, then launches)
-            if (!f) { rec_flush(c); f = try_fused_moe_route(c, g, i); }
+            if (!f) f = try_fused_moe_route(c, g, i);
             if (!f) f = try_fused_prefill_glu(c, g, i);
             if (!f) f = try_fused_prefill_qkv(c, g, i);
             if (!f) f = try_fused_prefill_add(c, g, i);
-        } else if (node->op == GGML_OP_SET_ROWS) { rec_flush(c); f = try_fused_kv_store(c, g, i); }
-        else if (node->op == GGML_OP_GET_ROWS) { rec_flush(c); f = try_fused_moe_combine(c, g, i); }
+        } else if (node->op == GGML_OP_SET_ROWS) f = try_fused_kv_store(c, g, i);
+        else if (node->op == GGML_OP_GET_ROWS) f = try_fused_moe_combine(c, g, i);
         else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);
         if (f) {
             consumed = f;
@@ -1873,9 +1775,6 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             goto done;
         }
     }
-    // held-back grouped launches (decode_fused.hip: the per-layer chain) go out before anything else touches the stream; only an
-    // RMS_NORM may still be absorbed into the next grouped launch's prologue
-    if (node->op != GGML_OP_RMS_NORM) rec_flush(c);
     switch (node->op) {
         case GGML_OP_MUL_MAT:    if (tensor_is_split(s0)) op_mul_mat_split(c, node); else op_mul_mat(c, node); break;
         case GGML_OP_MUL_MAT_ID: op_mul_mat_id(c, node); break;
@@ -1939,11 +1838,9 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                         // router kernel, which also writes the product for the expert mat-vecs that follow
                         if (mm && mm->op == GGML_OP_MUL_MAT && mm->src[1] == mul && mm->src[0]->type == GGML_TYPE_F32 && node->ne[1] == 1 && w->ne[0] == node->ne[0] &&
                             ggml_nelements(w) == w->ne[0] && is_row_vec_f32(s0) && is_row_vec_f32(mul) && s0->data != mul->data) {
-                            rec_flush(c);
                             const int f = try_fused_moe_route(c, g, jn, node, w);
                             if (f) { consumed = jn + f - i; break; }
                         }
-                        rec_flush(c);
                         if (mm && (mm->op == GGML_OP_MUL_MAT) && mm->src[1] == mul && ggml_is_quantized(mm->src[0]->type) &&
                             act_kind_for((int) mm->src[0]->type) > 0 && rms_norm_mul_quant_supported(node->ne[0]) && node->ne[1] <= 8 && node->ne[2] == 1 && node->ne[3] == 1 &&
                             w->ne[0] == node->ne[0] && ggml_nelements(w) == w->ne[0] && s0->nb[0] == 4 &&
@@ -1978,7 +1875,6 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
                     }
                 }
             }
-            rec_flush(c);
             pp_flush(c);
             rms_norm(desc(s0), desc(node), op_f32(node, 0), c->stream);
             c->cnt.kernels_launched++;
@@ -2033,33 +1929,63 @@ done:
     return consumed;
 }
 
-static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g) {
+// ---- the hipGraph cache ----------------------------------------------------------------------------------------
+// A decode graph is captured the second time its signature is seen and replayed afterwards. The capture is cut into SEGMENTS (a few launches, then a few
+// layers, then the rest), each its own executable graph: a replay checks and launches segment 0 first, so the GPU starts on the token while the host is
+// still checking and launching the rest — one 166-node hipGraphLaunch took 62 us of host time during which the GPU sat idle, on top of 21 us for the
+// 1125-node signature (llama-bench synchronizes after every token, so that gap is paid per token).
+// What makes launching a prefix safe: (1) a TOPOLOGY pass over the whole graph first (every node and its source tensors are the cached graph's: who reads
+// what decides which intermediates a fused group may leave unwritten); (2) a segment is launched only once its nodes' full signatures (op, type, shape,
+// strides, placement, op_params, the sources' placement and layout) match and every segment before it has been launched. If a later segment does not
+// match (same topology, another parameter), the remaining nodes run eagerly, behind the prefix already launched.
+static void end_capture_segment(mi_backend_ctx * c, graph_entry & e, int begin, int end) {
+    hipGraph_t graph = nullptr;
+    MI_CHECK_G(hipStreamEndCapture(c->stream, &graph));
+    c->capturing = false;
+    graph_seg sg = { begin, end, nullptr };
+    size_t n_nodes = 0;
+    if (graph && hipGraphGetNodes(graph, nullptr, &n_nodes) == hipSuccess && n_nodes > 0) {
+        const hipError_t err = hipGraphInstantiate(&sg.exec, graph, nullptr, nullptr, 0);
+        if (err != hipSuccess) { (void) hipGraphDestroy(graph); throw mi_graph_error{ err, __FILE__, __LINE__ }; }
+    } else (void) hipGetLastError();
+    if (graph) MI_CHECK_G(hipGraphDestroy(graph));
+    e.segs.push_back(sg);
+}
+
+// runs nodes [start, n_nodes). cap != NULL: under stream capture into cap's segments (the caller has begun the first capture; the last one is ended here)
+static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g, int start = 0, graph_entry * cap = nullptr) {
     c->rope_tab_valid = false;      // every pass over a graph (eager or under capture) fills the token's rotation table itself
     // the grouped mat-vec module keeps its launch hooks per host thread: (re)install this backend's for the thread that computes
     mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
     c->aq.valid = false;
     c->uses.clear();
-    c->rec.clear();
-    c->rec_on = c->use_chain && c->use_fusion && !c->profiling && c->chain_err != nullptr && !c->split_graph && mul_mat_vec_q_stream_enabled();
-    if (!c->capturing) {      // eager pass: its phase tables are staged through one pinned area, which the previous eager pass's copies may still be reading
-        if (c->chain_prog_used) MI_CHECK_G(hipStreamSynchronize(c->stream));
-        c->chain_prog_used = 0; c->chain_ws_used = 0;
-    }
     if (c->use_fusion) {
         for (int i = 0; i < g->n_nodes; i++) {
             for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[i]->src[s]) c->uses[g->nodes[i]->src[s]]++;
         }
     }
     c->pp.active = false;
-    for (int i = 0; i < g->n_nodes; ) i += compute_node(c, g, i);
-    rec_flush(c);
+    // segment sizes in kernel launches: the first is small (the GPU starts early), the second covers the time the host needs to launch the rest
+    static const int seg_kernels[2] = { getenv("GGML_MI355X_GRAPH_SEG0") ? atoi(getenv("GGML_MI355X_GRAPH_SEG0")) : 6, getenv("GGML_MI355X_GRAPH_SEG1") ? atoi(getenv("GGML_MI355X_GRAPH_SEG1")) : 24 };
+    int seg_begin = start; uint64_t k0 = c->cnt.kernels_launched;
+    for (int i = start; i < g->n_nodes; ) {
+        i += compute_node(c, g, i);
+        if (cap && i < g->n_nodes && cap->segs.size() < 2 && seg_kernels[cap->segs.size()] > 0 && !c->pp.active &&
+            c->cnt.kernels_launched - k0 >= (uint64_t) seg_kernels[cap->segs.size()]) {
+            end_capture_segment(c, *cap, seg_begin, i);
+            c->aq.valid = false;      // nothing cached is carried over a cut (the next segment may one day run behind an eager prefix)
+            MI_CHECK_G(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
+            c->capturing = true;
+            seg_begin = i; k0 = c->cnt.kernels_launched;
+        }
+    }
     pp_flush(c);
-    c->rec_on = false;
+    if (cap) end_capture_segment(c, *cap, seg_begin, g->n_nodes);
     c->aq.valid = false;
 }
 
 // (round 3: 64-bit lanes — one multiply per 8 bytes instead of one per 4, two independent chains for the op parameters — and only the sources that
-// exist are walked: the per-token signature of a 1125-node decode graph was 21 us of host time)
+// exist are walked)
 static inline uint64_t sig_mix(uint64_t h, uint64_t v) { h = (h ^ v)*0x9E3779B97F4A7C15ull; return h ^ (h >> 32); }
 static inline uint32_t hash_params(const int32_t * p) {
     uint64_t w[GGML_MAX_OP_PARAMS/8];
@@ -2076,6 +2002,7 @@ static inline void fill_sig(node_sig & s, const struct ggml_tensor * n) {
     for (int d = 0; d < 3; d++) s.nb[d] = n->nb[d + 1];
     for (int j = 0; j < GGML_MAX_SRC; j++) {
         const struct ggml_tensor * t = n->src[j];
+        s.src[j] = t;
         if (!t) { s.src_data[j] = NULL; s.src_hash[j] = 0u; continue; }
         s.src_data[j] = t->data;
         uint64_t h0 = sig_mix(0x452821E638D01377ull, (uint64_t) t->type), h1 = 0xBE5466CF34E90C6Cull;
@@ -2088,9 +2015,39 @@ static inline void fill_sig(node_sig & s, const struct ggml_tensor * n) {
     s.flags = (uint32_t) n->flags;
 }
 
+static void free_entry(graph_entry & e) {
+    for (auto & sg : e.segs) if (sg.exec) (void) hipGraphExecDestroy(sg.exec);
+    e.segs.clear();
+}
 static void drop_graphs(mi_backend_ctx * c) {
-    for (auto & e : c->graphs) { if (e.exec) (void) hipGraphExecDestroy(e.exec); for (void * p : e.owned_dev) (void) hipFree(p); }
+    for (auto & e : c->graphs) free_entry(e);
     c->graphs.clear();
+}
+
+// ---- replay, fast path: the cached graph this submission most likely is (same first node, same length, most recently used) ----
+static graph_entry * replay_candidate(mi_backend_ctx * c, const struct ggml_cgraph * g) {
+    graph_entry * best = nullptr;
+    for (auto & e : c->graphs) {
+        if (e.segs.empty() || (int) e.sig.size() != g->n_nodes || e.sig[0].node != g->nodes[0]) continue;
+        if (!best || e.last_use > best->last_use) best = &e;
+    }
+    return best;
+}
+static bool topology_matches(const graph_entry & e, const struct ggml_cgraph * g) {
+    static_assert(sizeof(((struct ggml_tensor *) 0)->src) == sizeof(((node_sig *) 0)->src), "node_sig::src mirrors ggml_tensor::src");
+    for (int i = 0; i < g->n_nodes; i++) {
+        const struct ggml_tensor * n = g->nodes[i];
+        if (n != e.sig[i].node || memcmp(n->src, e.sig[i].src, sizeof(n->src)) != 0) return false;
+    }
+    return true;
+}
+static bool signature_matches(const graph_entry & e, const struct ggml_cgraph * g, int begin, int end) {
+    node_sig ns;
+    for (int i = begin; i < end; i++) {
+        fill_sig(ns, g->nodes[i]);
+        if (memcmp(&ns, &e.sig[i], sizeof(ns)) != 0) return false;
+    }
+    return true;
 }
 
 // find (or create) the cache entry whose signature equals this graph's
@@ -2115,8 +2072,8 @@ static graph_entry & graph_lookup(mi_backend_ctx * c, const struct ggml_cgraph *
     }
     if (best) { best->last_use = ++c->graph_tick; best->seen++; return *best; }
     if ((int) c->graphs.size() >= MI_MAX_GRAPHS) {
-        if (lru->exec) { MI_CHECK_G(hipStreamSynchronize(c->stream)); MI_CHECK_G(hipGraphExecDestroy(lru->exec)); }
-        for (void * p : lru->owned_dev) (void) hipFree(p);
+        if (!lru->segs.empty()) MI_CHECK_G(hipStreamSynchronize(c->stream));
+        free_entry(*lru);
         *lru = graph_entry();
         lru->sig = c->cur_sig; lru->digest = c->cur_digest; lru->last_use = ++c->graph_tick; lru->seen = 1;
         return *lru;
@@ -2150,9 +2107,10 @@ static enum ggml_status be_graph_compute(ggml_backend_t backend, struct ggml_cgr
             hipGraph_t graph = nullptr;
             (void) hipStreamEndCapture(c->stream, &graph);
             if (graph) (void) hipGraphDestroy(graph);
-            c->capturing = false; c->cap_entry = nullptr; c->chain_uploads.clear();
+            c->capturing = false;
         }
-        c->rec.clear(); c->rec_on = false; c->aq.valid = false; c->pp.active = false;
+        if (c->cap_entry) { free_entry(*c->cap_entry); c->cap_entry = nullptr; }      // a partly captured graph is not replayable
+        c->aq.valid = false; c->pp.active = false; c->up.n = 0;
         // a throw inside the row-split fork leaves the current device on a peer, and peer streams that were already launched may still write dst:
         // back to this backend's device, and nothing is returned before they have finished
         set_device(c->device);
@@ -2167,15 +2125,51 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
     c->cnt.graphs_computed++;
+    uploads_flush(c);       // the inputs the host has set (set_tensor_async) go out first, as one launch
 
+    static const bool timing2 = getenv("GGML_MI355X_HOST_TIMING") != nullptr;
+    static double t_first = 0, t_rest = 0; static long n_rep = 0;
+    const bool try_graph = c->use_graphs && (!c->profiling || c->prof_in_graph) && g->n_nodes >= 8;
+
+    // ---- fast path: replay segment by segment ----
+    if (try_graph) {
+        const auto ta = std::chrono::steady_clock::now();
+        graph_entry * e = replay_candidate(c, g);
+        if (e && topology_matches(*e, g)) {
+            size_t si = 0; auto tb = ta;
+            for (; si < e->segs.size(); si++) {
+                const graph_seg & sg = e->segs[si];
+                if (!signature_matches(*e, g, sg.begin, sg.end)) break;
+                if (sg.exec) MI_CHECK_G(hipGraphLaunch(sg.exec, c->stream));
+                if (si == 0 && timing2) tb = std::chrono::steady_clock::now();
+            }
+            if (si == e->segs.size()) {
+                e->last_use = ++c->graph_tick; e->seen++;
+                c->cnt.graph_replays++;
+                if (timing2) {
+                    const auto tc = std::chrono::steady_clock::now();
+                    t_first += std::chrono::duration<double, std::micro>(tb - ta).count(); t_rest += std::chrono::duration<double, std::micro>(tc - tb).count();
+                    if (++n_rep % 128 == 0) fprintf(stderr, "ggml-mi355x: replay host us: until segment 0 is launched %.1f, the other %zu segments %.1f (n_nodes %d, %zu cached)\n", t_first/n_rep, e->segs.size() - 1, t_rest/n_rep, g->n_nodes, c->graphs.size());
+                }
+                return GGML_STATUS_SUCCESS;
+            }
+            if (si > 0) {      // same topology, a parameter changed behind an identical prefix: the prefix is on the stream, the rest runs eagerly
+                c->prof_suspend = false;
+                run_nodes(c, g, e->segs[si].begin);
+                return GGML_STATUS_SUCCESS;
+            }
+        }
+    }
+
+    // ---- everything else: buffers this graph needs (allocated outside any capture; a captured graph holds their addresses) ----
     if (!c->rope_tab) { if (hipMalloc((void **) &c->rope_tab, 4096) != hipSuccess) { (void) hipGetLastError(); c->rope_tab = nullptr; } }
     if (!c->moe_ws) {
         if (hipMalloc((void **) &c->moe_ws, 4096) == hipSuccess) { MI_CHECK_G(hipMemsetAsync(c->moe_ws, 0, 4096, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream)); }
         else { (void) hipGetLastError(); c->moe_ws = nullptr; }
     }
-    if (!c->chain_err) {     // the error words of the kernels with bounded waits (host-mapped)
-        if (hipHostMalloc((void **) &c->chain_err, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **) &c->err_dev, c->chain_err, 0) == hipSuccess) memset(c->chain_err, 0, 64);
-        else { (void) hipGetLastError(); c->chain_err = nullptr; c->err_dev = nullptr; c->use_chain = false; }
+    if (!c->err_host) {      // the error words of the kernels with bounded waits (host-mapped)
+        if (hipHostMalloc((void **) &c->err_host, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void **) &c->err_dev, c->err_host, 0) == hipSuccess) memset(c->err_host, 0, 64);
+        else { (void) hipGetLastError(); c->err_host = nullptr; c->err_dev = nullptr; }
     }
     if (!c->fin_img) {       // allocated once, outside any capture; the counters are zero between launches (the kernels re-arm them)
         if (hipMalloc(&c->fin_img, mi_backend_ctx::FIN_IMG_BYTES) != hipSuccess) { (void) hipGetLastError(); c->fin_img = nullptr; }
@@ -2183,18 +2177,11 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
             MI_CHECK_G(hipMemsetAsync(c->fin_cnt, 0, (mi_backend_ctx::FIN_COUNTERS + 8)*4, c->stream)); MI_CHECK_G(hipStreamSynchronize(c->stream));
         } else if (c->fin_img) { (void) hipGetLastError(); (void) hipFree(c->fin_img); c->fin_img = nullptr; c->fin_cnt = nullptr; }
     }
-    if (!c->wo_planes) {
-        if (hipMalloc((void **) &c->wo_planes, (size_t) mi_backend_ctx::WO_PLANES_MAX*mi_backend_ctx::WO_PLANE_STRIDE*4) != hipSuccess) { (void) hipGetLastError(); c->wo_planes = nullptr; }
-    }
     if (!c->attn_part) {     // <= 8 tokens x 128 heads x 32 ranges x (128 + 2) floats: allocated once, outside any capture
         const size_t pb = (size_t) 8*128*32*130*4;
         if (hipMalloc((void **) &c->attn_part, pb) == hipSuccess) c->attn_part_bytes = pb; else (void) hipGetLastError();
     }
-    static const bool timing2 = getenv("GGML_MI355X_HOST_TIMING") != nullptr;
-    static double t_need = 0, t_look = 0, t_launch = 0; static long n_rep = 0;
-    const auto ta = std::chrono::steady_clock::now();
     const size_t need = graph_scratch_need(g);
-    const auto tb = std::chrono::steady_clock::now();
     if (need > c->scratch_size) {
         MI_CHECK_G(hipStreamSynchronize(c->stream));
         if (c->scratch) MI_CHECK_G(hipFree(c->scratch));
@@ -2204,7 +2191,6 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         if (hipMalloc(&c->scratch, sz) != hipSuccess) { (void) hipGetLastError(); return GGML_STATUS_ALLOC_FAILED; }
         c->scratch_size = sz;
     }
-
     {
         size_t kv_need = 0;
         for (int i = 0; i < g->n_nodes; i++) if (g->nodes[i]->op == GGML_OP_FLASH_ATTN_EXT) { size_t kb, vb; fa_kv16_plan(g->nodes[i], kb, vb); kv_need = std::max(kv_need, kb + vb); }
@@ -2219,58 +2205,31 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
         }
     }
 
-    // hipGraph path: launch-bound decode graphs (~10^3 tiny kernels per token) are captured the second time their
-    // signature is seen, then replayed while the signature is unchanged.
     c->split_graph = false;
     for (int i = 0; i < g->n_nodes && !c->split_graph; i++) c->split_graph = g->nodes[i]->op == GGML_OP_MUL_MAT && tensor_is_split(g->nodes[i]->src[0]);
     if (c->split_graph) {     // several devices' streams take part: eager execution, no capture (the fusion matchers leave split weights to op_mul_mat_split)
         run_nodes(c, g);
         return GGML_STATUS_SUCCESS;
     }
-    const bool try_graph = c->use_graphs && (!c->profiling || c->prof_in_graph) && g->n_nodes >= 8;
     c->prof_suspend = try_graph && c->prof_in_graph;     // only what is captured gets recorded in that mode
     if (try_graph) {
         graph_entry & e = graph_lookup(c, g);
-        if (e.exec) {
-            const auto tc = std::chrono::steady_clock::now();
-            MI_CHECK_G(hipGraphLaunch(e.exec, c->stream));
+        if (!e.segs.empty()) {      // (a cached graph the fast path did not pick: e.g. several sequences' graphs taking turns)
+            for (const graph_seg & sg : e.segs) if (sg.exec) MI_CHECK_G(hipGraphLaunch(sg.exec, c->stream));
             c->cnt.graph_replays++;
-            if (timing2) {
-                const auto td = std::chrono::steady_clock::now();
-                t_need += std::chrono::duration<double, std::micro>(tb - ta).count(); t_look += std::chrono::duration<double, std::micro>(tc - tb).count();
-                t_launch += std::chrono::duration<double, std::micro>(td - tc).count();
-                if (++n_rep % 128 == 0) fprintf(stderr, "ggml-mi355x: replay host us: scratch-need %.1f lookup %.1f launch %.1f (n_nodes %d, %zu cached)\n", t_need/n_rep, t_look/n_rep, t_launch/n_rep, g->n_nodes, c->graphs.size());
-            }
             return GGML_STATUS_SUCCESS;
         }
         if (e.seen >= 2) {
-            hipGraph_t graph = nullptr;
-            if (c->use_chain && c->chain_err && e.owned_dev.empty()) {       // room for the chained launches' phase tables and counters of this graph (no allocation inside a capture)
-                void * pd = nullptr; void * wd = nullptr;
-                const size_t pcap = mi_backend_ctx::CHAIN_MAX_PHASES*mul_mat_vec_q_chain_phase_bytes(), wcap = (size_t) mul_mat_vec_q_chain_ws_words(mi_backend_ctx::CHAIN_MAX_PHASES)*4;
-                if (hipMalloc(&pd, pcap) == hipSuccess && hipMalloc(&wd, wcap) == hipSuccess) { e.owned_dev.push_back(pd); e.owned_dev.push_back(wd); }
-                else { (void) hipGetLastError(); if (pd) (void) hipFree(pd); }
-            }
+            c->cap_entry = &e;
             MI_CHECK_G(hipStreamBeginCapture(c->stream, hipStreamCaptureModeThreadLocal));
             c->prof_suspend = false;
-            c->capturing = true; c->cap_entry = &e; c->chain_uploads.clear(); c->cap_prog_used = 0; c->cap_ws_used = 0;
-            run_nodes(c, g);
-            c->capturing = false; c->cap_entry = nullptr;
+            c->capturing = true;
+            run_nodes(c, g, 0, &e);
+            c->cap_entry = nullptr;
             c->prof_suspend = c->prof_in_graph;
-            MI_CHECK_G(hipStreamEndCapture(c->stream, &graph));
-            for (auto & up : c->chain_uploads) MI_CHECK_G(hipMemcpy(up.dev, up.host.data(), up.host.size(), hipMemcpyHostToDevice));     // the phase tables the captured launches read
-            c->chain_uploads.clear();
-            hipError_t err = hipGraphInstantiate(&e.exec, graph, nullptr, nullptr, 0);
-            MI_CHECK_G(hipGraphDestroy(graph));
-            if (err == hipSuccess) {
-                c->cnt.graph_captures++;
-                MI_CHECK_G(hipGraphLaunch(e.exec, c->stream));
-                return GGML_STATUS_SUCCESS;
-            }
-            fprintf(stderr, "ggml-mi355x: hipGraphInstantiate failed (%s): staying eager\n", hipGetErrorString(err));
-            (void) hipGetLastError();
-            e.exec = nullptr;
-            c->use_graphs = false;   // instantiate failed: stay eager
+            c->cnt.graph_captures++;
+            for (const graph_seg & sg : e.segs) if (sg.exec) MI_CHECK_G(hipGraphLaunch(sg.exec, c->stream));
+            return GGML_STATUS_SUCCESS;
         }
     }
     run_nodes(c, g);
@@ -2280,11 +2239,13 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
 static void be_event_record(ggml_backend_t backend, ggml_backend_event_t event) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
+    uploads_flush(c);
     MI_CHECK(hipEventRecord((hipEvent_t) event->context, c->stream));
 }
 static void be_event_wait(ggml_backend_t backend, ggml_backend_event_t event) {
     mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
     set_device(c->device);
+    uploads_flush(c);
     MI_CHECK(hipStreamWaitEvent(c->stream, (hipEvent_t) event->context, 0));
 }
 
@@ -2388,6 +2349,8 @@ static void * reg_get_proc_address(ggml_backend_reg_t, const char * name) {
     if (strcmp(name, "ggml_backend_mi355x_reset_counters") == 0) return (void *) ggml_backend_mi355x_reset_counters;
     if (strcmp(name, "ggml_backend_mi355x_set_option") == 0)   return (void *) ggml_backend_mi355x_set_option;
     if (strcmp(name, "ggml_backend_mi355x_get_profile") == 0)  return (void *) ggml_backend_mi355x_get_profile;
+    if (strcmp(name, "ggml_backend_mi355x_tensor_set_from_device_async") == 0) return (void *) ggml_backend_mi355x_tensor_set_from_device_async;
+    if (strcmp(name, "ggml_backend_mi355x_tensor_get_to_device_async") == 0)   return (void *) ggml_backend_mi355x_tensor_get_to_device_async;
     if (strcmp(name, "ggml_backend_mi355x_test_quantize") == 0) return (void *) ggml_backend_mi355x_test_quantize;
     if (strcmp(name, "ggml_backend_mi355x_test_hbm_read_gbps") == 0) return (void *) ggml_backend_mi355x_test_hbm_read_gbps;
     return NULL;
@@ -2496,7 +2459,6 @@ ggml_backend_t ggml_backend_mi355x_init(int device) {
     MI_CHECK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     if (const char * e = getenv("GGML_MI355X_GRAPHS")) c->use_graphs = atoi(e) != 0;
     if (const char * e = getenv("GGML_MI355X_FUSION")) c->use_fusion = atoi(e) != 0;
-    if (const char * e = getenv("GGML_MI355X_CHAIN")) c->use_chain = atoi(e) != 0;
     ggml_backend_t backend = new ggml_backend{ mi_guid(), mi_backend_iface, &d.dev, c };
     return backend;
 }
@@ -2542,6 +2504,20 @@ ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device
 
 bool ggml_backend_is_mi355x(ggml_backend_t backend) { return backend != NULL && ggml_guid_matches(backend->guid, mi_guid()); }
 
+void ggml_backend_mi355x_tensor_set_from_device_async(ggml_backend_t backend, struct ggml_tensor * tensor, const void * dev_src, size_t offset, size_t size) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    uploads_flush(c);
+    MI_CHECK(hipMemcpyAsync((char *) tensor->data + offset, dev_src, size, hipMemcpyDeviceToDevice, c->stream));
+}
+void ggml_backend_mi355x_tensor_get_to_device_async(ggml_backend_t backend, const struct ggml_tensor * tensor, void * dev_dst, size_t offset, size_t size) {
+    GGML_ASSERT(ggml_backend_is_mi355x(backend));
+    mi_backend_ctx * c = (mi_backend_ctx *) backend->context;
+    set_device(c->device);
+    uploads_flush(c);
+    MI_CHECK(hipMemcpyAsync(dev_dst, (const char *) tensor->data + offset, size, hipMemcpyDeviceToDevice, c->stream));
+}
 void * ggml_backend_mi355x_get_stream(ggml_backend_t backend) {
     GGML_ASSERT(ggml_backend_is_mi355x(backend));
     return (void *) ((mi_backend_ctx *) backend->context)->stream;
@@ -2567,12 +2543,6 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
         c->prof.clear();
         c->profiling = value != 0; c->prof_in_graph = value == 2; c->prof_suspend = false;
         mul_mat_vec_q_fused_set_hooks(c->profiling ? prof_hook_pre : nullptr, c->profiling ? prof_hook_post : nullptr, c);
-        return 0;
-    }
-    if (strcmp(key, "chain") == 0) {
-        c->use_chain = value != 0;
-        MI_CHECK(hipStreamSynchronize(c->stream));
-        drop_graphs(c);
         return 0;
     }
     if (strcmp(key, "fusion") == 0) {

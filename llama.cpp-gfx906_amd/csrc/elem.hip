@@ -851,6 +851,26 @@ void moe_combine(const float * probs, const int32_t * ids, int n_used, int mode,
     hipLaunchKernelGGL(k_moe_combine, dim3((unsigned)((n_embd/4 + 255)/256)), dim3(256), 0, stream, a);
 }
 
+// ---- small host -> device uploads of one graph's inputs (positions, mask, cache indices, one embedding row ...) as ONE launch: the sources sit in a
+// pinned, device-mapped staging area (backend.cpp: be_set_tensor_async), every item is copied by its own workgroups straight over PCIe ----
+__global__ void __launch_bounds__(256) k_upload_batch(const upload_batch b) {
+    int it = 0, blk = (int) blockIdx.x;
+#pragma unroll
+    for (int i = 0; i < UPLOAD_BATCH_MAX; i++) if (i < b.n && it == i && blk >= b.blocks[i]) { blk -= b.blocks[i]; it = i + 1; }
+    if (it >= b.n) return;
+    const char * src = (const char *) b.src[it]; char * dst = (char *) b.dst[it];
+    const uint32_t bytes = b.bytes[it];
+    const uint32_t o = (uint32_t) blk*4096u + threadIdx.x*16u;
+    if (o >= bytes) return;
+    if ((((uintptr_t) src | (uintptr_t) dst) & 15) == 0 && o + 16 <= bytes) { *(int4v *) (dst + o) = *(const int4v *) (src + o); return; }
+    for (uint32_t j = o; j < o + 16 && j < bytes; j++) dst[j] = src[j];
+}
+void upload_batch_launch(const upload_batch & b, hipStream_t stream) {
+    int blocks = 0;
+    for (int i = 0; i < b.n; i++) blocks += b.blocks[i];
+    if (blocks > 0) hipLaunchKernelGGL(k_upload_batch, dim3((unsigned) blocks), dim3(256), 0, stream, b);
+}
+
 // ---- HBM probe ----------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(256) k_hbm_read(const int4v * p, size_t n16, unsigned * sink) {
     int acc = 0;

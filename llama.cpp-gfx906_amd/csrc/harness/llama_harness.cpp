@@ -200,7 +200,12 @@ struct mi_llama {
     // pinned staging for the per-step inputs (set_inputs: src/llama-graph.cpp:16-58)
     ggml_backend_buffer_t hbuf = nullptr;
     uint8_t * hbase = nullptr; size_t hsize = 0; int hslot = 0;   // 4-slot ring: a slot is reused only 4 decodes later
-    std::vector<float> logits;
+    // the result of the last decode (logits of the last token, or l_out on a non-final layer-split rank) in PINNED host memory from the device's host buffer
+    // type, as llama_context::output_reserve allocates buf_output (src/llama-context.cpp:1260-1330): the read-back is then one asynchronous copy
+    ggml_backend_buffer_t lbuf = nullptr; float * logits = nullptr; size_t logits_cap = 0, logits_n = 0;   // capacity / valid count in floats
+    typedef void (*dev_set_fn)(ggml_backend_t, struct ggml_tensor *, const void *, size_t, size_t);
+    typedef void (*dev_get_fn)(ggml_backend_t, const struct ggml_tensor *, void *, size_t, size_t);
+    dev_set_fn set_from_device = nullptr; dev_get_fn get_to_device = nullptr;      // hand-offs through raw device buffers (layer split over RCCL)
     // a model read from a GGUF file (mi_llama_create_from_gguf): the mapping stays open for the input layer's rows
     std::unique_ptr<mi355x::gguf_file> gf;
     const uint8_t * tok_embd = nullptr; int tok_embd_type = 0; size_t tok_embd_row = 0;   // token_embd.weight in the mapping (host side: see gguf_tools.cpp)
@@ -477,6 +482,20 @@ void free_graph(graph_inst & g) {
     g = graph_inst();
 }
 
+// room for n floats of results in pinned host memory (grows; the old contents are not kept)
+bool reserve_result(mi_llama * m, size_t n) {
+    if (n <= m->logits_cap) return true;
+    ggml_backend_synchronize(m->backend);
+    if (m->lbuf) { ggml_backend_buffer_free(m->lbuf); m->lbuf = nullptr; } else free(m->logits);
+    m->logits = nullptr; m->logits_cap = 0;
+    ggml_backend_buffer_type_t hbt = ggml_backend_dev_host_buffer_type(ggml_backend_get_device(m->backend));
+    if (hbt) { m->lbuf = ggml_backend_buft_alloc_buffer(hbt, n*4); if (m->lbuf) m->logits = (float *) ggml_backend_buffer_get_base(m->lbuf); }
+    if (!m->logits) m->logits = (float *) malloc(n*4);
+    if (!m->logits) return false;
+    m->logits_cap = n;
+    return true;
+}
+
 // deterministic synthetic embedding row for a token id (stands in for get_rows(tok_embd) on the CPU)
 void synth_embedding(float * dst, int n_embd, int32_t token, uint64_t seed) {
     rng64 r(seed ^ (0x5851F42D4C957F2Dull*(uint64_t)(token + 1)));
@@ -659,7 +678,13 @@ mi_llama * create_body(mi_llama * m) {
         if (m->hbuf) m->hbase = (uint8_t *) ggml_backend_buffer_get_base(m->hbuf);
     }
     if (!m->hbase) m->hbase = (uint8_t *) malloc(m->hsize);
-    m->logits.resize(hp.has_output ? hp.n_vocab : hp.n_embd);
+    {
+        ggml_backend_reg_t reg = ggml_backend_dev_backend_reg(ggml_backend_get_device(backend));
+        m->set_from_device = (mi_llama::dev_set_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_tensor_set_from_device_async");
+        m->get_to_device = (mi_llama::dev_get_fn) ggml_backend_reg_get_proc_address(reg, "ggml_backend_mi355x_tensor_get_to_device_async");
+    }
+    m->logits_n = (size_t)(hp.has_output ? hp.n_vocab : hp.n_embd);
+    if (!reserve_result(m, m->logits_n)) { fprintf(stderr, "mi_llama: cannot allocate the output buffer\n"); abort(); }
     return m;
 }
 
@@ -750,6 +775,7 @@ GGML_API void mi_llama_free(struct mi_llama * m) {
     ggml_backend_synchronize(m->backend);
     for (auto & kv : m->graphs) free_graph(kv.second);
     if (m->hbuf) ggml_backend_buffer_free(m->hbuf); else free(m->hbase);
+    if (m->lbuf) ggml_backend_buffer_free(m->lbuf); else free(m->logits);
     if (m->wbuf) ggml_backend_buffer_free(m->wbuf);
     if (m->wsplit_buf) ggml_backend_buffer_free(m->wsplit_buf);
     if (m->kvbuf) ggml_backend_buffer_free(m->kvbuf);
@@ -764,7 +790,7 @@ GGML_API uint64_t mi_llama_weight_bytes(const struct mi_llama * m) {
 }
 GGML_API int      mi_llama_n_past(const struct mi_llama * m, int seq) { return m->n_past[seq]; }
 GGML_API void     mi_llama_kv_clear(struct mi_llama * m) { for (auto & p : m->n_past) p = 0; for (auto & c : m->swa_cell_pos) std::fill(c.begin(), c.end(), -1); }   // llama_memory_clear(mem, false): metadata only (llama-bench.cpp:1974)
-GGML_API int      mi_llama_n_result(const struct mi_llama * m) { return (int) m->logits.size(); }
+GGML_API int      mi_llama_n_result(const struct mi_llama * m) { return (int) m->logits_n; }
 
 // tensor access for graph-level parity tests
 GGML_API struct ggml_tensor * mi_llama_get_tensor(struct mi_llama * m, const char * name) {
@@ -779,6 +805,7 @@ GGML_API struct ggml_tensor * mi_llama_get_tensor(struct mi_llama * m, const cha
 //   dev_act_in  : optional DEVICE pointer, f32 [n_embd, n_tokens]: activations handed over from the previous layer-split rank
 //   result_host : optional host buffer for the result (n_vocab logits of the last token, or [n_embd, n_tokens] l_out on non-final ranks)
 //   dev_result_out : optional DEVICE pointer that receives the result instead (hand-off to the next rank)
+//   do_sync : bit 0 = synchronize before returning; bit 1 = no host read-back (measurements)
 GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * tokens, int n_tokens, const void * dev_act_in,
                              float * result_host, void * dev_result_out, int do_sync) {
     const mi_llama_hparams & hp = m->hp;
@@ -822,7 +849,8 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
     auto stage = [&](size_t bytes) { uint8_t * p = hp_ + off; off += (bytes + 255) & ~(size_t) 255; if (off > slot_size) { fprintf(stderr, "mi_llama: staging overflow\n"); abort(); } return p; };
 
     if (dev_act_in) {
-        ggml_backend_tensor_set_async(m->backend, g.inp_embd, dev_act_in, 0, ggml_nbytes(g.inp_embd));   // device-to-device
+        if (!m->set_from_device) return -4;
+        m->set_from_device(m->backend, g.inp_embd, dev_act_in, 0, ggml_nbytes(g.inp_embd));   // device-to-device
     } else {
         float * e = (float *) stage((size_t) n_embd*n_tokens*4);
         if (m->tok_embd) for (int i = 0; i < n_tokens; i++) { const int32_t tk = tokens ? tokens[i] : i; if (tk < 0 || tk >= hp.n_vocab) return -1; }   // llama_decode: "invalid token" (src/llama-batch.cpp:60-75)
@@ -913,14 +941,16 @@ GGML_API int mi_llama_decode(struct mi_llama * m, int seq, const int32_t * token
     const size_t rbytes = ggml_nbytes(g.result);
     if (dev_result_out) {
         // device-to-device hand-off buffer (consumed by the caller's RCCL send)
-        ggml_backend_tensor_get_async(m->backend, g.result, dev_result_out, 0, rbytes);
+        if (!m->get_to_device) return -4;
+        m->get_to_device(m->backend, g.result, dev_result_out, 0, rbytes);
     }
-    if (result_host || (!dev_result_out && hp.has_output)) {
-        if (m->logits.size()*4 < rbytes) m->logits.resize(rbytes/4);
-        ggml_backend_tensor_get_async(m->backend, g.result, result_host ? result_host : m->logits.data(), 0, rbytes);
+    if (result_host || (!dev_result_out && !(do_sync & 2))) {
+        // result_host == NULL: into the model's own pinned output buffer (mi_llama_last_logits), as llama_decode leaves the logits in buf_output
+        if (!result_host) { if (!reserve_result(m, rbytes/4)) return -2; m->logits_n = rbytes/4; }
+        ggml_backend_tensor_get_async(m->backend, g.result, result_host ? result_host : m->logits, 0, rbytes);
     }
     m->n_past[seq] += n_tokens;
-    if (do_sync) ggml_backend_synchronize(m->backend);   // llama_synchronize (llama-bench.cpp:1806 does it after every token)
+    if (do_sync & 1) ggml_backend_synchronize(m->backend);   // llama_synchronize (llama-bench.cpp:1806 does it after every token)
     return 0;
 }
 
@@ -933,7 +963,7 @@ GGML_API void mi_llama_synth_embedding(const struct mi_llama * m, int32_t token,
     synth_embedding(out, m->hp.n_embd, token, m->seed);
 }
 
-GGML_API const float * mi_llama_last_logits(const struct mi_llama * m) { return m->logits.data(); }
+GGML_API const float * mi_llama_last_logits(const struct mi_llama * m) { return m->logits; }
 
 // number of graph nodes in the decode graph for (n_tokens, n_kv) — reporting only
 GGML_API int mi_llama_graph_nodes(struct mi_llama * m, int n_tokens) {

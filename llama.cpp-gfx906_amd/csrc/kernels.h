@@ -66,10 +66,6 @@ void mul_mat_vec_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_
 // x: f32 rows of k floats at x + i*x_row_stride; scratch: mul_mat_q_scratch_bytes(k, n, m) bytes (the bf16 copy of x + the split-K planes)
 // (scratch_ready: it already holds the copy of exactly this x — the caller's cache — so the conversion pass is skipped)
 // res != NULL: dst = W.x + res (f32 rows of m floats at res + i*res_row_stride; may be dst itself) — the residual ADD of build_attn / build_ffn
-// Q4_K x Q8_K activations on the int8 matrix cores (mmq_i8.hip), n > 8 tokens: opt-in (GGML_MI355X_MMQ_I8=1) while it is being measured
-bool mul_mat_q_i8_supported(int type_a, int64_t m, int64_t k, int64_t n);
-bool mul_mat_q_i8(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k, const act_q8 & act, int64_t n,
-                  float * dst, size_t dst_col_stride_bytes, hipStream_t stream);
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m);
 void mul_mat_q(int type_a, const void * W, size_t w_row_stride, int64_t m, int64_t k,
                const float * x, size_t x_row_stride, int64_t n, void * scratch, bool scratch_ready, float * dst, size_t dst_col_stride_bytes,
@@ -244,20 +240,14 @@ struct mmvq_input {
     const float * norm_w;  // PRO_NORM: y = (x * rsqrt(mean(x^2) + eps)) * norm_w, then quantized — RMS_NORM -> MUL folded in
     float eps;
     int act_kind;
-    // PRO_NORM only: the vector is not materialized yet — it is x[i] + planes[0][i] + planes[1][i] + ... (added in that order: the partial planes of the
-    // k-sliced attention + wo launch, attn_wo.hip, on top of the residual x) and the launch also stores that sum to x_out (the graph's ADD result)
+    // PRO_NORM only, planes != NULL (then pl_probs != NULL too): the vector is not materialized yet and the launch also stores it to x_out (the graph's
+    // ADD result)
     const float * planes; int n_planes; int plane_stride; float * x_out;
-    // ... or, pl_probs != NULL, the tail of build_moe_ffn (src/llama-graph.cpp:887-1012) left unevaluated: the planes are the used experts' outputs and the vector
+    // — the tail of build_moe_ffn (src/llama-graph.cpp:887-1012) left unevaluated: the planes are the used experts' outputs and the vector
     // is sum_u planes[u][i] * w_u (+ x[i], the residual, when x != NULL), w_u from pl_probs[pl_ids[u]] normalised (pl_mode 0) or soft_max'ed (1) — k_moe_combine's
     // arithmetic in k_moe_combine's order
     const float * pl_probs; const int32_t * pl_ids; int pl_mode;
 };
-// one token: attention + output projection as one launch writing n_head_kv partial planes (attn_wo.hip); planes_sum: the stand-alone consumer
-bool attn_wo_supported(int type, int64_t m, int64_t k, int64_t hd, int64_t n_kv, int64_t n_head, int64_t n_head_kv);
-void attn_wo(const void * q, size_t q_nb2, const void * k, size_t k_nb1, size_t k_nb2, const void * v, size_t v_nb1, size_t v_nb2,
-             const void * mask, bool mask_f16, const float * sinks, int64_t hd, int64_t n_kv, int64_t n_head, int64_t n_head_kv, float scale,
-             int type, const void * W, size_t w_row_stride, int64_t m, float * planes, int64_t plane_stride, hipStream_t stream);
-void planes_sum(const float * res, const float * planes, int n_planes, int plane_stride, float * x_out, int64_t m, hipStream_t stream);
 bool mul_mat_vec_q_fused_supported(int64_t k, int act_kind);
 bool mul_mat_vec_q_fused_prologue_supported(int64_t k, int act_kind);        // PRO_QUANT / PRO_NORM limits (k % 256, or k % 32 with Q8_0 activations)
 bool mul_mat_vec_q_fused_can_group(int type_a, int type_b);         // may these two weight types share one grouped launch
@@ -270,15 +260,6 @@ bool mul_mat_vec_q_stream_enabled(void);       // GGML_MI355X_STREAM (default 1)
 bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope);
 void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                           hipEvent_t e0, hipEvent_t e1, const char ** kernel_name);
-// a CHAIN of grouped launches as one persistent launch (k_mmvq_chain, mmvq_stream.h): phase j + 1 reads what phase j wrote (or older data);
-// each item must be one mul_mat_vec_q_stream_takes says yes to. The phase table lives in device memory (prog_dev: n*phase_bytes, copied from
-// the host table _build fills), ws = n*ws_words counter words that are ZERO when the launch starts, err = a host-visible word (set if a wait gave up)
-struct mmvq_chain_item { mmvq_group grp[MMVQ_MAX_GROUPS]; int n_groups; int64_t k; mmvq_input in; bool has_rope; mmvq_rope rope; };
-struct mmvq_chain_launch { int n_phases, blocks; size_t lds; uint64_t weight_bytes; int cfg[4]; };
-size_t mul_mat_vec_q_chain_phase_bytes(void);
-int    mul_mat_vec_q_chain_ws_words(int n_phases);
-bool   mul_mat_vec_q_chain_build(const mmvq_chain_item * items, int n, void * prog_host, mmvq_chain_launch * out);
-void   mul_mat_vec_q_chain_launch(const void * prog_dev, const mmvq_chain_launch & L, unsigned * ws, unsigned * err_dev, hipStream_t stream);
 bool mul_mat_vec_q_fused_fin_supported(int64_t m, int64_t k_in);   // may a GLU launch with m output rows carry an mmvq_fin
 int  mul_mat_vec_q_fused_share(const mmvq_group * groups, int n_groups, int fw, int * block_end);   // workgroups per group (one workgroup per CU in all)
 // (round 1's chained launch held launches back; nothing is held back any more: flush is a no-op kept for its call sites)
@@ -290,6 +271,11 @@ void mul_mat_vec_q_fused_set_launch_events(hipEvent_t e0, hipEvent_t e1);
 const char * mul_mat_vec_q_fused_last_kernel(void);     // name of the instantiation the last grouped launch used
 void mul_mat_vec_q_fused_set_hooks(mmvq_launch_hook pre, mmvq_launch_hook post, void * ctx);
 int  mul_mat_vec_q_fused_pending(uint64_t * weight_bytes);
+
+// ---- small uploads batched into one launch (backend.cpp: be_set_tensor_async / uploads_flush) ----
+constexpr int UPLOAD_BATCH_MAX = 12;
+struct upload_batch { int n; const void * src[UPLOAD_BATCH_MAX]; void * dst[UPLOAD_BATCH_MAX]; uint32_t bytes[UPLOAD_BATCH_MAX]; int blocks[UPLOAD_BATCH_MAX]; };   // blocks[i] = ceil(bytes[i] / 4096)
+void upload_batch_launch(const upload_batch & b, hipStream_t stream);
 
 // ---- test / bench support ------------------------------------------------------------------
 // raw streaming read of `bytes` (16 B/lane, nontemporal) — measures the achievable HBM rate on the box

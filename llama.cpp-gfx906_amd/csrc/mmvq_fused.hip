@@ -267,9 +267,8 @@ void mul_mat_vec_q_fused(const mmvq_group * groups, int n_groups, int64_t k, con
                          const mmvq_fin * fin) {
     mmvq_input in = in_;
     if (in.planes && !mul_mat_vec_q_stream_takes(groups, n_groups, k, in, rope)) {
-        // partial planes (attn_wo.hip) and a consumer that is not the streamed kernel: add them up first, then the vector exists like any other
-        if (in.pl_probs) moe_combine(in.pl_probs, in.pl_ids, in.n_planes, in.pl_mode, in.planes, (size_t) in.plane_stride*4, k, in.x, in.x_out, stream);
-        else planes_sum(in.x, in.planes, in.n_planes, in.plane_stride, in.x_out, k, stream);
+        // a pending MoE combine and a consumer that is not the streamed kernel: evaluate it first, then the vector exists like any other
+        moe_combine(in.pl_probs, in.pl_ids, in.n_planes, in.pl_mode, in.planes, (size_t) in.plane_stride*4, k, in.x, in.x_out, stream);
         in.x = in.x_out; in.planes = nullptr; in.n_planes = 0; in.x_out = nullptr; in.pl_probs = nullptr; in.pl_ids = nullptr;
     }
     if (mul_mat_vec_q_stream_takes(groups, n_groups, k, in, rope)) {      // the streamed kernel (mmvq_stream.h); callers do not pass it a `fin`

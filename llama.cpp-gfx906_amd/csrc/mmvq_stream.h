@@ -73,31 +73,12 @@ struct st_args {
     const int8_t * a_qs; const float * a_d; const int16_t * a_bs;      // PRO_Q8: the n = 1 image act_q8_carve lays out
     fused_rope rope;
     st_group g[MMVQ_MAX_GROUPS];
-    // PRO_NORM, at most 16 blocks: x is the residual and the vector is x + plane 0 + plane 1 + ... (attn_wo.hip's partial planes, in this order);
-    // workgroup 0 also stores the sum to x_out
+    // PRO_NORM, at most 16 blocks, planes != NULL: the pending MoE combine (kernels.h mmvq_input) — the vector is sum_u w_u * plane u (+ x, the residual);
+    // workgroup 0 also stores it to x_out
     const float * planes; int n_planes, plane_stride; float * x_out;
-    const float * pl_probs; const int32_t * pl_ids; int pl_mode;      // != NULL: weighted planes (the MoE combine, kernels.h mmvq_input)
+    const float * pl_probs; const int32_t * pl_ids; int pl_mode;
     unsigned long long * stamps;              // diagnostic builds (-DMI_STAMPS): [workgroup][wave][8]
 };
-// ---- a CHAIN of such launches as ONE launch (k_mmvq_chain): consecutive mat-vecs of the decode graph (wo -> gate/up/SwiGLU -> down -> the next
-// layer's norm+QKV ...) as phases of a persistent kernel. Every workgroup walks the phases in order; its loader runs ahead into the next
-// phases' weights (they depend on nothing) while the consumers finish a phase, hand its rows over and wait for everybody else's:
-// the kernel boundary, the launch ramp, the first-byte latency and the prologue of each phase overlap the stream instead of stopping it.
-// Hand-off (MI355X guide, inter-workgroup visibility, the drained-sc1 form): a phase's outputs leave with write-through (sc1) stores, every
-// storing wave drains them, the workgroup arrives at the phase's counter (agent-scope atomic add); the next phase's consumers poll that
-// counter (sc1 load) and read activations / residuals with sc1 loads.
-struct st_phase {
-    st_args a;
-    int n_active;                             // workgroups that take part (= a.block_end[a.n_groups - 1])
-    int wait_idx, sig_idx;                    // words of the launch's counter array: wait until ws[wait_idx] >= wait_target before reading inputs; add 1 to ws[sig_idx] when this workgroup's rows are stored (-1: none)
-    unsigned wait_target;
-};
-constexpr int ST_WS_WORDS = 512;              // counter words per phase: 8 shards, 256 bytes apart (256 arrivals at ONE word take ~3 us; workgroup b arrives at shard b % 8)
-struct st_chain_cfg {                         // the LDS carve, the same in every phase (the loader is phases ahead of the consumers)
-    int nb_max, npart_max, slot_stride, S;
-};
-struct st_chain_dbg { unsigned long long * stamps; };      // diagnostic builds (-DMI_STAMPS): [phase][workgroup][wave][8]
-
 // LDS-DMA, 1 KiB per instruction: lane l's 16 bytes at gbase + OFF + 16*l -> LDS M0 + OFF + 16*l (the instruction's offset field advances
 // BOTH addresses). gbase and the LDS address are wave-uniform (scalar registers), voff = 16*lane: nothing per piece is vector work — a
 // loader that did 64-bit vector address arithmetic per piece was instruction-bound at 13 GB/s per CU. M0 is compiler-reserved, but the
@@ -457,24 +438,6 @@ static __device__ __forceinline__ float st_row_sum(const float * part, int row, 
     return s;
 }
 
-// ---- loads / stores of bytes another workgroup of the SAME launch wrote or will read (CHAIN): sc1 = served by / written through to L2 and
-// beyond, never this CU's L1. Raw buffer instructions so that the compiler keeps counting them (aux 16 = sc1). ----
-typedef __attribute__((ext_vector_type(4))) unsigned int st_u4;
-static __device__ __forceinline__ __amdgpu_buffer_rsrc_t st_rsrc(const void * base) {
-    return __builtin_amdgcn_make_buffer_rsrc((void *) base, 0, 0x7FFFFFFF, 0x00020000);
-}
-template <bool CHAIN> static __device__ __forceinline__ float4v st_ldx4(const float * base, int elem) {
-    if (CHAIN) { const st_u4 v = __builtin_amdgcn_raw_buffer_load_b128(st_rsrc(base), elem*4, 0, 16); return __builtin_bit_cast(float4v, v); }
-    return *(const float4v *) (base + elem);
-}
-template <bool CHAIN> static __device__ __forceinline__ float st_ldx1(const float * base, int elem) {
-    if (CHAIN) return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(st_rsrc(base), elem*4, 0, 16));
-    return base[elem];
-}
-template <bool CHAIN> static __device__ __forceinline__ void st_stx1(float * base, int elem, float v) {
-    if (CHAIN) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), st_rsrc(base), elem*4, 0, 16);
-    else base[elem] = v;
-}
 
 // where a workgroup's LDS regions are
 struct st_lds {
@@ -608,7 +571,7 @@ static __device__ __forceinline__ void st_prologue_q8(const st_args & p, const s
 // the dependent chains of the wave-wide maxima and sums interleave — chunk after chunk behind a branch each cost ~0.5 us per chunk
 // IMG: 0 = Q8_K blocks (K-quant weights); 1 = the workgroup's weights are Q8_0 in 256-weight units — the image is the CPU path's Q8_0 instead (32-element
 // blocks, f16-rounded scales: quant_core.h); 2 = the same Q8_0 activation for the ten-block units (k % 256 != 0: the last 256-piece is partial)
-template <int NA, bool CHAIN, bool FIRST, int IMG>
+template <int NA, bool FIRST, int IMG>
 static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const st_lds & L, int x_off, int seq, int & n_norm, int lane, int wave) {
     constexpr bool Q80 = IMG != 0;
     const int nchunk = p.nchunk;
@@ -618,10 +581,10 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
     for (int i = 0; i < NA; i++) {
         const int c = min(wave + ST_NC*i, nchunk - 1);
         const bool in_k = IMG < 2 || c*256 + lane*4 < p.k;
-        xv[i] = in_k && p.x ? st_ldx4<CHAIN>(p.x, x_off + c*256 + lane*4) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
+        xv[i] = in_k && p.x ? *(const float4v *) (p.x + x_off + c*256 + lane*4) : float4v{ 0.0f, 0.0f, 0.0f, 0.0f };
         wv[i] = norm && in_k ? *(const float4v *) (p.norm_w + (size_t) c*256 + lane*4) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
     }
-    if constexpr (NA <= 2 && !CHAIN) {
+    if constexpr (NA <= 2) {
         if (p.planes) {
             float4v pv[NA][8];
 #pragma unroll
@@ -633,7 +596,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
             }
             // the planes' weights (MoE combine): every thread derives the same few numbers — probs[ids[u]], then the normalisation of k_moe_combine (elem.hip)
             float w[8];
-            if (p.pl_probs) {
+            {
                 float pr[8];
 #pragma unroll
                 for (int u = 0; u < 8; u++) pr[u] = u < p.n_planes ? p.pl_probs[p.pl_ids[u]] : 0.0f;
@@ -658,16 +621,13 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
             if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #pragma unroll
             for (int i = 0; i < NA; i++) {
-                if (p.pl_probs) {
+                {
                     float4v acc = pv[i][0];
                     acc.x *= w[0]; acc.y *= w[0]; acc.z *= w[0]; acc.w *= w[0];
 #pragma unroll
                     for (int pl = 1; pl < 8; pl++) if (pl < p.n_planes) { acc.x += pv[i][pl].x*w[pl]; acc.y += pv[i][pl].y*w[pl]; acc.z += pv[i][pl].z*w[pl]; acc.w += pv[i][pl].w*w[pl]; }
                     if (p.x) { acc.x += xv[i].x; acc.y += xv[i].y; acc.z += xv[i].z; acc.w += xv[i].w; }
                     xv[i] = acc;
-                } else {
-#pragma unroll
-                    for (int pl = 0; pl < 8; pl++) if (pl < p.n_planes) { xv[i].x += pv[i][pl].x; xv[i].y += pv[i][pl].y; xv[i].z += pv[i][pl].z; xv[i].w += pv[i][pl].w; }
                 }
                 const int c = wave + ST_NC*i;
                 if (blockIdx.x == 0 && c < nchunk && (IMG < 2 || c*256 + lane*4 < p.k)) *(float4v *) (p.x_out + (size_t) c*256 + lane*4) = xv[i];
@@ -746,7 +706,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
 // ================= the consumers' share of one phase =================
 //   seq: how many phases this workgroup has run before (its LDS counters are cumulative); FIRST: the launch's first phase — the activation
 //   loads are queued before the loader starts (the barrier every wave of the workgroup takes exactly once)
-template <int TYPE, bool CHAIN, bool FIRST>
+template <int TYPE, bool FIRST>
 static __device__ __forceinline__ void st_consumer_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, int seq, int & n_norm,
                                                          int lane, int wave, unsigned long long * stamps) {
     typedef st_unit<TYPE> U;
@@ -764,10 +724,10 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
     const int mode = p.mode;
     constexpr int ST_IMG = TYPE == ST_MXFP4_B10 ? 3 : TYPE == ST_Q8_0_B10 ? 2 : (TYPE == T_Q8_0 || TYPE == T_Q4_0) ? 1 : 0;
     if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
-    else if (p.nchunk <= 8)   st_prologue_f32<1, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else if (p.nchunk <= 16)  st_prologue_f32<2, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else if (p.nchunk <= 32)  st_prologue_f32<4, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else                st_prologue_f32<8, CHAIN, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (p.nchunk <= 8)   st_prologue_f32<1, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (p.nchunk <= 16)  st_prologue_f32<2, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (p.nchunk <= 32)  st_prologue_f32<4, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else                st_prologue_f32<8, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
     ST_STAMP(1);
     st_consumers_meet(&sync[2], lane, seq);
     ST_STAMP(2);
@@ -790,7 +750,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
         }
     } else if (ctid < R) {
         const int row = r0 + ctid;
-        if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, e_tab + row); if (g.res2) e_q0 = st_ldx1<CHAIN>(g.res2, row); }
+        if (g.epi == EPI_ADD) { e_r0 = g.res[e_tab + row]; if (g.res2) e_q0 = g.res2[row]; }
         if (g.epi == EPI_GLU && g.b_gate) { e_r0 = g.b_gate[e_tab + row]; e_q0 = g.b_up[e_tab + row]; }
         if (g.st_mode == 2) e_i0 = g.st_idx[row];
     }
@@ -845,7 +805,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
             float s0 = st_row_sum(part, ra, npr), s1 = st_row_sum(part, rb, npr);
             if (g.res) { s0 += e_r0; s1 += e_r1; }              // bias first, then the rotation
             if (ip < half) { const float a = s0, b = s1; s0 = a*e_c - b*e_s; s1 = a*e_s + b*e_c; }
-            st_stx1<CHAIN>(g.dst, r0 + ra, s0); st_stx1<CHAIN>(g.dst, r0 + rb, s1);
+            g.dst[r0 + ra] = s0; g.dst[r0 + rb] = s1;
             if (g.st_mode == 1) { uint16_t * q = g.st16 + idx0*g.st_row_elems; q[r0 + ra] = f32_to_f16_bits(s0); q[r0 + rb] = f32_to_f16_bits(s1); }
             else if (g.st_mode == 2) { g.st16[e_i0] = f32_to_f16_bits(s0); g.st16[e_i1] = f32_to_f16_bits(s1); }
         }
@@ -854,7 +814,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
             float s0 = st_row_sum(part, rr, npr);
             const int row = r0 + rr;
             if (rr != ctid) {
-                if (g.epi == EPI_ADD) { e_r0 = st_ldx1<CHAIN>(g.res, e_tab + row); e_q0 = g.res2 ? st_ldx1<CHAIN>(g.res2, row) : 0.0f; }
+                if (g.epi == EPI_ADD) { e_r0 = g.res[e_tab + row]; e_q0 = g.res2 ? g.res2[row] : 0.0f; }
                 if (g.epi == EPI_GLU && g.b_gate) { e_r0 = g.b_gate[e_tab + row]; e_q0 = g.b_up[e_tab + row]; }
                 if (g.st_mode == 2) e_i0 = g.st_idx[row];
             }
@@ -871,7 +831,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
                 s0 += e_r0;
                 if (g.res2) s0 += e_q0;
             }
-            st_stx1<CHAIN>(g.dst, row, s0);
+            g.dst[row] = s0;
             if (g.st_mode == 1) g.st16[idx0*g.st_row_elems + row] = f32_to_f16_bits(s0);
             else if (g.st_mode == 2) g.st16[e_i0] = f32_to_f16_bits(s0);
         }
@@ -933,82 +893,8 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) 
         return;
     }
     int n_norm = 0;
-    if (is_a) st_consumer_phase<TA, false, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
-    else      st_consumer_phase<TB, false, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
-}
-
-// ---- a chain of grouped launches as one launch ----
-template <bool NT>
-__global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_chain(const st_phase * __restrict__ prog, const int n_phases, unsigned * ws, unsigned * err, const st_chain_cfg cfg, const st_chain_dbg dbg) {
-    extern __shared__ __attribute__((aligned(16))) char lds[];
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int b = blockIdx.x;
-    const st_lds L = st_carve(lds, cfg.nb_max, cfg.npart_max, cfg.slot_stride, cfg.S);
-    unsigned long long * stamps = dbg.stamps; (void) stamps;
-    ST_STAMP(0);
-    if (threadIdx.x < ST_SYNC_WORDS) L.sync[threadIdx.x] = 0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();            // (the chain's first phase queues its activation loads behind this barrier: one barrier per wave, and the loader must not wait for consumers)
-    int slot0 = 0;
-    if (wave == ST_NC) {
-        st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        for (int ph = 0; ph < n_phases; ph++) {
-            const st_phase & P = prog[ph];
-            if (b >= P.n_active) continue;
-            int first, nwg;
-            const int gi = st_group_of(P.a, b, first, nwg);
-            const st_group & g = P.a.g[gi];
-            const int wg = b - first;
-            if (g.type == T_Q4_K)      st_loader_phase<T_Q4_K, NT>(P.a, g, wg, nwg, L, slot0, ls, lane);
-            else if (g.type == T_Q5_K) st_loader_phase<T_Q5_K, NT>(P.a, g, wg, nwg, L, slot0, ls, lane);
-            else                       st_loader_phase<T_Q6_K, NT>(P.a, g, wg, nwg, L, slot0, ls, lane);
-            slot0 += st_phase_slots(P.a, g, wg, nwg);
-#ifdef MI_STAMPS
-            if (dbg.stamps) { stamps = dbg.stamps + (size_t) ph*256*(ST_NC + 1)*8; ST_STAMP(1); }      // this phase's slots are all issued
-#endif
-        }
-        st_loader_drain(L, slot0, ls, lane);
-        return;
-    }
-    int seq = 0, n_norm = 0;
-    for (int ph = 0; ph < n_phases; ph++) {
-        const st_phase & P = prog[ph];
-        if (b >= P.n_active) continue;
-        int first, nwg;
-        const int gi = st_group_of(P.a, b, first, nwg);
-        const st_group & g = P.a.g[gi];
-        const int wg = b - first;
-#ifdef MI_STAMPS
-        if (dbg.stamps) stamps = dbg.stamps + (size_t) ph*256*(ST_NC + 1)*8;
-        if (ph > 0) ST_STAMP(0);
-#endif
-        // ---- the inputs of this phase exist once every workgroup of the phase that makes them has arrived ----
-        if (P.wait_idx >= 0) {
-            if (wave == 0) {
-                bool ok = false;
-                const unsigned * wp = ws + (size_t) P.wait_idx*ST_WS_WORDS + (lane & 7)*64;
-                for (int spin = 0; spin < (1 << 22); spin++) {
-                    unsigned v = lane < 8 ? __hip_atomic_load(wp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-                    v += dpp_i<0xB1>((int) v); v += dpp_i<0x4E>((int) v); v += dpp_i<0x141>((int) v);      // lanes 0..7 = half a DPP row
-                    if ((unsigned) __builtin_amdgcn_readfirstlane((int) v) >= P.wait_target) { ok = true; break; }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-                if (!ok && lane == 0) __hip_atomic_store(err, 0x57000000u | (unsigned) ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);      // gave up: the results are wrong, the host is told
-                asm volatile("" ::: "memory");
-                if (lane == 0) st_flag_st(&L.sync[5], (uint32_t)(seq + 1));
-            } else st_wait_ge(&L.sync[5], (uint32_t)(seq + 1));
-        }
-        if (g.type == T_Q4_K)      st_consumer_phase<T_Q4_K, true, false>(P.a, g, wg, nwg, L, slot0, seq, n_norm, lane, wave, stamps);
-        else if (g.type == T_Q5_K) st_consumer_phase<T_Q5_K, true, false>(P.a, g, wg, nwg, L, slot0, seq, n_norm, lane, wave, stamps);
-        else                       st_consumer_phase<T_Q6_K, true, false>(P.a, g, wg, nwg, L, slot0, seq, n_norm, lane, wave, stamps);
-        slot0 += st_phase_slots(P.a, g, wg, nwg);
-        // ---- this workgroup's rows are stored: drain, meet (which also frees the image and the partials for the next phase), arrive ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        st_consumers_meet(&L.sync[3], lane, 2*seq + 1);
-        ST_STAMP(7);
-        if (P.sig_idx >= 0 && threadIdx.x == 0) __hip_atomic_fetch_add(ws + (size_t) P.sig_idx*ST_WS_WORDS + (b & 7)*64, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        seq++;
-    }
+    if (is_a) st_consumer_phase<TA, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
+    else      st_consumer_phase<TB, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
 }
 
 } // namespace mi355x

@@ -12,19 +12,13 @@
 
 namespace mi355x {
 
-template <int TA, int TB, bool GLU> static void st_launch_t(const st_args & a, int blocks, size_t lds, bool nt, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, const char ** kname) {
-    static char name_nt[64] = "", name_pl[64] = "";
-    if (!name_nt[0]) { snprintf(name_nt, sizeof(name_nt), "k_mmvq_stream<%d, %d, true, %s>", TA, TB, GLU ? "true" : "false"); snprintf(name_pl, sizeof(name_pl), "k_mmvq_stream<%d, %d, false, %s>", TA, TB, GLU ? "true" : "false"); }
-    *kname = nt ? name_nt : name_pl;
+template <int TA, int TB, bool GLU> static void st_launch_t(const st_args & a, int blocks, size_t lds, hipStream_t stream, hipEvent_t e0, hipEvent_t e1, const char ** kname) {
+    static char name[64] = "";
+    if (!name[0]) snprintf(name, sizeof(name), "k_mmvq_stream<%d, %d, true, %s>", TA, TB, GLU ? "true" : "false");
+    *kname = name;
     MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, true, GLU>);
-    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_stream<TA, TB, false, GLU>);
-    if (e0) {
-        if (nt) hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, true, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
-        else    hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, false, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
-    } else {
-        if (nt) hipLaunchKernelGGL((k_mmvq_stream<TA, TB, true, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
-        else    hipLaunchKernelGGL((k_mmvq_stream<TA, TB, false, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
-    }
+    if (e0) hipExtLaunchKernelGGL((k_mmvq_stream<TA, TB, true, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, e0, e1, 0, a);
+    else    hipLaunchKernelGGL((k_mmvq_stream<TA, TB, true, GLU>), dim3((unsigned) blocks), dim3(ST_THREADS), lds, stream, a);
 }
 
 static int st_unit_bytes(int type) { return type == T_Q4_K ? 144 : type == T_Q5_K ? 176 : type == T_Q6_K ? 210 : type == T_Q8_0 ? 272 : type == T_Q4_0 ? 144 : type == ST_Q8_0_B10 ? 340 : type == ST_MXFP4_B10 ? 170 : 0; }
@@ -87,7 +81,7 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     if (in.mode == PRO_Q8) { if (((uintptr_t) in.act.qs % 16) || ((uintptr_t) in.act.bsums % 16) || !in.act.d) return false; }
     else { if ((!in.x && !(in.planes && in.pl_probs)) || ((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
     const int64_t nb = b10 ? k/320 : k/256;
-    if (in.planes && (in.mode != PRO_NORM || (k + 255)/256 > 16 || (in.pl_probs && !in.pl_ids) || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
+    if (in.planes && (in.mode != PRO_NORM || (k + 255)/256 > 16 || !in.pl_probs || !in.pl_ids || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
     int ta = -1, tb = -1;
     for (int i = 0; i < n_groups; i++) {
         const mmvq_group & g = groups[i];
@@ -184,8 +178,8 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
 
 void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, hipStream_t stream,
                           hipEvent_t e0, hipEvent_t e1, const char ** kname) {
-    static int nt_env = -1, ring_env = -1;
-    if (nt_env < 0) { const char * e = getenv("GGML_MI355X_STREAM_NT"); nt_env = e ? atoi(e) : 1; const char * r = getenv("GGML_MI355X_STREAM_RING"); ring_env = r ? atoi(r) : 0; }
+    static int ring_env = -1;
+    if (ring_env < 0) { const char * r = getenv("GGML_MI355X_STREAM_RING"); ring_env = r ? atoi(r) : 0; }
     st_args a; size_t fixed_max; int slot_max, nslots_max, npart_max, ta, tb; double bytes_total;
     const int blocks = st_fill(groups, n_groups, k, in, rope, a, fixed_max, slot_max, nslots_max, npart_max, ta, tb, bytes_total);
     int S = (int)((163840 - (int64_t) fixed_max)/slot_max);
@@ -205,74 +199,20 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
         g_st_next++;
     }
 #endif
-    const bool nt = nt_env != 0;
     const bool glu = n_groups == 1 && groups[0].epi == EPI_GLU;
-    if (ta == T_Q4_K && tb == T_Q4_K)      { if (glu) st_launch_t<T_Q4_K, T_Q4_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q4_K, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
-    else if (ta == T_Q5_K && tb == T_Q5_K) { if (glu) st_launch_t<T_Q5_K, T_Q5_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q5_K, T_Q5_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
-    else if (ta == T_Q6_K && tb == T_Q6_K) { if (glu) st_launch_t<T_Q6_K, T_Q6_K, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q6_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
-    else if (ta == ST_Q8_0_B10)  { if (glu) st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
-    else if (ta == ST_MXFP4_B10) { if (glu) st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
-    else if (ta == T_Q4_0 && tb == T_Q4_0) { if (glu) st_launch_t<T_Q4_0, T_Q4_0, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q4_0, T_Q4_0, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
-    else if (ta == T_Q8_0 && tb == T_Q8_0) { if (glu) st_launch_t<T_Q8_0, T_Q8_0, true>(a, blocks, lds, nt, stream, e0, e1, kname); else st_launch_t<T_Q8_0, T_Q8_0, false>(a, blocks, lds, nt, stream, e0, e1, kname); }
-    else if (ta == T_Q8_0 && tb == T_Q4_K) st_launch_t<T_Q8_0, T_Q4_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q8_0 && tb == T_Q6_K) st_launch_t<T_Q8_0, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q4_K && tb == T_Q5_K) st_launch_t<T_Q4_K, T_Q5_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q4_K && tb == T_Q6_K) st_launch_t<T_Q4_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
-    else if (ta == T_Q5_K && tb == T_Q6_K) st_launch_t<T_Q5_K, T_Q6_K, false>(a, blocks, lds, nt, stream, e0, e1, kname);
+    if (ta == T_Q4_K && tb == T_Q4_K)      { if (glu) st_launch_t<T_Q4_K, T_Q4_K, true>(a, blocks, lds, stream, e0, e1, kname); else st_launch_t<T_Q4_K, T_Q4_K, false>(a, blocks, lds, stream, e0, e1, kname); }
+    else if (ta == T_Q5_K && tb == T_Q5_K) { if (glu) st_launch_t<T_Q5_K, T_Q5_K, true>(a, blocks, lds, stream, e0, e1, kname); else st_launch_t<T_Q5_K, T_Q5_K, false>(a, blocks, lds, stream, e0, e1, kname); }
+    else if (ta == T_Q6_K && tb == T_Q6_K) { if (glu) st_launch_t<T_Q6_K, T_Q6_K, true>(a, blocks, lds, stream, e0, e1, kname); else st_launch_t<T_Q6_K, T_Q6_K, false>(a, blocks, lds, stream, e0, e1, kname); }
+    else if (ta == ST_Q8_0_B10)  { if (glu) st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, true>(a, blocks, lds, stream, e0, e1, kname); else st_launch_t<ST_Q8_0_B10, ST_Q8_0_B10, false>(a, blocks, lds, stream, e0, e1, kname); }
+    else if (ta == ST_MXFP4_B10) { if (glu) st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, true>(a, blocks, lds, stream, e0, e1, kname); else st_launch_t<ST_MXFP4_B10, ST_MXFP4_B10, false>(a, blocks, lds, stream, e0, e1, kname); }
+    else if (ta == T_Q4_0 && tb == T_Q4_0) { if (glu) st_launch_t<T_Q4_0, T_Q4_0, true>(a, blocks, lds, stream, e0, e1, kname); else st_launch_t<T_Q4_0, T_Q4_0, false>(a, blocks, lds, stream, e0, e1, kname); }
+    else if (ta == T_Q8_0 && tb == T_Q8_0) { if (glu) st_launch_t<T_Q8_0, T_Q8_0, true>(a, blocks, lds, stream, e0, e1, kname); else st_launch_t<T_Q8_0, T_Q8_0, false>(a, blocks, lds, stream, e0, e1, kname); }
+    else if (ta == T_Q8_0 && tb == T_Q4_K) st_launch_t<T_Q8_0, T_Q4_K, false>(a, blocks, lds, stream, e0, e1, kname);
+    else if (ta == T_Q8_0 && tb == T_Q6_K) st_launch_t<T_Q8_0, T_Q6_K, false>(a, blocks, lds, stream, e0, e1, kname);
+    else if (ta == T_Q4_K && tb == T_Q5_K) st_launch_t<T_Q4_K, T_Q5_K, false>(a, blocks, lds, stream, e0, e1, kname);
+    else if (ta == T_Q4_K && tb == T_Q6_K) st_launch_t<T_Q4_K, T_Q6_K, false>(a, blocks, lds, stream, e0, e1, kname);
+    else if (ta == T_Q5_K && tb == T_Q6_K) st_launch_t<T_Q5_K, T_Q6_K, false>(a, blocks, lds, stream, e0, e1, kname);
     else { fprintf(stderr, "mul_mat_vec_q_stream: type pair (%d, %d) has no kernel\n", ta, tb); abort(); }
-}
-
-// ---- chains (k_mmvq_chain) ----
-size_t mul_mat_vec_q_chain_phase_bytes(void) { return sizeof(st_phase); }
-int    mul_mat_vec_q_chain_ws_words(int n_phases) { return n_phases*ST_WS_WORDS; }
-
-// builds the phase table of `n` consecutive grouped launches (each one mul_mat_vec_q_stream_takes) into prog_host; false: they do not fit one launch
-bool mul_mat_vec_q_chain_build(const mmvq_chain_item * items, int n, void * prog_host, mmvq_chain_launch * out) {
-    st_phase * prog = (st_phase *) prog_host;
-    st_chain_cfg cfg = { 0, 0, 0, 0 };
-    int nslots_sum = 0, blocks_max = 0; uint64_t wbytes = 0;
-    for (int j = 0; j < n; j++) {
-        const mmvq_chain_item & it = items[j];
-        size_t fixed; int slot, nslots, npart, ta, tb; double bytes;
-        st_phase & P = prog[j];
-        const int blocks = st_fill(it.grp, it.n_groups, it.k, it.in, it.has_rope ? &it.rope : nullptr, P.a, fixed, slot, nslots, npart, ta, tb, bytes);
-        if (ta == T_Q8_0 || tb == T_Q8_0 || ta == T_Q4_0 || tb == T_Q4_0 || it.k % 256 != 0) return false;      // (the chain kernel instantiates the K-quant units only)
-        P.a.stamps = nullptr;
-        P.n_active = blocks;
-        P.wait_idx = j > 0 ? j - 1 : -1; P.wait_target = j > 0 ? (unsigned) prog[j - 1].n_active : 0;
-        P.sig_idx = j + 1 < n ? j : -1;
-        cfg.nb_max = std::max(cfg.nb_max, P.a.nb); cfg.npart_max = std::max(cfg.npart_max, npart); cfg.slot_stride = std::max(cfg.slot_stride, slot);
-        nslots_sum += nslots; blocks_max = std::max(blocks_max, blocks); wbytes += (uint64_t) bytes;
-    }
-    const size_t fixed = 2*ST_SYNC_WORDS*4 + (size_t) cfg.nb_max*ST_ACT_STRIDE + (size_t)((cfg.nb_max + 3) & ~3)*4 + 64 + (size_t) cfg.npart_max*4 + 16;
-    int S = (int)((163840 - (int64_t) fixed)/cfg.slot_stride);
-    if (S > nslots_sum) S = nslots_sum;
-    if (S > ST_MAX_RING) S = ST_MAX_RING;
-    if (S < (nslots_sum < 4 ? nslots_sum : 4)) return false;
-    cfg.S = S;
-    static_assert(sizeof(st_chain_cfg) == sizeof(out->cfg), "mmvq_chain_launch::cfg holds an st_chain_cfg");
-    memcpy(out->cfg, &cfg, sizeof(cfg));
-    out->n_phases = n; out->blocks = blocks_max; out->lds = fixed + (size_t) S*cfg.slot_stride; out->weight_bytes = wbytes;
-    return true;
-}
-
-void mul_mat_vec_q_chain_launch(const void * prog_dev, const mmvq_chain_launch & Lc, unsigned * ws, unsigned * err_dev, hipStream_t stream) {
-    static int nt_env = -1;
-    if (nt_env < 0) { const char * e = getenv("GGML_MI355X_STREAM_NT"); nt_env = e ? atoi(e) : 1; }
-    st_chain_cfg cfg; memcpy(&cfg, Lc.cfg, sizeof(cfg));
-    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_chain<true>);
-    MI_LDS_LIMIT_OR_DIE(163840, k_mmvq_chain<false>);
-    st_chain_dbg dbg = { nullptr };
-#ifdef MI_STAMPS
-    // each chained launch takes n_phases consecutive stamp slots (one per phase, [workgroup][wave][8] like the single launches)
-    if (g_st_stamps && g_st_next + Lc.n_phases <= g_st_slots && Lc.blocks <= 256) {
-        dbg.stamps = g_st_stamps + (size_t) g_st_next*256*(ST_NC + 1)*8;
-        for (int j = 0; j < Lc.n_phases; j++) { st_stamp_meta & sm = g_st_meta[g_st_next + j]; sm = st_stamp_meta{}; sm.blocks = Lc.blocks; sm.k = -1 - j; sm.mode = Lc.n_phases; }
-        g_st_next += Lc.n_phases;
-    }
-#endif
-    if (nt_env) hipLaunchKernelGGL((k_mmvq_chain<true>), dim3((unsigned) Lc.blocks), dim3(ST_THREADS), Lc.lds, stream, (const st_phase *) prog_dev, Lc.n_phases, ws, err_dev, cfg, dbg);
-    else        hipLaunchKernelGGL((k_mmvq_chain<false>), dim3((unsigned) Lc.blocks), dim3(ST_THREADS), Lc.lds, stream, (const st_phase *) prog_dev, Lc.n_phases, ws, err_dev, cfg, dbg);
 }
 
 } // namespace mi355x

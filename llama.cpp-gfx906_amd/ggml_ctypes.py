@@ -92,6 +92,7 @@ MI355X_EXPORTS = [
     "ggml_backend_mi355x_buffer_type", "ggml_backend_mi355x_host_buffer_type", "ggml_backend_mi355x_get_stream",
     "ggml_backend_mi355x_get_counters", "ggml_backend_mi355x_reset_counters", "ggml_backend_mi355x_set_option",
     "ggml_backend_mi355x_get_profile", "ggml_backend_mi355x_split_buffer_type",
+    "ggml_backend_mi355x_tensor_set_from_device_async", "ggml_backend_mi355x_tensor_get_to_device_async",
 ]
 
 

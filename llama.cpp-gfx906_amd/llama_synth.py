@@ -96,6 +96,7 @@ def harness():
         L.mi_llama_kv_clear.argtypes = [C.c_void_p]
         L.mi_llama_n_result.restype = C.c_int; L.mi_llama_n_result.argtypes = [C.c_void_p]
         L.mi_llama_get_tensor.restype = gg.tensor_p; L.mi_llama_get_tensor.argtypes = [C.c_void_p, C.c_char_p]
+        L.mi_llama_last_logits.restype = C.c_void_p; L.mi_llama_last_logits.argtypes = [C.c_void_p]
         L.mi_llama_decode.restype = C.c_int
         L.mi_llama_decode.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
         L.mi_llama_synth_embedding.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
@@ -161,22 +162,26 @@ class SynthLlama:
             raise KeyError(name)
         return t
 
-    def decode(self, tokens, dev_act_in=None, dev_result_out=None, want_host=True, sync=True, n_tokens=None, seq=0):
-        """one llama_decode of len(tokens) tokens; returns the host result (logits of the last token) or None"""
+    def decode(self, tokens, dev_act_in=None, dev_result_out=None, want_host=True, sync=True, n_tokens=None, seq=0, view=False):
+        """one llama_decode of len(tokens) tokens; returns the host result (logits of the last token) or None. The result lands in the model's pinned
+        output buffer (llama_context's buf_output, src/llama-context.cpp:1260-1330): view=True returns a numpy view of it (valid until the next decode,
+        like llama_get_logits), otherwise a copy"""
         if tokens is not None:
             tok = np.ascontiguousarray(tokens, dtype=np.int32)
             n = tok.size; tp = tok.ctypes.data_as(C.c_void_p)
         else:
             n = n_tokens; tp = None
-        out = None; op = None
-        if want_host:
-            n_res = self.n_result if self.has_output else self.cfg["n_embd"] * n
-            out = np.empty(n_res, dtype=np.float32); op = out.ctypes.data_as(C.c_void_p)
-        rc = self.L.mi_llama_decode(self.m, seq, tp, n, C.c_void_p(dev_act_in) if dev_act_in else None, op,
-                                    C.c_void_p(dev_result_out) if dev_result_out else None, int(sync))
+        rc = self.L.mi_llama_decode(self.m, seq, tp, n, C.c_void_p(dev_act_in) if dev_act_in else None, None,
+                                    C.c_void_p(dev_result_out) if dev_result_out else None, int(bool(sync)) | (0 if want_host else 2))
         if rc != 0:
             raise RuntimeError(f"mi_llama_decode returned {rc}")
-        return out
+        if not want_host or dev_result_out:
+            return None
+        n_res = self.L.mi_llama_n_result(self.m)
+        out = np.ctypeslib.as_array(C.cast(self.L.mi_llama_last_logits(self.m), C.POINTER(C.c_float)), shape=(n_res,))
+        if not sync:
+            return out if view else None        # (not complete before the caller synchronizes)
+        return out if view else out.copy()
 
     def embedding(self, token):
         out = np.empty(self.cfg["n_embd"], dtype=np.float32)

@@ -507,12 +507,11 @@ def test_two_backends_from_two_threads():
         assert np.array_equal(single[i], multi[i])
 
 
-@pytest.mark.parametrize("env,value", [("GGML_MI355X_CHAIN", "1"), ("GGML_MI355X_STREAM", "0"), ("GGML_MI355X_ATTN_WO", "1")])
+@pytest.mark.parametrize("env,value", [("GGML_MI355X_STREAM", "0"), ("GGML_MI355X_GRAPH_SEG0", "0"), ("GGML_MI355X_UPLOAD_BATCH", "0")])
 def test_other_decode_arrangements_stay_correct(env, value):
-    """The decode arrangements that are not the default read their switch once per process: consecutive grouped mat-vecs as phases of one persistent launch (GGML_MI355X_CHAIN=1: hand-offs inside the kernel, measured slower in round 3), round 2's register-ring mat-vec
-    kernels instead of the streamed ones (GGML_MI355X_STREAM=0), and attention + wo as one k-sliced launch whose partial planes the next launch's prologue adds up
-    (GGML_MI355X_ATTN_WO=1, csrc/attn_wo.hip: head size 128 — the 8B-width and tiny-hd128 cases; measured slower in round 3) — the oracle comparisons of this file again, in a
-    child process with the switch set."""
+    """The arrangements that are not the default read their switch once per process: round 2's register-ring mat-vec kernels instead of the streamed ones
+    (GGML_MI355X_STREAM=0), a captured graph as ONE executable graph instead of segments (GGML_MI355X_GRAPH_SEG0=0), one copy per set_tensor_async instead of
+    the batched upload launch (GGML_MI355X_UPLOAD_BATCH=0) — the oracle comparisons of this file again, in a child process with the switch set."""
     import os
     import subprocess
     import sys
@@ -521,8 +520,7 @@ def test_other_decode_arrangements_stay_correct(env, value):
     child_env = dict(os.environ, MI_NESTED_PYTEST="1")
     child_env[env] = value
     r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-m", "gpu", "-q", "-x", "-p", "no:cacheprovider", "-k",
-                        "test_synthetic_llama_matches_oracle or test_graph_replay_is_bitwise_neutral or test_kv_clear_restarts_sequence or test_flash_attention_graph"
-                        + (" or test_llama3_8b_full_width_layers_match_oracle or test_neox_rope_folded or test_synthetic_moe_matches_oracle" if env == "GGML_MI355X_ATTN_WO" else "")],
+                        "test_synthetic_llama_matches_oracle or test_graph_replay_is_bitwise_neutral or test_kv_clear_restarts_sequence or test_flash_attention_graph"],
                        env=child_env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]

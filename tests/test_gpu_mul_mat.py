@@ -208,18 +208,3 @@ def test_streamed_column_kernel_forced_for_q6_k():
                         "-k", "test_mul_mat_model_shapes and q6_K"], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert " passed" in r.stdout and "failed" not in r.stdout, r.stdout[-500:]
-
-
-def test_int8_matrix_core_prefill_kernel_opt_in():
-    """csrc/mmq_i8.hip (Q4_K x Q8_K activations on v_mfma_i32_32x32x32_i8; opt-in while it is slower than the bf16 kernel — DESIGN.md): its 8-wave and 4-wave forms
-    against the oracle's CPU-style product, whose integer arithmetic they restate (NMSE <= 1e-6 where the bf16 kernel is held to 5e-4). In a child
-    process: the switch is read once per process."""
-    import os
-    import subprocess
-    import sys
-    from pathlib import Path
-    root = Path(__file__).resolve().parent.parent
-    for waves in ("8", "4"):
-        env = dict(os.environ, GGML_MI355X_MMQ_I8="1", GGML_MI355X_MMQ_I8_WAVES=waves)
-        r = subprocess.run([sys.executable, str(root / "tools" / "i8_check.py")], env=env, capture_output=True, text=True, timeout=600)
-        assert r.returncode == 0 and "I8 OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -2,7 +2,8 @@
 
 Needs the diagnostic build:  MI355X_BUILD_VARIANT=stamps MI_EXTRA_HIPFLAGS=-DMI_STAMPS python llama.cpp-gfx906_amd/build.py
 and MI355X_BUILD_VARIANT=stamps when running. Every wave stamps (100 MHz clock common to all CUs): 0 entry; consumers: 1 activation loads
-queued + first barrier passed, 2 image ready, 3 first slot landed, 4 last slot computed, 5 all consumers done, 6 exit; loader: 1 everything landed."""
+queued + first barrier passed, 2 image ready, 3 first slot landed, 4 last slot computed, 5 all consumers done, 6 exit; loader: 1 everything landed, 2 the next
+launch's prefetch issued and returned (= the loader wave's exit)."""
 import ctypes as C
 import json
 import os
@@ -39,40 +40,23 @@ for s in range(used):
 sig = [mm[0] for mm in metas]
 period = next(p for p in range(1, used + 1) if used % p == 0 and all(sig[i] == sig[i % p] for i in range(used)))
 last = metas[used - period:]
-if any(mm[0][1] < 0 for mm in last):
-    # chained launches: a slot per phase; stamps 0 phase start, 1 (consumers) loads queued / (loader) phase's slots all issued, 2 image ready,
-    # 3 first slot landed, 4 last slot computed, 5 consumers met, 6 rows stored, 7 stores drained + met (the arrival at the phase's counter follows)
-    t_base = min(int(st[:, :, :][st[:, :, :] > 0].min()) for _, _, st in last)
-    print(f"period {period} phases/token (chained)")
-    print(" idx ph/n | start med/max | x back+queued | image | 1st slot | loader issued | last slot | met | stored | drained  (us after the phase's first start; med/max over waves)")
-    prev = None
-    for i, ((blocks, k, rws, ta, tb, mode, glu), nb, st) in enumerate(last[:16] + last[-5:]):
-        t = (st.astype(np.int64) - t_base) / 100.0
-        t[st == 0] = np.nan
-        cons = t[:, :8, :]; load = t[:, 8, :]
-        t0 = np.nanmin(cons[:, :, 0])
-        def mm(a): return f"{np.nanmedian(a) - t0:5.2f} {np.nanmax(a) - t0:5.2f}"
-        print(f"{i:3d} {-1-k:2d}/{mode:<2d} | abs {t0:8.2f} {'' if prev is None else '(+%.2f)' % (t0 - prev):>8s} | {mm(cons[:, :, 0])} | {mm(cons[:, :, 1])} | {mm(cons[:, :, 2])} | {mm(cons[:, :, 3])} | {mm(load[:, 1])} | {mm(cons[:, :, 4])} | {mm(cons[:, :, 5])} | {mm(cons[:, :, 6])} | {mm(cons[:, :, 7])}")
-        prev = t0
-    m.free()
-    sys.exit(0)
 t_base = min(int(st[:, :, 0][st[:, :, 0] > 0].min()) for _, _, st in last)
 names = ["entry", "loads queued", "image ready", "first slot", "last slot done", "consumers met", "exit"]
 print(f"period {period} stream launches/token")
-print(" idx   MB   wgs  mode glu | gap | entry med/max | image med/max | 1st slot med/max | loader landed med/max | last slot med/max | exit med/max | dur | TB/s")
+print(" idx   MB   wgs  mode glu | gap | entry med/max | image med/max | 1st slot med/max | loader landed med/max | prefetch done med/max | last slot med/max | exit med/max | dur (incl. loader exit) | TB/s")
 prev_end = None; tl = []
 for i, ((blocks, k, rws, ta, tb, mode, glu), nb, st) in enumerate(last):
     t = (st.astype(np.int64) - t_base) / 100.0
     t[st == 0] = np.nan
     cons = t[:, :8, :]; load = t[:, 8, :]
-    t0 = np.nanmin(t[:, :, 0]); tend = np.nanmax(cons[:, :, 6])
+    t0 = np.nanmin(t[:, :, 0]); tend = max(np.nanmax(cons[:, :, 6]), np.nanmax(load[:, 2]) if np.isfinite(load[:, 2]).any() else 0.0)
     def mm(a): return (float(np.nanmedian(a) - t0), float(np.nanmax(a) - t0))
     e = dict(idx=i, MB=nb / 1e6, wgs=blocks, mode=mode, glu=glu, types=[ta, tb], gap=None if prev_end is None else t0 - prev_end,
-             entry=mm(t[:, :, 0]), image=mm(cons[:, :, 2]), first=mm(cons[:, :, 3]), landed=mm(load[:, 1]), last=mm(cons[:, :, 4]), exit=mm(cons[:, :, 6]), dur=tend - t0)
+             entry=mm(t[:, :, 0]), image=mm(cons[:, :, 2]), first=mm(cons[:, :, 3]), landed=mm(load[:, 1]), pf=mm(load[:, 2]) if np.isfinite(load[:, 2]).any() else (float('nan'), float('nan')), last=mm(cons[:, :, 4]), exit=mm(cons[:, :, 6]), dur=tend - t0)
     prev_end = tend; tl.append(e)
     if i < 14 or i >= len(last) - 2:
         print(f"{i:3d} {e['MB']:6.2f} {blocks:4d} {mode:4d} {glu:3d} | {('%.2f' % e['gap']) if e['gap'] is not None else '   -':>5s} | {e['entry'][0]:5.2f} {e['entry'][1]:5.2f} | {e['image'][0]:5.2f} {e['image'][1]:5.2f} | "
-              f"{e['first'][0]:5.2f} {e['first'][1]:5.2f} | {e['landed'][0]:5.2f} {e['landed'][1]:5.2f} | {e['last'][0]:5.2f} {e['last'][1]:5.2f} | {e['exit'][0]:5.2f} {e['exit'][1]:5.2f} | {e['dur']:5.2f} | {e['MB'] / e['dur'] / 1e0 / 1e3 * 1e3 / 1e3:5.2f}")
+              f"{e['first'][0]:5.2f} {e['first'][1]:5.2f} | {e['landed'][0]:5.2f} {e['landed'][1]:5.2f} | {e['pf'][0]:5.2f} {e['pf'][1]:5.2f} | {e['last'][0]:5.2f} {e['last'][1]:5.2f} | {e['exit'][0]:5.2f} {e['exit'][1]:5.2f} | {e['dur']:5.2f} | {e['MB'] / e['dur'] / 1e0 / 1e3 * 1e3 / 1e3:5.2f}")
 print(f"sum of stream-launch durations {sum(e['dur'] for e in tl):.1f} us; gaps between consecutive stream launches (attention etc. inside) {sum(e['gap'] or 0 for e in tl):.1f} us; span {tl[-1]['dur'] + sum((e['gap'] or 0) + e['dur'] for e in tl[:-1]):.1f} us")
 json.dump({"model": model, "ftype": ftype, "launches": tl}, open(out, "w"))
 m.free()
