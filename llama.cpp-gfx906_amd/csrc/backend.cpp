@@ -392,6 +392,7 @@ struct mi_backend_ctx {
     // first rotated mat-vec launch comes up (and again if a launch asks for other rope parameters), read by every such launch after it
     float * rope_tab = nullptr; mmvq_rope rope_tab_key = {}; bool rope_tab_valid = false;
     static constexpr size_t FIN_IMG_BYTES = 64*1024; static constexpr int FIN_COUNTERS = 256;
+    void * cvt = nullptr; size_t cvt_size = 0;                  // the F32 copy of an F16 src1 of a quantized MUL_MAT
     void * kv16 = nullptr; size_t kv16_size = 0;                // FLASH_ATTN_EXT: dense f16 copies of a quantized / bf16 cache view, and the transposed V of the prefill kernel (kv_to_f16)
     // a MoE combine left pending (try_fused_moe_combine): the vector x_out = res + sum_u w_u * plane u does not exist until the launch that reads it (the next
     // norm + mat-vec launch, streamed kernel) has evaluated it in its prologue, or pp_flush has
@@ -490,6 +491,7 @@ static void be_free(ggml_backend_t backend) {
     if (c->attn_part) (void) hipFree(c->attn_part);
     if (c->moe_ws) (void) hipFree(c->moe_ws);
     if (c->kv16) (void) hipFree(c->kv16);
+    if (c->cvt) (void) hipFree(c->cvt);
     if (c->err_host) (void) hipHostFree(c->err_host);
     if (c->up.host) { (void) hipHostFree(c->up.host); (void) hipEventDestroy(c->up.ev[0]); (void) hipEventDestroy(c->up.ev[1]); }
     if (c->fin_img) (void) hipFree(c->fin_img);
@@ -639,9 +641,9 @@ static bool mi_supports_op(const struct ggml_tensor * op) {
             if (ggml_is_quantized(s0->type)) {
                 // quantized weights x F32 activations: the hot path
                 if (!mul_mat_vec_q_supported((int) s0->type)) return false;
-                if (s1->type != GGML_TYPE_F32) return false;
+                if (s1->type != GGML_TYPE_F32 && s1->type != GGML_TYPE_F16) return false;      // (F16 activations: converted to F32 first — tests/test-backend-ops.cpp:5715-5716)
                 if (s0->ne[0] % ggml_blck_size(s0->type) != 0) return false;
-                if (s1->nb[0] != sizeof(float)) return false;
+                if (s1->nb[0] != ggml_type_size(s1->type)) return false;
                 if (s0->nb[0] != ggml_type_size(s0->type)) return false;
                 return true;
             }
@@ -652,6 +654,8 @@ static bool mi_supports_op(const struct ggml_tensor * op) {
         }
         case GGML_OP_MUL_MAT_ID: {
             if (op->type != GGML_TYPE_F32 || s1->type != GGML_TYPE_F32) return false;
+            if (s0->type == GGML_TYPE_F16 || s0->type == GGML_TYPE_F32 || s0->type == GGML_TYPE_BF16)      // an unquantized expert stack (tests/test-backend-ops.cpp:5821-5824)
+                return op->src[2]->type == GGML_TYPE_I32 && op->nb[0] == 4;
             if (!ggml_is_quantized(s0->type) || !mul_mat_vec_q_supported((int) s0->type)) return false;
             if (s0->ne[0] % ggml_blck_size(s0->type) != 0) return false;
             if (s1->nb[0] != sizeof(float)) return false;
@@ -771,6 +775,17 @@ static constexpr int ACT_KIND_BF16 = -16;   // aq.kind of the dense bf16 copy th
 static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml_tensor * out = nullptr, const struct ggml_tensor * res = nullptr, mmq_deferred * defer = nullptr) {
     const struct ggml_tensor * a = dst->src[0];
     const struct ggml_tensor * b = dst->src[1];
+    struct ggml_tensor b32;
+    if (ggml_is_quantized(a->type) && b->type == GGML_TYPE_F16) {
+        // F16 activations (tests/test-backend-ops.cpp:5715-5716): a dense F32 copy first (the CPU backend converts src1 to the weights' vec_dot type row by row as well),
+        // then the F32 path
+        b32 = *b; b32.type = GGML_TYPE_F32; b32.data = c->cvt;
+        b32.nb[0] = 4; b32.nb[1] = (size_t) b->ne[0]*4; b32.nb[2] = b32.nb[1]*b->ne[1]; b32.nb[3] = b32.nb[2]*b->ne[2];
+        cpy(desc(b), desc(&b32), c->stream);
+        c->cnt.kernels_launched++;
+        c->aq.valid = false;
+        b = &b32;
+    }
     if (ggml_is_quantized(a->type)) {
         const int kind = act_kind_for((int) a->type);
         const int64_t K = a->ne[0], M = a->ne[1], N = b->ne[1];
@@ -884,9 +899,15 @@ static void op_mul_mat_id(mi_backend_ctx * c, struct ggml_tensor * dst) {
     const struct ggml_tensor * as  = dst->src[0];
     const struct ggml_tensor * b   = dst->src[1];
     const struct ggml_tensor * ids = dst->src[2];
-    const int kind = act_kind_for((int) as->type);
     const int64_t K = as->ne[0], M = as->ne[1];
     const int64_t n_used = ids->ne[0], n_tokens = ids->ne[1], n_b = b->ne[1];
+    if (!ggml_is_quantized(as->type)) {      // F16 / BF16 / F32 expert stack
+        mul_mat_id_dense((int) as->type, as->data, as->nb[0], as->nb[1], as->nb[2], M, K, b->data, b->nb[0], b->nb[1], b->nb[2], n_b,
+                         ids->data, ids->nb[0], ids->nb[1], n_used, n_tokens, as->ne[2], (float *) dst->data, dst->nb[1], dst->nb[2], c->stream);
+        c->cnt.kernels_launched++;
+        return;
+    }
+    const int kind = act_kind_for((int) as->type);
     // many tokens: sort the (token, slot) pairs by expert on the device and run the MFMA tile kernel per expert; the mat-vec kernel
     // below would read every expert matrix once per pair
     if (n_used*n_tokens > 4*MMVQ_MAX_N && mul_mat_q_id_supported(as->ne[2], n_used, n_tokens) && dst->nb[0] == sizeof(float)) {
@@ -2202,6 +2223,22 @@ static enum ggml_status be_graph_compute_impl(ggml_backend_t backend, struct ggm
             const size_t sz = kv_need + (kv_need >> 1);      // (the cache view grows with the context: fewer re-allocations)
             if (hipMalloc(&c->kv16, sz) != hipSuccess) { (void) hipGetLastError(); return GGML_STATUS_ALLOC_FAILED; }
             c->kv16_size = sz;
+        }
+    }
+
+    {
+        size_t cv_need = 0;
+        for (int i = 0; i < g->n_nodes; i++) {
+            const struct ggml_tensor * nd = g->nodes[i];
+            if (nd->op == GGML_OP_MUL_MAT && ggml_is_quantized(nd->src[0]->type) && nd->src[1]->type == GGML_TYPE_F16) cv_need = std::max(cv_need, (size_t) ggml_nelements(nd->src[1])*4 + 256);
+        }
+        if (cv_need > c->cvt_size) {
+            MI_CHECK_G(hipStreamSynchronize(c->stream));
+            if (c->cvt) MI_CHECK_G(hipFree(c->cvt));
+            c->cvt = nullptr; c->cvt_size = 0;
+            drop_graphs(c);
+            if (hipMalloc(&c->cvt, cv_need) != hipSuccess) { (void) hipGetLastError(); return GGML_STATUS_ALLOC_FAILED; }
+            c->cvt_size = cv_need;
         }
     }
 

@@ -109,6 +109,9 @@ struct mm_dense_args {
     float * dst; size_t nb1, nb2, nb3;
 };
 void mul_mat_dense(const mm_dense_args & p, hipStream_t stream);
+// MUL_MAT_ID over an F16 / BF16 / F32 expert stack (correctness path: a wave per (row, pair))
+void mul_mat_id_dense(int type_a, const void * as, size_t nb00, size_t nb01, size_t nb02, int64_t m, int64_t k, const void * b, size_t nb10, size_t nb11, size_t nb12, int64_t n_b,
+                      const void * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert, float * dst, size_t nb1, size_t nb2, hipStream_t stream);
 // matrix-core form for more than 8 columns of f16 x f32 (prefill attention): f32 b is converted to f16 in `scratch`
 bool   mul_mat_dense_mfma_supported(const mm_dense_args & p);
 size_t mul_mat_dense_mfma_scratch_bytes(const mm_dense_args & p);

@@ -97,4 +97,35 @@ void mul_mat_dense(const mm_dense_args & p, hipStream_t stream) {
     else             hipLaunchKernelGGL((k_mm_dense<NC, 0>), grid, dim3(256), 0, stream, p);
 }
 
+// ---- MUL_MAT_ID over an F16 / BF16 / F32 expert stack (tests/test-backend-ops.cpp:5821-5824 with base_types F32 / F16; an unquantized MoE checkpoint) ----
+// dst[:, slot, token] = as[:, :, ids[slot, token]] . b[:, slot % ne11, token]: one wave per (output row, pair), the expert index read on the device.
+// Correctness path: a wave streams its row with whatever stride the stack has; F16 weights round src1 to F16 first, as ggml-cpu's F16 vec_dot does.
+struct mm_id_dense_args { const char * as; int type_a; int64_t k, m; size_t nb00, nb01, nb02; const char * b; size_t nb10, nb11, nb12; int64_t n_b;
+                          const char * ids; size_t ids_nb0, ids_nb1; int64_t n_used, n_tokens, n_expert; char * dst; size_t nb1, nb2; };
+__global__ void __launch_bounds__(256) k_mm_id_dense(const mm_id_dense_args p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t row = (int64_t) blockIdx.x*4 + (threadIdx.x >> 6);
+    if (row >= p.m) return;
+    const int64_t slot = blockIdx.y, tok = blockIdx.z;
+    const int e = *(const int32_t *) (p.ids + slot*p.ids_nb0 + tok*p.ids_nb1);
+    float acc = 0.0f;
+    if (e >= 0 && e < p.n_expert) {
+        const char * a = p.as + (size_t) e*p.nb02 + row*p.nb01;
+        const char * b = p.b + (slot % p.n_b)*p.nb11 + tok*p.nb12;
+        for (int64_t k = lane; k < p.k; k += 64) {
+            float bv = *(const float *) (b + k*p.nb10);
+            if (p.type_a == T_F16) bv = f16_bits_to_f32(f32_to_f16_bits(bv));
+            acc += ld_a(a + k*p.nb00, p.type_a)*bv;
+        }
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) *(float *) (p.dst + row*4 + slot*p.nb1 + tok*p.nb2) = acc;
+}
+void mul_mat_id_dense(int type_a, const void * as, size_t nb00, size_t nb01, size_t nb02, int64_t m, int64_t k, const void * b, size_t nb10, size_t nb11, size_t nb12, int64_t n_b,
+                      const void * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert, float * dst, size_t nb1, size_t nb2, hipStream_t stream) {
+    if (m == 0 || n_used*n_tokens == 0) return;
+    const mm_id_dense_args p = { (const char *) as, type_a, k, m, nb00, nb01, nb02, (const char *) b, nb10, nb11, nb12, n_b, (const char *) ids, ids_nb0, ids_nb1, n_used, n_tokens, n_expert, (char *) dst, nb1, nb2 };
+    hipLaunchKernelGGL(k_mm_id_dense, dim3((unsigned)((m + 3)/4), (unsigned) n_used, (unsigned) n_tokens), dim3(256), 0, stream, p);
+}
+
 } // namespace mi355x

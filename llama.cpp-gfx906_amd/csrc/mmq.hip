@@ -621,6 +621,286 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
 }
 
 
+// ---- wave-specialized form (round 4) ------------------------------------------------------------------------------------------------
+// k_mmq / k_mmq16 make every wave do everything (load, decode, LDS store, operand reads, MFMA) in lock step between barriers: the parts of a k-step ADD UP
+// (tools/glu_ablation.py: 62 + 48 + 50 + 38 us over a 51 us floor) and the matrix cores sit at ~36 %. Here the roles are split:
+//   * waves 0-7 (two per SIMD) only read operand fragments and issue MFMAs: a wave owns 64 weight rows x 128 tokens (128 accumulator registers; ROWS = 128:
+//     32 rows x 128 tokens), 6 ds_read_b128 per 8 MFMAs; the SIMD's two MFMA waves cover each other's LDS latency;
+//   * waves 8-11 (one per SIMD) are PRODUCERS: global loads two k-steps ahead (registers), the reference dequantization to bf16, the LDS commits of
+//     the next step's weight tile and activation tile — their VALU work runs beside the MFMA waves' matrix instructions (separate pipes).
+// One barrier per k-step, two LDS stages. Tile: ROWS = 256 weight rows (DUAL: 128 rows of the gate tensor + the same 128 rows of the up tensor, SwiGLU in the
+// epilogue through an LDS exchange between the wave pairs) x 256 tokens x 64 k: a weight is decoded once per 256 tokens, and per k-step a CU stages 72 KB for
+// 256 MFMAs (the 128 x 256 tile: 54 KB for 128). 3 waves per SIMD: <= 168 registers.
+// The activation tile (256 tokens x 64 k, rows padded to 144 bytes like the weight tile) comes by LDS-DMA issued by the MFMA waves: 37 pieces of 64 16-byte
+// chunks = 7 rows of 9 chunks + the first chunk of the next row (written again, with the same bytes, by the next piece), so that every piece has the SAME
+// per-lane source offset and a wave-uniform base — no registers, no ds_write, and the waves that issue them have no other memory traffic to wait for.
+constexpr int MQ_WS_XPIECES = 37, MQ_WS_XTILE = ((MQ_WS_XPIECES*63 + 1)*16 + 127) & ~127;
+template <int TYPE, int ROWS, bool DUAL, int TYPE2 = TYPE>
+__global__ void __launch_bounds__(768) __attribute__((amdgpu_waves_per_eu(3, 3))) k_mmq_ws(const mmq_args p) {
+    extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
+    constexpr int BN = 256, WTILE = ROWS*MQ_LD, XTILE = MQ_WS_XTILE, STAGE = WTILE + XTILE;
+    constexpr int NR = ROWS/128;                             // 32-row sub-tiles per MFMA wave
+    constexpr int TROWS = DUAL ? 128 : ROWS;                 // rows of one tensor per tile
+    static_assert(!DUAL || ROWS == 256, "the dual tile is 2 x 128 rows");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int khalf = p.ksplit > 1 ? (int) blockIdx.y / p.mtiles : 0;
+    int mt = (int) blockIdx.y - khalf*p.mtiles;
+    const int n0 = blockIdx.x*BN;
+    const int n = p.n, k = p.k;
+    int m = p.m, col0 = 0; bool use2 = false;
+    const char * W = p.W;
+    size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst;
+    if (!DUAL && p.nseg) {                     // workgroup-uniform (tile0 counts TROWS-row tiles here)
+        const int si = (mt >= p.seg[1].tile0 ? 1 : 0) + (p.nseg > 2 && mt >= p.seg[2].tile0 ? 1 : 0);
+        W = p.seg[si].W; m = p.seg[si].m; w_row_stride = p.seg[si].w_row_stride; seg_dst = p.seg[si].dst; seg_dst_nb1 = p.seg[si].dst_nb1;
+        col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0;
+    }
+    const int m0 = mt*TROWS;
+    const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);
+    char * dst = p.ksplit > 1 ? p.dst2 + (size_t) khalf*p.m*p.n*4 + (size_t) col0*4 : seg_dst;
+    const size_t dst_nb1 = p.ksplit > 1 ? (size_t) p.m*4 : seg_dst_nb1;
+    const int nsteps_all = (k + MQ_BK - 1)/MQ_BK;
+    const int nsteps = p.ksplit > 1 ? nsteps_all/p.ksplit : nsteps_all;
+    const int step0 = khalf*nsteps;
+
+    if (wave >= 8) {
+        // ================= producers =================
+        const int ptid = tid - 512, prow = ptid >> 1, shalf = ptid & 1;
+        constexpr int NW = ROWS/128;             // weight chunks (32 k of one row) per thread and step
+        const char * wrow_p[NW];
+#pragma unroll
+        for (int c = 0; c < NW; c++) {
+            const int lr = prow + 128*c;         // row of the LDS tile; DUAL: rows 128.. are the second tensor's rows 0..
+            const int tr = DUAL ? prow : lr;
+            wrow_p[c] = ((DUAL && c) ? p.W2 : W) + (size_t) min(m0 + tr, m - 1)*w_row_stride;
+        }
+        // registers: the weights' raw blocks two k-steps ahead (two stages: HBM latency)
+        struct w_regs { raw32 rw[NW]; };
+        auto run = [&](auto type_tag) {
+            constexpr int TY = decltype(type_tag)::value;
+            auto fetch_w = [&](w_regs & r, int step) {
+                const int kcl = min(step*MQ_BK + 32*shalf, k - 32);
+#pragma unroll
+                for (int c = 0; c < NW; c++) r.rw[c] = load_raw32<TY>(wrow_p[c], kcl >> 5);
+            };
+            auto commit_w = [&](const w_regs & r, int step, int buf) {
+#ifdef MI_MMQ_DBG
+                if (p.dbg & 8) return;
+                if (p.dbg & 1) {
+#pragma unroll
+                    for (int c = 0; c < NW; c++)
+#pragma unroll
+                        for (int g = 0; g < 4; g++) *(int4v *) (lds + buf*STAGE + (prow + 128*c)*MQ_LD + shalf*64 + 16*g) = r.rw[c].v[g & 1];
+                    return;
+                }
+#endif
+                const int c32 = min(step*MQ_BK + 32*shalf, k - 32) >> 5;
+#pragma unroll
+                for (int c = 0; c < NW; c++) {
+                    const dq_head h = decode_head<TY>(r.rw[c], c32);
+                    char * wp = lds + buf*STAGE + (prow + 128*c)*MQ_LD + shalf*64;
+#pragma unroll
+                    for (int g = 0; g < 4; g++) {
+                        int4v wpk;
+                        if (TY == T_MXFP4) wpk = decode8_bf16_mxfp4(r.rw[c], h, g);
+                        else {
+                            float lo[4], hi[4];
+                            decode4<TY>(r.rw[c], h, c32, 2*g, 2*g, lo);
+                            decode4<TY>(r.rw[c], h, c32, 2*g + 1, 2*g + 1, hi);
+                            wpk.x = (int) pack_bf16(lo[0], lo[1]); wpk.y = (int) pack_bf16(lo[2], lo[3]);
+                            wpk.z = (int) pack_bf16(hi[0], hi[1]); wpk.w = (int) pack_bf16(hi[2], hi[3]);
+                        }
+                        *(int4v *) (wp + 16*g) = wpk;
+                    }
+                }
+            };
+            // four register stages: the loads of step s + 3 are issued while step s + 1 is decoded — a k-step lasts ~1 us, an HBM load under this traffic ~2 us
+            // (with two stages the whole kernel ran at the latency of one load per step: 76 us with everything else switched off)
+            w_regs w0, w1, w2, w3;
+            fetch_w(w0, step0); fetch_w(w1, step0 + 1); fetch_w(w2, step0 + 2);
+            commit_w(w0, step0, 0);
+            __syncthreads();
+            int s = 0;
+            for (; s + 3 < nsteps; s += 4) {
+                fetch_w(w3, step0 + s + 3); commit_w(w1, step0 + s + 1, 1); __syncthreads();
+                fetch_w(w0, step0 + s + 4); commit_w(w2, step0 + s + 2, 0); __syncthreads();
+                fetch_w(w1, step0 + s + 5); commit_w(w3, step0 + s + 3, 1); __syncthreads();
+                fetch_w(w2, step0 + s + 6); commit_w(w0, step0 + s + 4, 0); __syncthreads();
+            }
+            // the last 0..3 steps (what is committed past the end goes to the buffer nobody reads; w1, w2, w3 then w0 hold steps s + 1, s + 2, s + 3, s + 4)
+            if (s < nsteps)     { fetch_w(w3, step0 + s + 3); commit_w(w1, step0 + s + 1, 1); __syncthreads(); }
+            if (s + 1 < nsteps) { commit_w(w2, step0 + s + 2, 0); __syncthreads(); }
+            if (s + 2 < nsteps) { commit_w(w3, step0 + s + 3, 1); __syncthreads(); }
+        };
+        if constexpr (TYPE2 != TYPE) { if (use2) run(std::integral_constant<int, TYPE2>{}); else run(std::integral_constant<int, TYPE>{}); }
+        else run(std::integral_constant<int, TYPE>{});
+        if (DUAL) { __syncthreads(); if (p.y16) __syncthreads(); }      // (the epilogue's barriers: exchange, then — with a bf16 output — staging)
+        return;
+    }
+
+    // ================= MFMA waves =================
+    // v_mfma_f32_16x16x32_bf16: the chip holds a higher clock on this shape than on 32x32x16 at the same cycles per FLOP (MI355X_MICROARCH.md, DVFS item 7).
+    // A (tokens): lane l holds token l & 15, k = 8 (l >> 4) .. + 8 of a 32-deep slice; B (weight rows) likewise; D: col (weight row) = l & 15, row (token) = 4 (l >> 4) + reg.
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    const int wr = wave & 3, wn = wave >> 2;                 // LDS-tile rows wr*(ROWS/4).., tokens wn*128..
+    constexpr int NT = 8, NB = 2*NR;                          // 16-token / 16-row sub-tiles per wave
+    f32x4 acc[NT][NB];
+#pragma unroll
+    for (int i = 0; i < NT; i++)
+#pragma unroll
+        for (int j = 0; j < NB; j++) acc[i][j] = f32x4{ 0.0f, 0.0f, 0.0f, 0.0f };
+    const int foff = (lane & 15)*MQ_LD + (lane >> 4)*16;
+    // the activation tile of a step: this wave's pieces P = wave, wave + 8, ... (lane l of a piece: chunk l % 9 of row 7 P + l / 9; chunk 8 is the row's padding — it
+    // re-reads chunk 0 — and lane 63 is chunk 0 of row 7 P + 7)
+    const uint32_t x_voff = (uint32_t)(lane/9)*(uint32_t) kp*2u + (uint32_t)((lane % 9) & 7)*16u;
+    const char * const x_tile = (const char *) (p.X + (size_t) n0*kp);
+    auto dma_x = [&](int step, int buf) {
+        const char * gstep = x_tile + (size_t) min(step*MQ_BK, kp - MQ_BK)*2;
+        const uint32_t lbase = (uint32_t)(size_t)(const char __attribute__((address_space(3))) *) (lds + buf*STAGE + WTILE);
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int P = wave + 8*q;
+            if (P < MQ_WS_XPIECES) {
+                // (uniform by construction; said again so that the compiler keeps them in scalar registers)
+                const uint64_t ga = (uint64_t)(uintptr_t)(gstep + (size_t)(7*P)*kp*2);
+                const char * g = (const char *)(uintptr_t)(((uint64_t)(uint32_t) __builtin_amdgcn_readfirstlane((int)(ga >> 32)) << 32) | (uint32_t) __builtin_amdgcn_readfirstlane((int)(uint32_t) ga));
+                const uint32_t ldst = (uint32_t) __builtin_amdgcn_readfirstlane((int)(lbase + (uint32_t) P*(63*16)));
+                asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2" :: "v"(x_voff), "s"(ldst), "s"(g) : "memory");
+            }
+        }
+    };
+    dma_x(step0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                         // step 0 is in buffer 0
+    for (int s = 0; s < nsteps; s++) {
+#ifdef MI_MMQ_DBG
+        if (!(p.dbg & 32))
+#endif
+        dma_x(step0 + s + 1, (s + 1) & 1);                   // (past the end: a clamped step into the buffer nobody reads)
+        const char * lw = lds + (s & 1)*STAGE + wr*(ROWS/4)*MQ_LD + foff;
+        const char * lx = lds + (s & 1)*STAGE + WTILE + wn*128*MQ_LD + foff;
+        // A k-step is 2 slices of 32 k x 8 slots (token sub-tile i) of NB MFMAs each. Operand fragments are read ONE SLOT AHEAD into the other register set and the
+        // order is pinned: left alone under the 168-register cap, the compiler funnels every fragment through one register set (ds_read, s_waitcnt lgkmcnt(0),
+        // MFMAs, again) and every read shows its whole latency.
+        int4v af[2], bf[NB];      // (the weight fragments of a slice in ONE register set, re-read at the slice boundary: a second set does not fit 168 registers)
+        af[0] = *(const int4v *) lx;
+#pragma unroll
+        for (int j = 0; j < NB; j++) bf[j] = *(const int4v *) (lw + j*16*MQ_LD);
+#ifdef MI_MMQ_DBG
+#define MI_WS_RD(c_) if (!(p.dbg & 16)) { c_ }
+#define MI_WS_MM(t_) if (p.dbg & 2) { asm volatile("" :: "v"(af[(t_) & 1]), "v"(bf[0])); } else
+#else
+#define MI_WS_RD(c_) { c_ }
+#define MI_WS_MM(t_)
+#endif
+#define MI_WS_SLOT(t_) { \
+            MI_WS_RD( if ((t_) + 1 < 16) af[((t_) + 1) & 1] = *(const int4v *) (lx + (((t_) + 1) & 7)*16*MQ_LD + (((t_) + 1) >> 3)*64); ) \
+            MI_WS_MM(t_) { _Pragma("unroll") for (int j = 0; j < NB; j++) \
+                acc[(t_) & 7][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, af[(t_) & 1]), __builtin_bit_cast(bf16x8, bf[j]), acc[(t_) & 7][j], 0, 0, 0); } \
+            __builtin_amdgcn_sched_group_barrier(0x100, ((t_) + 1 < 16 ? 1 : 0), 0); \
+            __builtin_amdgcn_sched_group_barrier(0x008, NB, 0); \
+            if ((t_) == 7) { MI_WS_RD( _Pragma("unroll") for (int j = 0; j < NB; j++) bf[j] = *(const int4v *) (lw + j*16*MQ_LD + 64); ) __builtin_amdgcn_sched_group_barrier(0x100, NB, 0); } }
+        MI_WS_SLOT(0) MI_WS_SLOT(1) MI_WS_SLOT(2) MI_WS_SLOT(3) MI_WS_SLOT(4) MI_WS_SLOT(5) MI_WS_SLOT(6) MI_WS_SLOT(7)
+        MI_WS_SLOT(8) MI_WS_SLOT(9) MI_WS_SLOT(10) MI_WS_SLOT(11) MI_WS_SLOT(12) MI_WS_SLOT(13) MI_WS_SLOT(14) MI_WS_SLOT(15)
+#undef MI_WS_SLOT
+#undef MI_WS_RD
+#undef MI_WS_MM
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // this wave's pieces of the next step's activation tile have landed
+        __syncthreads();
+    }
+
+    // ---- store: D[row = token][col = weight row]; col = lane & 15, row = 4*(lane >> 4) + r ----
+    if constexpr (DUAL) {
+        // waves wr = 0, 1 hold the gate product of tile rows wr*64.., waves wr = 2, 3 the up product of the same rows: each pair exchanges half of its
+        // accumulators through LDS (the stages are free now) and finishes half of the 64 x 128 elements: token sub-tiles 0..3 by the gate wave, 4..7 by the up wave
+        const bool is_up = wr >= 2;                                          // wave-uniform
+        float * xch = (float *) lds + (size_t) wave*(4*NB*4*64);           // this wave's outgoing half: [sub-tile][j][r][lane]
+        // (accumulator indices are compile-time constants in every branch: a run-time index sends the whole array to scratch)
+        auto send = [&](auto base_tag) {
+            constexpr int B = decltype(base_tag)::value;
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int j = 0; j < NB; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) xch[((ii*NB + j)*4 + r)*64 + lane] = acc[B + ii][j][r];
+        };
+        if (is_up) send(std::integral_constant<int, 0>{}); else send(std::integral_constant<int, 4>{});      // the sub-tiles the partner finishes
+        __syncthreads();
+        const float * pin = (const float *) lds + (size_t)(wave ^ 2)*(4*NB*4*64);
+        // the finished 64 tokens x 64 rows of this wave: f32 straight to dst if asked for; the bf16 copy the next mat-mul reads goes through LDS so that it leaves as
+        // whole 128-byte rows (a lane holds ONE column of four tokens: stored directly that is 2-byte elements in 32-byte runs, and the launch ran 6 % slower in the model)
+        constexpr int YLD = 64*2 + 16;                                       // bytes per staged token row (padded)
+        auto finish = [&](auto base_tag, auto up_tag) {
+            constexpr int B = decltype(base_tag)::value; constexpr bool UP = decltype(up_tag)::value;
+            float y[4][NB][4];
+#pragma unroll
+            for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                for (int j = 0; j < NB; j++)
+#pragma unroll
+                    for (int r = 0; r < 4; r++) {
+                        const float other = pin[((ii*NB + j)*4 + r)*64 + lane];
+                        const float g = UP ? other : acc[B + ii][j][r], u = UP ? acc[B + ii][j][r] : other;
+                        y[ii][j][r] = (g/(1.0f + expf(-g)))*u;              // silu(gate)*up, as elem.hip k_glu
+                    }
+            if (p.dst) {
+#pragma unroll
+                for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                    for (int j = 0; j < NB; j++) {
+                        const int col = m0 + (wr & 1)*64 + j*16 + (lane & 15);
+#pragma unroll
+                        for (int r = 0; r < 4; r++) {
+                            const int row = n0 + wn*128 + (B + ii)*16 + 4*(lane >> 4) + r;
+                            if (col < m && row < n) *(float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4) = y[ii][j][r];
+                        }
+                    }
+            }
+            if (p.y16) {
+                __syncthreads();                                             // every wave has read its partner's half: the exchange area is free
+                char * stg = lds + (size_t) wave*(64*YLD);
+#pragma unroll
+                for (int ii = 0; ii < 4; ii++)
+#pragma unroll
+                    for (int j = 0; j < NB; j++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++)
+                            *(uint16_t *) (stg + (ii*16 + 4*(lane >> 4) + r)*YLD + (j*16 + (lane & 15))*2) = (uint16_t) pack_bf16(y[ii][j][r], y[ii][j][r]);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (only this wave reads what it staged)
+                const int colb = m0 + (wr & 1)*64;
+#pragma unroll
+                for (int q = 0; q < 8; q++) {
+                    const int tk = q*8 + (lane >> 3), ch = lane & 7;         // token row of the staged tile, 16-byte chunk (8 rows of the weight tile)
+                    const int row = n0 + wn*128 + B*16 + tk, col = colb + ch*8;
+                    const int4v v = *(const int4v *) (stg + tk*YLD + ch*16);
+                    if (row < n && (m & 7) == 0 && col + 8 <= m) *(int4v *) (p.y16 + (size_t) row*m + col) = v;
+                    else if (row < n) { for (int t = 0; t < 8; t++) if (col + t < m) p.y16[(size_t) row*m + col + t] = *(const uint16_t *) (stg + tk*YLD + ch*16 + 2*t); }
+                }
+            }
+        };
+        if (is_up) finish(std::integral_constant<int, 4>{}, std::true_type{}); else finish(std::integral_constant<int, 0>{}, std::false_type{});
+    } else {
+#pragma unroll
+        for (int i = 0; i < NT; i++)
+#pragma unroll
+            for (int j = 0; j < NB; j++) {
+                const int col = m0 + wr*(ROWS/4) + j*16 + (lane & 15);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int row = n0 + wn*128 + i*16 + 4*(lane >> 4) + r;
+                    if (col < m && row < n) {
+                        float * o = (float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4);
+                        if (p.res && p.ksplit == 1) *o = acc[i][j][r] + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
+                        else *o = acc[i][j][r];
+                    }
+                }
+            }
+    }
+}
+constexpr size_t MQ_LDS_BYTES_WS256 = 2*((size_t) 256*MQ_LD + MQ_WS_XTILE);
+static bool mmq_ws_on() { static const bool on = !getenv("GGML_MI355X_MMQ_WS") || atoi(getenv("GGML_MI355X_MMQ_WS")) != 0; return on; }
+
 constexpr size_t MQ_LDS_BYTES = 4*(size_t) MQ_BM*MQ_LD;
 constexpr size_t MQ_LDS_BYTES_256 = 2*(size_t)(MQ_BM + 256)*MQ_LD;
 constexpr size_t MQ_LDS_BYTES_DUAL = 2*(size_t)(2*MQ_BM + 256)*MQ_LD;
@@ -638,7 +918,8 @@ static void launch_mmq_wide(dim3 grid, const mmq_args & a, hipStream_t stream) {
     hipLaunchKernelGGL((k_mmq<T_, 256>), grid, dim3(512), MQ_LDS_BYTES_256, stream, a);
 }
 
-static size_t mmq_x_bytes(int64_t k, int64_t n) { return ((size_t) n*mmq_kp(k)*2 + 255) & ~(size_t) 255; }
+// (room for whole 256-token tiles + 8 rows behind the last one: k_mmq_ws copies an activation tile HBM/L2 -> LDS in 1 KiB pieces of 7 rows + one chunk; rows past n are never stored)
+static size_t mmq_x_bytes(int64_t k, int64_t n) { return ((size_t)((n + 255)/256*256 + 8)*mmq_kp(k)*2 + 255) & ~(size_t) 255; }
 size_t mul_mat_q_x_bytes(int64_t k, int64_t n) { return mmq_x_bytes(k, n); }
 size_t mul_mat_q_scratch_bytes(int64_t k, int64_t n, int64_t m) { return mmq_x_bytes(k, n) + (size_t) 4*m*n*4 + 512; }     // bf16 copy of x | up to 4 split-k planes
 
@@ -816,6 +1097,12 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
 // gate / up + SwiGLU of build_ffn (src/llama-graph.cpp:632-774) for many tokens: dst[n][m] = silu(Wg.x) * (Wu.x)
 template <int T_>
 static void launch_mmq_dual(dim3 grid, const mmq_args & a, hipStream_t stream) {
+    // the wave-specialized kernel where its producers' four register stages fit (Q4_K, MXFP4: 168 registers, no scratch; the other formats' raw blocks are larger and spill)
+    if constexpr (T_ == T_Q4_K || T_ == T_MXFP4) if (mmq_ws_on()) {
+        MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_WS256, k_mmq_ws<T_, 256, true>);
+        hipLaunchKernelGGL((k_mmq_ws<T_, 256, true>), grid, dim3(768), MQ_LDS_BYTES_WS256, stream, a);
+        return;
+    }
     MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_DUAL, k_mmq<T_, 256, true>);
     hipLaunchKernelGGL((k_mmq<T_, 256, true>), grid, dim3(512), MQ_LDS_BYTES_DUAL, stream, a);
 }

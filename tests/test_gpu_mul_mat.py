@@ -85,6 +85,26 @@ def test_mul_mat_small(name, n):
     check(QTYPES[name], w, x, got)
 
 
+# tests/test-backend-ops.cpp:5715-5716: every quantized type against F16 activations (n = 1 and a prompt-sized n)
+@pytest.mark.parametrize("n", [1, 3, 40])
+@pytest.mark.parametrize("name", list(QTYPES))
+def test_mul_mat_f16_src1(name, n):
+    rng = np.random.default_rng(77 + n)
+    m, k = 32, 512
+    L = gg.base(); be = backend()
+    w = orc.random_blocks(rng, QTYPES[name], (m,), k)
+    x16 = rng.uniform(-1, 1, size=(n, k)).astype(np.float16)
+    with gg.Context() as ctx:
+        a = ctx.new_tensor(QTYPES[name], [k, m]); b = ctx.new_tensor(gg.F16, [k, n])
+        out = L.ggml_mul_mat(ctx.ctx, a, b)
+        assert be.supports_op(out)
+        assert ctx.alloc(be)
+        gg.tensor_set(a, w); gg.tensor_set(b, x16)
+        be.compute(gg.graph_of(ctx, out))
+        got = gg.tensor_get(out)[0, 0].copy()
+    check(QTYPES[name], w, x16.astype(np.float32), got)
+
+
 # golden fixtures (reference dequantization x f64 product), k = 256 and the "stream-k fixup" k = 1024 (:5759-5761)
 @pytest.mark.parametrize("k", [256, 1024])
 @pytest.mark.parametrize("name", list(QTYPES))

@@ -275,6 +275,30 @@ def test_moe_router_at_model_widths(n_expert, k, bias, softmax):
                 assert np.array_equal(got_s[:4], top), (rep, got_s[:4], top)
 
 
+@pytest.mark.parametrize("tname", ["f16", "f32"])
+@pytest.mark.parametrize("n_mats,n_used,bcast_b,n", [(4, 2, True, 1), (8, 2, False, 5), (8, 4, False, 40)])
+def test_mul_mat_id_unquantized_expert_stack(tname, n_mats, n_used, bcast_b, n):
+    """MUL_MAT_ID over an F16 / F32 expert stack (tests/test-backend-ops.cpp:5821-5824 with base_types F32, F16 :5241-5249): the product against float64;
+    F16 weights round src1 to F16 first, as ggml-cpu's vec_dot_f16 does (the oracle does the same)."""
+    rng = np.random.default_rng(21 + n)
+    m, k = 48, 160
+    t = gg.F16 if tname == "f16" else gg.F32
+    w = rng.uniform(-1, 1, size=(n_mats, m, k)).astype(np.float16 if tname == "f16" else np.float32)
+    ids_full = np.stack([rng.permutation(n_mats) for _ in range(n)]).astype(np.int32)
+    nb = 1 if bcast_b else n_used
+    b_ = rng.uniform(-1, 1, size=(1, n, nb, k)).astype(np.float32)
+    with gg.Context() as ctx:
+        as_ = ctx.new_tensor(t, (k, m, n_mats)); ids = ctx.new_tensor(gg.I32, (n_mats, n)); b = ctx.new_tensor(gg.F32, (k, nb, n))
+        idv = L.ggml_view_2d(ctx.ctx, ids, n_used, n, n_mats * 4, 0)
+        got = run(ctx, L.ggml_mul_mat_id(ctx.ctx, as_, b, idv), [(as_, w.reshape(1, n_mats, m, k)), (ids, ids_full.reshape(1, 1, n, n_mats)), (b, b_)])
+    bb = b_[0].astype(np.float16).astype(np.float64) if tname == "f16" else b_[0].astype(np.float64)
+    exp = np.empty((n, n_used, m))
+    for tk in range(n):
+        for u in range(n_used):
+            exp[tk, u] = w[ids_full[tk, u]].astype(np.float64) @ bb[tk, u % nb]
+    assert orc.nmse(exp, got[0]) <= 1e-7
+
+
 @pytest.mark.parametrize("name", list(QTYPES))
 @pytest.mark.parametrize("n_mats,n_used,bcast_b,n", [(4, 1, False, 1), (4, 2, True, 1), (8, 2, False, 1), (8, 4, False, 5), (8, 2, True, 32), (8, 8, False, 3)])
 def test_mul_mat_id(name, n_mats, n_used, bcast_b, n):
