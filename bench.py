@@ -362,10 +362,16 @@ def main():
         # with a single-process run of the same token streams)
         dump = {"on": False, "rows": []} if os.environ.get("BENCH_DUMP_LOGITS") else None
 
+        # per-stage clock (rank 0 prints every rank's numbers): seconds this rank spent computing its layers, blocked on the hand-off from the stage before,
+        # and blocked on a send buffer still in flight — summed over the timed steps only
+        clock = {"on": False, "compute": 0.0, "recv_wait": 0.0, "send_wait": 0.0}
+
         def post_recv(j):
             recv_work[j % lsp.N_BUF] = dist.irecv(recv_buf[j % lsp.N_BUF], src=rank - 1, group=pg)
         def wait_recv(j):
+            t = time.perf_counter()
             recv_work[j % lsp.N_BUF].wait(); recv_work[j % lsp.N_BUF] = None; tcur.synchronize()
+            if clock["on"]: clock["recv_wait"] += time.perf_counter() - t
         def send(j):
             b = j % lsp.N_BUF
             send_work[b] = dist.isend(send_buf[b], dst=rank + 1, group=pg)
@@ -379,8 +385,10 @@ def main():
 
         def stage(seq, j, has_input):
             b = j % lsp.N_BUF
+            t_in = time.perf_counter()
             if send_work[b] is not None:          # buffer reuse: the send issued N_BUF steps ago must be done
                 send_work[b].wait(); tcur.synchronize(); send_work[b] = None
+            t_c = time.perf_counter()
             if has_input and transport == "gloo":      # debug transport: the hand-off was received into host memory
                 recv_dev[b].copy_(recv_buf[b]); tcur.synchronize()
             out = m.decode(tokens[j % len(tokens):j % len(tokens) + 1] if not has_input else None, n_tokens=1, seq=seq,
@@ -389,6 +397,8 @@ def main():
                            want_host=has_out, sync=True)
             if rank < world - 1 and transport == "gloo":
                 send_buf[b].copy_(send_dev[b]); tcur.synchronize()
+            if clock["on"]:
+                clock["send_wait"] += t_c - t_in; clock["compute"] += time.perf_counter() - t_c
             if dump is not None and has_out and dump["on"]:
                 dump["rows"].append((seq, pos[seq], out.copy()))
             pos[seq] += 1
@@ -404,7 +414,9 @@ def main():
             dump["on"] = True
         sync_all(); t0 = time.perf_counter()
         log(f"[rank {rank}] timed region: {K} pipeline steps")
+        clock["on"] = True
         lsp.run_steps(tr, K, stage, 0, n_seq)
+        clock["on"] = False
         log(f"[rank {rank}] timed steps done")
         sync_all(); dt = time.perf_counter() - t0
         tmax = torch.tensor([dt], dtype=torch.float64)          # default group = gloo
@@ -412,6 +424,31 @@ def main():
         dt = float(tmax.item())
         result.update(value=K / dt, ms_per_step=dt / K * 1e3)
         result["extra"] = {"layers": [list(r) for r in ranges], "sequences_in_flight": n_seq, "handoff_bytes": n_embd * 4}
+        # hand-off latency, measured after the timed region: 32 ping-pongs of one hand-off message over every link in turn (rank r <-> r + 1), one way = half
+        # the round trip, through the same transport and buffers the pipeline uses
+        lat = [0.0] * world
+        for link in range(world - 1):
+            dist.barrier()
+            if rank in (link, link + 1):
+                peer = link + 1 if rank == link else link
+                for it in range(40):
+                    if it == 8: tcur.synchronize(); tl = time.perf_counter()
+                    if rank == link:
+                        dist.send(send_buf[0], dst=peer, group=pg); dist.recv(recv_buf[0], src=peer, group=pg)
+                    else:
+                        dist.recv(recv_buf[0], src=peer, group=pg); dist.send(send_buf[0], dst=peer, group=pg)
+                    tcur.synchronize()
+                if rank == link: lat[link] = (time.perf_counter() - tl) / 32 / 2 * 1e6
+        per_rank = torch.tensor([[clock["compute"], clock["recv_wait"], clock["send_wait"]] + lat], dtype=torch.float64)
+        gathered = [torch.zeros_like(per_rank) for _ in range(world)]
+        dist.all_gather(gathered, per_rank)                     # default group = gloo
+        result["extra"]["stages"] = [{"rank": r, "layers": list(ranges[r][:2]), "output_layer": bool(ranges[r][2]),
+                                      "compute_ms_per_step": round(float(gathered[r][0, 0]) / K * 1e3, 4),
+                                      "recv_wait_ms_per_step": round(float(gathered[r][0, 1]) / K * 1e3, 4),
+                                      "send_buffer_wait_ms_per_step": round(float(gathered[r][0, 2]) / K * 1e3, 4),
+                                      "handoff_to_next_one_way_us": round(float(gathered[r][0, 3 + r]), 1) if r < world - 1 else None} for r in range(world)]
+        result["extra"]["stages_note"] = ("host clocks around the synchronised stage call and around the blocking waits, timed steps only; a step's wall time = compute + "
+                                          "recv_wait + send_buffer_wait + loop overhead; the hand-off latency is a ping-pong of one n_embd x f32 message after the timed region")
         # llama-bench's own -sm layer number: ONE sequence, a token does not start before the previous one is through the last stage
         # (tools/llama-bench/llama-bench.cpp:1791-1810). Untimed by the contract's `value` (whole-job aggregate); reported beside it.
         if dump is not None:

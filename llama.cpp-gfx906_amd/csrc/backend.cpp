@@ -2514,12 +2514,11 @@ ggml_backend_buffer_type_t ggml_backend_mi355x_split_buffer_type(int main_device
     want.cum[n] = 1.0f;
     // every device that CAN receive rows must be mapped into the main device's address space and back: not only those with a share — the rounding of
     // split_rows hands remainder rows to the devices behind the last share too (shares [1, 0], 300 rows: 44 rows on device 1)
+    // From split_rows' rounding: device i < n - 1 holds rows [round64(nrows*cum[i]), round64(nrows*cum[i + 1])) — empty exactly when its share is zero — and the LAST
+    // device holds everything behind round64(nrows*cum[n - 1]), which is non-empty for some row count whatever its share (a fixed list of probe counts
+    // missed row counts like 2880)
     bool gets_rows[GGML_MI355X_MAX_DEVICES] = {};
-    for (const int64_t nrows : { (int64_t) 1, (int64_t) 44, (int64_t) 300, (int64_t) 4096, (int64_t) 14336, (int64_t) 128256 }) {
-        int64_t row_lo[GGML_MI355X_MAX_DEVICES + 1];
-        split_rows(&want, nrows, row_lo);
-        for (int i = 0; i < n; i++) if (row_lo[i + 1] > row_lo[i]) gets_rows[i] = true;
-    }
+    for (int i = 0; i < n; i++) gets_rows[i] = share[i] > 0 || i == n - 1;
     for (int i = 0; i < n; i++) {
         if ((share[i] == 0 && !gets_rows[i]) || G().devices[i].id == G().devices[main_device].id) continue;
         int ab = 0, ba = 0;

@@ -285,7 +285,7 @@ void upload_random(mi_llama * m, ggml_tensor * t, float sigma, uint64_t seed, st
 
 // build_moe_ffn (src/llama-graph.cpp:811-1023) for the two gatings the configs use: SOFTMAX + norm_w (llm_build_llama's MoE branch,
 // src/llama-model.cpp:6082-6092) and SOFTMAX_WEIGHT + biases + SWIGLU_OAI (gpt-oss, src/llama-model.cpp:17700-17711)
-ggml_tensor * build_moe_ffn(ggml_context * ctx0, ggml_cgraph * gf, const mi_llama_hparams & hp, const layer & L, ggml_tensor * cur) {
+ggml_tensor * build_moe_ffn(ggml_context * ctx0, ggml_cgraph * gf, const mi_llama_hparams & hp, const layer & L, ggml_tensor * cur, ggml_tensor ** experts_out = nullptr) {
     const int64_t n_embd = cur->ne[0], n_tokens = cur->ne[1], n_expert = hp.n_expert, n_used = hp.n_expert_used;
     const bool oai = hp.arch == 1;
     ggml_tensor * logits = ggml_mul_mat(ctx0, L.ffn_gate_inp, cur);                             // [n_expert, n_tokens]   :838
@@ -312,6 +312,7 @@ ggml_tensor * build_moe_ffn(ggml_context * ctx0, ggml_cgraph * gf, const mi_llam
                             : ggml_swiglu_split(ctx0, gate, up);                                // :947
     ggml_tensor * experts = ggml_mul_mat_id(ctx0, L.ffn_down, act, selected);                   // [n_embd, n_used, n_tokens]   :981
     if (L.down_b) experts = ggml_add_id(ctx0, experts, L.down_b, selected);                     // :985
+    if (experts_out) *experts_out = experts;      // (what the combine reads: dead after it — see MI_HARNESS_ALIAS_MOE in build_graph)
     experts = ggml_mul(ctx0, experts, weights);                                                 // :990
     ggml_tensor * moe_out = nullptr;                                                            // :996-1012: views ordered before the adds
     std::vector<ggml_tensor *> views;
@@ -359,7 +360,17 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
 
     ggml_tensor * inpL = g.inp_embd;
     ggml_tensor * cur = nullptr;
+    std::vector<ggml_tensor *> dbg_q, dbg_experts;      // per layer: the rotated Q tensor; the experts' outputs the MoE combine reads (MI_HARNESS_ALIAS_MOE)
     const int n_local = (int) m->layers.size();
+    // MI_HARNESS_TAP="<layer>:<point>" (tools/fmt_first_step.py): the graph is built and computed as always, but the tensor read back as the "result" is an
+    // intermediate one — attn_norm, v, attn, wo, ffn_norm, glu, down of that layer, or result_norm. With fusions on, a tensor a fused launch never writes reads as stale memory.
+    ggml_tensor * tapped = nullptr;
+    const char * tap_env = getenv("MI_HARNESS_TAP");
+    auto tap = [&](int li, const char * point, ggml_tensor * t) {
+        if (!tap_env) return;
+        char want[64]; snprintf(want, sizeof(want), "%d:%s", li, point);
+        if (strcmp(want, tap_env) == 0) { tapped = t; ggml_set_output(t); }
+    };
     for (int li = 0; li < n_local; li++) {
         const layer & L = m->layers[li];
         const bool last_layer = last_rank && li == n_local - 1;
@@ -374,6 +385,7 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
         cur = ggml_rms_norm(ctx0, inpL, hp.f_norm_rms_eps);
         cur = ggml_mul(ctx0, cur, L.attn_norm);
 
+        tap(li, "attn_norm", cur);
         // self-attention
         ggml_tensor * Qcur = ggml_mul_mat(ctx0, L.wq, cur);
         if (L.bq) Qcur = ggml_add(ctx0, Qcur, L.bq);                  // src/llama-model.cpp:17636-17639
@@ -381,12 +393,14 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
         if (L.bk) Kcur = ggml_add(ctx0, Kcur, L.bk);
         ggml_tensor * Vcur = ggml_mul_mat(ctx0, L.wv, cur);
         if (L.bv) Vcur = ggml_add(ctx0, Vcur, L.bv);
+        tap(li, "v", Vcur);
         Qcur = ggml_reshape_3d(ctx0, Qcur, hd, n_head,    n_tokens);
         Kcur = ggml_reshape_3d(ctx0, Kcur, hd, n_head_kv, n_tokens);
         Vcur = ggml_reshape_3d(ctx0, Vcur, hd, n_head_kv, n_tokens);
         Qcur = ggml_rope_ext(ctx0, Qcur, g.inp_pos, m->rope_freqs, (int) hd, hp.rope_type, hp.n_ctx_orig, hp.rope_freq_base, hp.rope_freq_scale, 0.0f, 1.0f, 32.0f, 1.0f);
         Kcur = ggml_rope_ext(ctx0, Kcur, g.inp_pos, m->rope_freqs, (int) hd, hp.rope_type, hp.n_ctx_orig, hp.rope_freq_base, hp.rope_freq_scale, 0.0f, 1.0f, 32.0f, 1.0f);
 
+        dbg_q.push_back(Qcur);
         // build_attn: q/k/v first so that they are not reordered (src/llama-graph.cpp:1449-1453)
         ggml_build_forward_expand(g.gf, Qcur);
         ggml_build_forward_expand(g.gf, Kcur);
@@ -437,7 +451,9 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
             cur = ggml_cont_2d(ctx0, cur, cur->ne[0]*cur->ne[1], cur->ne[2]*cur->ne[3]);
             ggml_build_forward_expand(g.gf, cur);
         }
+        tap(li, "attn", cur);
         cur = ggml_mul_mat(ctx0, L.wo, cur);
+        tap(li, "wo", cur);
         if (L.bo) cur = ggml_add(ctx0, cur, L.bo);                    // src/llama-graph.cpp:1479-1481
 
         if (last_layer) {   // src/llama-model.cpp:6052-6055
@@ -449,13 +465,16 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
         // feed-forward: build_norm + build_ffn(LLM_FFN_SILU, LLM_FFN_PAR)
         cur = ggml_rms_norm(ctx0, ffn_inp, hp.f_norm_rms_eps);
         cur = ggml_mul(ctx0, cur, L.ffn_norm);
+        tap(li, "ffn_norm", cur);
         if (hp.n_expert > 0) {
-            cur = build_moe_ffn(ctx0, g.gf, hp, L, cur);              // src/llama-model.cpp:6075-6093 / :17700-17711
+            { ggml_tensor * ex = nullptr; cur = build_moe_ffn(ctx0, g.gf, hp, L, cur, &ex); dbg_experts.push_back(ex); }              // src/llama-model.cpp:6075-6093 / :17700-17711
         } else {
             ggml_tensor * tmp = ggml_mul_mat(ctx0, L.ffn_up, cur);
             cur = ggml_mul_mat(ctx0, L.ffn_gate, cur);
             cur = ggml_swiglu_split(ctx0, cur, tmp);
+            tap(li, "glu", cur);
             cur = ggml_mul_mat(ctx0, L.ffn_down, cur);
+            tap(li, "down", cur);
         }
         cur = ggml_add(ctx0, cur, ffn_inp);
         inpL = cur;
@@ -465,14 +484,26 @@ graph_inst build_graph(mi_llama * m, int seq, int n_tokens, int n_kv, int n_kv_s
         cur = ggml_rms_norm(ctx0, cur, hp.f_norm_rms_eps);
         cur = ggml_mul(ctx0, cur, m->output_norm);
         ggml_set_name(cur, "result_norm");            // res->t_embd (src/llama-model.cpp:6113): read back by llama_context for embeddings, no OUTPUT flag
+        tap(n_local - 1, "result_norm", cur);
         cur = ggml_mul_mat(ctx0, m->output, cur);     // lm_head
     }
     ggml_set_output(cur);
-    g.result = cur;
+    g.result = tapped ? tapped : cur;
     ggml_build_forward_expand(g.gf, cur);
 
     g.buf = ggml_backend_alloc_ctx_tensors(ctx0, m->backend);
     if (!g.buf) { fprintf(stderr, "mi_llama: compute buffer allocation failed\n"); abort(); }
+    // MI_HARNESS_ALIAS_MOE=1 (tests): this harness gives every tensor memory of its own, ggml-alloc does not — it hands a dead tensor's memory to the next one that
+    // fits. Reproduce the case ADVICE r3 describes: layer i's rotated Q lives where layer i - 1's expert outputs were (dead after that layer's combine), so a launch
+    // that still READS those outputs while it writes Q races unless the backend notices the overlap
+    if (getenv("MI_HARNESS_ALIAS_MOE") && atoi(getenv("MI_HARNESS_ALIAS_MOE")) != 0) {
+        for (size_t li = 1; li < dbg_q.size() && li - 1 < dbg_experts.size(); li++) {
+            ggml_tensor * q = dbg_q[li]; ggml_tensor * ex = dbg_experts[li - 1];
+            if (!q || !ex || q->view_src || ggml_nbytes(q) > ggml_nbytes(ex)) continue;
+            q->data = ex->data;
+            for (int i = 0; i < ggml_graph_n_nodes(g.gf); i++) { ggml_tensor * t = ggml_graph_node(g.gf, i); if (t->view_src == q) t->data = (char *) q->data + t->view_offs; }
+        }
+    }
     return g;
 }
 

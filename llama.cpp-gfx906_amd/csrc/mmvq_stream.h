@@ -61,6 +61,10 @@ struct st_group {
     // and res_eid != 0: EPI_ADD's res is such a table too (MUL_MAT_ID -> ADD_ID)
     const float * b_gate; const float * b_up; int res_eid;
     int ralign;                               // rows are dealt to workgroups in multiples of this (2: rotation pairs, head size: NEOX pairs)
+    // NEOX rotation as TWO row streams (neox2 > 0): workgroup wg owns pairs [wg*neox2, (wg + 1)*neox2) of the group's m/2 pairs — rows h*hd + i .. of a head's first
+    // half through W and their partners h*hd + hd/2 + i .. through W2 = W + hd/2 rows, exactly the gate / up arrangement — so that a head is spread over
+    // hd/2/neox2 workgroups instead of held by one (gpt-oss's norm + QKV launch ran on ~100 of 256 CUs); neox_hh = hd/2
+    int neox2, neox_hh;
     int npart_max;                            // floats of partial sums the largest workgroup of this group needs (the LDS carve is the same in all of them)
     float glu_alpha, glu_limit;
 };
@@ -446,6 +450,7 @@ struct st_lds {
 // rows of workgroup wg of nwg in group g: [r0, r0 + R), dealt in multiples of ralign (which also keeps every workgroup's first byte 16-byte
 // aligned — Q6_K rows are 210 nb bytes); the rows past the last whole unit belong to the last workgroup
 static __device__ __forceinline__ void st_rows(const st_group & g, int wg, int nwg, int & r0, int & R) {
+    if (g.neox2) { const int p0 = wg*g.neox2; r0 = (p0/g.neox_hh)*(2*g.neox_hh) + p0 % g.neox_hh; R = g.neox2; return; }      // first-half rows; the partners are neox_hh rows further
     const int nru = g.m/g.ralign;
     r0 = (int)((long long) wg*nru/nwg)*g.ralign;
     R = (wg == nwg - 1 ? g.m : (int)((long long)(wg + 1)*nru/nwg)*g.ralign) - r0;
@@ -476,11 +481,11 @@ static __device__ __forceinline__ void st_loader_publish(const st_lds & L, st_lo
     if (l > s.landed) { s.landed = l; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) l); }
 }
 template <int TYPE, bool NT>
-static __device__ __forceinline__ void st_loader_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, st_loader_state & ls, int lane) {
+static __device__ __forceinline__ void st_loader_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, st_loader_state & ls, int lane, int expert) {
     typedef st_unit<TYPE> U;
     constexpr int PPS = (64*U::UB + 1023)/1024;
     const int nb = p.nb;
-    const bool GLU = g.epi == EPI_GLU;
+    const bool GLU = g.epi == EPI_GLU || g.neox2 > 0;      // two row streams
     int r0, R; st_rows(g, wg, nwg, r0, R);
     const int n1 = R*nb, ns1 = (n1 + 63) >> 6, nslots = GLU ? 2*ns1 : ns1;
     const int S = L.S;
@@ -492,7 +497,7 @@ static __device__ __forceinline__ void st_loader_phase(const st_args & p, const 
     }
     ls.p_slot0 = ls.c_slot0; ls.p_base = ls.c_base; ls.c_slot0 = slot0; ls.c_base = ls.pieces; ls.c_pps = PPS;
     const long long row_off = (long long) r0*nb*U::UB;
-    const long long e_off = g.eid ? (long long) __builtin_amdgcn_readfirstlane(g.eid[0])*g.estride : 0;      // (the expert the router picked: read here, on the device)
+    const long long e_off = g.eid ? (long long) expert*g.estride : 0;      // (the expert the router picked: read on the device — k_mmvq_stream requests it before the first barrier)
     const char * const w0 = g.W + e_off + row_off; const char * const w1 = GLU ? g.W2 + e_off + row_off : w0;
     // the tensor's last 16-byte chunk (the grid of chunks starts at this workgroup's first byte, which is 16-byte aligned), relative to that byte. A tensor
     // whose size is not a multiple of 16 ends inside that chunk: it is read in place — up to 15 bytes of the zeroed padding every quantized tensor of this
@@ -512,7 +517,7 @@ static __device__ __forceinline__ void st_loader_phase(const st_args & p, const 
         }
         const uint32_t dst = L.ring_a + (uint32_t) ring_i*L.slot_stride;
         if (il == ns1 - 1) {       // the stream's last slot may reach past the end of the tensor
-            const long long lim = lim_all - (long long) il*(64*U::UB);
+            const long long lim = lim_all - (long long) il*(64*U::UB) - ((si && g.neox2) ? (long long) g.neox_hh*nb*U::UB : 0);      // (the partner stream starts neox_hh rows further in)
             st_dma_slot_clamped<NT, PPS>(gb, voff, dst, (uint32_t)(lim < 0x7FFFFFFF ? lim : 0x7FFFFFFF));
         } else st_dma_slot<NT, PPS>(gb, voff, dst);
         ls.pieces += PPS;
@@ -711,7 +716,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
                                                          int lane, int wave, unsigned long long * stamps) {
     typedef st_unit<TYPE> U;
     const int nb = p.nb;
-    const bool GLU = g.epi == EPI_GLU;
+    const bool GLU = g.epi == EPI_GLU || g.neox2 > 0;      // two row streams
     int r0, R; st_rows(g, wg, nwg, r0, R);
     const int n1 = R*nb, ns1 = (n1 + 63) >> 6, nslots = GLU ? 2*ns1 : ns1;
     const int S = L.S;
@@ -740,10 +745,11 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
     if (g.epi == EPI_ROPE) {
         const fused_rope & rp = p.rope;
         const int pr = ctid, hd = rp.head_dim;
-        if (pr < (R >> 1)) {
+        if (pr < (g.neox2 ? R : (R >> 1))) {
             int ra, rb, ip;
-            if (rp.neox) { const int hh = pr/(hd >> 1), i = pr - hh*(hd >> 1); ra = hh*hd + i; rb = ra + (hd >> 1); ip = i; }
-            else         { ra = 2*pr; rb = ra + 1; ip = ((r0 + ra) % hd) >> 1; }
+            if (g.neox2)      { ra = pr; rb = pr + g.neox_hh; ip = (r0 + pr) % hd; }      // (rows relative to r0; the partner was streamed through W2)
+            else if (rp.neox) { const int hh = pr/(hd >> 1), i = pr - hh*(hd >> 1); ra = hh*hd + i; rb = ra + (hd >> 1); ip = i; }
+            else              { ra = 2*pr; rb = ra + 1; ip = ((r0 + ra) % hd) >> 1; }
             if (g.res) { e_r0 = g.res[r0 + ra]; e_r1 = g.res[r0 + rb]; }
             if (ip < (rp.n_dims >> 1)) { e_c = rp.tab[2*ip]; e_s = rp.tab[2*ip + 1]; }
             if (g.st_mode == 2) { e_i0 = g.st_idx[r0 + ra]; e_i1 = g.st_idx[r0 + rb]; }
@@ -791,18 +797,19 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
     if (g.epi == EPI_ROPE) {
         const fused_rope & rp = p.rope;
         const int hd = rp.head_dim, half = rp.n_dims >> 1;
-        for (int pr = ctid; pr < (R >> 1); pr += ST_NC*64) {
-            // the two rows of pair pr (local): NORM (2 pr, 2 pr + 1); NEOX: i and i + hd/2 inside one head (ralign = hd)
+        for (int pr = ctid; pr < (g.neox2 ? R : (R >> 1)); pr += ST_NC*64) {
+            // the two rows of pair pr (local): NORM (2 pr, 2 pr + 1); NEOX: i and i + hd/2 inside one head (ralign = hd), or — two row streams — row pr of each stream
             int ra, rb, ip;
-            if (rp.neox) { const int hh = pr/(hd >> 1), i = pr - hh*(hd >> 1); ra = hh*hd + i; rb = ra + (hd >> 1); ip = i; }
-            else         { ra = 2*pr; rb = ra + 1; ip = ((r0 + ra) % hd) >> 1; }
+            if (g.neox2)      { ra = pr; rb = pr + g.neox_hh; ip = (r0 + pr) % hd; }
+            else if (rp.neox) { const int hh = pr/(hd >> 1), i = pr - hh*(hd >> 1); ra = hh*hd + i; rb = ra + (hd >> 1); ip = i; }
+            else              { ra = 2*pr; rb = ra + 1; ip = ((r0 + ra) % hd) >> 1; }
             if (pr != ctid) {       // (not the prefetched pair: a workgroup with more than 1024 rotated rows)
                 e_r0 = e_r1 = 0.0f; e_c = 1.0f; e_s = 0.0f;
                 if (g.res) { e_r0 = g.res[r0 + ra]; e_r1 = g.res[r0 + rb]; }
                 if (ip < half) { e_c = rp.tab[2*ip]; e_s = rp.tab[2*ip + 1]; }
                 if (g.st_mode == 2) { e_i0 = g.st_idx[r0 + ra]; e_i1 = g.st_idx[r0 + rb]; }
             }
-            float s0 = st_row_sum(part, ra, npr), s1 = st_row_sum(part, rb, npr);
+            float s0 = st_row_sum(part, ra, npr), s1 = g.neox2 ? st_row_sum(part2, pr, npr) : st_row_sum(part, rb, npr);
             if (g.res) { s0 += e_r0; s1 += e_r1; }              // bias first, then the rotation
             if (ip < half) { const float a = s0, b = s1; s0 = a*e_c - b*e_s; s1 = a*e_s + b*e_c; }
             g.dst[r0 + ra] = s0; g.dst[r0 + rb] = s1;
@@ -862,7 +869,7 @@ static __device__ __forceinline__ st_lds st_carve(char * lds, int nb_max, int np
 static __device__ __forceinline__ int st_phase_slots(const st_args & a, const st_group & g, int wg, int nwg) {
     int r0, R; st_rows(g, wg, nwg, r0, R);
     const int ns1 = (R*a.nb + 63) >> 6;
-    return g.epi == EPI_GLU ? 2*ns1 : ns1;
+    return (g.epi == EPI_GLU || g.neox2 > 0) ? 2*ns1 : ns1;
 }
 
 // ---- one grouped launch ----
@@ -883,11 +890,17 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) 
     ST_STAMP(0);
     if (threadIdx.x < ST_SYNC_WORDS) L.sync[threadIdx.x] = 0;
     if (wave == ST_NC) {
+        // an expert stack: which expert — a value the router launch has just written, i.e. a load that misses this CU's caches — is requested BEFORE the barrier
+        // the loader shares with the consumers' activation loads and collected after it (the first DMA used to wait ~1 us for it behind that barrier)
+        int e_raw = 0;
+        if (g.eid) asm volatile("global_load_dword %0, %1, off" : "=v"(e_raw) : "v"(g.eid) : "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (g.eid) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_raw) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
+        const int expert = __builtin_amdgcn_readfirstlane(e_raw);
         st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (is_a) st_loader_phase<TA, NT>(p, g, wg, nwg, L, 0, ls, lane);
-        else      st_loader_phase<TB, NT>(p, g, wg, nwg, L, 0, ls, lane);
+        if (is_a) st_loader_phase<TA, NT>(p, g, wg, nwg, L, 0, ls, lane, expert);
+        else      st_loader_phase<TB, NT>(p, g, wg, nwg, L, 0, ls, lane, expert);
         st_loader_drain(L, st_phase_slots(p, g, wg, nwg), ls, lane);
         ST_STAMP(1);
         return;

@@ -70,6 +70,9 @@ bool mul_mat_vec_q_stream_enabled(void) {
     return on != 0;
 }
 
+static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope, st_args & a,
+                   size_t & fixed_max, int & slot_max, int & nslots_max, int & npart_max, int & ta, int & tb, double & bytes_total);
+
 // can (and does) this grouped launch go to the streamed kernel?
 bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t k, const mmvq_input & in, const mmvq_rope * rope) {
     if (!mul_mat_vec_q_stream_enabled() || n_groups < 1 || n_groups > MMVQ_MAX_GROUPS) return false;
@@ -103,7 +106,12 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
         if (g.epi == EPI_ADD && !g.res) return false;
         if (g.m < 1) return false;
     }
-    return true;
+    // the LDS carve must leave room for a ring of at least two slots (rows whose block count is not a multiple of 16 keep one partial sum per unit: a
+    // workgroup with many such rows can fill the LDS with them) — otherwise the register-ring kernels take the launch (the launcher used to abort)
+    st_args a; size_t fixed_max; int slot_max, nslots_max, npart_max, fa, fb; double bytes_total;
+    (void) st_fill(groups, n_groups, k, in, rope, a, fixed_max, slot_max, nslots_max, npart_max, fa, fb, bytes_total);
+    const int64_t S = fixed_max < 163840 ? (163840 - (int64_t) fixed_max)/slot_max : 0;
+    return S >= (nslots_max < 2 ? nslots_max : 2);
 }
 
 // fills the phase descriptor of one grouped launch; returns the workgroups it uses. fixed: LDS bytes besides the ring; slot: bytes of a ring slot;
@@ -142,7 +150,7 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
         s.m = g.m; s.type = st_utype(g.type, k); s.epi = g.epi; s.st_mode = g.st_mode; s.glu_alpha = g.glu_alpha; s.glu_limit = g.glu_limit;
         s.eid = g.eid; s.estride = (long long) g.estride; s.x_off = g.x_off;
         s.b_gate = g.b_gate; s.b_up = g.b_up; s.res_eid = g.res_eid;
-        s.ralign = 1;
+        s.ralign = 1; s.neox2 = 0; s.neox_hh = 0;
         if (g.epi == EPI_ROPE) s.ralign = (rope->p.mode & 2) ? rope->head_dim : 2;
         while (((int64_t) s.ralign*nb*st_unit_bytes(s.type)) % 16 != 0) s.ralign *= 2;      // a workgroup's rows start on a 16-byte boundary (LDS-DMA source)
         const int nru = std::max(1, g.m/s.ralign);
@@ -150,10 +158,33 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
         sh = sh < 1 ? 1 : (sh > nru ? nru : sh);
         share[i] = sh; used += sh;
     }
+    // NEOX groups as two row streams (mmvq_stream.h: st_group::neox2): the smallest number of pairs per workgroup c for which every such group gets EXACTLY m/2/c
+    // workgroups and the launch still fits the chip; the other groups share what is left
+    static const bool neox2_on = !getenv("GGML_MI355X_NEOX2") || atoi(getenv("GGML_MI355X_NEOX2")) != 0;
+    if (neox2_on && rope && (rope->p.mode & 2) && rope->head_dim >= 16) {
+        const int hh = rope->head_dim/2;
+        for (int c = 4; c < hh; c *= 2) {
+            int fixed = 0, others = 0; bool ok = hh % c == 0;
+            for (int i = 0; i < n_groups && ok; i++) {
+                if (groups[i].epi == EPI_ROPE) { ok = (groups[i].m/2) % c == 0 && ((int64_t) c*nb*st_unit_bytes(a.g[i].type)) % 16 == 0 && ((int64_t) hh*nb*st_unit_bytes(a.g[i].type)) % 16 == 0 && !groups[i].eid; fixed += groups[i].m/2/c; }
+                else others++;
+            }
+            if (!ok || fixed + others > budget) continue;
+            double obytes = 0; for (int i = 0; i < n_groups; i++) if (groups[i].epi != EPI_ROPE) obytes += gbytes[i];
+            used = 0;
+            for (int i = 0; i < n_groups; i++) {
+                st_group & s = a.g[i];
+                if (groups[i].epi == EPI_ROPE) { s.neox2 = c; s.neox_hh = hh; s.ralign = c; s.W2 = s.W + (size_t) hh*nb*st_unit_bytes(s.type); share[i] = groups[i].m/2/c; }
+                else { const int nru = std::max(1, groups[i].m/s.ralign); int sh = (int)((double)(budget - fixed)*gbytes[i]/obytes); share[i] = sh < 1 ? 1 : (sh > nru ? nru : sh); }
+                used += share[i];
+            }
+            break;
+        }
+    }
     // hand the workgroups rounding left over to the groups with the most bytes per workgroup
     while (used < budget) {
         int best = -1; double bw = 0;
-        for (int i = 0; i < n_groups; i++) { const int nru = std::max(1, groups[i].m/a.g[i].ralign); if (share[i] < nru && gbytes[i]/share[i] > bw) { bw = gbytes[i]/share[i]; best = i; } }
+        for (int i = 0; i < n_groups; i++) { const int nru = std::max(1, groups[i].m/a.g[i].ralign); if (!a.g[i].neox2 && share[i] < nru && gbytes[i]/share[i] > bw) { bw = gbytes[i]/share[i]; best = i; } }
         if (best < 0) break;
         share[best]++; used++;
     }
@@ -161,15 +192,16 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
         const mmvq_group & g = groups[i];
         st_group & s = a.g[i];
         const int nru = std::max(1, g.m/s.ralign), sh = share[i];
-        const int Rmax = ((nru + sh - 1)/sh)*s.ralign + (g.m - (g.m/s.ralign)*s.ralign);
+        const int Rmax = s.neox2 ? s.neox2 : ((nru + sh - 1)/sh)*s.ralign + (g.m - (g.m/s.ralign)*s.ralign);
         const bool row16 = (nb & 15) == 0;
-        s.npart_max = (row16 ? Rmax*(nb >> 4) : Rmax*nb)*(g.epi == EPI_GLU ? 2 : 1);
+        const int streams = (g.epi == EPI_GLU || s.neox2) ? 2 : 1;
+        s.npart_max = (row16 ? Rmax*(nb >> 4) : Rmax*nb)*streams;
         npart_max = std::max(npart_max, s.npart_max);
         const size_t fixed = 2*ST_SYNC_WORDS*4 + (size_t) nb*a.act_stride + (size_t)((nb + 3) & ~3)*4 + 64 + (size_t) s.npart_max*4 + 16;
         fixed_max = std::max(fixed_max, fixed);
         const int pps = (64*st_unit_bytes(s.type) + 1023)/1024;
         slot_max = std::max(slot_max, pps*1024);
-        nslots_max = std::max(nslots_max, (int)(((int64_t) Rmax*nb + 63)/64)*(g.epi == EPI_GLU ? 2 : 1));
+        nslots_max = std::max(nslots_max, (int)(((int64_t) Rmax*nb + 63)/64)*streams);
         blocks += sh;
         a.block_end[i] = blocks;
     }

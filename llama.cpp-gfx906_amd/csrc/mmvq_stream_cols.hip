@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(ST_THREADS, 1) k_mmvq_stream_cols(const st_arg
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0 };
-        st_loader_phase<TYPE, NT>(p, g, wg, nwg, L, 0, ls, lane);
+        st_loader_phase<TYPE, NT>(p, g, wg, nwg, L, 0, ls, lane, 0);
         st_loader_drain(L, nslots, ls, lane);
         return;
     }

@@ -40,6 +40,14 @@ def test_two_rank_layer_split_equals_single_process(ftype, tmp_path):
     assert line["n_gpus"] == G and line["steps"] == K and line["value"] > 0 and line["scaling"] == "weak"
     ranges = lsp.layer_ranges(ls.MODELS["tiny4"]["n_layer"], G)
     assert line["layers"] == [list(x) for x in ranges] and ranges[0][1] > 0 and ranges[1][1] > ranges[1][0], "both ranks must own layers"
+    # rank 0 reports every stage's clock: compute + waits account for the step time, and every link has a measured hand-off latency
+    st = line["stages"]
+    assert [e["rank"] for e in st] == list(range(G)) and [e["layers"] for e in st] == [list(x[:2]) for x in ranges]
+    for e in st:
+        assert e["compute_ms_per_step"] > 0 and e["recv_wait_ms_per_step"] >= 0 and e["send_buffer_wait_ms_per_step"] >= 0
+        assert e["compute_ms_per_step"] + e["recv_wait_ms_per_step"] + e["send_buffer_wait_ms_per_step"] <= line["ms_per_step"]*1.05
+        assert (e["handoff_to_next_one_way_us"] is None) == (e["rank"] == G - 1) and (e["rank"] == G - 1 or e["handoff_to_next_one_way_us"] > 0)
+    assert st[0]["recv_wait_ms_per_step"] == 0
     d = np.load(dump)
     assert len(d["seq"]) == K, "every rank runs K local steps (local step j of stage r is pipeline tick j + r)"
     # single process, whole model, the same streams: sequence s is fed tokens[j] at the ticks j = s, s + G, ...

@@ -129,6 +129,10 @@ def test_mul_mat_golden(name, k, golden_dir):
     # of Q6_K at k = 14336 (8 do not leave two slots: the matrix-core kernel takes those)
     ("q4_K", 4096, 14336, 3), ("q5_K", 1000, 6144, 4), ("q6_K", 4096, 4096, 8), ("q4_K", 300, 2048, 6), ("q6_K", 4097, 14336, 7), ("q5_K", 4096, 14336, 8),
     ("q4_K", 14336, 4096, 2), ("q6_K", 7, 2048, 5),
+    # one column through the STREAMED kernel at the model's row lengths against the oracle: Q4_0 / Q8_0 units on the Q8_0 activation image and Q6_K units,
+    # 16-lane row reductions (k / 256 = 16, 56), rows that do not divide by 256 workgroups
+    ("q4_0", 4096, 4096, 1), ("q4_0", 4096, 14336, 1), ("q4_0", 14336, 4096, 1), ("q6_K", 4096, 14336, 1), ("q6_K", 14336, 4096, 1), ("q8_0", 4096, 14336, 1), ("q5_K", 4096, 14336, 1),
+    ("q4_0", 1003, 4096, 1), ("q6_K", 4099, 4096, 1),
 ])
 def test_mul_mat_model_shapes(name, m, k, n):
     rng = np.random.default_rng(m * 131 + k)

@@ -18,7 +18,9 @@ with gg.Context() as ctx:
     act = L.ggml_swiglu_split(ctx.ctx, L.ggml_mul_mat(ctx.ctx, g_, x), L.ggml_mul_mat(ctx.ctx, u_, x))
     ctx.alloc(be)
     gg.tensor_set(g_, orc.random_blocks(rng, QTYPES["q4_K"], (ff,), k)); gg.tensor_set(u_, orc.random_blocks(rng, QTYPES["q4_K"], (ff,), k))
-    gg.tensor_set(x, rng.uniform(-1, 1, size=(n, k)).astype(np.float32))
+    if os.environ.get('ZERO_DATA'):      # the same instruction stream on all-zero operands: what the chip's clock does under less switching activity (DVFS check)
+        gg.tensor_set(g_, np.zeros_like(orc.random_blocks(rng, QTYPES['q4_K'], (ff,), k))); gg.tensor_set(u_, np.zeros_like(orc.random_blocks(rng, QTYPES['q4_K'], (ff,), k)))
+    gg.tensor_set(x, rng.uniform(-1, 1, size=(n, k)).astype(np.float32) if not os.environ.get('ZERO_DATA') else np.zeros((n, k), np.float32))
     gr = gg.graph_of(ctx, act)
     for _ in range(3): be.compute(gr)
     be.synchronize(); t0 = time.perf_counter()

@@ -63,4 +63,26 @@ for name, (k, m, n_exp, n_used) in [("mxfp4", (2880, 2880, 32, 4)), ("q4_K", (40
         else:
             e["TFLOPs"] = round(2.0 * m * k * n * n_used / us / 1e6, 1)
         out.append(e); print(e, flush=True)
+# FLASH_ATTN_EXT perf cases (tests/test-backend-ops.cpp:6210-6216): head size 64 / 128, 8 KV heads, nr = 1 / 4 query heads per KV head, kv = 4096 / 8192 / 16384
+# cached cells, ONE token, f16 K / V, f16 mask; GB/s = K + V bytes read once per launch
+for kv in (4096, 8192, 16384):
+    for hs in (64, 128):
+        for nr in (1, 4):
+            rng = np.random.default_rng(5)
+            n_head_kv, n_head, T = 8, 8*nr, 1
+            kc = rng.uniform(-1, 1, size=(1, 1, kv, hs*n_head_kv)).astype(np.float16); vc = rng.uniform(-1, 1, size=(1, 1, kv, hs*n_head_kv)).astype(np.float16)
+            with gg.Context() as ctx:
+                k_l = ctx.new_tensor(gg.F16, (hs*n_head_kv, kv)); v_l = ctx.new_tensor(gg.F16, (hs*n_head_kv, kv))
+                q_cur = ctx.new_tensor(gg.F32, (hs, n_head, T)); m_ = ctx.new_tensor(gg.F16, (kv, 64))
+                k = L.ggml_view_3d(ctx.ctx, k_l, hs, n_head_kv, kv, hs*2, hs*n_head_kv*2, 0); v = L.ggml_view_3d(ctx.ctx, v_l, hs, n_head_kv, kv, hs*2, hs*n_head_kv*2, 0)
+                q = L.ggml_permute(ctx.ctx, q_cur, 0, 2, 1, 3); k = L.ggml_permute(ctx.ctx, k, 0, 2, 1, 3); v = L.ggml_permute(ctx.ctx, v, 0, 2, 1, 3)
+                fa = L.ggml_flash_attn_ext(ctx.ctx, q, k, v, m_, float(1.0/np.sqrt(hs)), 0.0, 0.0)
+                L.ggml_flash_attn_ext_set_prec(fa, 10)
+                assert be.supports_op(fa); ctx.alloc(be)
+                gg.tensor_set(k_l, kc); gg.tensor_set(v_l, vc); gg.tensor_set(q_cur, rng.uniform(-1, 1, size=(1, T, n_head, hs)).astype(np.float32))
+                gg.tensor_set(m_, np.zeros((1, 1, 64, kv), np.float16))
+                us = timed(gg.graph_of(ctx, fa), 50)
+            e = {"op": "FLASH_ATTN_EXT", "hs": hs, "n_head_kv": n_head_kv, "nr": nr, "kv": kv, "n_tokens": 1, "type_kv": "f16", "us": round(us, 2),
+                 "GBps_kv": round((kc.nbytes + vc.nbytes)/us/1e3, 1)}
+            out.append(e); print(e, flush=True)
 json.dump(out, open(sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/op_perf.json", "w"), indent=1)
