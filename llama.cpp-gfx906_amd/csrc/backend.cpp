@@ -385,6 +385,7 @@ struct mi_backend_ctx {
 
     void * scratch = nullptr;      // quantized activations
     size_t scratch_size = 0;
+    int moe_dual = -1;                  // option "moe_dual"
     float * moe_ws = nullptr;                                   // logits + arrival counter of the multi-workgroup router kernel (moe_route)
     // producer-side activation quantization (mmvq_fin): the image a GLU launch writes for the mat-vec that follows + its arrival counters
     void * fin_img = nullptr; unsigned * fin_cnt = nullptr;
@@ -742,8 +743,12 @@ static size_t graph_scratch_need(const struct ggml_cgraph * g) {
             if (n->op == GGML_OP_MUL_MAT && rows > MMVQ_MAX_N) s = mul_mat_q_scratch_bytes(b->ne[0], rows, n->src[0]->ne[1]) + mul_mat_q_x_bytes(b->ne[0], rows);   // + room for a producer's copy above its own
             if (n->op == GGML_OP_MUL_MAT_ID) {
                 const struct ggml_tensor * ids = n->src[2];
-                const size_t sg = mul_mat_q_id_scratch_bytes(b->ne[0], b->ne[1], ids->ne[1], ids->ne[0], n->src[0]->ne[2]);
+                size_t sg = mul_mat_q_id_scratch_bytes(b->ne[0], b->ne[1], ids->ne[1], ids->ne[0], n->src[0]->ne[2]);
                 if (sg > s) s = sg;
+                if (b->ne[1] == 1 && ids->ne[0]*ids->ne[1] > 4*MMVQ_MAX_N) {      // the fused expert chain of a prompt pass keeps the GLU result (rows of this tensor's m) beside the input copy
+                    sg = mul_mat_q_id_plan(nullptr, b->ne[0], ids->ne[1], ids->ne[0], n->src[0]->ne[2], n->src[0]->ne[1]).bytes;
+                    if (sg > s) s = sg;
+                }
             }
             if (s > need) need = s;
         } else if (n->op == GGML_OP_MUL_MAT && n->src[0]->type == GGML_TYPE_F16 && n->src[1]->type == GGML_TYPE_F32 && n->src[1]->ne[1] > MMVQ_MAX_N) {
@@ -1531,6 +1536,157 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
     return consumed;
 }
 
+// Prompt pass (many tokens) through the experts of build_moe_ffn (src/llama-graph.cpp:914-990):
+//   MUL_MAT_ID(up) [ADD_ID] ; MUL_MAT_ID(gate) [ADD_ID] ; GLU (swiglu | swiglu_oai) ; MUL_MAT_ID(down) [ADD_ID] [MUL weights]
+// as: ONE bf16 copy of the layer input, ONE sort of the (token, slot) pairs by expert, ONE dual tile launch (both products of an expert's pairs against one
+// activation tile, biases and the GLU in its epilogue, result as bf16 rows per pair) and ONE tile launch for the down projection reading those rows (bias and routing
+// weight in its epilogue). Node by node the same work is 3 copies + 3 sorts + 3 tile launches + up to 5 element kernels, and every expert's gate and up tiles stage the same
+// activation rows twice. The down half is taken only if it follows directly; intermediates are skipped only if nobody else reads them.
+static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i);
+static bool moe_mmq_ok(const struct ggml_tensor * n) {
+    if (n->op != GGML_OP_MUL_MAT_ID) return false;
+    const struct ggml_tensor * as = n->src[0]; const struct ggml_tensor * b = n->src[1]; const struct ggml_tensor * ids = n->src[2];
+    if (!ggml_is_quantized(as->type) || act_kind_for((int) as->type) < 0 || as->nb[0] != ggml_type_size(as->type) || as->ne[3] != 1) return false;
+    if (ids->type != GGML_TYPE_I32 || ids->ne[2] != 1 || ids->ne[3] != 1) return false;
+    const int64_t n_used = ids->ne[0], n_tokens = ids->ne[1];
+    if (n_used*n_tokens <= 4*MMVQ_MAX_N || !mul_mat_q_id_supported(as->ne[2], n_used, n_tokens)) return false;
+    if (b->type != GGML_TYPE_F32 || b->nb[0] != 4 || b->ne[2] != n_tokens || b->ne[3] != 1 || !(b->ne[1] == 1 || b->ne[1] == n_used)) return false;
+    return n->type == GGML_TYPE_F32 && n->nb[0] == 4 && n->ne[0] == as->ne[1] && n->ne[1] == n_used && n->ne[2] == n_tokens && n->ne[3] == 1;
+}
+static int try_fused_prefill_moe(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    static const bool on = !getenv("GGML_MI355X_PREFILL_MOE") || atoi(getenv("GGML_MI355X_PREFILL_MOE")) != 0;
+    if (!on) return 0;
+    struct ggml_tensor * up = g->nodes[i];
+    if (!moe_mmq_ok(up) || up->src[1]->ne[1] != 1 || !is_internal(c, up)) return 0;
+    const struct ggml_tensor * as = up->src[0]; const struct ggml_tensor * b = up->src[1]; const struct ggml_tensor * ids = up->src[2];
+    const int64_t K = as->ne[0], M = as->ne[1], E = as->ne[2], n_used = ids->ne[0], n_tokens = ids->ne[1];
+    if (M % 64 != 0) return 0;                  // the GLU rows are the down projection's bf16 activation rows: no padding between them
+    auto bias_of = [&](struct ggml_tensor * mm, const struct ggml_tensor * w, int & j) -> struct ggml_tensor * {      // the ADD_ID that consumes mm, if it is next
+        const int jn = next_real(g, j);
+        if (jn < 0) return nullptr;
+        struct ggml_tensor * ad = g->nodes[jn];
+        if (ad->op != GGML_OP_ADD_ID || ad->src[0] != mm || ad->src[2] != ids || ad->type != GGML_TYPE_F32 || !ggml_are_same_shape(ad, mm) || ad->nb[0] != 4) return nullptr;
+        const struct ggml_tensor * bt = ad->src[1];
+        if (bt->type != GGML_TYPE_F32 || bt->ne[0] != w->ne[1] || bt->nb[0] != 4 || bt->nb[1] % 4 || bt->ne[1] != w->ne[2] || !is_internal(c, mm)) return nullptr;
+        j = jn;
+        return ad;
+    };
+    int j = i;
+    struct ggml_tensor * a_b = bias_of(up, as, j);
+    if (a_b && !is_internal(c, a_b)) return 0;
+    const int jo = next_real(g, j);
+    struct ggml_tensor * other = jo > 0 ? g->nodes[jo] : nullptr;
+    if (!other || !moe_mmq_ok(other) || other->src[1] != b || other->src[2] != ids || other->src[0]->type != as->type || other->src[0]->ne[0] != K || other->src[0]->ne[1] != M ||
+        other->src[0]->ne[2] != E || other->src[0]->nb[1] != as->nb[1] || other->src[0]->nb[2] != as->nb[2] || !is_internal(c, other)) return 0;
+    j = jo;
+    struct ggml_tensor * o_b = bias_of(other, other->src[0], j);
+    if ((o_b && !is_internal(c, o_b)) || (!a_b) != (!o_b)) return 0;
+    if (a_b && a_b->src[1]->nb[1] != o_b->src[1]->nb[1]) return 0;
+    const int jg = next_real(g, j);
+    struct ggml_tensor * gl = jg > 0 ? g->nodes[jg] : nullptr;
+    struct ggml_tensor * a_out = a_b ? a_b : up; struct ggml_tensor * o_out = o_b ? o_b : other;
+    if (!gl || gl->op != GGML_OP_GLU || gl->op_params[1] != 0 || (ggml_get_glu_op(gl) != GGML_GLU_OP_SWIGLU && ggml_get_glu_op(gl) != GGML_GLU_OP_SWIGLU_OAI) ||
+        !((gl->src[0] == o_out && gl->src[1] == a_out) || (gl->src[0] == a_out && gl->src[1] == o_out)) || gl->type != GGML_TYPE_F32 || gl->nb[0] != 4 ||
+        gl->ne[0] != M || gl->ne[1] != n_used || gl->ne[2] != n_tokens || gl->ne[3] != 1) return 0;
+    const bool a_is_gate = gl->src[0] == a_out;           // out = act(src0) * src1: src0 is the gate side
+    const struct ggml_tensor * w_gate = (a_is_gate ? up : other)->src[0]; const struct ggml_tensor * w_up = (a_is_gate ? other : up)->src[0];
+    const struct ggml_tensor * bg = a_is_gate ? a_b : o_b; const struct ggml_tensor * bu = a_is_gate ? o_b : a_b;
+    const bool oai = ggml_get_glu_op(gl) == GGML_GLU_OP_SWIGLU_OAI;
+
+    // the down half: MUL_MAT_ID(down, gl, ids) [ADD_ID] [MUL weights], directly behind the GLU
+    int consumed_to = jg, between_from = 0, between_to = 0;       // [between_from, between_to): the routing weights' nodes between the down product and its MUL
+    struct ggml_tensor * down = nullptr; struct ggml_tensor * d_out = nullptr; const struct ggml_tensor * d_bias = nullptr; const struct ggml_tensor * d_scale = nullptr;
+    {
+        const int jd = next_real(g, jg);
+        struct ggml_tensor * dn = jd > 0 ? g->nodes[jd] : nullptr;
+        if (dn && moe_mmq_ok(dn) && dn->src[1] == gl && dn->src[2] == ids && dn->src[0]->ne[0] == M && dn->src[0]->ne[2] == E && dn->nb[0] == 4) {
+            down = dn; d_out = dn; consumed_to = jd;
+            int jj = jd;
+            struct ggml_tensor * ad = bias_of(dn, dn->src[0], jj);
+            if (ad) { d_out = ad; d_bias = ad->src[1]; consumed_to = jj; }
+            // MUL(experts, weights): the graph lists a node's sources depth-first, so the routing weights' own nodes (GET_ROWS of the probabilities, their
+            // normalisation: src/llama-graph.cpp:887-908) sit BETWEEN the down product and the MUL. They do not depend on anything of this chain: they are
+            // computed first (node by node), then the down launch applies the weight in its epilogue.
+            int jm = jj; bool between_ok = true;
+            for (int hop = 0; hop < 12; hop++) {
+                jm = next_real(g, jm);
+                if (jm < 0) break;
+                const struct ggml_tensor * t = g->nodes[jm];
+                if (t->op == GGML_OP_MUL && t->src[0] == d_out) break;
+                const bool light = t->op == GGML_OP_GET_ROWS || t->op == GGML_OP_SOFT_MAX || t->op == GGML_OP_SUM_ROWS || t->op == GGML_OP_DIV || t->op == GGML_OP_SCALE;
+                bool reads_chain = false;
+                for (int q = 0; q < GGML_MAX_SRC; q++) {
+                    const struct ggml_tensor * sq = t->src[q];
+                    while (sq) { if (sq == up || sq == other || sq == a_out || sq == o_out || sq == gl || sq == dn || sq == d_out) reads_chain = true; sq = sq->view_src; }
+                }
+                if (!light || reads_chain) { between_ok = false; break; }
+            }
+            struct ggml_tensor * ml = jm > 0 && between_ok ? g->nodes[jm] : nullptr;
+            if (ml && ml->op == GGML_OP_MUL && ml->src[0] == d_out && is_internal(c, d_out) && ml->type == GGML_TYPE_F32 && ggml_are_same_shape(ml, d_out) && ml->nb[0] == 4) {
+                const struct ggml_tensor * wt = ml->src[1];
+                if (wt->type == GGML_TYPE_F32 && wt->ne[0] == 1 && wt->ne[1] == n_used && wt->ne[2] == n_tokens && wt->ne[3] == 1 &&
+                    !ranges_overlap(ml->data, ggml_nbytes(ml), wt->data, ggml_nbytes(wt))) { d_scale = wt; d_out = ml; between_from = jj + 1; between_to = jm; consumed_to = jm; }
+            }
+        }
+    }
+    const mmq_moe_plan pl = mul_mat_q_id_plan(c->scratch, K, n_tokens, n_used, E, M);
+    if (pl.bytes > c->scratch_size) return 0;
+    const bool gl_f32 = !down || !is_internal(c, gl);      // somebody else reads the GLU result as a tensor
+    c->aq.valid = false;     // the scratch is reused
+    // Few pairs per expert (gpt-oss at 512 tokens: 64): the dual kernel — one 256-pair tile per expert, eight decoding waves, both tensors against one activation tile
+    // (pp512 18.7k -> 22.2k tok/s). Many (Mixtral: ~128): the dual kernel's single workgroup per CU decodes at half the rate of two 128-pair workgroups (926 us against
+    // 2 x 350 - 390 + 62 for the GLU kernel), so the two products stay separate launches of the 128-pair kernel: the up launch writes its tensor, the gate launch reads
+    // it back in its epilogue and evaluates the GLU there.
+    static const int dual_env = getenv("GGML_MI355X_MOE_DUAL") ? atoi(getenv("GGML_MI355X_MOE_DUAL")) : -1;
+    const int dual_opt = c->moe_dual >= 0 ? c->moe_dual : dual_env;
+    const bool dual = dual_opt >= 0 ? dual_opt != 0 : n_used*n_tokens <= 96*E;
+    const int tile = dual ? 256 : mul_mat_q_id_tile(n_used, n_tokens, E);
+    if (!dual && gl_f32) {      // the gate launch reads the up tensor while it writes the GLU tensor: the same element by the same lane if they are one buffer, a race if they overlap otherwise
+        const struct ggml_tensor * u_chk = a_is_gate ? o_out : a_out;
+        if (gl->data != u_chk->data && ranges_overlap(gl->data, ggml_nbytes(gl), u_chk->data, ggml_nbytes(u_chk))) return 0;
+    }
+    mul_mat_q_id_act16((const float *) b->data, b->nb[1], b->nb[2], K, 1, n_tokens, pl.xb, c->stream);
+    mul_mat_q_id_sort((const int32_t *) ids->data, ids->nb[0], ids->nb[1], n_used, n_tokens, E, tile, pl.table, c->stream);
+    mmq_moe_epi eg;
+    eg.oai = oai ? 1 : 0; eg.alpha = oai ? op_f32(gl, 2) : 0.0f; eg.limit = oai ? op_f32(gl, 3) : 0.0f;
+    if (dual) {
+        if (bg) { eg.bias = (const float *) bg->src[1]->data; eg.bias2 = (const float *) bu->src[1]->data; eg.bias_stride = bg->src[1]->nb[1]/4; }
+        mul_mat_q_id_tiles((int) as->type, w_gate->data, w_up->data, as->nb[1], as->nb[2], M, K, pl.xb, 1, pl.table, tile, n_used, n_tokens, E, eg,
+                           gl_f32 ? (float *) gl->data : nullptr, gl->nb[1], gl->nb[2], down ? pl.y16 : nullptr, c->stream);
+        c->cnt.mmq_launches++; c->cnt.kernels_launched += 3;
+    } else {
+        struct ggml_tensor * u_out = a_is_gate ? o_out : a_out;       // the up side's last tensor: its memory holds the up product (+ bias) between the two launches
+        mmq_moe_epi eu;
+        if (bu) { eu.bias = (const float *) bu->src[1]->data; eu.bias_stride = bu->src[1]->nb[1]/4; }
+        mul_mat_q_id_tiles((int) as->type, w_up->data, nullptr, as->nb[1], as->nb[2], M, K, pl.xb, 1, pl.table, tile, n_used, n_tokens, E, eu,
+                           (float *) u_out->data, u_out->nb[1], u_out->nb[2], nullptr, c->stream);
+        if (bg) { eg.bias = (const float *) bg->src[1]->data; eg.bias_stride = bg->src[1]->nb[1]/4; }
+        eg.glu_up = (const float *) u_out->data; eg.glu_up_nb1 = u_out->nb[1]; eg.glu_up_nb2 = u_out->nb[2];
+        mul_mat_q_id_tiles((int) as->type, w_gate->data, nullptr, as->nb[1], as->nb[2], M, K, pl.xb, 1, pl.table, tile, n_used, n_tokens, E, eg,
+                           gl_f32 ? (float *) gl->data : nullptr, gl->nb[1], gl->nb[2], down ? pl.y16 : nullptr, c->stream);
+        c->cnt.mmq_launches += 2; c->cnt.kernels_launched += 4;
+    }
+    c->cnt.weight_bytes += (uint64_t) 2*E*M*ggml_row_size(as->type, K);
+    if (down) {
+        if (between_to > between_from) {
+            const bool uf = c->use_fusion; c->use_fusion = false;
+            for (int q = between_from; q < between_to; ) q += compute_node(c, g, q);
+            c->use_fusion = uf;
+        }
+        const struct ggml_tensor * ad = down->src[0];
+        mmq_moe_epi ed;
+        if (d_bias) { ed.bias = (const float *) d_bias->data; ed.bias_stride = d_bias->nb[1]/4; }
+        if (d_scale) { ed.scale = (const float *) d_scale->data; ed.scale_nb0 = d_scale->nb[1]; ed.scale_nb1 = d_scale->nb[2]; }
+        const int tile_d = mul_mat_q_id_tile(n_used, n_tokens, E);
+        if (tile_d != tile) mul_mat_q_id_sort((const int32_t *) ids->data, ids->nb[0], ids->nb[1], n_used, n_tokens, E, tile_d, pl.table2, c->stream);
+        mul_mat_q_id_tiles((int) ad->type, ad->data, nullptr, ad->nb[1], ad->nb[2], ad->ne[1], M, pl.y16, n_used, tile_d != tile ? pl.table2 : pl.table, tile_d, n_used, n_tokens, E, ed,
+                           (float *) d_out->data, d_out->nb[1], d_out->nb[2], nullptr, c->stream);
+        c->cnt.mmq_launches++; c->cnt.kernels_launched += tile_d != tile ? 2 : 1;
+        c->cnt.weight_bytes += (uint64_t) E*ad->ne[1]*ggml_row_size(ad->type, M);
+    }
+    return consumed_to - i + 1;
+}
+
 // MUL_MAT(F32 router weights, x) [-> ADD bias] [-> SOFT_MAX] -> ARGSORT desc, one token (src/llama-graph.cpp:838-883)
 // norm / normw != NULL: x (= lg->src[1]) is MUL(RMS_NORM(norm->src[0]), normw), not computed yet: the router kernel computes it and writes it
 static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i, const struct ggml_tensor * norm = nullptr, const struct ggml_tensor * normw = nullptr) {
@@ -1789,7 +1945,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
             if (!f) f = try_fused_prefill_add(c, g, i);
         } else if (node->op == GGML_OP_SET_ROWS) f = try_fused_kv_store(c, g, i);
         else if (node->op == GGML_OP_GET_ROWS) f = try_fused_moe_combine(c, g, i);
-        else if (node->op == GGML_OP_MUL_MAT_ID) f = try_fused_moe_experts(c, g, i);
+        else if (node->op == GGML_OP_MUL_MAT_ID) { f = try_fused_moe_experts(c, g, i); if (!f) f = try_fused_prefill_moe(c, g, i); }
         if (f) {
             consumed = f;
             fresh_aq = c->aq_fresh; c->aq_fresh = false;
@@ -2583,6 +2739,12 @@ int ggml_backend_mi355x_set_option(ggml_backend_t backend, const char * key, int
     }
     if (strcmp(key, "fusion") == 0) {
         c->use_fusion = value != 0;
+        MI_CHECK(hipStreamSynchronize(c->stream));
+        drop_graphs(c);
+        return 0;
+    }
+    if (strcmp(key, "moe_dual") == 0) {       // the prompt pass's expert chain: -1 = by pairs per expert (default), 0 = gate / up as two launches, 1 = the dual launch
+        c->moe_dual = value;
         MI_CHECK(hipStreamSynchronize(c->stream));
         drop_graphs(c);
         return 0;

@@ -101,6 +101,20 @@ void   mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_ex
                     const float * b, size_t b_nb1, size_t b_nb2, int64_t n_b,
                     const int32_t * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert,
                     void * scratch, float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream);
+// The pieces of the above, for the fused expert chain of a prompt pass (backend.cpp try_fused_prefill_moe): one sort and one bf16 copy of the layer input serve
+// gate, up and down; gate / up run as ONE dual launch with the ADD_ID biases and the (oai) SwiGLU in its epilogue and hand the down projection bf16 rows per pair;
+// the down launch adds its ADD_ID bias and multiplies with the routing weight (MUL(experts, weights), src/llama-graph.cpp:990)
+struct mmq_moe_epi { const float * bias = nullptr; const float * bias2 = nullptr; size_t bias_stride = 0; const float * scale = nullptr; size_t scale_nb0 = 0, scale_nb1 = 0;
+                     int oai = 0; float alpha = 0.0f, limit = 0.0f;
+                     const float * glu_up = nullptr; size_t glu_up_nb1 = 0, glu_up_nb2 = 0; };     // (single-tensor launch as the gate half of a GLU: the finished up half, f32 [m, n_used, n_tokens])
+struct mmq_moe_plan { uint16_t * xb; int * table; int * table2; uint16_t * y16; size_t bytes; };     // table: 256-pair tiles (dual launch); table2: the down launch's tiles
+mmq_moe_plan mul_mat_q_id_plan(void * scratch, int64_t k, int64_t n_tokens, int64_t n_used, int64_t n_expert, int64_t m_glu);
+int    mul_mat_q_id_tile(int64_t n_used, int64_t n_tokens, int64_t n_expert);      // pairs per tile: 128 or 256
+void   mul_mat_q_id_sort(const int32_t * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert, int tile, int * table, hipStream_t stream);
+void   mul_mat_q_id_act16(const float * b, size_t b_nb1, size_t b_nb2, int64_t k, int64_t n_b, int64_t n_tokens, uint16_t * xb, hipStream_t stream);
+void   mul_mat_q_id_tiles(int type_a, const void * W, const void * W2, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
+                          const uint16_t * xb, int64_t n_b, const int * table, int tile, int64_t n_used, int64_t n_tokens, int64_t n_expert,
+                          const mmq_moe_epi & epi, float * dst, size_t dst_nb1, size_t dst_nb2, uint16_t * y16, hipStream_t stream);
 
 // ---- dense f16/f32 x f32 mat-mul with ggml broadcast (attention K.Q and V.KQ; tests/test-backend-ops.cpp:5791-5813)
 struct mm_dense_args {

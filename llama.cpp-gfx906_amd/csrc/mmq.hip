@@ -206,6 +206,13 @@ struct mmq_args {
     int moe_max_tiles, n_used, n_b;            // pair = token*n_used + slot; X row of a pair = token*n_b + slot % n_b
     fused_rope rope;                           // for segments with .rope (wq, wk): RESHAPE -> ROPE of build_attn folded into the epilogue / the combine pass
     int nseg; mmq_seg seg[3];                  // nseg > 0: W / m / dst / strides per segment; p.m = the summed rows (the width of a split-k plane)
+    // MUL_MAT_ID epilogues (MOE kernels): per-expert bias rows (ADD_ID, src/llama-graph.cpp:927,940,985) for W / W2, the SwiGLU flavour of the dual kernel,
+    // and (single-tensor kernel) the routing weight of the pair — MUL(experts, weights), :990 — applied after the bias
+    const float * bias; const float * bias2; size_t bias_stride;   // floats between two experts' bias rows
+    const float * scale; size_t scale_nb0, scale_nb1;       // weight of (token, slot) at scale + slot*nb0 + token*nb1 (bytes)
+    int glu_oai; float glu_alpha, glu_limit;
+    const char * glu_up; size_t glu_up_nb1, glu_up_nb2;     // single-tensor MOE kernel: != NULL: this launch is the GATE product and the up product (+ bias) is already in memory
+                                                            // at glu_up + slot*nb1 + token*nb2: the epilogue evaluates the GLU and writes y16 / dst like the dual kernel
     int dbg;                                   // -DMI_MMQ_DBG builds only (a runtime branch in this loop costs 10 % of pp512): GGML_MI355X_MMQ_DBG ablations for timing, wrong results: 1 = no weight decode, 2 = no MFMAs, 4 = no global loads inside the loop, 8 = no LDS commits
 };
 
@@ -217,7 +224,12 @@ struct mmq_args {
 // DUAL (BN = 256 only): two weight tensors against the same activations and their SwiGLU in the epilogue — waves 0-3 dequantize the
 // gate tile, waves 4-7 the up tile (every wave has dequantization work now), every wave multiplies its 64 x 64 token / row tile with
 // both: 32 MFMAs per k-step and wave against one 64-element dequantization, one result tensor instead of two plus a GLU kernel
-template <int TYPE, int BN = MQ_BN, bool DUAL = false, int TYPE2 = TYPE>
+// MOE: MUL_MAT_ID tile-table mode (a tile = up to BN (token, slot) pairs of one expert). With 256-pair tiles a wave whose 64 pairs are past the tile's count skips
+// its matrix-core work altogether and only stages (experts of a prompt pass hold ~64 - 128 pairs each: the kernel is bound by the weight decode).
+// What counts is how many waves per CU DECODE: the 128-pair kernel runs two workgroups of four decoding waves per CU, the single-tensor 256-pair kernel one workgroup
+// in which only waves 0-3 decode — at ~128 pairs per expert it decodes each expert once instead of 1.5 times and is still 30 % slower. The dual 256-pair kernel has
+// eight decoding waves (four per tensor) and one activation tile for both tensors: that one pays.
+template <int TYPE, int BN = MQ_BN, bool DUAL = false, int TYPE2 = TYPE, bool MOE = false>
 __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mmq(const mmq_args p) {   // LDS allows 8 waves per CU anyway; without the
     // occupancy pin the scheduler reverts the interleaved order below to keep a third wave's worth of registers free
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile [| W2 tile] | X tile)
@@ -243,12 +255,12 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     const uint16_t * X = p.X + (size_t) blockIdx.z*n*kp;
     char * dst = p.ksplit > 1 ? p.dst2 + (size_t) khalf*p.m*p.n*4 + (size_t) col0*4 : seg_dst + (size_t) i12*p.dst_nb2 + (size_t) i13*p.dst_nb3;
     const size_t dst_nb1 = p.ksplit > 1 ? (size_t) p.m*4 : seg_dst_nb1;
-    int moe_first = 0, moe_cnt = 0;
+    int moe_first = 0, moe_cnt = 0, moe_e = 0;
     const int * moe_pairs = nullptr;
-    if (p.moe) {                               // workgroup-uniform
+    if (MOE) {                                 // workgroup-uniform
         if ((int) blockIdx.x >= p.moe[0]) return;
         const int * t = p.moe + 1 + 3*blockIdx.x;
-        W = p.W + (size_t) t[0]*p.w_nb2; moe_first = t[1]; moe_cnt = t[2];
+        moe_e = t[0]; W = p.W + (size_t) moe_e*p.w_nb2; moe_first = t[1]; moe_cnt = t[2];
         moe_pairs = p.moe + 1 + 3*p.moe_max_tiles;
     }
 
@@ -265,9 +277,9 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     const int srow = tid >> 1, shalf = tid & 1;
     const bool w_role = DUAL || BN == MQ_BM || tid < 2*MQ_BM;        // wave-uniform
     const int wt = DUAL ? tid >> 8 : 0;                              // DUAL: which weight tile this thread dequantizes
-    const char * wrow_p = (DUAL && wt ? p.W2 : W) + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*w_row_stride;
+    const char * wrow_p = (DUAL && wt ? (MOE ? p.W2 + (size_t) moe_e*p.w_nb2 : p.W2) : W) + (size_t) min(m0 + (srow & (MQ_BM - 1)), m - 1)*w_row_stride;
     const uint16_t * xrow_p = X + (size_t) min(n0 + srow, n - 1)*kp;
-    if (p.moe) {
+    if (MOE) {
         const int pair = moe_pairs[moe_first + min(srow, moe_cnt - 1)];
         xrow_p = p.X + (size_t)((pair/p.n_used)*p.n_b + (pair % p.n_used) % p.n_b)*kp;
     }
@@ -283,8 +295,9 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     // Every iteration is the same straight-line block: steps past the end are fetched from clamped addresses and committed to a
     // buffer nobody reads; in a k tail (k % 64 == 32) the activation copy holds zeros, so the clamped (finite) weights drop out.
     struct stage_regs { raw32 rw; int4v xv[4]; };
-    auto run = [&](auto w_role_tag, auto type_tag) {
+    auto run = [&](auto w_role_tag, auto type_tag, auto mf_tag) {
         constexpr bool WR = decltype(w_role_tag)::value;
+        constexpr bool MF = decltype(mf_tag)::value;       // false (MOE only): this wave's pairs are all past the tile's count — stage, do not multiply
         constexpr int TY = decltype(type_tag)::value;      // the block format this workgroup's segment is decoded as
         auto fetch = [&](stage_regs & r, int step) {
 #ifdef MI_MMQ_DBG
@@ -362,6 +375,10 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
         auto iteration = [&](stage_regs & cur, stage_regs & nxt, int s, int buf) {
             fetch(nxt, step0 + s + 2);
             const dq_head h = head_of(cur, step0 + s + 1);
+            if constexpr (!MF) {
+#pragma unroll
+                for (int kk = 0; kk < MQ_BK/16; kk++) commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk);
+            } else {
             frags f0, f1;       // operand fragments, read one k-slice ahead (the dual kernel has no registers left for that)
             if (!DUAL) read_frags(f0, buf, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -375,6 +392,7 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
                 if (!DUAL) { __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); }
                 else       { commit_piece(cur, h, step0 + s + 1, buf ^ 1, kk); __builtin_amdgcn_sched_barrier(0); mfma_row(f, 1); }
                 __builtin_amdgcn_sched_barrier(0);
+            }
             }
             __syncthreads();
             __builtin_amdgcn_sched_barrier(0);
@@ -397,10 +415,14 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
         if (s < nsteps) iteration(p1, p0, s, 0);
     };
     if constexpr (TYPE2 != TYPE) {
-        if (use2) { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE2>{}); else run(std::false_type{}, std::integral_constant<int, TYPE2>{}); }
-        else      { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{});  else run(std::false_type{}, std::integral_constant<int, TYPE>{}); }
+        if (use2) { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE2>{}, std::true_type{}); else run(std::false_type{}, std::integral_constant<int, TYPE2>{}, std::true_type{}); }
+        else      { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{}, std::true_type{});  else run(std::false_type{}, std::integral_constant<int, TYPE>{}, std::true_type{}); }
+    } else if constexpr (MOE && BN == 256) {
+        const bool live = wn*64 < moe_cnt;             // wave-uniform
+        if (live) { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{}, std::true_type{});  else run(std::false_type{}, std::integral_constant<int, TYPE>{}, std::true_type{}); }
+        else      { if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{}, std::false_type{}); else run(std::false_type{}, std::integral_constant<int, TYPE>{}, std::false_type{}); }
     } else {
-        if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{}); else run(std::false_type{}, std::integral_constant<int, TYPE>{});
+        if (w_role) run(std::true_type{}, std::integral_constant<int, TYPE>{}, std::true_type{}); else run(std::false_type{}, std::integral_constant<int, TYPE>{}, std::true_type{});
     }
     // ---- store: D[row = token][col = weight row]; col = lane & 31, row = (r & 3) + 8*(r >> 2) + 4*(lane >> 5) ----
 #pragma unroll
@@ -411,11 +433,28 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
 #pragma unroll
             for (int r = 0; r < 16; r++) {
                 const int row = n0 + wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
-                if (p.moe) {
-                    const int rt = row - n0;
+                if (MOE) {
+                    const int rt = MOE ? wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5) : 0;
                     if (col < m && rt < moe_cnt) {
                         const int pair = moe_pairs[moe_first + rt];
-                        *(float *) (p.dst + (size_t)(pair/p.n_used)*p.dst_nb2 + (size_t)(pair % p.n_used)*p.dst_nb1 + (size_t) col*4) = acc[i][j][r];
+                        const int tok = pair/p.n_used, slot = pair - tok*p.n_used;
+                        float v = acc[i][j][r];
+                        if (p.bias) v += p.bias[(size_t) moe_e*p.bias_stride + col];
+                        if (DUAL || p.glu_up) {
+                            float u;
+                            if (DUAL) { u = acc2[DUAL ? i : 0][DUAL ? j : 0][r]; if (p.bias2) u += p.bias2[(size_t) moe_e*p.bias_stride + col]; }
+                            else u = *(const float *) (p.glu_up + (size_t) tok*p.glu_up_nb2 + (size_t) slot*p.glu_up_nb1 + (size_t) col*4);
+                            float y;
+                            if (p.glu_oai) {          // elem.hip k_glu, GGML_GLU_OP_SWIGLU_OAI
+                                const float xc = fminf(v, p.glu_limit), gc = fmaxf(fminf(u, p.glu_limit), -p.glu_limit);
+                                y = (xc/(1.0f + expf(-xc*p.glu_alpha)))*(gc + 1.0f);
+                            } else y = (v/(1.0f + expf(-v)))*u;
+                            if (p.dst) *(float *) (p.dst + (size_t) tok*p.dst_nb2 + (size_t) slot*p.dst_nb1 + (size_t) col*4) = y;
+                            if (p.y16) { const uint32_t pk = pack_bf16(y, y); p.y16[(size_t) pair*m + col] = (uint16_t) pk; }
+                        } else {
+                            if (p.scale) v *= *(const float *) ((const char *) p.scale + (size_t) slot*p.scale_nb0 + (size_t) tok*p.scale_nb1);
+                            *(float *) (p.dst + (size_t) tok*p.dst_nb2 + (size_t) slot*p.dst_nb1 + (size_t) col*4) = v;
+                        }
                     }
                 } else if (col < m && row < n) {
                     float * o = (float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4);
@@ -466,7 +505,9 @@ template <> __device__ __forceinline__ raw32 load_raw8<T_Q6_K>(const char * row,
     return r;
 }
 
-template <int TYPE, int TYPE2 = TYPE>
+// MOE: the tile-table mode of k_mmq (a tile = up to 256 (token, slot) pairs of one expert) with all 16 waves decoding; a wave whose 64 pairs are past the tile's
+// count stages and decodes but skips its matrix-core work
+template <int TYPE, int TYPE2 = TYPE, bool MOE = false>
 __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];      // 2 x (W tile | X tile)
     constexpr int BN = 256, WTILE = MQ_BM*MQ_LD, XTILE = BN*MQ_LD, STAGE = WTILE + XTILE;
@@ -489,6 +530,14 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
     const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);
     char * dst = p.ksplit > 1 ? p.dst2 + (size_t) khalf*p.m*p.n*4 + (size_t) col0*4 : seg_dst;
     const size_t dst_nb1 = p.ksplit > 1 ? (size_t) p.m*4 : seg_dst_nb1;
+    int moe_first = 0, moe_cnt = 0, moe_e = 0;
+    const int * moe_pairs = nullptr;
+    if (MOE) {                                 // workgroup-uniform
+        if ((int) blockIdx.x >= p.moe[0]) return;
+        const int * t = p.moe + 1 + 3*blockIdx.x;
+        moe_e = t[0]; W = p.W + (size_t) moe_e*p.w_nb2; moe_first = t[1]; moe_cnt = t[2];
+        moe_pairs = p.moe + 1 + 3*p.moe_max_tiles;
+    }
 
     f32x16 acc[2];
 #pragma unroll
@@ -501,13 +550,18 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
     const int xrow = tid >> 2, xq = tid & 3;
     const char * wrow_p = W + (size_t) min(m0 + wrow, m - 1)*w_row_stride;
     const uint16_t * xrow_p = p.X + (size_t) min(n0 + xrow, n - 1)*kp + 16*xq;
+    if (MOE) {
+        const int pair = moe_pairs[moe_first + min(xrow, moe_cnt - 1)];
+        xrow_p = p.X + (size_t)((pair/p.n_used)*p.n_b + (pair % p.n_used) % p.n_b)*kp + 16*xq;
+    }
     const int nsteps_all = (k + MQ_BK - 1)/MQ_BK;
     const int nsteps = p.ksplit > 1 ? nsteps_all/p.ksplit : nsteps_all;
     const int step0 = khalf*nsteps;
 
     struct stage_regs { raw32 rw; int4v xv[2]; };
-    auto run = [&](auto type_tag) {
+    auto run = [&](auto type_tag, auto mf_tag) {
         constexpr int TY = decltype(type_tag)::value;
+        constexpr bool MF = decltype(mf_tag)::value;
         auto fetch = [&](stage_regs & r, int step) {
             const int kcl = min(step*MQ_BK + 32*wchunk, k - 32);
             r.rw = load_raw8<TY>(wrow_p, kcl >> 5, wq);
@@ -531,6 +585,18 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
             fetch(nxt, step0 + s + 2);
             const int c32 = c32_of(step0 + s + 1);
             const dq_head h = decode_head<TY>(cur.rw, c32);
+            if constexpr (!MF) {
+                float lo[4], hi[4];
+                *(int4v *) (xpos(buf ^ 1)) = cur.xv[0]; *(int4v *) (xpos(buf ^ 1) + 16) = cur.xv[1];
+                decode4<TY>(cur.rw, h, c32, 0, 2*wq, lo); decode4<TY>(cur.rw, h, c32, 1, 2*wq + 1, hi);
+                int4v wpk;
+                wpk.x = (int) pack_bf16(lo[0], lo[1]); wpk.y = (int) pack_bf16(lo[2], lo[3]);
+                wpk.z = (int) pack_bf16(hi[0], hi[1]); wpk.w = (int) pack_bf16(hi[2], hi[3]);
+                *(int4v *) (wpos(buf ^ 1)) = wpk;
+                __syncthreads();
+                __builtin_amdgcn_sched_barrier(0);
+                return;
+            }
             frags f0, f1;
             read_frags(f0, buf, 0);
             __builtin_amdgcn_sched_barrier(0);
@@ -593,9 +659,11 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
         if (s < nsteps) iteration(p1, p0, s, 0);
     };
     if constexpr (TYPE2 != TYPE) {
-        if (use2) run(std::integral_constant<int, TYPE2>{}); else run(std::integral_constant<int, TYPE>{});
+        if (use2) run(std::integral_constant<int, TYPE2>{}, std::true_type{}); else run(std::integral_constant<int, TYPE>{}, std::true_type{});
+    } else if constexpr (MOE) {
+        if (wn*64 < moe_cnt) run(std::integral_constant<int, TYPE>{}, std::true_type{}); else run(std::integral_constant<int, TYPE>{}, std::false_type{});     // wave-uniform
     } else {
-        run(std::integral_constant<int, TYPE>{});
+        run(std::integral_constant<int, TYPE>{}, std::true_type{});
     }
     // ---- store: D[row = token][col = weight row] ----
 #pragma unroll
@@ -605,6 +673,28 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
         for (int r = 0; r < 16; r++) {
             const int row = n0 + wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
             float v = acc[i][r];
+            if (MOE) {         // as k_mmq's MOE epilogue: bias, then the GLU against a finished up product, or the routing weight
+                const int rt = wn*64 + i*32 + (r & 3) + 8*(r >> 2) + 4*(lane >> 5);
+                if (col < m && rt < moe_cnt) {
+                    const int pair = moe_pairs[moe_first + rt];
+                    const int tok = pair/p.n_used, slot = pair - tok*p.n_used;
+                    if (p.bias) v += p.bias[(size_t) moe_e*p.bias_stride + col];
+                    if (p.glu_up) {
+                        const float u = *(const float *) (p.glu_up + (size_t) tok*p.glu_up_nb2 + (size_t) slot*p.glu_up_nb1 + (size_t) col*4);
+                        float y;
+                        if (p.glu_oai) {
+                            const float xc = fminf(v, p.glu_limit), gc = fmaxf(fminf(u, p.glu_limit), -p.glu_limit);
+                            y = (xc/(1.0f + expf(-xc*p.glu_alpha)))*(gc + 1.0f);
+                        } else y = (v/(1.0f + expf(-v)))*u;
+                        if (p.dst) *(float *) (p.dst + (size_t) tok*p.dst_nb2 + (size_t) slot*p.dst_nb1 + (size_t) col*4) = y;
+                        if (p.y16) { const uint32_t pk = pack_bf16(y, y); p.y16[(size_t) pair*m + col] = (uint16_t) pk; }
+                    } else {
+                        if (p.scale) v *= *(const float *) ((const char *) p.scale + (size_t) slot*p.scale_nb0 + (size_t) tok*p.scale_nb1);
+                        *(float *) (p.dst + (size_t) tok*p.dst_nb2 + (size_t) slot*p.dst_nb1 + (size_t) col*4) = v;
+                    }
+                }
+                continue;
+            }
             if (do_rope) {                     // workgroup-uniform: the pair (2i, 2i + 1) of a head sits in two neighbouring lanes (m is even, heads start at even columns)
                 const float other = __shfl_xor(v, 1);
                 float x0 = (col & 1) ? other : v, x1 = (col & 1) ? v : other;
@@ -1134,7 +1224,7 @@ void mul_mat_q_glu(int type_a, const void * Wg, const void * Wu, size_t w_row_st
 // ---- MUL_MAT_ID for many tokens: pairs (token, slot) sorted by expert, then the tiled kernel above per (expert, 128 pairs) ----
 // one workgroup: counts per expert, tile table, counting sort of the pair ids. Which position a pair gets inside its expert's
 // range is not deterministic (LDS atomics) and does not matter: every pair's result row is computed independently.
-struct moe_sort_args { const char * ids; size_t ids_nb0, ids_nb1; int n_used, n_tokens, n_expert, max_tiles; int * out; };
+struct moe_sort_args { const char * ids; size_t ids_nb0, ids_nb1; int n_used, n_tokens, n_expert, max_tiles; int * out; int tile; };
 __global__ void __launch_bounds__(256) k_moe_sort(const moe_sort_args p) {
     __shared__ int cnt[256], off[256], cur[256];
     const int tid = threadIdx.x, n_pairs = p.n_used*p.n_tokens;
@@ -1150,7 +1240,7 @@ __global__ void __launch_bounds__(256) k_moe_sort(const moe_sort_args p) {
         int * tiles = p.out + 1;
         for (int e = 0; e < p.n_expert; e++) {
             off[e] = o;
-            for (int r = 0; r < cnt[e]; r += MQ_BN) { tiles[3*nt] = e; tiles[3*nt + 1] = o + r; tiles[3*nt + 2] = min(MQ_BN, cnt[e] - r); nt++; }
+            for (int r = 0; r < cnt[e]; r += p.tile) { tiles[3*nt] = e; tiles[3*nt + 1] = o + r; tiles[3*nt + 2] = min(p.tile, cnt[e] - r); nt++; }
             o += cnt[e];
         }
         p.out[0] = nt;
@@ -1163,29 +1253,68 @@ __global__ void __launch_bounds__(256) k_moe_sort(const moe_sort_args p) {
     }
 }
 
-static int moe_max_tiles(int64_t n_pairs, int64_t n_expert) { return (int)(n_pairs/MQ_BN + n_expert); }
+static int moe_max_tiles(int64_t n_pairs, int64_t n_expert) { return (int)(n_pairs/MQ_BN + n_expert); }      // (an upper bound for 128- and 256-pair tiles)
+static size_t moe_table_bytes(int64_t n_pairs, int64_t n_expert) { return ((size_t)(1 + 3*moe_max_tiles(n_pairs, n_expert) + n_pairs)*4 + 255) & ~(size_t) 255; }
 bool mul_mat_q_id_supported(int64_t n_expert, int64_t n_used, int64_t n_tokens) { return n_expert <= 256 && n_used*n_tokens < (1 << 24); }
 size_t mul_mat_q_id_scratch_bytes(int64_t k, int64_t n_b, int64_t n_tokens, int64_t n_used, int64_t n_expert) {
-    return mmq_x_bytes(k, n_b*n_tokens) + (size_t)(1 + 3*moe_max_tiles(n_used*n_tokens, n_expert) + n_used*n_tokens)*4 + 256;
+    return mmq_x_bytes(k, n_b*n_tokens) + moe_table_bytes(n_used*n_tokens, n_expert) + 256;
 }
-
-void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
-                  const float * b, size_t b_nb1, size_t b_nb2, int64_t n_b,
-                  const int32_t * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert,
-                  void * scratch, float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream) {
-    if (m == 0 || n_used*n_tokens == 0) return;
-    uint16_t * xb = (uint16_t *) scratch;
-    int * table = (int *) ((char *) scratch + mmq_x_bytes(k, n_b*n_tokens));
-    const int max_tiles = moe_max_tiles(n_used*n_tokens, n_expert);
+// the fused expert chain (gate / up / GLU -> down): bf16 copy of the layer input | tile table | bf16 GLU result, one row per (token, slot) pair
+mmq_moe_plan mul_mat_q_id_plan(void * scratch, int64_t k, int64_t n_tokens, int64_t n_used, int64_t n_expert, int64_t m_glu) {
+    mmq_moe_plan pl;
+    pl.xb = (uint16_t *) scratch;
+    pl.table = (int *) ((char *) scratch + mmq_x_bytes(k, n_tokens));
+    pl.table2 = (int *) ((char *) pl.table + moe_table_bytes(n_used*n_tokens, n_expert));
+    pl.y16 = (uint16_t *) ((char *) pl.table2 + moe_table_bytes(n_used*n_tokens, n_expert));
+    pl.bytes = mmq_x_bytes(k, n_tokens) + 2*moe_table_bytes(n_used*n_tokens, n_expert) + (((size_t) n_used*n_tokens*mmq_kp(m_glu)*2 + 255) & ~(size_t) 255) + 256;
+    return pl;
+}
+int mul_mat_q_id_tile(int64_t n_used, int64_t n_tokens, int64_t n_expert) {
+    static const int forced = getenv("GGML_MI355X_MOE_TILE") ? atoi(getenv("GGML_MI355X_MOE_TILE")) : 0;
+    if (forced == 128 || forced == 256) return forced;
+    // measured at 512 tokens: Mixtral (~128 pairs per expert, every wave of a tile multiplies): 128-pair tiles 9.85k tok/s, 256-pair tiles on the 16-wave kernel 7.9k
+    // (on k_mmq<256> 6.97k); gpt-oss (64 pairs per expert: a quarter of the 16-wave kernel's waves multiply, all sixteen decode): 256-pair tiles 22.85k, 128-pair 21.7k
+    return n_used*n_tokens <= 96*n_expert ? 256 : 128;
+}
+void mul_mat_q_id_sort(const int32_t * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert, int tile, int * table, hipStream_t stream) {
+    moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, moe_max_tiles(n_used*n_tokens, n_expert), table, tile };
+    hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
+}
+void mul_mat_q_id_act16(const float * b, size_t b_nb1, size_t b_nb2, int64_t k, int64_t n_b, int64_t n_tokens, uint16_t * xb, hipStream_t stream) {
     act16_args pa = { (const char *) b, b_nb1, b_nb2, 0, k, n_b, n_tokens, xb };     // dense [token][n_b][k] bf16
     hipLaunchKernelGGL((k_act_to_16<false>), dim3((unsigned)((mmq_kp(k) + 1023)/1024), (unsigned) n_b, (unsigned) n_tokens), dim3(256), 0, stream, pa);
-    moe_sort_args ps = { (const char *) ids, ids_nb0, ids_nb1, (int) n_used, (int) n_tokens, (int) n_expert, max_tiles, table };
-    hipLaunchKernelGGL(k_moe_sort, dim3(1), dim3(256), 0, stream, ps);
-    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, nullptr, nullptr,
+}
+
+template <int T_>
+static void launch_mmq_moe(dim3 grid, const mmq_args & a, int tile, bool dual, hipStream_t stream) {
+    if (dual) {
+        MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_DUAL, k_mmq<T_, 256, true, T_, true>);
+        hipLaunchKernelGGL((k_mmq<T_, 256, true, T_, true>), grid, dim3(512), MQ_LDS_BYTES_DUAL, stream, a);
+    } else if (tile == 256) {
+        MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES_256, k_mmq16<T_, T_, true>);
+        hipLaunchKernelGGL((k_mmq16<T_, T_, true>), grid, dim3(1024), MQ_LDS_BYTES_256, stream, a);
+    } else {
+        MI_LDS_LIMIT_OR_DIE(MQ_LDS_BYTES, k_mmq<T_, 128, false, T_, true>);
+        hipLaunchKernelGGL((k_mmq<T_, 128, false, T_, true>), grid, dim3(256), MQ_LDS_BYTES, stream, a);
+    }
+}
+
+// the tiled kernel over a sorted pair table. xb: bf16 rows [token][n_b][kp(k)] (n_b == 1: every slot of a token reads the token's row; n_b == n_used: a row per pair);
+// W2 != NULL: the dual kernel (tile must be 256): GLU(W.x + bias, W2.x + bias2) -> dst (f32, may be NULL) and / or y16 (bf16 rows of m per pair)
+void mul_mat_q_id_tiles(int type_a, const void * W, const void * W2, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
+                        const uint16_t * xb, int64_t n_b, const int * table, int tile, int64_t n_used, int64_t n_tokens, int64_t n_expert,
+                        const mmq_moe_epi & epi, float * dst, size_t dst_nb1, size_t dst_nb2, uint16_t * y16, hipStream_t stream) {
+    if (m == 0 || n_used*n_tokens == 0) return;
+    if (W2 && tile != 256) { fprintf(stderr, "mmq_id: the dual kernel runs 256-pair tiles\n"); abort(); }
+    const int max_tiles = moe_max_tiles(n_used*n_tokens, n_expert);
+    mmq_args a = { (const char *) W, w_row_stride, w_expert_stride, 0, (int) m, (int) k, xb, (int)(n_used*n_tokens), (char *) dst, dst_nb1, dst_nb2, 0, 1, 1, 1, 1, 0, nullptr, nullptr, 0, y16, (const char *) W2,
                    table, max_tiles, (int) n_used, (int) n_b };
     a.mtiles = (int)((m + MQ_BM - 1)/MQ_BM);
+    a.bias = epi.bias; a.bias2 = epi.bias2; a.bias_stride = epi.bias_stride; a.scale = epi.scale; a.scale_nb0 = epi.scale_nb0; a.scale_nb1 = epi.scale_nb1;
+    a.glu_oai = epi.oai; a.glu_alpha = epi.alpha; a.glu_limit = epi.limit;
+    a.glu_up = (const char *) epi.glu_up; a.glu_up_nb1 = epi.glu_up_nb1; a.glu_up_nb2 = epi.glu_up_nb2;
     const dim3 grid((unsigned) max_tiles, (unsigned) a.mtiles, 1);
-#define MI_MMQ(T_) hipLaunchKernelGGL((k_mmq<T_>), grid, dim3(256), MQ_LDS_BYTES, stream, a)
+#define MI_MMQ(T_) launch_mmq_moe<T_>(grid, a, tile, W2 != nullptr, stream)
     switch (type_a) {
         case T_Q4_0:  MI_MMQ(T_Q4_0);  break;
         case T_Q8_0:  MI_MMQ(T_Q8_0);  break;
@@ -1196,6 +1325,19 @@ void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expe
         default: fprintf(stderr, "mmq_id: unsupported type %d\n", type_a); abort();
     }
 #undef MI_MMQ
+}
+
+void mul_mat_q_id(int type_a, const void * W, size_t w_row_stride, size_t w_expert_stride, int64_t m, int64_t k,
+                  const float * b, size_t b_nb1, size_t b_nb2, int64_t n_b,
+                  const int32_t * ids, size_t ids_nb0, size_t ids_nb1, int64_t n_used, int64_t n_tokens, int64_t n_expert,
+                  void * scratch, float * dst, size_t dst_nb1, size_t dst_nb2, hipStream_t stream) {
+    if (m == 0 || n_used*n_tokens == 0) return;
+    uint16_t * xb = (uint16_t *) scratch;
+    int * table = (int *) ((char *) scratch + mmq_x_bytes(k, n_b*n_tokens));
+    const int tile = mul_mat_q_id_tile(n_used, n_tokens, n_expert);
+    mul_mat_q_id_act16(b, b_nb1, b_nb2, k, n_b, n_tokens, xb, stream);
+    mul_mat_q_id_sort(ids, ids_nb0, ids_nb1, n_used, n_tokens, n_expert, tile, table, stream);
+    mul_mat_q_id_tiles(type_a, W, nullptr, w_row_stride, w_expert_stride, m, k, xb, n_b, table, tile, n_used, n_tokens, n_expert, mmq_moe_epi{}, dst, dst_nb1, dst_nb2, nullptr, stream);
 }
 
 // f16 x f32 with ggml broadcast on the matrix cores (n > 8 columns): a rows contiguous f16, b rows contiguous f32

@@ -340,7 +340,7 @@ def test_moe_full_width_layers_match_oracle(model, ftype):
     gpt-oss-20b (2880 x 2880, 32 experts top-4, MXFP4 experts, ADD_ID biases, swiglu_oai, sinks, the sliding-window cache pair), a small
     vocabulary. Single-token steps run the fused grouped launches — router (k_moe_route_wide from 16 experts on: the granule hand-off at 32),
     one launch for all used experts' gate / up / GLU, one for their down projections (the expert index read on the device), the combine —
-    and a 12-token pass runs the grouped MFMA path. A routing near-tie would show as ~1e-1, so the choices are compared too."""
+    and a 20-token pass runs the grouped MFMA path (the fused expert chain of try_fused_prefill_moe). A routing near-tie would show as ~1e-1, so the choices are compared too."""
     be = backend()
     be.set_option("graphs", 1); be.set_option("fusion", 1)
     m = ls.SynthLlama(be, model, ftype, n_ctx=64, seed=6, n_layer=2, n_vocab=512)
@@ -349,14 +349,25 @@ def test_moe_full_width_layers_match_oracle(model, ftype):
         W = read_weights(m)
         rc = RefLlama(m.cfg, W, 64, "cpu16")
         be.reset_counters()
-        for i, (toks, gate) in enumerate((([3], 1e-3), ([7], 1e-3), ([9], 1e-3), ([11], 1e-3), ([3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8], 2e-3), ([2], 2e-3))):
+        long_pass = [3, 1, 4, 1, 5, 9, 2, 6, 5, 3, 5, 8, 9, 7, 9, 3, 2, 3, 8, 4]     # 20 tokens: > 32 (token, slot) pairs for top-2 as well: the fused expert chain of a prompt pass
+        for i, (toks, gate) in enumerate((([3], 1e-3), ([7], 1e-3), ([9], 1e-3), ([11], 1e-3), (long_pass, 2e-3), ([2], 2e-3))):
             emb = np.stack([m.embedding(t) for t in toks])
             got = m.decode(toks)
             exp_c = rc.decode(emb)
             assert np.isfinite(got).all()
             assert orc.nmse(exp_c, got) <= gate, (i, len(toks), orc.nmse(exp_c, got))
         assert be.counters()["mmvq_launches"] > 0
+        # the same prompt pass on an empty cache with the expert chain in both forms (gate and up as two launches with the GLU in the second one's epilogue | the dual
+        # launch; the default picks by pairs per expert, and is what the loop above compared with the oracle): the same logits. (Node by node is compared at op level, tests/test_gpu_ops.py
+        # test_moe_expert_chain_many_tokens: at model level switching every fusion off moves the router's inputs enough to flip a near-tie among 32 experts.)
+        outs = []
+        for v in (0, 1):
+            be.set_option("moe_dual", v); m.kv_clear()
+            outs.append(m.decode(long_pass).copy())
+        be.set_option("moe_dual", -1)
+        assert orc.nmse(outs[0], outs[1]) <= 1e-6, orc.nmse(outs[0], outs[1])
     finally:
+        be.set_option("moe_dual", -1); be.set_option("fusion", 1)
         m.free()
 
 

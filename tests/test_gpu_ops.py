@@ -348,6 +348,69 @@ def test_mul_mat_id_prefill_grouped(name, n_mats, n_used, bcast_b, n, m, k):
     assert orc.nmse(exp, got[0]) <= 5e-4, orc.nmse(exp, got[0])
 
 
+@pytest.mark.parametrize("gname,dname,n_mats,n_used,n,m,k,biased,oai,weighted", [
+    ("q4_K", "q4_K", 8, 2, 512, 256, 512, False, False, True),      # Mixtral: swiglu, no biases, the routing-weight multiply; ~128 pairs per expert: gate and up as two launches
+    ("mxfp4", "mxfp4", 4, 2, 300, 320, 320, True, True, True),      # ... the two-launch form with biases and swiglu_oai
+    ("q4_K", "q4_K", 8, 2, 300, 256, 512, False, False, True),      # fewer pairs per expert: the dual launch
+    ("q4_K", "q6_K", 8, 2, 150, 256, 256, False, False, True),      # ... its Q6_K down matrices
+    ("mxfp4", "mxfp4", 32, 4, 130, 320, 320, True, True, True),     # gpt-oss: ADD_ID biases, swiglu_oai, 10-block rows
+    ("q8_0", "q4_0", 8, 2, 70, 128, 256, True, False, False),       # the chain ends at the ADD_ID
+    ("q5_K", "q5_K", 4, 2, 40, 256, 256, False, True, False),        # ... at the down product
+])
+def test_moe_expert_chain_many_tokens(gname, dname, n_mats, n_used, n, m, k, biased, oai, weighted):
+    """The experts of build_moe_ffn for a prompt pass (src/llama-graph.cpp:914-990): MUL_MAT_ID(up) [ADD_ID]; MUL_MAT_ID(gate) [ADD_ID]; swiglu | swiglu_oai;
+    MUL_MAT_ID(down) [ADD_ID] [MUL weights]. With fusions on this is one copy, one dual tile launch and one down launch (+ a sort each) (backend.cpp try_fused_prefill_moe);
+    with fusions off, node by node. Both against the exact product of the dequantized weights (bf16 operands: the MUL_MAT_ID gate), and against each other:
+    the fused chain rounds the same values to bf16 at the same places, so only the ragged last digits of expf differ."""
+    rng = np.random.default_rng(500 + n)
+    gt, dt = QTYPES[gname], QTYPES[dname]
+    wu = orc.random_blocks(rng, gt, (n_mats, m), k); wg = orc.random_blocks(rng, gt, (n_mats, m), k); wd = orc.random_blocks(rng, dt, (n_mats, k), m)
+    ids_full = np.stack([rng.permutation(n_mats) for _ in range(n)]).astype(np.int32)
+    ids_full[: n // 3, 0] = 1                       # an overloaded expert
+    x_ = rng.uniform(-1, 1, size=(1, n, 1, k)).astype(np.float32)
+    bu_ = rng.uniform(-1, 1, size=(1, 1, n_mats, m)).astype(np.float32); bg_ = rng.uniform(-1, 1, size=(1, 1, n_mats, m)).astype(np.float32)
+    bd_ = rng.uniform(-1, 1, size=(1, 1, n_mats, k)).astype(np.float32)
+    wt_ = rng.uniform(0.1, 1, size=(1, n, n_used, 1)).astype(np.float32)
+    be = backend(); outs = {}
+    for fusion in (1, 0):
+        be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            up_w = ctx.new_tensor(gt, (k, m, n_mats)); gate_w = ctx.new_tensor(gt, (k, m, n_mats)); down_w = ctx.new_tensor(dt, (m, k, n_mats))
+            ids = ctx.new_tensor(gg.I32, (n_mats, n)); x = ctx.new_tensor(gg.F32, (k, 1, n)); wt = ctx.new_tensor(gg.F32, (1, n_used, n))
+            bu = ctx.new_tensor(gg.F32, (m, n_mats)); bg = ctx.new_tensor(gg.F32, (m, n_mats)); bd = ctx.new_tensor(gg.F32, (k, n_mats))
+            idv = L.ggml_view_2d(ctx.ctx, ids, n_used, n, n_mats * 4, 0)
+            up = L.ggml_mul_mat_id(ctx.ctx, up_w, x, idv)
+            if biased: up = L.ggml_add_id(ctx.ctx, up, bu, idv)
+            gate = L.ggml_mul_mat_id(ctx.ctx, gate_w, x, idv)
+            if biased: gate = L.ggml_add_id(ctx.ctx, gate, bg, idv)
+            act = L.ggml_swiglu_oai(ctx.ctx, gate, up, 1.702, 7.0) if oai else L.ggml_swiglu_split(ctx.ctx, gate, up)
+            o = L.ggml_mul_mat_id(ctx.ctx, down_w, act, idv)
+            if biased: o = L.ggml_add_id(ctx.ctx, o, bd, idv)
+            if weighted: o = L.ggml_mul(ctx.ctx, o, wt)
+            be.reset_counters()
+            outs[fusion] = run(ctx, o, [(up_w, wu), (gate_w, wg), (down_w, wd), (ids, ids_full.reshape(1, 1, n, n_mats)), (x, x_), (wt, wt_), (bu, bu_), (bg, bg_), (bd, bd_)])[0].copy()
+            if fusion: assert be.counters()["kernels_launched"] in (4, 5), be.counters()       # copy, sort, dual launch, down launch | copy, sort, up launch, gate launch, down launch
+    be.set_option("fusion", 1)
+    du = orc.dequantize(wu.reshape(n_mats * m, -1), gt).reshape(n_mats, m, k).astype(np.float64)
+    dg = orc.dequantize(wg.reshape(n_mats * m, -1), gt).reshape(n_mats, m, k).astype(np.float64)
+    dd = orc.dequantize(wd.reshape(n_mats * k, -1), dt).reshape(n_mats, k, m).astype(np.float64)
+    exp = np.empty((n, n_used, k))
+    for t in range(n):
+        for u in range(n_used):
+            e = ids_full[t, u]
+            a = du[e] @ x_[0, t, 0].astype(np.float64) + (bu_[0, 0, e] if biased else 0.0)
+            g_ = dg[e] @ x_[0, t, 0].astype(np.float64) + (bg_[0, 0, e] if biased else 0.0)
+            if oai:
+                xc = np.minimum(g_, 7.0); gc = np.clip(a, -7.0, 7.0); h = xc / (1.0 + np.exp(-1.702 * xc)) * (gc + 1.0)
+            else:
+                h = g_ / (1.0 + np.exp(-g_)) * a
+            y = dd[e] @ h + (bd_[0, 0, e] if biased else 0.0)
+            exp[t, u] = y * (wt_[0, t, u, 0] if weighted else 1.0)
+    assert outs[1].shape == exp.shape
+    assert orc.nmse(exp, outs[1]) <= 5e-4 and orc.nmse(exp, outs[0]) <= 5e-4, (orc.nmse(exp, outs[1]), orc.nmse(exp, outs[0]))
+    assert orc.nmse(outs[0], outs[1]) <= 1e-6, orc.nmse(outs[0], outs[1])
+
+
 @pytest.mark.parametrize("name", list(QTYPES))
 def test_mul_mat_id_golden(name, golden_dir):
     g = np.load(golden_dir / f"mulmatid_{name}.npz")
