@@ -821,7 +821,7 @@ static void op_mul_mat(mi_backend_ctx * c, struct ggml_tensor * dst, struct ggml
                                        c->aq.s_inner == b->nb[1];
                     void * scr = (char *) c->scratch + (ready ? c->aq.off : 0);
                     if (out) mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, scr, ready, (float *) out->data, out->nb[1],
-                                       (const float *) res->data, res->nb[1], c->stream, defer);
+                                       (const float *) res->data, res->ne[1] == 1 && N > 1 ? 0 : res->nb[1], c->stream, defer);     // (a bias row: the same addend for every token)
                     else     mul_mat_q((int) a->type, W, a->nb[1], M, K, (const float *) bp, b->nb[1], N, scr, ready, d, dst->nb[1], nullptr, 0, c->stream);
                     if (ready) c->cnt.act_quant_reused++;
                     else c->aq = { bp, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
@@ -1536,6 +1536,49 @@ static int try_fused_moe_experts(mi_backend_ctx * c, struct ggml_cgraph * g, int
     return consumed;
 }
 
+// Prompt pass: the slot sum that ends build_moe_ffn (src/llama-graph.cpp:996-1012) — ADD(view 0, view 1), ADD(., view 2), ... over the n_used slot views of the
+// weighted experts' outputs — and the residual ADD behind it (src/llama-model.cpp:6096) as one pass instead of n_used launches
+static int try_fused_slot_sum(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
+    struct ggml_tensor * ad = g->nodes[i];
+    const struct ggml_tensor * v0 = ad->src[0]; const struct ggml_tensor * v1 = ad->src[1];
+    if (ad->type != GGML_TYPE_F32 || !v0 || !v1 || !v0->view_src || v0->view_src != v1->view_src) return 0;
+    const struct ggml_tensor * ex = v0->view_src;
+    const int64_t M = ex->ne[0], n_used = ex->ne[1], T = ex->ne[2];
+    if (ex->type != GGML_TYPE_F32 || ex->ne[3] != 1 || n_used < 2 || n_used > 8 || T < 2 || M % 4 || ex->nb[0] != 4 || ex->nb[1] % 16 || ex->nb[2] % 16 || ((uintptr_t) ex->data % 16)) return 0;
+    auto is_slot = [&](const struct ggml_tensor * v, int64_t u) {
+        return v->view_src == ex && v->type == GGML_TYPE_F32 && v->ne[0] == M && v->ne[1] == T && v->ne[2] == 1 && v->ne[3] == 1 && v->nb[0] == 4 && v->nb[1] == ex->nb[2] &&
+               (const char *) v->data == (const char *) ex->data + u*ex->nb[1];
+    };
+    if (!is_slot(v0, 0) || !is_slot(v1, 1)) return 0;
+    int jl = i; const struct ggml_tensor * prev = ad;
+    for (int64_t u = 2; u < n_used; u++) {
+        if (!is_internal(c, prev)) return 0;
+        const int ja = next_real(g, jl); if (ja < 0) return 0;
+        const struct ggml_tensor * a2 = g->nodes[ja];
+        if (a2->op != GGML_OP_ADD || a2->type != GGML_TYPE_F32 || a2->src[0] != prev || !is_slot(a2->src[1], u)) return 0;
+        prev = a2; jl = ja;
+    }
+    struct ggml_tensor * out = g->nodes[jl];
+    const struct ggml_tensor * res = nullptr;
+    if (is_internal(c, out)) {
+        const int jr = next_real(g, jl);
+        struct ggml_tensor * ra = jr > 0 ? g->nodes[jr] : nullptr;
+        if (ra && ra->op == GGML_OP_ADD && ra->type == GGML_TYPE_F32 && (ra->src[0] == out || ra->src[1] == out)) {
+            const struct ggml_tensor * r = ra->src[0] == out ? ra->src[1] : ra->src[0];
+            if (r != out && r->type == GGML_TYPE_F32 && ggml_are_same_shape(r, out) && ggml_are_same_shape(ra, out) && r->nb[0] == 4 && r->nb[1] % 16 == 0 && ((uintptr_t) r->data % 16) == 0) {
+                res = r; out = ra; jl = jr;
+            }
+        }
+    }
+    if (out->ne[0] != M || out->ne[1] != T || out->ne[2] != 1 || out->ne[3] != 1 || out->nb[0] != 4 || out->nb[1] % 16 || ((uintptr_t) out->data % 16)) return 0;
+    // every element is read and written by the same lane, so `out` may be the residual's or slot 0's own memory (an in-place ADD) — but not a shifted overlap
+    if ((out->data != ex->data || out->nb[1] != ex->nb[2]) && ranges_overlap(out->data, ggml_nbytes(out), ex->data, ggml_nbytes(ex))) return 0;
+    if (res && (out->data != res->data || out->nb[1] != res->nb[1]) && ranges_overlap(out->data, ggml_nbytes(out), res->data, ggml_nbytes(res))) return 0;
+    moe_slot_sum(ex->data, ex->nb[1], ex->nb[2], (int) n_used, M, T, res ? (const float *) res->data : nullptr, res ? res->nb[1] : 0, (float *) out->data, out->nb[1], c->stream);
+    c->cnt.kernels_launched++;
+    return jl - i + 1;
+}
+
 // Prompt pass (many tokens) through the experts of build_moe_ffn (src/llama-graph.cpp:914-990):
 //   MUL_MAT_ID(up) [ADD_ID] ; MUL_MAT_ID(gate) [ADD_ID] ; GLU (swiglu | swiglu_oai) ; MUL_MAT_ID(down) [ADD_ID] [MUL weights]
 // as: ONE bf16 copy of the layer input, ONE sort of the (token, slot) pairs by expert, ONE dual tile launch (both products of an expert's pairs against one
@@ -1776,29 +1819,36 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
     static const bool on = !getenv("GGML_MI355X_PREFILL_QKV") || atoi(getenv("GGML_MI355X_PREFILL_QKV")) != 0;
     if (!on) return 0;
     const struct ggml_tensor * b = g->nodes[i]->src[1];
-    struct chain { int mm, rope, end; } ch[3];
-    int nc = 0, at = i;
+    // a chain: MUL_MAT [-> ADD bias (gpt-oss's bq / bk / bv, src/llama-model.cpp:17636-17645)] [-> (RESHAPE ->) ROPE]; the ADDs run as their own launches behind the
+    // grouped mat-mul, like ROPEs that cannot ride on it
+    struct chain { int mm, add, rope, end; } ch[3];
+    int nc = 0, at = i; bool any_add = false;
     while (nc < 3 && at >= 0) {
         struct ggml_tensor * n = g->nodes[at];
         if (n->op != GGML_OP_MUL_MAT) break;
         const struct ggml_tensor * a = n->src[0];
         if (n->src[1] != b || !ggml_is_quantized(a->type) || tensor_is_split(a) || b->type != GGML_TYPE_F32 || b->ne[1] <= MMVQ_MAX_N || b->ne[2] != 1 || b->ne[3] != 1 ||
             a->ne[2] != 1 || a->ne[3] != 1 || b->nb[0] != 4 || a->ne[0] != g->nodes[i]->src[0]->ne[0] || n->nb[0] != 4) break;
-        ch[nc] = { at, -1, at };
-        const int j = next_real(g, at);
-        if (j > 0 && g->nodes[j]->op == GGML_OP_ROPE && base_of(g->nodes[j]->src[0]) == n) { ch[nc].rope = j; ch[nc].end = j; }
+        ch[nc] = { at, -1, -1, at };
+        const struct ggml_tensor * last = n;
+        int j = next_real(g, at);
+        if (j > 0 && g->nodes[j]->op == GGML_OP_ADD && (g->nodes[j]->src[0] == n || g->nodes[j]->src[1] == n) && g->nodes[j]->src[0] != b && g->nodes[j]->src[1] != b) {
+            ch[nc].add = j; ch[nc].end = j; last = g->nodes[j]; any_add = true;
+            j = next_real(g, j);
+        }
+        if (j > 0 && g->nodes[j]->op == GGML_OP_ROPE && base_of(g->nodes[j]->src[0]) == last) { ch[nc].rope = j; ch[nc].end = j; }
         nc++;
         at = next_real(g, ch[nc - 1].end);
     }
     if (nc < 2) return 0;
     for (int q = 0; q < nc; q++) {
-        const struct ggml_tensor * oq[2] = { g->nodes[ch[q].mm], ch[q].rope >= 0 ? g->nodes[ch[q].rope] : nullptr };
-        for (int u = 0; u < 2; u++) {
+        const struct ggml_tensor * oq[3] = { g->nodes[ch[q].mm], ch[q].rope >= 0 ? g->nodes[ch[q].rope] : nullptr, ch[q].add >= 0 ? g->nodes[ch[q].add] : nullptr };
+        for (int u = 0; u < 3; u++) {
             if (!oq[u]) continue;
             if (ranges_overlap(oq[u]->data, ggml_nbytes(oq[u]), b->data, ggml_nbytes(b))) return 0;
             for (int r = q + 1; r < nc; r++) {
-                const struct ggml_tensor * orr[2] = { g->nodes[ch[r].mm], ch[r].rope >= 0 ? g->nodes[ch[r].rope] : nullptr };
-                for (int v = 0; v < 2; v++) if (orr[v] && ranges_overlap(oq[u]->data, ggml_nbytes(oq[u]), orr[v]->data, ggml_nbytes(orr[v]))) return 0;
+                const struct ggml_tensor * orr[3] = { g->nodes[ch[r].mm], ch[r].rope >= 0 ? g->nodes[ch[r].rope] : nullptr, ch[r].add >= 0 ? g->nodes[ch[r].add] : nullptr };
+                for (int v = 0; v < 3; v++) if (orr[v] && ranges_overlap(oq[u]->data, ggml_nbytes(oq[u]), orr[v]->data, ggml_nbytes(orr[v]))) return 0;
             }
         }
     }
@@ -1806,7 +1856,7 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
     uint64_t wbytes = 0;
     // the ROPEs go into the launch (epilogue, or the pass that combines split-k planes) when they are NORM-mode, share one descriptor and
     // are the only readers of their mat-muls: the mat-mul then writes the ROPE node's tensor directly
-    mmvq_rope rd = {}; bool have_rd = false, rope_ok = true; int seg_rope[3] = { 0, 0, 0 };
+    mmvq_rope rd = {}; bool have_rd = false, rope_ok = !any_add; int seg_rope[3] = { 0, 0, 0 };
     for (int q = 0; q < nc && rope_ok; q++) {
         if (ch[q].rope < 0) continue;
         const struct ggml_tensor * mm = g->nodes[ch[q].mm]; const struct ggml_tensor * rp = g->nodes[ch[q].rope];
@@ -1856,7 +1906,26 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
             }
         }
     }
+    // bias rows (ADD behind a mat-mul, the mat-mul read by nobody else): the launch's epilogue adds them and writes the ADD's tensor
+    const float * seg_bias[3] = { nullptr, nullptr, nullptr }; float * bdst[3]; size_t bdstride[3]; bool biased = any_add;
+    for (int q = 0; q < nc && biased; q++) {
+        bdst[q] = dst[q]; bdstride[q] = dstride[q];
+        if (ch[q].add < 0) continue;
+        const struct ggml_tensor * mm = g->nodes[ch[q].mm]; const struct ggml_tensor * ad = g->nodes[ch[q].add];
+        const struct ggml_tensor * bt = ad->src[0] == mm ? ad->src[1] : ad->src[0];
+        biased = is_internal(c, mm) && ad->type == GGML_TYPE_F32 && ggml_are_same_shape(ad, mm) && ad->nb[0] == 4 && bt->type == GGML_TYPE_F32 && bt->ne[0] == m[q] &&
+                 ggml_nelements(bt) == m[q] && bt->nb[0] == 4;
+        seg_bias[q] = (const float *) bt->data; bdst[q] = (float *) ad->data; bdstride[q] = ad->nb[1];
+    }
     bool roped = fuse_rope, stored = have_kvs;
+    if (biased && mul_mat_q_multi(nc, types, W, wrs, m, bdst, bdstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, nullptr, nullptr, nullptr, c->stream, seg_bias)) {
+        prof_end(c);
+        if (ready) c->cnt.act_quant_reused++;
+        else c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
+        c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 1 : 2; c->cnt.weight_bytes += wbytes;
+        for (int q = 0; q < nc; q++) if (ch[q].rope >= 0) compute_node(c, g, ch[q].rope);
+        return ch[nc - 1].end - i + 1;
+    }
     bool done = fuse_rope && mul_mat_q_multi(nc, types, W, wrs, m, dst, dstride, K, (const float *) b->data, b->nb[1], N, c->scratch, c->scratch_size, ready, &rd, seg_rope,
                                              have_kvs ? &kvs : nullptr, c->stream);
     if (!done) {
@@ -1869,7 +1938,10 @@ static int try_fused_prefill_qkv(mi_backend_ctx * c, struct ggml_cgraph * g, int
     if (ready) c->cnt.act_quant_reused++;
     else c->aq = { b->data, K, N, 1, b->nb[1], 0, ACT_KIND_BF16, act_q8{}, true, (size_t)(N - 1)*b->nb[1] + (size_t) K*4 };
     c->cnt.mmq_launches++; c->cnt.kernels_launched += ready ? 1 : 2; c->cnt.weight_bytes += wbytes;
-    if (!roped) for (int q = 0; q < nc; q++) if (ch[q].rope >= 0) compute_node(c, g, ch[q].rope);
+    for (int q = 0; q < nc; q++) {
+        if (ch[q].add >= 0) compute_node(c, g, ch[q].add);
+        if (!roped && ch[q].rope >= 0) compute_node(c, g, ch[q].rope);
+    }
     return (stored ? kv_last : ch[nc - 1].end) - i + 1;
 }
 
@@ -1884,13 +1956,15 @@ static int try_fused_prefill_add(mi_backend_ctx * c, struct ggml_cgraph * g, int
     struct ggml_tensor * nx = g->nodes[j];
     if (nx->op != GGML_OP_ADD || (nx->src[0] != n && nx->src[1] != n) || nx->type != GGML_TYPE_F32 || !ggml_is_contiguous(nx) || !ggml_are_same_shape(nx, n)) return 0;
     const struct ggml_tensor * other = nx->src[0] == n ? nx->src[1] : nx->src[0];
-    if (other == n || other->type != GGML_TYPE_F32 || !ggml_are_same_shape(other, n) || other->nb[0] != 4) return 0;
+    // the addend: the residual stream (same shape), or a bias row (gpt-oss's bo, src/llama-graph.cpp:1479-1481) — then a row stride of 0
+    const bool bias_row = other->ne[0] == n->ne[0] && ggml_nelements(other) == n->ne[0] && n->ne[1] > 1;
+    if (other == n || other->type != GGML_TYPE_F32 || (!ggml_are_same_shape(other, n) && !bias_row) || other->nb[0] != 4) return 0;
     // the sum is the residual stream; if RMS_NORM -> MUL(w) reads it next (ffn_norm, the next layer's attn_norm: build_norm, src/llama-graph.cpp:597-630)
     // and the mat-mul splits k, ONE pass adds the planes and the residual, writes the sum and normalises it
     static const bool norm_on = !getenv("GGML_MI355X_PREFILL_COMBINE_NORM") || atoi(getenv("GGML_MI355X_PREFILL_COMBINE_NORM")) != 0;
     struct ggml_tensor * nrm = nullptr; struct ggml_tensor * mul = nullptr; const struct ggml_tensor * w = nullptr;
     const int jn = next_real(g, j);
-    if (norm_on && jn > 0 && jn + 1 < g->n_nodes && g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0] == nx && g->nodes[jn + 1]->op == GGML_OP_MUL) {
+    if (norm_on && !bias_row && jn > 0 && jn + 1 < g->n_nodes && g->nodes[jn]->op == GGML_OP_RMS_NORM && g->nodes[jn]->src[0] == nx && g->nodes[jn + 1]->op == GGML_OP_MUL) {
         nrm = g->nodes[jn]; mul = g->nodes[jn + 1];
         w = mul->src[0] == nrm ? mul->src[1] : (mul->src[1] == nrm ? mul->src[0] : nullptr);
         const int64_t M = n->ne[0];
@@ -1946,6 +2020,7 @@ static int compute_node(mi_backend_ctx * c, struct ggml_cgraph * g, int i) {
         } else if (node->op == GGML_OP_SET_ROWS) f = try_fused_kv_store(c, g, i);
         else if (node->op == GGML_OP_GET_ROWS) f = try_fused_moe_combine(c, g, i);
         else if (node->op == GGML_OP_MUL_MAT_ID) { f = try_fused_moe_experts(c, g, i); if (!f) f = try_fused_prefill_moe(c, g, i); }
+        else if (node->op == GGML_OP_ADD && s0 && s0->view_src) f = try_fused_slot_sum(c, g, i);
         if (f) {
             consumed = f;
             fresh_aq = c->aq_fresh; c->aq_fresh = false;

@@ -912,4 +912,22 @@ void hbm_read_probe(const void * p, size_t bytes, unsigned * sink, hipStream_t s
     else           hipLaunchKernelGGL(k_hbm_read, dim3(256*8), dim3(256), 0, stream, (const int4v *) p, bytes/16, sink);
 }
 
+// ---- many tokens: the expert-slot sum of build_moe_ffn (src/llama-graph.cpp:996-1012): ((slot0 + slot1) + slot2) + ... [+ residual], in ggml's order ----
+struct slot_sum_args { const char * ex; size_t nb1, nb2; int n_used; int64_t m4, n_tokens; const char * res; size_t res_nb1; char * dst; size_t dst_nb1; };
+__global__ void __launch_bounds__(256) k_slot_sum(const slot_sum_args p) {
+    const int64_t i = (int64_t) blockIdx.x*256 + threadIdx.x;
+    if (i >= p.m4*p.n_tokens) return;
+    const int64_t t = i/p.m4, c4 = i - t*p.m4;
+    const char * e = p.ex + (size_t) t*p.nb2 + (size_t) c4*16;
+    float4v a = *(const float4v *) e;
+    for (int u = 1; u < p.n_used; u++) { const float4v b = *(const float4v *) (e + (size_t) u*p.nb1); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    if (p.res) { const float4v b = *(const float4v *) (p.res + (size_t) t*p.res_nb1 + (size_t) c4*16); a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+    *(float4v *) (p.dst + (size_t) t*p.dst_nb1 + (size_t) c4*16) = a;
+}
+void moe_slot_sum(const void * experts, size_t nb1, size_t nb2, int n_used, int64_t m, int64_t n_tokens, const float * res, size_t res_nb1, float * dst, size_t dst_nb1, hipStream_t stream) {
+    if (m == 0 || n_tokens == 0) return;
+    const slot_sum_args p = { (const char *) experts, nb1, nb2, n_used, m/4, n_tokens, (const char *) res, res_nb1, (char *) dst, dst_nb1 };
+    hipLaunchKernelGGL(k_slot_sum, dim3((unsigned)((m/4*n_tokens + 255)/256)), dim3(256), 0, stream, p);
+}
+
 } // namespace mi355x

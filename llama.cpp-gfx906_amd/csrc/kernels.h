@@ -81,7 +81,8 @@ struct mmq_kv_store { uint16_t * st16[3]; const int64_t * st_idx[3]; int64_t st_
 // 2 or 3 mat-muls on the same activations (wq / wk / wv) as one launch of 256-token tiles; false = not done, run them one by one
 bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const size_t * w_row_stride, const int64_t * m, float * const * dst, const size_t * dst_stride,
                      int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready,
-                     const struct mmvq_rope * rope, const int * seg_rope, const struct mmq_kv_store * kvs, hipStream_t stream);     // rope != NULL: NORM rotary embedding on the segments flagged in seg_rope
+                     const struct mmvq_rope * rope, const int * seg_rope, const struct mmq_kv_store * kvs, hipStream_t stream,      // rope != NULL: NORM rotary embedding on the segments flagged in seg_rope
+                     const float * const * seg_bias = nullptr);     // seg_bias[s] != NULL: m[s] floats added to every row of segment s (only without a k split: else false)
 
 // gate / up + SwiGLU for many tokens in one kernel: dst[n][m] = silu(Wg.x) * (Wu.x) (both weight tensors of one type and shape);
 // supported when the 256-token tiles fill the chip
@@ -166,6 +167,8 @@ void moe_route(const float * w, size_t w_nb1, const float * x, const float * bia
 // n_used <= 8, n_embd % 4 == 0, 16-byte aligned rows (elem.hip: k_moe_combine)
 void moe_combine(const float * probs, const int32_t * ids, int n_used, int mode, const void * experts, size_t e_nb1, int64_t n_embd,
                  const float * res, float * dst, hipStream_t stream);
+// many tokens: dst[t] = ((experts[t][0] + experts[t][1]) + ...) [+ res[t]] (m % 4 == 0, 16-byte aligned rows; elem.hip: k_slot_sum)
+void moe_slot_sum(const void * experts, size_t nb1, size_t nb2, int n_used, int64_t m, int64_t n_tokens, const float * res, size_t res_nb1, float * dst, size_t dst_nb1, hipStream_t stream);
 void argsort(const tensor_desc & src, const tensor_desc & dst, int order, hipStream_t stream);
 void unary(int op, const tensor_desc & src, const tensor_desc & dst, hipStream_t stream);
 void glu(int glu_op, bool swapped, const tensor_desc & a, const tensor_desc * b, const tensor_desc & dst, float alpha, float limit, hipStream_t stream);

@@ -84,6 +84,45 @@ __global__ void __launch_bounds__(256) k_mm_dense(const mm_dense_args p) {
     }
 }
 
+// The FAST == 2 case with many columns (the MoE router of a prompt pass: 32 x 2880 f32 against 512 tokens): a wave owns NR weight rows x NC columns, so a k-chunk
+// is NR + NC loads for NR*NC*4 multiply-adds instead of 1 + NC for NC*4 — the same per-lane k assignment, expression and reduction as k_mm_dense<NC, 2>, hence the
+// same bits (the router's logits decide the routing: nothing is rounded differently from the one-token path)
+template <int NC, int NR>
+__global__ void __launch_bounds__(256) k_mm_dense_rows(const mm_dense_args p) {
+    const int lane = threadIdx.x & 63;
+    const int64_t r0 = ((int64_t) blockIdx.x*4 + (threadIdx.x >> 6))*NR;
+    if (r0 >= p.ne01) return;
+    const int64_t c0 = (int64_t) blockIdx.y*NC;
+    const int64_t i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
+    const int64_t i02 = i12/(p.ne12/p.ne02), i03 = i13/(p.ne13/p.ne03);
+    const char * a = (const char *) p.a + i02*p.nb02 + i03*p.nb03;
+    const char * b = (const char *) p.b + i12*p.nb12 + i13*p.nb13;
+    const int K = (int) p.ne00;
+    float acc[NR][NC];
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) acc[r][c] = 0.0f;
+    for (int k = lane*4; k < K; k += 256) {
+        float4v av[NR], bv[NC];
+#pragma unroll
+        for (int r = 0; r < NR; r++) av[r] = *(const float4v *) (a + (size_t) min(r0 + r, p.ne01 - 1)*p.nb01 + (size_t) k*4);
+#pragma unroll
+        for (int c = 0; c < NC; c++) bv[c] = *(const float4v *) (b + (size_t) min(c0 + c, p.ne11 - 1)*p.nb11 + (size_t) k*4);
+#pragma unroll
+        for (int r = 0; r < NR; r++)
+#pragma unroll
+            for (int c = 0; c < NC; c++) acc[r][c] += (av[r].x*bv[c].x + av[r].y*bv[c].y) + (av[r].z*bv[c].z + av[r].w*bv[c].w);
+    }
+#pragma unroll
+    for (int r = 0; r < NR; r++)
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const float s = wave_sum(acc[r][c]);
+            if (lane == 0 && r0 + r < p.ne01 && c0 + c < p.ne11) *(float *) ((char *) p.dst + (r0 + r)*4 + (c0 + c)*p.nb1 + i12*p.nb2 + i13*p.nb3) = s;
+        }
+}
+
 void mul_mat_dense(const mm_dense_args & p, hipStream_t stream) {
     if (p.ne01 == 0 || p.ne11 == 0 || p.ne12*p.ne13 == 0) return;
     const bool fast = p.type_a == T_F16 && p.type_b == T_F32 && p.nb00 == 2 && p.nb10 == 4 && (p.ne00 % 2 == 0);
@@ -93,6 +132,13 @@ void mul_mat_dense(const mm_dense_args & p, hipStream_t stream) {
                         ((uintptr_t) p.a % 16) == 0 && ((uintptr_t) p.b % 16) == 0 && p.nb01 % 16 == 0 && p.nb02 % 16 == 0 && p.nb03 % 16 == 0 &&
                         p.nb11 % 16 == 0 && p.nb12 % 16 == 0 && p.nb13 % 16 == 0;
     if (fast)        hipLaunchKernelGGL((k_mm_dense<NC, 1>), grid, dim3(256), 0, stream, p);
+    else if (fast32 && p.ne11 >= 64 && p.ne01 >= 32) {
+        const dim3 g4((unsigned)((p.ne01 + 15)/16), (unsigned)((p.ne11 + NC - 1)/NC), (unsigned)(p.ne12*p.ne13));
+        hipLaunchKernelGGL((k_mm_dense_rows<NC, 4>), g4, dim3(256), 0, stream, p);
+    } else if (fast32 && p.ne11 >= 64 && p.ne01 >= 8) {      // (few experts: two rows per wave keep enough waves in flight)
+        const dim3 g2((unsigned)((p.ne01 + 7)/8), (unsigned)((p.ne11 + NC - 1)/NC), (unsigned)(p.ne12*p.ne13));
+        hipLaunchKernelGGL((k_mm_dense_rows<NC, 2>), g2, dim3(256), 0, stream, p);
+    }
     else if (fast32) hipLaunchKernelGGL((k_mm_dense<NC, 2>), grid, dim3(256), 0, stream, p);
     else             hipLaunchKernelGGL((k_mm_dense<NC, 0>), grid, dim3(256), 0, stream, p);
 }

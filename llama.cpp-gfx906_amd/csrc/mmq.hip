@@ -189,7 +189,7 @@ constexpr int MQ_BM = 128, MQ_BN = 128, MQ_BK = 64, MQ_LD = MQ_BK*2 + 16;   // L
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
 // several weight tensors against the same activations in one launch (wq / wk / wv): the m-tiles of the segments are laid end to end
-struct mmq_seg { const char * W; char * dst; size_t w_row_stride, dst_nb1; int m, tile0, col0, type2, rope; };   // col0: first column in a split-k plane; type2: decode
+struct mmq_seg { const char * W; char * dst; size_t w_row_stride, dst_nb1; int m, tile0, col0, type2, rope; const float * bias; };   // bias: NULL, or m floats added to every token's row (no k split)   // col0: first column in a split-k plane; type2: decode
                                                // as TYPE2; rope: the NORM rotary embedding (mmq_args::rope) is applied to this segment's rows of heads
 struct mmq_args {
     const char * W; size_t w_row_stride, w_nb2, w_nb3; int m, k;
@@ -244,11 +244,11 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
     int m = p.m, col0 = 0; bool use2 = false;
     const int i12 = blockIdx.z % p.ne12, i13 = blockIdx.z / p.ne12;
     const char * W = p.W + (size_t)(i12/p.r2)*p.w_nb2 + (size_t)(i13/p.r3)*p.w_nb3;
-    size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst;
+    size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst; const float * seg_bias = nullptr;
     if (p.nseg) {                              // workgroup-uniform
         const int si = (mt >= p.seg[1].tile0 ? 1 : 0) + (p.nseg > 2 && mt >= p.seg[2].tile0 ? 1 : 0);
         W = p.seg[si].W; m = p.seg[si].m; w_row_stride = p.seg[si].w_row_stride; seg_dst = p.seg[si].dst; seg_dst_nb1 = p.seg[si].dst_nb1;
-        col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0;
+        col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0; seg_bias = p.seg[si].bias;
     }
     const int m0 = mt*MQ_BM;
     const int kp = (k + MQ_BK - 1) & ~(MQ_BK - 1);               // row length of the activation copy (zero-padded)
@@ -464,6 +464,7 @@ __global__ void __launch_bounds__(BN*2) __attribute__((amdgpu_waves_per_eu(2, 2)
                         if (p.y16) { const uint32_t pk = pack_bf16(y, y); p.y16[(size_t) row*m + col] = (uint16_t) pk; }
                     }
                     else if (p.res && p.ksplit == 1) *o = acc[i][j][r] + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
+                    else if (seg_bias && p.ksplit == 1) *o = acc[i][j][r] + seg_bias[col];
                     else *o = acc[i][j][r];
                 }
             }
@@ -519,11 +520,11 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
     const int n = p.n, k = p.k;
     int m = p.m, col0 = 0; bool use2 = false, do_rope = false;
     const char * W = p.W;
-    size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst;
+    size_t w_row_stride = p.w_row_stride, seg_dst_nb1 = p.dst_nb1; char * seg_dst = p.dst; const float * seg_bias = nullptr;
     if (p.nseg) {                              // workgroup-uniform
         const int si = (mt >= p.seg[1].tile0 ? 1 : 0) + (p.nseg > 2 && mt >= p.seg[2].tile0 ? 1 : 0);
         W = p.seg[si].W; m = p.seg[si].m; w_row_stride = p.seg[si].w_row_stride; seg_dst = p.seg[si].dst; seg_dst_nb1 = p.seg[si].dst_nb1;
-        col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0;
+        col0 = p.seg[si].col0; use2 = p.seg[si].type2 != 0; mt -= p.seg[si].tile0; seg_bias = p.seg[si].bias;
         do_rope = p.seg[si].rope != 0 && p.ksplit == 1;           // with a k split the combine pass rotates
     }
     const int m0 = mt*MQ_BM;
@@ -704,6 +705,7 @@ __global__ void __launch_bounds__(1024) k_mmq16(const mmq_args p) {
             if (col < m && row < n) {
                 float * o = (float *) (dst + (size_t) row*dst_nb1 + (size_t) col*4);
                 if (p.res && p.ksplit == 1) *o = v + *(const float *) (p.res + (size_t) row*p.res_nb1 + (size_t) col*4);
+                else if (seg_bias && p.ksplit == 1) *o = v + seg_bias[col];
                 else *o = v;
             }
         }
@@ -1119,7 +1121,7 @@ static void launch_mmq_multi(dim3 grid, const mmq_args & a, hipStream_t stream) 
 // false: not done (too few tiles for 256-token tiles, an unsupported mix of types, scratch too small) — the caller runs them one by one
 bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const size_t * w_row_stride, const int64_t * m, float * const * dst, const size_t * dst_stride,
                      int64_t k, const float * x, size_t x_row_stride, int64_t n, void * scratch, size_t scratch_size, bool scratch_ready,
-                     const mmvq_rope * rope, const int * seg_rope, const mmq_kv_store * kvs, hipStream_t stream) {
+                     const mmvq_rope * rope, const int * seg_rope, const mmq_kv_store * kvs, hipStream_t stream, const float * const * seg_bias) {
     if (nseg < 2 || nseg > 3 || n < 256) return false;
     static const bool w16 = !getenv("GGML_MI355X_MMQ16") || atoi(getenv("GGML_MI355X_MMQ16")) != 0;
     if (rope) {        // epilogue / combine-pass ROPE: 16-wave kernel only, heads of an even size that start at column multiples of 4
@@ -1136,7 +1138,8 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
     a.nseg = nseg;
     int64_t m_tot = 0; int tiles = 0; bool vec_ok = true;
     for (int s = 0; s < nseg; s++) {
-        a.seg[s] = { (const char *) W[s], (char *) dst[s], w_row_stride[s], dst_stride[s], (int) m[s], tiles, (int) m_tot, types[s] != t1 ? 1 : 0, rope && seg_rope[s] ? 1 : 0 };
+        a.seg[s] = { (const char *) W[s], (char *) dst[s], w_row_stride[s], dst_stride[s], (int) m[s], tiles, (int) m_tot, types[s] != t1 ? 1 : 0, rope && seg_rope[s] ? 1 : 0,
+                     seg_bias ? seg_bias[s] : nullptr };
         vec_ok = vec_ok && m[s] % 4 == 0 && dst_stride[s] % 16 == 0 && ((uintptr_t) dst[s] % 16) == 0;
         m_tot += m[s]; tiles += (int)((m[s] + MQ_BM - 1)/MQ_BM);
     }
@@ -1149,10 +1152,12 @@ bool mul_mat_q_multi(int nseg, const int * types, const void * const * W, const 
     if (wt >= 160) a.ksplit = 1;
     else if (wt*2 >= 160 && k % 512 == 0 && k >= 2048 && vec_ok) a.ksplit = 2;
     else if (wt*4 >= 160 && k % 1024 == 0 && k >= 4096 && vec_ok) a.ksplit = 4;
+    else if (wt >= 64) a.ksplit = 1;        // k does not split (gpt-oss: 2880): still one launch of 80 tiles instead of three of 64 + 8 + 8 on 256 CUs
     else return false;
     // the rotation rides on the combine pass (one sincos per pair, no lane exchange); in the mat-mul epilogue both lanes of a pair would
     // evaluate it (measured: pp2048 -2.6 % against separate ROPE kernels), so without a k split the caller keeps its ROPE launches
     if ((rope || kvs) && a.ksplit == 1) return false;
+    if (seg_bias && a.ksplit != 1) return false;          // (the bias rides on the epilogue only)
     if (mmq_x_bytes(k, n) + (a.ksplit > 1 ? (size_t) a.ksplit*m_tot*n*4 : 0) + 512 > scratch_size) return false;
     if (!scratch_ready) {
         act16_args pa = { (const char *) x, x_row_stride, 0, 0, k, n, 1, (uint16_t *) scratch };

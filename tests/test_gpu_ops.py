@@ -411,6 +411,62 @@ def test_moe_expert_chain_many_tokens(gname, dname, n_mats, n_used, n, m, k, bia
     assert orc.nmse(outs[0], outs[1]) <= 1e-6, orc.nmse(outs[0], outs[1])
 
 
+@pytest.mark.parametrize("name,k", [("q8_0", 320), ("q4_K", 512)])
+def test_prompt_pass_qkv_with_bias_rows(name, k):
+    """gpt-oss's attention projections in a prompt pass (src/llama-model.cpp:17636-17645): MUL_MAT(wq) + bq, MUL_MAT(wk) + bk, MUL_MAT(wv) + bv on the same 512
+    tokens. Fused: ONE grouped launch (k = 2880 does not split, 80 tiles) with the bias rows added in its epilogue (backend.cpp try_fused_prefill_qkv); node by node:
+    three launches and three ADDs. Same operands, same order of accumulation: the same bits; and the exact product within the MUL_MAT gate."""
+    rng = np.random.default_rng(31)
+    qt = QTYPES[name]; n = 512; ms = (4096, 512, 512)
+    ws = [orc.random_blocks(rng, qt, (m,), k) for m in ms]
+    bs = [rng.uniform(-1, 1, size=(1, 1, 1, m)).astype(np.float32) for m in ms]
+    x_ = rng.uniform(-1, 1, size=(1, 1, n, k)).astype(np.float32)
+    be = backend(); outs = {}
+    for fusion in (1, 0):
+        be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            x = ctx.new_tensor(gg.F32, (k, n))
+            wt = [ctx.new_tensor(qt, (k, m)) for m in ms]; bt = [ctx.new_tensor(gg.F32, (m,)) for m in ms]
+            o = [L.ggml_add(ctx.ctx, L.ggml_mul_mat(ctx.ctx, w, x), b) for w, b in zip(wt, bt)]
+            gf = gg.graph_of(ctx, *o)
+            assert ctx.alloc(be)
+            for t, a in list(zip(wt, ws)) + list(zip(bt, bs)) + [(x, x_)]: gg.tensor_set(t, a)
+            be.reset_counters(); be.compute(gf)
+            outs[fusion] = [gg.tensor_get(t)[0, 0].copy() for t in o]
+            if fusion: assert be.counters()["kernels_launched"] == 2, be.counters()      # the bf16 copy of x, the grouped launch
+    be.set_option("fusion", 1)
+    for q in range(3):
+        exp = orc.dequantize(ws[q], qt).astype(np.float64) @ x_[0, 0].astype(np.float64).T + bs[q][0, 0, 0][:, None].astype(np.float64)
+        assert orc.nmse(exp.T, outs[1][q]) <= 5e-4
+        assert np.array_equal(outs[1][q], outs[0][q]), (q, orc.nmse(outs[0][q], outs[1][q]))
+
+
+@pytest.mark.parametrize("n_used,with_res", [(2, True), (4, True), (4, False), (8, True)])
+def test_moe_slot_sum_many_tokens(n_used, with_res):
+    """The end of build_moe_ffn for a prompt pass (src/llama-graph.cpp:996-1012 + the residual ADD of src/llama-model.cpp:6096): the ADD chain over the slot views of
+    the experts' outputs, fused into one pass (backend.cpp try_fused_slot_sum) — bit-identical to node-by-node execution, same order of additions."""
+    rng = np.random.default_rng(900 + n_used)
+    m, n = 320, 37
+    ex_ = rng.uniform(-1, 1, size=(1, n, n_used, m)).astype(np.float32); res_ = rng.uniform(-1, 1, size=(1, 1, n, m)).astype(np.float32)
+    be = backend(); outs = {}
+    for fusion in (1, 0):
+        be.set_option("fusion", fusion)
+        with gg.Context() as ctx:
+            ex = ctx.new_tensor(gg.F32, (m, n_used, n)); res = ctx.new_tensor(gg.F32, (m, n))
+            views = [L.ggml_view_2d(ctx.ctx, ex, m, n, n_used * m * 4, u * m * 4) for u in range(n_used)]
+            o = views[0]
+            for u in range(1, n_used): o = L.ggml_add(ctx.ctx, o, views[u])
+            if with_res: o = L.ggml_add(ctx.ctx, o, res)
+            be.reset_counters()
+            outs[fusion] = run(ctx, o, [(ex, ex_), (res, res_)])[0, 0].copy()
+            if fusion: assert be.counters()["kernels_launched"] == 1, be.counters()
+    be.set_option("fusion", 1)
+    exp = ex_[0, :, 0]
+    for u in range(1, n_used): exp = exp + ex_[0, :, u]
+    if with_res: exp = exp + res_[0, 0]
+    assert np.array_equal(outs[1], outs[0]) and np.array_equal(outs[1], exp.astype(np.float32))
+
+
 @pytest.mark.parametrize("name", list(QTYPES))
 def test_mul_mat_id_golden(name, golden_dir):
     g = np.load(golden_dir / f"mulmatid_{name}.npz")
