@@ -297,7 +297,7 @@ def main():
             # of the same workload is quoted (the newest round's), and only when its kernel is the dominant launch found live
             try:
                 pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-                for fn in ("r03_pmc_fetch_size_summary.json", "r02_pmc_fetch_size_summary.json", "r01_l_pmc_fetch_size_summary.json"):
+                for fn in ("r04_pmc_fetch_size_summary.json", "r03_pmc_fetch_size_summary.json", "r02_pmc_fetch_size_summary.json", "r01_l_pmc_fetch_size_summary.json"):
                     pmc_file = os.path.join(pdir, fn)
                     if roof["traffic"] is not None or not (args.model == "llama3-8b" and args.ftype == "Q4_K_M" and os.path.exists(pmc_file)):
                         continue

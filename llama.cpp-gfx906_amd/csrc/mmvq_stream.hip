@@ -111,7 +111,14 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     st_args a; size_t fixed_max; int slot_max, nslots_max, npart_max, fa, fb; double bytes_total;
     (void) st_fill(groups, n_groups, k, in, rope, a, fixed_max, slot_max, nslots_max, npart_max, fa, fb, bytes_total);
     const int64_t S = fixed_max < 163840 ? (163840 - (int64_t) fixed_max)/slot_max : 0;
-    return S >= (nslots_max < 2 ? nslots_max : 2);
+    if (S < (nslots_max < 2 ? nslots_max : 2)) return false;
+    // experiment knob: launches that stream fewer bytes than this go to the register-ring kernel (is the streamed kernel's envelope a loss on the small launches?)
+    static const double min_bytes = getenv("GGML_MI355X_STREAM_MIN_MB") ? atof(getenv("GGML_MI355X_STREAM_MIN_MB"))*1e6 : 0.0;
+    if (min_bytes > 0.0 && bytes_total < min_bytes && !in.planes && !b10) {
+        for (int i = 0; i < n_groups; i++) if (groups[i].eid || groups[i].epi == EPI_GLU || (groups[i].epi == EPI_ROPE && rope && (rope->p.mode & 2))) return true;
+        return false;
+    }
+    return true;
 }
 
 // fills the phase descriptor of one grouped launch; returns the workgroups it uses. fixed: LDS bytes besides the ring; slot: bytes of a ring slot;
