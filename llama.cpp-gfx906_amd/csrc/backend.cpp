@@ -387,6 +387,9 @@ struct mi_backend_ctx {
     size_t scratch_size = 0;
     int moe_dual = -1;                  // option "moe_dual"
     float * moe_ws = nullptr;                                   // logits + arrival counter of the multi-workgroup router kernel (moe_route)
+    // the last router launch of this graph pass: it ranked `vals` (probabilities, or logits) into `sorted` and left the eight best values in rank order at moe_ws + 64
+    // (floats the kernel does not use otherwise): a combine that gathers vals[sorted[u]] takes them from there — one load instead of two dependent cold ones
+    struct { bool valid = false; const void * vals = nullptr; const void * sorted = nullptr; } rt;
     // producer-side activation quantization (mmvq_fin): the image a GLU launch writes for the mat-vec that follows + its arrival counters
     void * fin_img = nullptr; unsigned * fin_cnt = nullptr;
     // the rotation table of the token being decoded ((cos, sin) per pair index; mmvq_rope::table): filled by one small launch when a graph's
@@ -1239,7 +1242,7 @@ static int try_fused_mmv(mi_backend_ctx * c, struct ggml_cgraph * g, int i, cons
         for (int q = 0; q < nc && !clash; q++) {
             const void * d = chains[q].out_ptr; const size_t nb = chains[q].out_bytes;
             clash = (c->pp.res && ranges_overlap(d, nb, c->pp.res, (size_t) c->pp.m*4)) || ranges_overlap(d, nb, c->pp.planes, planes_bytes) ||
-                    ranges_overlap(d, nb, c->pp.probs, c->pp.probs_bytes) || ranges_overlap(d, nb, c->pp.ids, (size_t) c->pp.n_planes*4);
+                    ranges_overlap(d, nb, c->pp.probs, c->pp.probs_bytes) || (c->pp.ids && ranges_overlap(d, nb, c->pp.ids, (size_t) c->pp.n_planes*4));
         }
         if (clash) pp_flush(c);
         else {
@@ -1416,6 +1419,8 @@ static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int
     // the sum's first reader is the norm of a grouped mat-vec launch (the next layer's norm + QKV, or the final norm + lm_head): that launch's prologue
     // evaluates the combine itself (weighted planes, mmvq_stream.h) — this kernel and its boundary go. Anything else: pp_flush runs it after all.
     static const bool defer_on = !getenv("GGML_MI355X_MOE_COMBINE_DEFER") || atoi(getenv("GGML_MI355X_MOE_COMBINE_DEFER")) != 0;
+    // the values this combine gathers are the ones the router just ranked (same tensors): its top-8 list is probs[ids[u]] already
+    const bool direct = c->rt.valid && c->moe_ws && pr->data == c->rt.vals && ids->data == c->rt.sorted && ids->nb[0] == 4;
     {
         const int jn = next_real(g, jl);
         const int jm2 = jn > 0 ? next_real(g, jn) : -1;
@@ -1434,11 +1439,11 @@ static int try_fused_moe_combine(mi_backend_ctx * c, struct ggml_cgraph * g, int
             pp_flush(c);
             c->pp.active = true; c->pp.res = res; c->pp.x_out = (float *) out->data; c->pp.n_planes = (int) n_used; c->pp.m = n_embd;
             c->pp.planes = (const float *) ex->data; c->pp.stride = (int)(ex->nb[1]/4);
-            c->pp.probs = (const float *) pr->data; c->pp.probs_bytes = ggml_nbytes(pr); c->pp.ids = (const int32_t *) ids->data; c->pp.mode = mode;
+            c->pp.probs = direct ? c->moe_ws + 64 : (const float *) pr->data; c->pp.probs_bytes = direct ? 32 : ggml_nbytes(pr); c->pp.ids = direct ? nullptr : (const int32_t *) ids->data; c->pp.mode = mode;
             return jl - i + 1;
         }
     }
-    moe_combine((const float *) pr->data, (const int32_t *) ids->data, (int) n_used, mode, ex->data, ex->nb[1], n_embd, res, (float *) out->data, c->stream);
+    moe_combine(direct ? c->moe_ws + 64 : (const float *) pr->data, direct ? nullptr : (const int32_t *) ids->data, (int) n_used, mode, ex->data, ex->nb[1], n_embd, res, (float *) out->data, c->stream);
     c->cnt.kernels_launched++;
     return jl - i + 1;
 }
@@ -1760,13 +1765,16 @@ static int try_fused_moe_route(mi_backend_ctx * c, struct ggml_cgraph * g, int i
     }
     if (nd->op != GGML_OP_ARGSORT || nd->src[0] != cur || nd->op_params[0] != GGML_SORT_ORDER_DESC || nd->type != GGML_TYPE_I32 ||
         !ggml_is_contiguous(nd) || ggml_nelements(nd) != E) return 0;
+    static const bool topv_on = !getenv("GGML_MI355X_MOE_TOPV") || atoi(getenv("GGML_MI355X_MOE_TOPV")) != 0;
+    float * topv = topv_on && c->moe_ws ? c->moe_ws + 64 : nullptr;
     if (norm) {
         if (!moe_route_norm_supported(K, E, c->moe_ws) || ((uintptr_t) normw->data % 16) || ((uintptr_t) norm->src[0]->data % 16) || ((uintptr_t) x->data % 16)) return 0;
         moe_route((const float *) w->data, w->nb[1], (const float *) norm->src[0]->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws,
-                  (const float *) normw->data, op_f32(norm, 0), (float *) x->data, c->err_dev);
+                  (const float *) normw->data, op_f32(norm, 0), (float *) x->data, c->err_dev, topv);
     } else {
-        moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws, nullptr, 0.0f, nullptr, c->err_dev);
+        moe_route((const float *) w->data, w->nb[1], (const float *) x->data, bias, K, E, softmax, logits_out, probs_out, (int32_t *) nd->data, c->stream, c->moe_ws, nullptr, 0.0f, nullptr, c->err_dev, topv);
     }
+    c->rt.valid = topv != nullptr; c->rt.vals = softmax ? (const void *) probs_out : (const void *) logits_out; c->rt.sorted = nd->data;
     c->cnt.kernels_launched++;
     return j - i + 1;
 }
@@ -2216,7 +2224,7 @@ static void run_nodes(mi_backend_ctx * c, struct ggml_cgraph * g, int start = 0,
             for (int s = 0; s < GGML_MAX_SRC; s++) if (g->nodes[i]->src[s]) c->uses[g->nodes[i]->src[s]]++;
         }
     }
-    c->pp.active = false;
+    c->pp.active = false; c->rt.valid = false;
     // segment sizes in kernel launches: the first is small (the GPU starts early), the second covers the time the host needs to launch the rest
     static const int seg_kernels[2] = { getenv("GGML_MI355X_GRAPH_SEG0") ? atoi(getenv("GGML_MI355X_GRAPH_SEG0")) : 6, getenv("GGML_MI355X_GRAPH_SEG1") ? atoi(getenv("GGML_MI355X_GRAPH_SEG1")) : 24 };
     int seg_begin = start; uint64_t k0 = c->cnt.kernels_launched;

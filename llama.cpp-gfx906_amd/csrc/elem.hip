@@ -597,7 +597,9 @@ struct moe_route_args { const float * w; size_t w_nb1; const float * x; const fl
                         // norm_w != NULL (the wide kernel only): x is the RAW residual stream and the router's input is y = (x * rsqrt(mean(x^2) + eps)) * norm_w
                         // (build_norm's RMS_NORM -> MUL folded in); workgroup 0 also writes y to y_out, where the expert mat-vecs read it
                         const float * norm_w; float eps; float * y_out;
-                        unsigned * err; };      // host-mapped error words (may be NULL): [1] = the ranking workgroup gave up waiting for a logit
+                        unsigned * err;         // host-mapped error words (may be NULL): [1] = the ranking workgroup gave up waiting for a logit
+                        float * topv; };        // may be NULL: the eight best values (probabilities, or logits without soft_max) in rank order — what GET_ROWS(probs, selected) gathers, handed
+                                                // to the combine directly so that its reader does not chase ids -> probs through two cold loads
 __global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
     __shared__ float v[256];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;      // 16 waves: the rows of 32 experts are 2 per wave
@@ -635,6 +637,7 @@ __global__ void __launch_bounds__(1024) k_moe_route(const moe_route_args p) {
         const float me = v[e];
         for (int j = 0; j < p.n_expert; j++) rank += (v[j] > me) || (v[j] == me && j < e);
         p.sorted[rank] = e;
+        if (p.topv && rank < 8) p.topv[rank] = me;
     }
 }
 // One workgroup streams the whole router matrix at ONE CU's rate (gpt-oss: 32 rows of 2880 floats = 368 KB: 13 us; Mixtral: 8 x 4096: 8 us). Here one
@@ -790,6 +793,7 @@ __global__ void __launch_bounds__(256) k_moe_route_wide(const moe_route_args p, 
         const float me = v[e];
         for (int j = 0; j < p.n_expert; j++) rank += (v[j] > me) || (v[j] == me && j < e);
         p.sorted[rank] = e;
+        if (p.topv && rank < 8) p.topv[rank] = me;
     }
 }
 bool moe_route_norm_supported(int64_t k, int64_t n_expert, const float * ws) {
@@ -797,8 +801,8 @@ bool moe_route_norm_supported(int64_t k, int64_t n_expert, const float * ws) {
     return ws && wide_on && n_expert >= 4 && n_expert <= 256 && k % 4 == 0;
 }
 void moe_route(const float * w, size_t w_nb1, const float * x, const float * bias, int64_t k, int64_t n_expert, bool softmax,
-               float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws, const float * norm_w, float eps, float * y_out, unsigned * err) {
-    moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted, norm_w, eps, y_out, err };
+               float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws, const float * norm_w, float eps, float * y_out, unsigned * err, float * topv) {
+    moe_route_args a = { w, w_nb1, x, bias, (int) k, (int) n_expert, softmax ? 1 : 0, logits, probs, sorted, norm_w, eps, y_out, err, topv };
     static const bool wide_on = !getenv("GGML_MI355X_MOE_ROUTE_WIDE") || atoi(getenv("GGML_MI355X_MOE_ROUTE_WIDE")) != 0;
     if (norm_w && !moe_route_norm_supported(k, n_expert, ws)) { fprintf(stderr, "moe_route: the norm is folded into the multi-workgroup kernel only\n"); abort(); }
     if (ws && wide_on && n_expert >= 4 && n_expert <= 256) hipLaunchKernelGGL(k_moe_route_wide, dim3((unsigned)((n_expert + MR_EPW - 1)/MR_EPW)), dim3(256), 0, stream, a, ws);
@@ -813,7 +817,7 @@ __global__ void __launch_bounds__(256) k_moe_combine(const moe_combine_args p) {
     float w[8];
     float pv[8];
 #pragma unroll
-    for (int u = 0; u < 8; u++) pv[u] = u < p.n_used ? p.probs[p.ids[u]] : 0.0f;
+    for (int u = 0; u < 8; u++) pv[u] = u < p.n_used ? (p.ids ? p.probs[p.ids[u]] : p.probs[u]) : 0.0f;      // ids == NULL: probs holds the selected values in slot order (the router's topv)
     if (p.mode == 0) {
         float sum = 0.0f;
 #pragma unroll

@@ -162,8 +162,9 @@ bool moe_route_norm_supported(int64_t k, int64_t n_expert, const float * ws);
 void moe_route(const float * w, size_t w_nb1, const float * x, const float * bias, int64_t k, int64_t n_expert, bool softmax,
                float * logits, float * probs, int32_t * sorted, hipStream_t stream, float * ws,
                const float * norm_w = nullptr, float eps = 0.0f, float * y_out = nullptr,    // ws: 257 zero-initialised words (>= 16 experts: several workgroups)
-               unsigned * err = nullptr);   // host-mapped words: err[1] is set when the ranking workgroup's bounded wait for a logit gave up
-// one token: dst[i] = sum_u experts[u][i] * w_u (+ res[i]); w from probs[ids[u]] normalised (mode 0) or soft_max'ed (mode 1);
+               unsigned * err = nullptr,    // host-mapped words: err[1] is set when the ranking workgroup's bounded wait for a logit gave up
+               float * topv = nullptr);     // 8 floats: the best values in rank order (moe_combine / the grouped mat-vec's plane weights take them with ids == NULL)
+// one token: dst[i] = sum_u experts[u][i] * w_u (+ res[i]); w from probs[ids[u]] (ids == NULL: probs[u]) normalised (mode 0) or soft_max'ed (mode 1);
 // n_used <= 8, n_embd % 4 == 0, 16-byte aligned rows (elem.hip: k_moe_combine)
 void moe_combine(const float * probs, const int32_t * ids, int n_used, int mode, const void * experts, size_t e_nb1, int64_t n_embd,
                  const float * res, float * dst, hipStream_t stream);

@@ -604,7 +604,7 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
             {
                 float pr[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) pr[u] = u < p.n_planes ? p.pl_probs[p.pl_ids[u]] : 0.0f;
+                for (int u = 0; u < 8; u++) pr[u] = u < p.n_planes ? (p.pl_ids ? p.pl_probs[p.pl_ids[u]] : p.pl_probs[u]) : 0.0f;      // (pl_ids == NULL: the router's values in slot order)
                 if (p.pl_mode == 0) {
                     float sum = 0.0f;
 #pragma unroll

@@ -84,7 +84,7 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     if (in.mode == PRO_Q8) { if (((uintptr_t) in.act.qs % 16) || ((uintptr_t) in.act.bsums % 16) || !in.act.d) return false; }
     else { if ((!in.x && !(in.planes && in.pl_probs)) || ((uintptr_t) in.x % 16) || (in.mode == PRO_NORM && ((uintptr_t) in.norm_w % 16))) return false; }
     const int64_t nb = b10 ? k/320 : k/256;
-    if (in.planes && (in.mode != PRO_NORM || (k + 255)/256 > 16 || !in.pl_probs || !in.pl_ids || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
+    if (in.planes && (in.mode != PRO_NORM || (k + 255)/256 > 16 || !in.pl_probs || in.n_planes < 1 || in.n_planes > 8 || !in.x_out || ((uintptr_t) in.planes % 16) || in.plane_stride % 4 || ((uintptr_t) in.x_out % 16))) return false;
     int ta = -1, tb = -1;
     for (int i = 0; i < n_groups; i++) {
         const mmvq_group & g = groups[i];
