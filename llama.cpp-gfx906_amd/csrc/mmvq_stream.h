@@ -72,7 +72,7 @@ struct st_args {
     int n_groups, k, nb, mode;                // nb: units per row (k / 256, or k / 320 for the ten-block units)
     int nchunk, act_stride;                   // 256-element pieces of the activation vector ((k + 255) / 256); bytes between the image's units
     int block_end[MMVQ_MAX_GROUPS];
-    uint32_t magic; int S; float eps; int pad0;
+    uint32_t magic; int S; float eps; int early;     // early: slots of the first phase the loader issues BEFORE it meets the consumers at the first barrier (0: none)
     const float * x; const float * norm_w;
     const int8_t * a_qs; const float * a_d; const int16_t * a_bs;      // PRO_Q8: the n = 1 image act_q8_carve lays out
     fused_rope rope;
@@ -481,7 +481,7 @@ static __device__ __forceinline__ void st_loader_publish(const st_lds & L, st_lo
     if (l > s.landed) { s.landed = l; if (lane == 0) st_flag_st(&L.sync[0], (uint32_t) l); }
 }
 template <int TYPE, bool NT>
-static __device__ __forceinline__ void st_loader_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, st_loader_state & ls, int lane, int expert) {
+static __device__ __forceinline__ void st_loader_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, st_loader_state & ls, int lane, int expert, int barrier_after = 0) {
     typedef st_unit<TYPE> U;
     constexpr int PPS = (64*U::UB + 1023)/1024;
     const int nb = p.nb;
@@ -522,9 +522,12 @@ static __device__ __forceinline__ void st_loader_phase(const st_args & p, const 
         } else st_dma_slot<NT, PPS>(gb, voff, dst);
         ls.pieces += PPS;
         if (++ring_i == S) ring_i = 0;
+        // (barrier_after > 0: the workgroup's first barrier — behind which the consumers' activation loads are queued — is met after this many slots are on their way)
+        if (barrier_after > 0 && i + 1 == barrier_after) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         asm volatile("s_waitcnt vmcnt(%0)" :: "n"(ST_INFLIGHT) : "memory");
         if (ls.pieces > ST_INFLIGHT) st_loader_publish<PPS>(L, ls, gi + 1, ST_INFLIGHT, lane);
     }
+    if (barrier_after > nslots) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }      // (fewer slots than that: the barrier is still met once)
     ls.p_magic = (65536 + PPS - 1)/PPS;       // (for the phase after this one)
 }
 // after the last phase: everything lands
@@ -894,13 +897,15 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) 
         // the loader shares with the consumers' activation loads and collected after it (the first DMA used to wait ~1 us for it behind that barrier)
         int e_raw = 0;
         if (g.eid) asm volatile("global_load_dword %0, %1, off" : "=v"(e_raw) : "v"(g.eid) : "memory");
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        // weights first (p.early slots, plain groups only): a CU returns its loads in request order, so with the activations in front the first slot lands ~1 us after
+        // THEY do (2 - 4 us into the launch: they are cold in another XCD's L2); a slot in front of them delays them by its ~0.3 us and is there when the image is
+        const int early = g.eid ? 0 : p.early;
+        if (!early) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         if (g.eid) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_raw) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
         const int expert = __builtin_amdgcn_readfirstlane(e_raw);
         st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0, 0 };
-        if (is_a) st_loader_phase<TA, NT>(p, g, wg, nwg, L, 0, ls, lane, expert);
-        else      st_loader_phase<TB, NT>(p, g, wg, nwg, L, 0, ls, lane, expert);
+        if (is_a) st_loader_phase<TA, NT>(p, g, wg, nwg, L, 0, ls, lane, expert, early);
+        else      st_loader_phase<TB, NT>(p, g, wg, nwg, L, 0, ls, lane, expert, early);
         st_loader_drain(L, st_phase_slots(p, g, wg, nwg), ls, lane);
         ST_STAMP(1);
         return;
