@@ -643,6 +643,13 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
         } else if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
     } else
     if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#ifdef MI_STAMPS
+    {   // diagnostic builds: when are the activation loads back? (stamp 7 of the wave; the stamp waits for them, which the product does not do here)
+        unsigned long long * stamps = p.stamps;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FIRST) { ST_STAMP(7); }
+    }
+#endif
     float scale = 1.0f;
     if (norm) {
         float ss = 0.0f;
@@ -711,6 +718,100 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
     }
 }
 
+// PRO_QUANT / PRO_NORM into Q8_K blocks, FOUR blocks per wave-instruction (round 4). st_prologue_f32 gives a wave one 256-element block at a time, four floats per
+// lane: per block a full-wave maximum (DPP row steps + readlanes), a ballot, a readlane, two correctly rounded divisions, the quad sums and seven masked byte
+// stores serve just four elements per lane — ~100 vector instructions per block, two consumer waves per SIMD: the image of a 14336-long vector was ready 4.7 us
+// into the launch with the loads back after 2.0 (stamps build), i.e. the quantizer, not memory, set the start of every launch's multiply phase.
+// Here a DPP ROW (16 lanes) owns a block and a lane 16 consecutive elements: the maximum is four row steps, the 16-element sums are per lane, a lane stores its
+// 16 quants as one 16-byte write, and every overhead instruction works for four blocks at once. Same arithmetic per element as quant_core.h's quant_frag_q8_K
+// (first element of largest magnitude, iscale = -127 / max, round to nearest even, min 127, d = 1 / iscale): the same bytes.
+//   quad q = blocks 4q .. 4q + 3; wave w owns quads w, w + 8, ...: NQ of them
+template <int NQ, bool FIRST>
+static __device__ __forceinline__ void st_prologue_q8k16(const st_args & p, const st_lds & L, int x_off, int seq, int & n_norm, int lane, int wave) {
+    const int nchunk = p.nchunk;
+    const bool norm = p.mode == PRO_NORM;
+    const int r = lane >> 4, l16 = lane & 15;
+    float4v xv[NQ][4], wv[NQ][4];
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int c = min(4*(wave + ST_NC*i) + r, nchunk - 1);       // (a block past the end: a clamped duplicate that is not stored)
+        const float * xs = p.x + x_off + c*256 + l16*16;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            xv[i][j] = *(const float4v *) (xs + 4*j);
+            wv[i][j] = norm ? *(const float4v *) (p.norm_w + (size_t) c*256 + l16*16 + 4*j) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
+        }
+    }
+    if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#ifdef MI_STAMPS
+    {   unsigned long long * stamps = p.stamps;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (FIRST) { ST_STAMP(7); }
+    }
+#endif
+    float scale = 1.0f;
+    if (norm) {
+        float ss = 0.0f;
+#pragma unroll
+        for (int i = 0; i < NQ; i++) {
+            if (4*(wave + ST_NC*i) + r < nchunk) {
+#pragma unroll
+                for (int j = 0; j < 4; j++) ss += (xv[i][j].x*xv[i][j].x + xv[i][j].y*xv[i][j].y) + (xv[i][j].z*xv[i][j].z + xv[i][j].w*xv[i][j].w);
+            }
+        }
+        ss = wave_sum(ss);
+        if (lane == 0) L.red[wave] = ss;
+        st_consumers_meet(&L.sync[4], lane, n_norm++);
+        const float * red = L.red;
+        ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
+        scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
+    }
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+        const int c = 4*(wave + ST_NC*i) + r;
+        float v[16];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            v[4*j] = xv[i][j].x; v[4*j + 1] = xv[i][j].y; v[4*j + 2] = xv[i][j].z; v[4*j + 3] = xv[i][j].w;
+            if (norm) { v[4*j] = (v[4*j]*scale)*wv[i][j].x; v[4*j + 1] = (v[4*j + 1]*scale)*wv[i][j].y; v[4*j + 2] = (v[4*j + 2]*scale)*wv[i][j].z; v[4*j + 3] = (v[4*j + 3]*scale)*wv[i][j].w; }
+        }
+        // the first element of largest magnitude (the reference's strict > keeps the first): the magnitude by a max tree, then — once the block's maximum is known —
+        // the lowest-indexed element that has it (scanned downwards, a later hit overrides): ~40 instructions where tracking (amax, value) pairs took ~105
+        float amax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
+        amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(v[8]), fabsf(v[9])), fmaxf(fabsf(v[10]), fabsf(v[11]))), fmaxf(fmaxf(fabsf(v[12]), fabsf(v[13])), fmaxf(fabsf(v[14]), fabsf(v[15])))));
+        const float rmax = row16_max(amax);
+        float mx = v[15];
+#pragma unroll
+        for (int e = 14; e >= 0; e--) mx = fabsf(v[e]) == rmax ? v[e] : mx;
+        const bool zero = rmax == 0.0f;
+        const unsigned long long ball = __ballot(amax == rmax);
+        const uint32_t mine = (uint32_t)(ball >> (lane & 48)) & 0xFFFFu;       // the row's lanes that hold the maximum: the lowest one holds the first such element
+        const int first = (lane & 48) + (int) __builtin_ctz(mine | 0x10000u);
+        const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(first << 2, __builtin_bit_cast(int, mx)));
+        const float maxv = zero ? 1.0f : got;
+        const float iscale = -127.0f/maxv;
+        int q[16], sum = 0;
+#pragma unroll
+        for (int e = 0; e < 16; e++) { q[e] = min(127, __float2int_rn(iscale*v[e])); sum += q[e]; }
+        int4v pk;
+        pk.x = (int) pack4_i8(q[0], q[1], q[2], q[3]);   pk.y = (int) pack4_i8(q[4], q[5], q[6], q[7]);
+        pk.z = (int) pack4_i8(q[8], q[9], q[10], q[11]); pk.w = (int) pack4_i8(q[12], q[13], q[14], q[15]);
+        if (zero) { pk = int4v{ 0, 0, 0, 0 }; sum = 0; }
+        const float d = zero ? 0.0f : 1.0f/iscale;
+        const int sum32 = sum + dpp_i<0xB1>(sum);       // (quad_perm [1,0,3,2]: the neighbour's 16-element sum)
+        if (c < nchunk) {
+            char * ab = L.act + (size_t) c*ST_ACT_STRIDE;
+            *(int4v *) (ab + l16*16) = pk;
+            int h, l;
+            st_hl(sum, h, l);
+            ab[272 + l16] = (char) h; ab[288 + l16] = (char) l;
+            st_hl(sum32, h, l);
+            if ((l16 & 1) == 0) { ab[256 + (l16 >> 1)] = (char) h; ab[264 + (l16 >> 1)] = (char) l; }
+            if (l16 == 0) L.dd[c] = d;
+        }
+    }
+}
+
 // ================= the consumers' share of one phase =================
 //   seq: how many phases this workgroup has run before (its LDS counters are cumulative); FIRST: the launch's first phase — the activation
 //   loads are queued before the loader starts (the barrier every wave of the workgroup takes exactly once)
@@ -732,6 +833,11 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
     const int mode = p.mode;
     constexpr int ST_IMG = TYPE == ST_MXFP4_B10 ? 3 : TYPE == ST_Q8_0_B10 ? 2 : (TYPE == T_Q8_0 || TYPE == T_Q4_0) ? 1 : 0;
     if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
+    else if (ST_IMG == 0 && !p.planes && p.x && !(p.early & 0x100) && p.nchunk <= 128) {      // (bit 8 of `early`: GGML_MI355X_STREAM_Q16=0, the one-block-per-wave quantizer)
+        if (p.nchunk <= 32)      st_prologue_q8k16<1, FIRST>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else if (p.nchunk <= 64) st_prologue_q8k16<2, FIRST>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else                     st_prologue_q8k16<4, FIRST>(p, L, g.x_off, seq, n_norm, lane, wave);
+    }
     else if (p.nchunk <= 8)   st_prologue_f32<1, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
     else if (p.nchunk <= 16)  st_prologue_f32<2, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
     else if (p.nchunk <= 32)  st_prologue_f32<4, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
@@ -899,10 +1005,11 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) 
         if (g.eid) asm volatile("global_load_dword %0, %1, off" : "=v"(e_raw) : "v"(g.eid) : "memory");
         // weights first (p.early slots, plain groups only): a CU returns its loads in request order, so with the activations in front the first slot lands ~1 us after
         // THEY do (2 - 4 us into the launch: they are cold in another XCD's L2); a slot in front of them delays them by its ~0.3 us and is there when the image is
-        const int early = g.eid ? 0 : p.early;
+        const int early = g.eid ? 0 : (p.early & 0xFF);
         if (!early) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
         if (g.eid) { asm volatile("s_waitcnt vmcnt(0)" : "+v"(e_raw) :: "memory"); __builtin_amdgcn_sched_barrier(0); }
         const int expert = __builtin_amdgcn_readfirstlane(e_raw);
+        ST_STAMP(3);        // (loader: the expert index is here — or nothing was waited for)
         st_loader_state ls = { 0, 0, 0, 0, 0, 0, 0, 0 };
         if (is_a) st_loader_phase<TA, NT>(p, g, wg, nwg, L, 0, ls, lane, expert, early);
         else      st_loader_phase<TB, NT>(p, g, wg, nwg, L, 0, ls, lane, expert, early);
