@@ -426,8 +426,9 @@ template <> struct st_unit<ST_MXFP4_B10> {
     }
 };
 
+constexpr int ST_NSTAMP = 16;      // stamps per wave (diagnostic builds)
 #ifdef MI_STAMPS
-#define ST_STAMP(i_) do { if (stamps && lane == 0) __hip_atomic_store(&stamps[((size_t) blockIdx.x*(ST_NC + 1) + wave)*8 + (i_)], (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
+#define ST_STAMP(i_) do { if (stamps && lane == 0) __hip_atomic_store(&stamps[((size_t) blockIdx.x*(ST_NC + 1) + wave)*ST_NSTAMP + (i_)], (unsigned long long) __builtin_amdgcn_s_memrealtime(), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)
 #else
 #define ST_STAMP(i_) do { } while (0)
 #endif
@@ -726,10 +727,10 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
 // 16 quants as one 16-byte write, and every overhead instruction works for four blocks at once. Same arithmetic per element as quant_core.h's quant_frag_q8_K
 // (first element of largest magnitude, iscale = -127 / max, round to nearest even, min 127, d = 1 / iscale): the same bytes.
 //   quad q = blocks 4q .. 4q + 3; wave w owns quads w, w + 8, ...: NQ of them
-template <int NQ, bool FIRST>
+template <int NQ, bool FIRST, bool NORM>
 static __device__ __forceinline__ void st_prologue_q8k16(const st_args & p, const st_lds & L, int x_off, int seq, int & n_norm, int lane, int wave) {
     const int nchunk = p.nchunk;
-    const bool norm = p.mode == PRO_NORM;
+    constexpr bool norm = NORM;      // (compile-time: as a run-time flag both forms were computed and selected between, square root and all)
     const int r = lane >> 4, l16 = lane & 15;
     float4v xv[NQ][4], wv[NQ][4];
 #pragma unroll
@@ -775,30 +776,53 @@ static __device__ __forceinline__ void st_prologue_q8k16(const st_args & p, cons
             v[4*j] = xv[i][j].x; v[4*j + 1] = xv[i][j].y; v[4*j + 2] = xv[i][j].z; v[4*j + 3] = xv[i][j].w;
             if (norm) { v[4*j] = (v[4*j]*scale)*wv[i][j].x; v[4*j + 1] = (v[4*j + 1]*scale)*wv[i][j].y; v[4*j + 2] = (v[4*j + 2]*scale)*wv[i][j].z; v[4*j + 3] = (v[4*j + 3]*scale)*wv[i][j].w; }
         }
-        // the first element of largest magnitude (the reference's strict > keeps the first): the magnitude by a max tree, then — once the block's maximum is known —
-        // the lowest-indexed element that has it (scanned downwards, a later hit overrides): ~40 instructions where tracking (amax, value) pairs took ~105
-        float amax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
-        amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(v[8]), fabsf(v[9])), fmaxf(fabsf(v[10]), fabsf(v[11]))), fmaxf(fmaxf(fabsf(v[12]), fabsf(v[13])), fmaxf(fabsf(v[14]), fabsf(v[15])))));
+        // the first element of largest magnitude (the reference's strict > keeps the first) is +max or -max: only its SIGN has to be found. A lane's largest and
+        // smallest element (two max trees) say whether +max, -max or both occur among its 16; both in one lane (never with real data, but exact all the same)
+        // takes the scan — lowest index wins — behind a wave-uniform branch
+        float pmax = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+        pmax = fmaxf(pmax, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
+        float nmin = fminf(fminf(fminf(v[0], v[1]), fminf(v[2], v[3])), fminf(fminf(v[4], v[5]), fminf(v[6], v[7])));
+        nmin = fminf(nmin, fminf(fminf(fminf(v[8], v[9]), fminf(v[10], v[11])), fminf(fminf(v[12], v[13]), fminf(v[14], v[15]))));
+        const float amax = fmaxf(pmax, -nmin);
         const float rmax = row16_max(amax);
-        float mx = v[15];
+        const bool has_pos = pmax == rmax, has_neg = -nmin == rmax;
+        float mx = has_neg ? -rmax : rmax;          // (a lane without the maximum: unused)
+        if (__ballot(has_pos && has_neg)) {
+            mx = v[15];
 #pragma unroll
-        for (int e = 14; e >= 0; e--) mx = fabsf(v[e]) == rmax ? v[e] : mx;
+            for (int e = 14; e >= 0; e--) mx = fabsf(v[e]) == rmax ? v[e] : mx;
+        }
         const bool zero = rmax == 0.0f;
         const unsigned long long ball = __ballot(amax == rmax);
         const uint32_t mine = (uint32_t)(ball >> (lane & 48)) & 0xFFFFu;       // the row's lanes that hold the maximum: the lowest one holds the first such element
         const int first = (lane & 48) + (int) __builtin_ctz(mine | 0x10000u);
         const float got = __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(first << 2, __builtin_bit_cast(int, mx)));
         const float maxv = zero ? 1.0f : got;
+#ifdef MI_STAMPS
+        { unsigned long long * stamps = p.stamps; if (FIRST && i == 0) { asm volatile("" :: "v"(maxv)); ST_STAMP(8); } }
+#endif
         const float iscale = -127.0f/maxv;
-        int q[16], sum = 0;
+        // round to nearest even by the reference's own device (nearest_int: add 1.5 * 2^23, the integer sits in the low mantissa bits): the quant is the low BYTE of
+        // the sum's bit pattern, so four of them are packed by byte selects without a conversion, and their sum is one signed dot4 against 1,1,1,1. (The reference's
+        // MIN(127, .) never binds: |iscale * x| <= 127 (1 + 2^-24)^2, which rounds to 127.)
+        uint32_t tb[16];
 #pragma unroll
-        for (int e = 0; e < 16; e++) { q[e] = min(127, __float2int_rn(iscale*v[e])); sum += q[e]; }
-        int4v pk;
-        pk.x = (int) pack4_i8(q[0], q[1], q[2], q[3]);   pk.y = (int) pack4_i8(q[4], q[5], q[6], q[7]);
-        pk.z = (int) pack4_i8(q[8], q[9], q[10], q[11]); pk.w = (int) pack4_i8(q[12], q[13], q[14], q[15]);
+        for (int e = 0; e < 16; e++) { const float t = iscale*v[e] + 12582912.0f; tb[e] = __builtin_bit_cast(uint32_t, t); }
+        int4v pk; int sum = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            uint32_t w = __builtin_amdgcn_perm(tb[4*j + 1], tb[4*j], 0x0c0c0400u);          // { t0.b0, t1.b0, 0, 0 }
+            w = __builtin_amdgcn_perm(tb[4*j + 2], w, 0x0c040100u);                          // { .., .., t2.b0, 0 }
+            w = __builtin_amdgcn_perm(tb[4*j + 3], w, 0x04020100u);                          // { .., .., .., t3.b0 }
+            pk[j] = (int) w;
+            sum = __builtin_amdgcn_sdot4((int) w, 0x01010101, sum, false);
+        }
         if (zero) { pk = int4v{ 0, 0, 0, 0 }; sum = 0; }
         const float d = zero ? 0.0f : 1.0f/iscale;
         const int sum32 = sum + dpp_i<0xB1>(sum);       // (quad_perm [1,0,3,2]: the neighbour's 16-element sum)
+#ifdef MI_STAMPS
+        { unsigned long long * stamps = p.stamps; if (FIRST && i == 0) { asm volatile("" :: "v"(pk.x), "v"(sum32), "v"(d)); ST_STAMP(9); } }
+#endif
         if (c < nchunk) {
             char * ab = L.act + (size_t) c*ST_ACT_STRIDE;
             *(int4v *) (ab + l16*16) = pk;
@@ -834,9 +858,15 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
     constexpr int ST_IMG = TYPE == ST_MXFP4_B10 ? 3 : TYPE == ST_Q8_0_B10 ? 2 : (TYPE == T_Q8_0 || TYPE == T_Q4_0) ? 1 : 0;
     if (mode == PRO_Q8) st_prologue_q8<FIRST>(p, L, ctid);
     else if (ST_IMG == 0 && !p.planes && p.x && !(p.early & 0x100) && p.nchunk <= 128) {      // (bit 8 of `early`: GGML_MI355X_STREAM_Q16=0, the one-block-per-wave quantizer)
-        if (p.nchunk <= 32)      st_prologue_q8k16<1, FIRST>(p, L, g.x_off, seq, n_norm, lane, wave);
-        else if (p.nchunk <= 64) st_prologue_q8k16<2, FIRST>(p, L, g.x_off, seq, n_norm, lane, wave);
-        else                     st_prologue_q8k16<4, FIRST>(p, L, g.x_off, seq, n_norm, lane, wave);
+        if (mode == PRO_NORM) {
+            if (p.nchunk <= 32)      st_prologue_q8k16<1, FIRST, true>(p, L, g.x_off, seq, n_norm, lane, wave);
+            else if (p.nchunk <= 64) st_prologue_q8k16<2, FIRST, true>(p, L, g.x_off, seq, n_norm, lane, wave);
+            else                     st_prologue_q8k16<4, FIRST, true>(p, L, g.x_off, seq, n_norm, lane, wave);
+        } else {
+            if (p.nchunk <= 32)      st_prologue_q8k16<1, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
+            else if (p.nchunk <= 64) st_prologue_q8k16<2, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
+            else                     st_prologue_q8k16<4, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
+        }
     }
     else if (p.nchunk <= 8)   st_prologue_f32<1, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
     else if (p.nchunk <= 16)  st_prologue_f32<2, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);

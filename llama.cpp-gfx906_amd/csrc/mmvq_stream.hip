@@ -48,7 +48,7 @@ extern "C" int mi355x_stream_stamps_enable(int n_slots) {
     if (g_st_stamps) { (void) hipFree(g_st_stamps); g_st_stamps = nullptr; }
     g_st_slots = n_slots > 4096 ? 4096 : n_slots; g_st_next = 0;
     if (g_st_slots <= 0) return 0;
-    const size_t bytes = (size_t) g_st_slots*256*(ST_NC + 1)*8*8;
+    const size_t bytes = (size_t) g_st_slots*256*(ST_NC + 1)*ST_NSTAMP*8;
     if (hipMalloc(&g_st_stamps, bytes) != hipSuccess) return -1;
     (void) hipMemset(g_st_stamps, 0, bytes);
     return 0;
@@ -57,7 +57,7 @@ extern "C" int mi355x_stream_stamps_used(void) { return g_st_next; }
 extern "C" int mi355x_stream_stamps_read(int slot, unsigned long long * out, int * meta, long long * bytes) {
     if (!g_st_stamps || slot < 0 || slot >= g_st_slots) return -1;
     const st_stamp_meta & m = g_st_meta[slot];
-    (void) hipMemcpy(out, g_st_stamps + (size_t) slot*256*(ST_NC + 1)*8, (size_t) 256*(ST_NC + 1)*8*8, hipMemcpyDeviceToHost);
+    (void) hipMemcpy(out, g_st_stamps + (size_t) slot*256*(ST_NC + 1)*ST_NSTAMP, (size_t) 256*(ST_NC + 1)*ST_NSTAMP*8, hipMemcpyDeviceToHost);
     meta[0] = m.blocks; meta[1] = m.k; meta[2] = m.rows; meta[3] = m.type_a; meta[4] = m.type_b; meta[5] = m.mode; meta[6] = m.glu;
     *bytes = m.bytes;
     return 0;
@@ -239,7 +239,7 @@ void mul_mat_vec_q_stream(const mmvq_group * groups, int n_groups, int64_t k, co
         st_stamp_meta & sm = g_st_meta[g_st_next];
         sm.blocks = blocks; sm.k = (int) k; sm.rows = 0; for (int i = 0; i < n_groups; i++) sm.rows += groups[i].m*(groups[i].epi == EPI_GLU ? 2 : 1);
         sm.type_a = ta; sm.type_b = tb; sm.mode = in.mode; sm.glu = groups[0].epi == EPI_GLU; sm.bytes = (long long) bytes_total;
-        a.stamps = g_st_stamps + (size_t) g_st_next*256*(ST_NC + 1)*8;
+        a.stamps = g_st_stamps + (size_t) g_st_next*256*(ST_NC + 1)*ST_NSTAMP;
         g_st_next++;
     }
 #endif
