@@ -580,11 +580,11 @@ static __device__ __forceinline__ void st_prologue_q8(const st_args & p, const s
 // the dependent chains of the wave-wide maxima and sums interleave — chunk after chunk behind a branch each cost ~0.5 us per chunk
 // IMG: 0 = Q8_K blocks (K-quant weights); 1 = the workgroup's weights are Q8_0 in 256-weight units — the image is the CPU path's Q8_0 instead (32-element
 // blocks, f16-rounded scales: quant_core.h); 2 = the same Q8_0 activation for the ten-block units (k % 256 != 0: the last 256-piece is partial)
-template <int NA, bool FIRST, int IMG>
+template <int NA, bool FIRST, int IMG, bool NORM>
 static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const st_lds & L, int x_off, int seq, int & n_norm, int lane, int wave) {
     constexpr bool Q80 = IMG != 0;
     const int nchunk = p.nchunk;
-    const bool norm = p.mode == PRO_NORM;
+    constexpr bool norm = NORM;        // (compile-time: see st_prologue_q8k16)
     float4v xv[NA], wv[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) {
@@ -868,10 +868,17 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
             else                     st_prologue_q8k16<4, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
         }
     }
-    else if (p.nchunk <= 8)   st_prologue_f32<1, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else if (p.nchunk <= 16)  st_prologue_f32<2, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else if (p.nchunk <= 32)  st_prologue_f32<4, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
-    else                st_prologue_f32<8, FIRST, ST_IMG>(p, L, g.x_off, seq, n_norm, lane, wave);
+    else if (mode == PRO_NORM) {
+        if (p.nchunk <= 8)        st_prologue_f32<1, FIRST, ST_IMG, true>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else if (p.nchunk <= 16)  st_prologue_f32<2, FIRST, ST_IMG, true>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else if (p.nchunk <= 32)  st_prologue_f32<4, FIRST, ST_IMG, true>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else                      st_prologue_f32<8, FIRST, ST_IMG, true>(p, L, g.x_off, seq, n_norm, lane, wave);
+    } else {
+        if (p.nchunk <= 8)        st_prologue_f32<1, FIRST, ST_IMG, false>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else if (p.nchunk <= 16)  st_prologue_f32<2, FIRST, ST_IMG, false>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else if (p.nchunk <= 32)  st_prologue_f32<4, FIRST, ST_IMG, false>(p, L, g.x_off, seq, n_norm, lane, wave);
+        else                      st_prologue_f32<8, FIRST, ST_IMG, false>(p, L, g.x_off, seq, n_norm, lane, wave);
+    }
     ST_STAMP(1);
     st_consumers_meet(&sync[2], lane, seq);
     ST_STAMP(2);
