@@ -841,7 +841,7 @@ static __device__ __forceinline__ void st_prologue_q8k16(const st_args & p, cons
 //   loads are queued before the loader starts (the barrier every wave of the workgroup takes exactly once)
 template <int TYPE, bool FIRST>
 static __device__ __forceinline__ void st_consumer_phase(const st_args & p, const st_group & g, int wg, int nwg, const st_lds & L, int slot0, int seq, int & n_norm,
-                                                         int lane, int wave, unsigned long long * stamps) {
+                                                         int lane, int wave, unsigned long long * stamps, int xt0 = 0, int xt1 = 0) {
     typedef st_unit<TYPE> U;
     const int nb = p.nb;
     const bool GLU = g.epi == EPI_GLU || g.neox2 > 0;      // two row streams
@@ -880,6 +880,7 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
         else                      st_prologue_f32<8, FIRST, ST_IMG, false>(p, L, g.x_off, seq, n_norm, lane, wave);
     }
     ST_STAMP(1);
+    asm volatile("s_waitcnt vmcnt(0)" :: "v"(xt0), "v"(xt1) : "memory");      // (the entry touches' registers are free from here on; nothing of this wave's is in flight any more)
     st_consumers_meet(&sync[2], lane, seq);
     ST_STAMP(2);
 
@@ -1024,6 +1025,19 @@ static __device__ __forceinline__ int st_phase_slots(const st_args & a, const st
 template <int TA, int TB, bool NT, bool GLU>
 __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) {
     extern __shared__ __attribute__((aligned(16))) char lds[];
+    // The activation vector (and the norm weights) are what every launch waits for first — written by the launch before on other XCDs, back ~1.5 us after they are
+    // asked for — and the loads that ask for them sit behind this kernel's whole set-up (group lookup, LDS carve, row ranges: several hundred instructions and a
+    // chain of scalar loads). One dword per 128-byte line, asked for here from two kernel-argument fields, starts the fetch; the real loads find the lines on their way.
+    // (the destination registers stay reserved until the image is built — in-order return: the real loads' data is back only after these — or the compiler would
+    // hand them to something else while the loads are still to write them: the first version of this hung the GPU box that way)
+    int xt0 = 0, xt1 = 0;
+    if (!(p.early & 0x200) && p.mode != PRO_Q8 && p.x) {
+        const uint32_t off = threadIdx.x*128u;
+        if (off < (uint32_t) p.k*4u) {
+            asm volatile("global_load_dword %0, %1, off" : "+v"(xt0) : "v"((const char *) p.x + off) : "memory");
+            if (p.mode == PRO_NORM) asm volatile("global_load_dword %0, %1, off" : "+v"(xt1) : "v"((const char *) p.norm_w + off) : "memory");
+        }
+    }
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     int first, nwg;
     const int gi = st_group_of(p, (int) blockIdx.x, first, nwg);
@@ -1055,8 +1069,8 @@ __global__ void __launch_bounds__(ST_THREADS, 3) k_mmvq_stream(const st_args p) 
         return;
     }
     int n_norm = 0;
-    if (is_a) st_consumer_phase<TA, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
-    else      st_consumer_phase<TB, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps);
+    if (is_a) st_consumer_phase<TA, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps, xt0, xt1);
+    else      st_consumer_phase<TB, true>(p, g, wg, nwg, L, 0, 0, n_norm, lane, wave, stamps, xt0, xt1);
 }
 
 } // namespace mi355x

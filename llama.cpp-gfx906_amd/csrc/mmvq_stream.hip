@@ -138,7 +138,8 @@ static int st_fill(const mmvq_group * groups, int n_groups, int64_t k, const mmv
     // (not kept: one batch of scalar loads over the whole 928-byte argument block at entry, so that the compiler's ~9 dependent s_loads before the first vector load
     // hit the scalar cache — same box, alternating: 604 / 600 tok/s with the batch, 617 / 617 without: the chain was not missing)
     { static const int early = getenv("GGML_MI355X_STREAM_EARLY") ? atoi(getenv("GGML_MI355X_STREAM_EARLY")) : 1;
-      static const int q16 = getenv("GGML_MI355X_STREAM_Q16") ? atoi(getenv("GGML_MI355X_STREAM_Q16")) : 1; a.early = (early & 0xFF) | (q16 ? 0 : 0x100); }
+      static const int q16 = getenv("GGML_MI355X_STREAM_Q16") ? atoi(getenv("GGML_MI355X_STREAM_Q16")) : 1; 
+      static const int touch = getenv("GGML_MI355X_STREAM_XTOUCH") ? atoi(getenv("GGML_MI355X_STREAM_XTOUCH")) : 1; a.early = (early & 0xFF) | (q16 ? 0 : 0x100) | (touch ? 0 : 0x200); }
     if (in.mode == PRO_Q8) { a.a_qs = in.act.qs; a.a_d = in.act.d; a.a_bs = in.act.bsums; }
     if (rope) a.rope = make_fused_rope(*rope);
 
