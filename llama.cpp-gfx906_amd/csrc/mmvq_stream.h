@@ -836,72 +836,6 @@ static __device__ __forceinline__ void st_prologue_q8k16(const st_args & p, cons
     }
 }
 
-// The same for the Q8_0 image of 256-weight units (Q4_0 / Q8_0 weights, k % 256 == 0): a 32-element block is two lanes of 16, four 256-element chunks per
-// wave-instruction. quant_core.h's quant_frag_q8_0 arithmetic: d = amax / 127 (stored f16-rounded), id = 1 / d, q = roundf(x * id).
-template <int NQ, bool FIRST, bool NORM>
-static __device__ __forceinline__ void st_prologue_q8016(const st_args & p, const st_lds & L, int x_off, int seq, int & n_norm, int lane, int wave) {
-    const int nchunk = p.nchunk;
-    constexpr bool norm = NORM;
-    const int r = lane >> 4, l16 = lane & 15;
-    float4v xv[NQ][4], wv[NQ][4];
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int c = min(4*(wave + ST_NC*i) + r, nchunk - 1);
-        const float * xs = p.x + x_off + c*256 + l16*16;
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            xv[i][j] = *(const float4v *) (xs + 4*j);
-            wv[i][j] = norm ? *(const float4v *) (p.norm_w + (size_t) c*256 + l16*16 + 4*j) : float4v{ 1.0f, 1.0f, 1.0f, 1.0f };
-        }
-    }
-    if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-    float scale = 1.0f;
-    if (norm) {
-        float ss = 0.0f;
-#pragma unroll
-        for (int i = 0; i < NQ; i++) {
-            if (4*(wave + ST_NC*i) + r < nchunk) {
-#pragma unroll
-                for (int j = 0; j < 4; j++) ss += (xv[i][j].x*xv[i][j].x + xv[i][j].y*xv[i][j].y) + (xv[i][j].z*xv[i][j].z + xv[i][j].w*xv[i][j].w);
-            }
-        }
-        ss = wave_sum(ss);
-        if (lane == 0) L.red[wave] = ss;
-        st_consumers_meet(&L.sync[4], lane, n_norm++);
-        const float * red = L.red;
-        ss = ((red[0] + red[1]) + (red[2] + red[3])) + ((red[4] + red[5]) + (red[6] + red[7]));
-        scale = 1.0f/sqrtf(ss/(float) p.k + p.eps);
-    }
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
-        const int c = 4*(wave + ST_NC*i) + r;
-        float v[16];
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-            v[4*j] = xv[i][j].x; v[4*j + 1] = xv[i][j].y; v[4*j + 2] = xv[i][j].z; v[4*j + 3] = xv[i][j].w;
-            if (norm) { v[4*j] = (v[4*j]*scale)*wv[i][j].x; v[4*j + 1] = (v[4*j + 1]*scale)*wv[i][j].y; v[4*j + 2] = (v[4*j + 2]*scale)*wv[i][j].z; v[4*j + 3] = (v[4*j + 3]*scale)*wv[i][j].w; }
-        }
-        float amax = fmaxf(fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fmaxf(fabsf(v[2]), fabsf(v[3]))), fmaxf(fmaxf(fabsf(v[4]), fabsf(v[5])), fmaxf(fabsf(v[6]), fabsf(v[7]))));
-        amax = fmaxf(amax, fmaxf(fmaxf(fmaxf(fabsf(v[8]), fabsf(v[9])), fmaxf(fabsf(v[10]), fabsf(v[11]))), fmaxf(fmaxf(fabsf(v[12]), fabsf(v[13])), fmaxf(fabsf(v[14]), fabsf(v[15])))));
-        amax = fmaxf(amax, dpp_f<0xB1>(amax));          // (quad_perm [1,0,3,2]: the other half of the 32-element block)
-        const float dd = amax/127.0f;
-        const float id = dd != 0.0f ? 1.0f/dd : 0.0f;
-        int q[16], sum = 0;
-#pragma unroll
-        for (int e = 0; e < 16; e++) { q[e] = (int) roundf(v[e]*id); sum += q[e]; }
-        int4v pk;
-        pk.x = (int) pack4_i8(q[0], q[1], q[2], q[3]);   pk.y = (int) pack4_i8(q[4], q[5], q[6], q[7]);
-        pk.z = (int) pack4_i8(q[8], q[9], q[10], q[11]); pk.w = (int) pack4_i8(q[12], q[13], q[14], q[15]);
-        sum += dpp_i<0xB1>(sum);
-        const float d8 = f16_bits_to_f32(f32_to_f16_bits(dd));      // the CPU path stores d as f16 and reads it back
-        if (c < nchunk) {
-            char * ab = L.act + (size_t) c*ST_ACT_STRIDE;
-            *(int4v *) (ab + l16*16) = pk;
-            if ((l16 & 1) == 0) { ((float *) (ab + 256))[l16 >> 1] = d8; ((int16_t *) (ab + 288))[l16 >> 1] = (int16_t) sum; }
-        }
-    }
-}
-
 // ================= the consumers' share of one phase =================
 //   seq: how many phases this workgroup has run before (its LDS counters are cumulative); FIRST: the launch's first phase — the activation
 //   loads are queued before the loader starts (the barrier every wave of the workgroup takes exactly once)
@@ -932,17 +866,6 @@ static __device__ __forceinline__ void st_consumer_phase(const st_args & p, cons
             if (p.nchunk <= 32)      st_prologue_q8k16<1, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
             else if (p.nchunk <= 64) st_prologue_q8k16<2, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
             else                     st_prologue_q8k16<4, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
-        }
-    }
-    else if (ST_IMG == 1 && !p.planes && p.x && !(p.early & 0x100) && p.nchunk <= 128) {      // (the Q8_0 image of 256-weight units, four chunks per wave-instruction)
-        if (mode == PRO_NORM) {
-            if (p.nchunk <= 32)      st_prologue_q8016<1, FIRST, true>(p, L, g.x_off, seq, n_norm, lane, wave);
-            else if (p.nchunk <= 64) st_prologue_q8016<2, FIRST, true>(p, L, g.x_off, seq, n_norm, lane, wave);
-            else                     st_prologue_q8016<4, FIRST, true>(p, L, g.x_off, seq, n_norm, lane, wave);
-        } else {
-            if (p.nchunk <= 32)      st_prologue_q8016<1, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
-            else if (p.nchunk <= 64) st_prologue_q8016<2, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
-            else                     st_prologue_q8016<4, FIRST, false>(p, L, g.x_off, seq, n_norm, lane, wave);
         }
     }
     else if (mode == PRO_NORM) {
