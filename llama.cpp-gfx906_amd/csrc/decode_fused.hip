@@ -201,6 +201,14 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     const bool split = p.nsplit > 1;
     const int kv_lo = split ? (int) blockIdx.z*p.kv_chunk : 0;
     int kv_n = split ? min(p.n_kv - kv_lo, p.kv_chunk) : p.n_kv;   // this workgroup's cells
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    constexpr int LPC = HD/8;                            // lanes per K row (8 f16 = 16 B each)
+    constexpr int CPW = 64/LPC;                          // K rows per wave step
+    constexpr int U = 4;
+    const int sub = lane % LPC, cw = lane / LPC;
+    // q: written by the launch before on other XCDs, i.e. the longest wait of this launch — asked for before anything else (the live scan below waits for the mask)
+    const float * qp = (const float *) (p.q + (size_t) t*p.q_nb1 + (size_t) h*p.q_nb2) + sub*8;
+    const float4v q0_ld = *(const float4v *) qp, q1_ld = *(const float4v *) (qp + 4);
     if (!VT && !split && p.live_scan && p.mask) {
         // flash attention pads the cache view to 256 cells; everything behind the last unmasked cell is dead weight for K, the soft_max and V: find that cell
         // first (one mask value per thread and trip) and walk only up to it (a multiple of 8 cells, at least 8)
@@ -218,22 +226,16 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
         kv_n = min(kv_n, max(8, (lm + 8) & ~7));
         __syncthreads();
     }
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    constexpr int LPC = HD/8;                            // lanes per K row (8 f16 = 16 B each)
-    constexpr int CPW = 64/LPC;                          // K rows per wave step
-    constexpr int U = 4;
-    const int sub = lane % LPC, cw = lane / LPC;
 
     // ---- scores: s[j] = scale * K[j].q + mask[j] ----
-    const float * qp = (const float *) (p.q + (size_t) t*p.q_nb1 + (size_t) h*p.q_nb2) + sub*8;
-    float4v q0 = *(const float4v *) qp, q1 = *(const float4v *) (qp + 4);
     if (!KQ) {
         // the no-flash-attention graph's K.q is MUL_MAT(F16 cache, F32 q): the CPU backend converts q to the F16 operand type first (vec_dot_type of
         // F16, tests/test-quantize-fns.cpp:82-99) — followed here, so that the logits match the CPU reference and not just the exact product
         // (round 3: 8192-position perplexity statistics put the f32-q kernel 1.4e-3 in ln PPL from the CPU arithmetic, all of it this rounding).
         // FLASH_ATTN_EXT on the CPU converts q the same way (its K operand type), so both forms of the kernel do
+        // (applied inside the loop, BEHIND each batch of K requests: done here, the wait for q — cold, written by the launch before — came first and the K rows were
+        // only asked for after q had arrived: two memory round trips in a row on a 5 us launch)
 #define MI_R16(x_) x_ = f16_bits_to_f32(f32_to_f16_bits(x_))
-        MI_R16(q0.x); MI_R16(q0.y); MI_R16(q0.z); MI_R16(q0.w); MI_R16(q1.x); MI_R16(q1.y); MI_R16(q1.z); MI_R16(q1.w);
     }
     const char * kbase = p.k + (size_t) hk*p.k_nb2 + (KT == T_F16 ? sub*16 : KQ ? (sub >> 2)*34 : 0) + (size_t) kv_lo*p.k_nb1;
     const bool alibi = p.max_bias > 0.0f;
@@ -252,7 +254,7 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
     }
     float mx = (p.sinks && !split) ? p.sinks[h] : -INFINITY;
     for (int j0 = wave*CPW + cw; j0 < kv_n; j0 += 4*CPW*U) {
-        int4v kreg[U]; float mreg[U];
+        int4v kreg[U]; float mreg[U]; uint32_t mraw[U];
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int j = min(j0 + u*4*CPW, kv_n - 1);
@@ -262,9 +264,16 @@ __global__ void __launch_bounds__(256) k_attn_decode(const attn_args p) {
             } else if (KT == T_F16)
             kreg[u] = *(const int4v *) (kbase + (size_t) j*p.k_nb1);
             else kreg[u] = kv_raw8<KT>(kbase + (size_t) j*p.k_nb1, sub);
-            mreg[u] = 0.0f;
-            if (mrow) mreg[u] = p.mask_f16 ? f16_bits_to_f32(*(const uint16_t *) (mrow + (size_t) j*2)) : *(const float *) (mrow + (size_t) j*4);
+            // (the mask value is only REQUESTED here — raw bits, converted below: converting an f16 mask value on the spot put a wait for every outstanding load
+            // behind each of the U row requests, one memory round trip per cell instead of one per batch: ISA of the -fa 1 form)
+            mraw[u] = 0;
+            if (mrow) { if (p.mask_f16) mraw[u] = *(const uint16_t *) (mrow + (size_t) j*2); else mraw[u] = *(const uint32_t *) (mrow + (size_t) j*4); }
         }
+#pragma unroll
+        for (int u = 0; u < U; u++) mreg[u] = !mrow ? 0.0f : p.mask_f16 ? f16_bits_to_f32((uint16_t) mraw[u]) : __builtin_bit_cast(float, mraw[u]);
+        float4v q0 = q0_ld, q1 = q1_ld;
+        asm volatile("" : "+v"(q0), "+v"(q1));      // (opaque: the conversion below is loop-invariant and would be hoisted back in front of the K requests)
+        if (!KQ) { MI_R16(q0.x); MI_R16(q0.y); MI_R16(q0.z); MI_R16(q0.w); MI_R16(q1.x); MI_R16(q1.y); MI_R16(q1.z); MI_R16(q1.w); }
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const int j = j0 + u*4*CPW;
