@@ -452,9 +452,11 @@ struct st_lds {
 // aligned — Q6_K rows are 210 nb bytes); the rows past the last whole unit belong to the last workgroup
 static __device__ __forceinline__ void st_rows(const st_group & g, int wg, int nwg, int & r0, int & R) {
     if (g.neox2) { const int p0 = wg*g.neox2; r0 = (p0/g.neox_hh)*(2*g.neox_hh) + p0 % g.neox_hh; R = g.neox2; return; }      // first-half rows; the partners are neox_hh rows further
-    const int nru = g.m/g.ralign;
-    r0 = (int)((long long) wg*nru/nwg)*g.ralign;
-    R = (wg == nwg - 1 ? g.m : (int)((long long)(wg + 1)*nru/nwg)*g.ralign) - r0;
+    // (32-bit: nwg * nru < 2^31 is checked on the host. As 64-bit divisions these two lines were ~240 scalar instructions in front of the loader's first request
+    // and of every consumer's activation loads)
+    const uint32_t nru = (uint32_t) g.m/(uint32_t) g.ralign;
+    r0 = (int)(((uint32_t) wg*nru/(uint32_t) nwg)*(uint32_t) g.ralign);
+    R = (wg == nwg - 1 ? g.m : (int)((((uint32_t) wg + 1u)*nru/(uint32_t) nwg)*(uint32_t) g.ralign)) - r0;
 }
 
 // ================= the loader's share of one phase: slots slot0 .. slot0 + nslots of the workgroup's slot sequence =================

@@ -112,6 +112,7 @@ bool mul_mat_vec_q_stream_takes(const mmvq_group * groups, int n_groups, int64_t
     (void) st_fill(groups, n_groups, k, in, rope, a, fixed_max, slot_max, nslots_max, npart_max, fa, fb, bytes_total);
     const int64_t S = fixed_max < 163840 ? (163840 - (int64_t) fixed_max)/slot_max : 0;
     if (S < (nslots_max < 2 ? nslots_max : 2)) return false;
+    for (int i = 0; i < n_groups; i++) if ((int64_t) 256*groups[i].m >= (1ll << 31)) return false;      // (the kernel deals rows with 32-bit arithmetic: workgroups x row units)
     // experiment knob: launches that stream fewer bytes than this go to the register-ring kernel (is the streamed kernel's envelope a loss on the small launches?)
     static const double min_bytes = getenv("GGML_MI355X_STREAM_MIN_MB") ? atof(getenv("GGML_MI355X_STREAM_MIN_MB"))*1e6 : 0.0;
     if (min_bytes > 0.0 && bytes_total < min_bytes && !in.planes && !b10) {

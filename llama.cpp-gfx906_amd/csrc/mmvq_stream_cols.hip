@@ -173,7 +173,7 @@ bool mul_mat_vec_q_stream_cols(int type_a, const void * W, size_t w_row_stride, 
     // n = 3 / 4 / 5 (4096 x 14336) against 17.7 / 19.6 / 20.7 for the kernels it would replace
     if (type_a == T_Q6_K && on < 2) return false;
     const int ub = type_a == T_Q4_K ? 144 : type_a == T_Q5_K ? 176 : type_a == T_Q6_K ? 210 : 0;
-    if (!ub || k % 2048 != 0 || k > 16384 || m < 1 || m >= (1ll << 24)) return false;       // (a row's blocks in groups of 8 or 16 lanes)
+    if (!ub || k % 2048 != 0 || k > 16384 || m < 1 || m >= (1ll << 23)) return false;       // (a row's blocks in groups of 8 or 16 lanes)
     const int nb = (int)(k/256);
     if (w_row_stride != (size_t) nb*ub || ((uintptr_t) W % 16) || ((uintptr_t) act.qs % 16) || ((uintptr_t) act.bsums % 16) || ((uintptr_t) dst % 4) || dst_col_stride_bytes % 4) return false;
     st_args a = st_args{};
