@@ -600,12 +600,14 @@ def test_two_backends_from_two_threads():
         assert np.array_equal(single[i], multi[i])
 
 
-@pytest.mark.parametrize("env,value", [("GGML_MI355X_STREAM", "0"), ("GGML_MI355X_GRAPH_SEG0", "0"), ("GGML_MI355X_UPLOAD_BATCH", "0"), ("GGML_MI355X_STREAM_EARLY", "0"), ("GGML_MI355X_STREAM_EARLY", "3")])
+@pytest.mark.parametrize("env,value", [("GGML_MI355X_STREAM", "0"), ("GGML_MI355X_GRAPH_SEG0", "0"), ("GGML_MI355X_UPLOAD_BATCH", "0"), ("GGML_MI355X_STREAM_EARLY", "0"), ("GGML_MI355X_STREAM_EARLY", "3"),
+                                       ("GGML_MI355X_STREAM_Q16", "0"), ("GGML_MI355X_STREAM_XTOUCH", "0")])
 def test_other_decode_arrangements_stay_correct(env, value):
     """The arrangements that are not the default read their switch once per process: round 2's register-ring mat-vec kernels instead of the streamed ones
     (GGML_MI355X_STREAM=0), a captured graph as ONE executable graph instead of segments (GGML_MI355X_GRAPH_SEG0=0), one copy per set_tensor_async instead of
     the batched upload launch (GGML_MI355X_UPLOAD_BATCH=0), the streamed kernel's loader meeting the first barrier before any weight slot is on its way or after three
-    (GGML_MI355X_STREAM_EARLY=0 | 3; default 1) — the oracle comparisons of this file again, in a child process with the switch set."""
+    (GGML_MI355X_STREAM_EARLY=0 | 3; default 1), the Q8_K activation image one block per wave (GGML_MI355X_STREAM_Q16=0), no early request for the
+    activation lines (GGML_MI355X_STREAM_XTOUCH=0) — the oracle comparisons of this file again, in a child process with the switch set."""
     import os
     import subprocess
     import sys
