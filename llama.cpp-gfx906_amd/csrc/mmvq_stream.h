@@ -608,9 +608,19 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
             // the planes' weights (MoE combine): every thread derives the same few numbers — probs[ids[u]], then the normalisation of k_moe_combine (elem.hip)
             float w[8];
             {
-                float pr[8];
+                // the weights' loads are REQUESTED here and the workgroup's first barrier follows at once: the loader stands at that barrier, and with the arithmetic
+                // below (a wait for the cold values, eight expf, a division) in front of it the whole weight stream of the launch started ~2 us late
+                float pr[8]; int idv[8];
 #pragma unroll
-                for (int u = 0; u < 8; u++) pr[u] = u < p.n_planes ? (p.pl_ids ? p.pl_probs[p.pl_ids[u]] : p.pl_probs[u]) : 0.0f;      // (pl_ids == NULL: the router's values in slot order)
+                for (int u = 0; u < 8; u++) {
+                    pr[u] = 0.0f; idv[u] = 0;
+                    if (u < p.n_planes) { if (p.pl_ids) idv[u] = p.pl_ids[u]; else pr[u] = p.pl_probs[u]; }      // (pl_ids == NULL: the router's values in slot order)
+                }
+                if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+                if (p.pl_ids) {
+#pragma unroll
+                    for (int u = 0; u < 8; u++) if (u < p.n_planes) pr[u] = p.pl_probs[idv[u]];
+                }
                 if (p.pl_mode == 0) {
                     float sum = 0.0f;
 #pragma unroll
@@ -629,7 +639,6 @@ static __device__ __forceinline__ void st_prologue_f32(const st_args & p, const 
                     for (int u = 0; u < 8; u++) w[u] *= inv;
                 }
             }
-            if (FIRST) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
 #pragma unroll
             for (int i = 0; i < NA; i++) {
                 {
